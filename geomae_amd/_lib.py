@@ -1,0 +1,88 @@
+"""ctypes binding of libgeomae_hip.so (the C ABI declared in include/geomae_hip.h).
+
+The HIP library IS the product: there is no CPU or eager-PyTorch fallback.  Importing
+`geomae_amd` works without it (config / registry / host logic are importable on CPU), but any
+compute entry point raises GeomaeLibraryError when the shared object is missing.
+"""
+import ctypes
+import os
+from ctypes import POINTER, c_double, c_float, c_int32, c_int64, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgeomae_hip.so")
+
+
+class GeomaeLibraryError(RuntimeError):
+    pass
+
+
+class GeomaeTargetConfig(ctypes.Structure):
+    _fields_ = [("grid_size", c_int32 * 3), ("ratio_low", c_int32 * 3), ("ratio_med", c_int32 * 3),
+                ("voxel_size_top", c_float * 3), ("voxel_size_med", c_float * 3),
+                ("voxel_size_low", c_float * 3), ("coors_range", c_float * 6)]
+
+
+class GeomaeWindowConfig(ctypes.Structure):
+    _fields_ = [("window_shape", c_int32 * 2), ("shift", c_int32 * 2), ("bev_shape", c_int32 * 2)]
+
+
+F3 = POINTER(c_float)
+P = c_void_p
+# name -> (restype, argtypes).  Every symbol declared in include/geomae_hip.h is listed here;
+# tests/test_abi.py checks the header, this table and the built library against each other.
+SIGNATURES = {
+    "geomae_last_error": (ctypes.c_char_p, []),
+    "geomae_abi_version": (c_int32, []),
+    "geomae_grid_size": (ctypes.c_int, [F3, F3, POINTER(c_int32)]),
+    "geomae_dynamic_voxelize": (ctypes.c_int, [P, c_int64, c_int32, F3, F3, P, P]),
+    "geomae_voxelize_batch3": (ctypes.c_int, [P, c_int64, c_int32, P, c_int32, F3, F3, F3, F3, P, P, P, P]),
+    "geomae_pillar_segment_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32]),
+    "geomae_pillar_segment": (ctypes.c_int, [P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P,
+                                             P, c_int64, P]),
+    "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P]),
+    "geomae_segment_max_forward": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P]),
+    "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
+    "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),
+    "geomae_geometry_targets": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P, P, c_int32, P, P,
+                                               POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P]),
+    "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
+    "geomae_window_build": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, P, P, P, P,
+                                           P, P, c_int64, P]),
+    "geomae_window_attention_forward": (ctypes.c_int, [P, c_int32, c_int32, c_int32, P, P, P, c_int32, c_int32, P,
+                                                       P, P]),
+    "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, c_int32,
+                                                        c_int32, P, P]),
+}
+
+_lib = None
+
+
+def load(path=None):
+    """dlopen the HIP library (fails loudly -- there is no fallback path)."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise GeomaeLibraryError(
+            f"{path} not found: build it with `python -m geomae_amd.csrc.build` "
+            "(hipcc --offload-arch=gfx950).  geomae_amd has no CPU / eager fallback.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError = ABI mismatch, loud
+        fn.restype = res
+        fn.argtypes = args
+    if lib.geomae_abi_version() != 1:
+        raise GeomaeLibraryError(f"ABI version {lib.geomae_abi_version()} != 1")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().geomae_last_error().decode("utf-8", "replace")
+        raise GeomaeLibraryError(f"{what} failed ({rc}): {msg}")
+
+
+def f3(values):
+    return (c_float * len(values))(*[float(v) for v in values])

@@ -1,0 +1,158 @@
+// Random token masking on device (gfx950).
+//
+// Reference: get_vanilla_mask_index (mmdet3d/models/detectors/multi_sub_voxel_dynamic_voxelnet_ssl.py:
+// 287-304): per sample, L pillars, len_keep = int(L * (1 - ratio)), torch.randperm(L) -> first
+// len_keep kept, the rest masked.  Only the SET matters downstream (attention is permutation
+// equivariant, every loss is a mean over masked tokens), so instead of a permutation we draw a
+// uniformly random subset of exactly len_keep pillars: counter-based 32-bit keys, a 3-pass
+// LDS radix select of the len_keep-th smallest key, then an order-preserving compaction --
+// ids_keep / ids_mask come out ascending, which keeps later gathers coalesced.
+// One workgroup per sample; no host sync.  cuda/torch RNG streams cannot be reproduced, so
+// parity tests inject ids (the Python boundary accepts them).
+#include "common.h"
+#include "../../include/geomae_hip.h"
+
+namespace geomae {
+
+constexpr int kMaskBlk = 1024;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t mask_key(uint64_t seed, int b, int i) {
+    uint32_t h = mix32((uint32_t)seed ^ mix32((uint32_t)(seed >> 32) + 0x9E3779B9U * (uint32_t)(b + 1)));
+    return mix32(mix32((uint32_t)i * 0x9E3779B1U + h) ^ (h * 0x85EBCA6BU + 0x27D4EB2FU));
+}
+
+__device__ int block_scan_1024(int v, int* total, int* sm /*>=17*/) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
+    }
+    if (lane == 63) sm[w] = incl;
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int k = 0; k < kMaskBlk / 64; ++k) {
+        int s = sm[k];
+        if (k < w) woff += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return woff + incl - v;
+}
+
+__global__ __launch_bounds__(kMaskBlk) void random_mask_kernel(const int32_t* __restrict__ sample_start,
+                                                               int n_batch, double keep_frac, uint64_t seed,
+                                                               int32_t* __restrict__ ids_keep,
+                                                               int32_t* __restrict__ ids_mask,
+                                                               int32_t* __restrict__ token_row,
+                                                               int32_t* __restrict__ counts) {
+    __shared__ int hist[4096];
+    __shared__ int sm[20];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need;
+    const int b = blockIdx.x;
+    const int p0 = sample_start[b];
+    const int L = sample_start[b + 1] - p0;
+    const int K = (int)((double)L * keep_frac);
+    int keep_base = 0, mask_base = 0, keep_total = 0, mask_total = 0;
+    for (int k = 0; k < n_batch; ++k) {
+        const int l = sample_start[k + 1] - sample_start[k];
+        const int kk = (int)((double)l * keep_frac);
+        if (k < b) { keep_base += kk; mask_base += l - kk; }
+        keep_total += kk;
+        mask_total += l - kk;
+    }
+    if (b == 0 && threadIdx.x == 0) { counts[0] = keep_total; counts[1] = mask_total; }
+
+    // ---- radix select: find T = K-th smallest key (0-based rank K-1); need = how many keys == T to keep
+    uint32_t prefix = 0, prefix_mask = 0;
+    int need = K;                       // rank still to resolve inside the current prefix bucket
+    const int shifts[3] = {20, 8, 0};
+    const int bits[3] = {12, 12, 8};
+    if (K > 0) {
+        for (int pass = 0; pass < 3; ++pass) {
+            const int nb = 1 << bits[pass];
+            for (int t = threadIdx.x; t < nb; t += kMaskBlk) hist[t] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < L; i += kMaskBlk) {
+                const uint32_t key = mask_key(seed, b, i);
+                if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1);
+            }
+            __syncthreads();
+            {   // parallel search of the bin holding rank `need`: 4 consecutive bins per thread
+                int h[4], v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int bin = threadIdx.x * 4 + k;
+                    h[k] = bin < nb ? hist[bin] : 0;
+                    v += h[k];
+                }
+                int tot;
+                int acc = block_scan_1024(v, &tot, sm);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (acc < need && acc + h[k] >= need) {
+                        s_prefix = prefix | ((uint32_t)(threadIdx.x * 4 + k) << shifts[pass]);
+                        s_need = need - acc;
+                    }
+                    acc += h[k];
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            need = s_need;
+            prefix_mask |= (uint32_t)(nb - 1) << shifts[pass];
+            __syncthreads();
+        }
+    }
+    const uint32_t T = prefix;          // keys < T are kept, the first `need` keys == T are kept
+    // ---- order-preserving compaction
+    int run_keep = 0, run_eq = 0;
+    for (int base = 0; base < L; base += kMaskBlk) {
+        const int i = base + threadIdx.x;
+        uint32_t key = 0;
+        int lt = 0, eq = 0;
+        if (i < L && K > 0) {
+            key = mask_key(seed, b, i);
+            lt = key < T;
+            eq = key == T;
+        }
+        int tot_eq, tot_keep;
+        const int eq_rank = run_eq + block_scan_1024(eq, &tot_eq, sm);
+        const int keep = lt | (eq & (eq_rank < need));
+        const int keep_rank = run_keep + block_scan_1024(keep, &tot_keep, sm);
+        if (i < L) {
+            const int p = p0 + i;
+            if (keep) {
+                ids_keep[keep_base + keep_rank] = p;
+                token_row[p] = keep_base + keep_rank;
+            } else {
+                const int r = mask_base + (i - keep_rank);
+                ids_mask[r] = p;
+                token_row[p] = keep_total + r;
+            }
+        }
+        run_eq += tot_eq;
+        run_keep += tot_keep;
+    }
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+extern "C" int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double keep_fraction,
+                                  uint64_t seed, int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row,
+                                  int32_t* counts, hipStream_t stream) {
+    GEOMAE_REQUIRE(sample_start && ids_keep && ids_mask && token_row && counts, "random_mask: null argument");
+    GEOMAE_REQUIRE(batch_size >= 1 && keep_fraction >= 0.0 && keep_fraction <= 1.0, "random_mask: bad arguments");
+    hipLaunchKernelGGL(random_mask_kernel, dim3(batch_size), dim3(kMaskBlk), 0, stream, sample_start, batch_size,
+                       keep_fraction, seed, ids_keep, ids_mask, token_row, counts);
+    return check_launch("random_mask_kernel");
+}

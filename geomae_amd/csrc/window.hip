@@ -1,0 +1,460 @@
+// SST window partition + per-window variable-length multi-head attention (gfx950).
+//
+// Reference: MultiMAESSTSPChoose.window_partition / get_voxel_keep_inds / get_flat2win_inds /
+// get_inner_win_inds (mmdet3d/models/backbones/multi_mae_sst_spearate_top_only.py:413-681),
+// flat2window / window2flat (mmdet3d/ops/sst/sst_ops.py:98-135,225-251) and WindowAttention
+// (mmdet3d/models/sst/sst_basic_block.py:26-61), which zero-pads every window to 56 or 144
+// tokens and runs nn.MultiheadAttention with a key-padding mask per bucket.
+//
+// Here a window is a CSR segment: no padding to a bucket size, no [W,T,C] tensors, no
+// .item() syncs.  window_build is a counting sort of tokens by window id over the dense
+// (B * nwx * nwy) window table; attention runs one wavefront per (window, head) with the
+// head's Q/K/V slices staged in LDS (<= 144 x 16 bf16 each) and the 16x16x16 bf16 MFMA
+// for QK^T, PV and all backward products, softmax in fp32 registers.  Tiles are 16 tokens
+// wide, so a window of n tokens costs ceil(n/16)^2 tiles instead of 56^2 or 144^2.
+#include "common.h"
+#include "../../include/geomae_hip.h"
+
+namespace geomae {
+
+constexpr int kWBlk = 256;
+
+struct WinGeom {
+    int wx, wy;        // window shape (x, y)
+    int nwx, nwy;      // windows per sample along x, y (incl. the +1 for shifts)
+    int shift_x, shift_y;
+};
+
+__device__ __forceinline__ void win_of(const int4 c, const WinGeom g, int* win, int* pos) {
+    const int sx = c.w + (g.shift_x > 0 ? g.wx - g.shift_x : 0);
+    const int sy = c.z + (g.shift_y > 0 ? g.wy - g.shift_y : 0);
+    *win = c.x * (g.nwx * g.nwy) + (sx / g.wx) * g.nwy + sy / g.wy;
+    *pos = (sx % g.wx) * g.wy + (sy % g.wy);
+}
+
+__global__ __launch_bounds__(kWBlk) void win_hist_kernel(const int4* __restrict__ coors, int n, WinGeom g,
+                                                         int32_t* __restrict__ table, int32_t* __restrict__ rank,
+                                                         int32_t* __restrict__ tok_win_id,
+                                                         int32_t* __restrict__ tok_pos) {
+    for (int i = blockIdx.x * kWBlk + threadIdx.x; i < n; i += gridDim.x * kWBlk) {
+        int w, p;
+        win_of(coors[i], g, &w, &p);
+        tok_win_id[i] = w;
+        tok_pos[i] = p;
+        rank[i] = atomicAdd(&table[w], 1);
+    }
+}
+
+// one workgroup: compact the non-empty windows (ascending id) and exclusive-scan their sizes
+__global__ __launch_bounds__(1024) void win_scan_kernel(int32_t* __restrict__ table, int n_slots,
+                                                        int32_t* __restrict__ win_start,
+                                                        int32_t* __restrict__ num_windows, int n_tokens) {
+    __shared__ int sm[40];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int run_occ = 0, run_cnt = 0;
+    for (int base = 0; base < n_slots; base += 1024) {
+        const int t = base + threadIdx.x;
+        const int v = t < n_slots ? table[t] : 0;
+        int occ = v > 0, cnt = v;
+        int io = occ, ic = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            int a = __shfl_up(io, o, 64), b = __shfl_up(ic, o, 64);
+            if (lane >= o) { io += a; ic += b; }
+        }
+        if (lane == 63) { sm[w] = io; sm[16 + w] = ic; }
+        __syncthreads();
+        int oo = 0, oc = 0, to = 0, tc = 0;
+        for (int k = 0; k < 16; ++k) {
+            if (k < w) { oo += sm[k]; oc += sm[16 + k]; }
+            to += sm[k]; tc += sm[16 + k];
+        }
+        __syncthreads();
+        const int eo = run_occ + oo + io - occ, ec = run_cnt + oc + ic - cnt;
+        if (t < n_slots) {
+            if (v > 0) { win_start[eo] = ec; table[t] = eo; } else { table[t] = -1; }
+        }
+        run_occ += to;
+        run_cnt += tc;
+    }
+    if (threadIdx.x == 0) { num_windows[0] = run_occ; win_start[run_occ] = n_tokens; }
+}
+
+__global__ __launch_bounds__(kWBlk) void win_place_kernel(int n, const int32_t* __restrict__ table,
+                                                          const int32_t* __restrict__ rank,
+                                                          const int32_t* __restrict__ win_start,
+                                                          int32_t* __restrict__ tok_win_id,
+                                                          int32_t* __restrict__ win_tokens) {
+    for (int i = blockIdx.x * kWBlk + threadIdx.x; i < n; i += gridDim.x * kWBlk) {
+        const int w = table[tok_win_id[i]];
+        tok_win_id[i] = w;     // now the compact (CSR) window index
+        win_tokens[win_start[w] + rank[i]] = i;
+    }
+}
+
+// make the in-window token order deterministic (ascending token index): rank sort, one wave / window
+__global__ __launch_bounds__(64) void win_sort_kernel(const int32_t* __restrict__ win_start,
+                                                      const int32_t* __restrict__ num_windows,
+                                                      int32_t* __restrict__ win_tokens) {
+    __shared__ int a[1024];
+    const int W = num_windows[0];
+    for (int w = blockIdx.x; w < W; w += gridDim.x) {
+        const int s = win_start[w], n = win_start[w + 1] - s;
+        if (n <= 1024) {
+            for (int t = threadIdx.x; t < n; t += 64) a[t] = win_tokens[s + t];
+            __syncthreads();
+            for (int t = threadIdx.x; t < n; t += 64) {
+                const int v = a[t];
+                int r = 0;
+                for (int u = 0; u < n; ++u) r += a[u] < v;
+                win_tokens[s + r] = v;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// =====================================================================================
+// attention core: one wavefront per (window, head); d_head = 16
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+constexpr int kDh = 16;
+constexpr int kMaxT = 144;                 // 12 x 12 window
+constexpr int kMaxTiles = kMaxT / 16;      // 9
+
+__device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
+
+__device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
+}
+
+// stage the head slice [T, 16] of a [n, ld] bf16 matrix (columns col0..col0+15) into LDS,
+// row-major rm[Tp][16] and/or transposed tr[16][Tp]; rows >= T are zero
+__device__ __forceinline__ void stage_head(const unsigned short* __restrict__ src, int ld, int col0,
+                                           const int32_t* __restrict__ toks, int T, int Tp,
+                                           unsigned short* rm, unsigned short* tr) {
+    const int lane = threadIdx.x;
+    for (int t = lane; t < Tp * 2; t += 64) {
+        const int row = t >> 1, half = t & 1;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < T) v = *reinterpret_cast<const uint4*>(src + (int64_t)toks[row] * ld + col0 + half * 8);
+        if (rm) *reinterpret_cast<uint4*>(rm + row * kDh + half * 8) = v;
+        if (tr) {
+            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) tr[(half * 8 + k) * Tp + row] = e[k];
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x4 lds4(const unsigned short* p) { return *reinterpret_cast<const bf16x4*>(p); }
+
+// qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
+__global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
+                                                          const int32_t* __restrict__ win_start,
+                                                          const int32_t* __restrict__ win_tokens,
+                                                          const int32_t* __restrict__ num_windows, float scale,
+                                                          unsigned short* __restrict__ out,
+                                                          float* __restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
+    __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
+    __shared__ __attribute__((aligned(16))) unsigned short Vt[kDh * kMaxT];
+    __shared__ int toks[kMaxT];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int W = num_windows[0];
+    const int C = n_heads * kDh;
+    for (int wh = blockIdx.x; wh < W * n_heads; wh += gridDim.x) {
+        const int w = wh / n_heads, h = wh - w * n_heads;
+        const int s0 = win_start[w];
+        const int T = win_start[w + 1] - s0;
+        const int nt = (T + 15) >> 4, Tp = nt * 16;
+        for (int t = lane; t < T; t += 64) toks[t] = win_tokens[s0 + t];
+        __syncthreads();
+        stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, nullptr);
+        stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, nullptr);
+        stage_head(qkv, 3 * C, 2 * C + h * kDh, toks, T, Tp, nullptr, Vt);
+        __syncthreads();
+        for (int it = 0; it < nt; ++it) {
+            // S^T tiles: A = K rows (keys), B = Q^T (queries): lane holds query i = it*16 + c,
+            // keys j = jt*16 + 4*g + r
+            const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
+            f32x4 st[kMaxTiles];
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < kMaxTiles; ++jt) {
+                if (jt < nt) {
+                    const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
+                    f32x4 z = {0, 0, 0, 0};
+                    st[jt] = mfma16(ka, qb, z);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int j = jt * 16 + 4 * g + r;
+                        st[jt][r] = j < T ? st[jt][r] * scale : -INFINITY;
+                        m = fmaxf(m, st[jt][r]);
+                    }
+                }
+            }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int jt = 0; jt < kMaxTiles; ++jt) {
+                if (jt < nt) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __expf(st[jt][r] - m);
+                        st[jt][r] = p;
+                        sum += p;
+                    }
+                }
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            // O tile = P V : A = P (row i = c, k = 4g + r), B = V (k = j, col = d) read from V^T
+            f32x4 o = {0, 0, 0, 0};
+#pragma unroll
+            for (int jt = 0; jt < kMaxTiles; ++jt) {
+                if (jt < nt) {
+                    bf16x4 pa;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) pa[r] = (short)f2bf(st[jt][r]);
+                    const bf16x4 vb = lds4(Vt + c * Tp + jt * 16 + 4 * g);
+                    o = mfma16(pa, vb, o);
+                }
+            }
+            // C layout: row i = 4g + r, col d = c ; the row statistics live in lane (i & 15)
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + 4 * g + r;
+                const float inv_i = __shfl(inv, 4 * g + r, 64);
+                if (i < T) out[(int64_t)toks[i] * C + h * kDh + c] = f2bf(o[r] * inv_i);
+            }
+            const int iq = it * 16 + c;
+            if (g == 0 && iq < T) lse[(int64_t)toks[iq] * n_heads + h] = m + __logf(sum);
+        }
+        __syncthreads();
+    }
+}
+
+// backward: dqkv [n, 3C] bf16 from dout [n, C] bf16, qkv, out, lse
+__global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* __restrict__ qkv,
+                                                          const unsigned short* __restrict__ out,
+                                                          const unsigned short* __restrict__ dout,
+                                                          const float* __restrict__ lse, int n_heads,
+                                                          const int32_t* __restrict__ win_start,
+                                                          const int32_t* __restrict__ win_tokens,
+                                                          const int32_t* __restrict__ num_windows, float scale,
+                                                          unsigned short* __restrict__ dqkv) {
+    __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
+        dOs[kMaxT * kDh], Qt[kDh * kMaxT], Kt[kDh * kMaxT], dOt[kDh * kMaxT];
+    __shared__ float Ls[kMaxT], Ds[kMaxT];
+    __shared__ int toks[kMaxT];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4, c = lane & 15;
+    const int W = num_windows[0];
+    const int C = n_heads * kDh;
+    for (int wh = blockIdx.x; wh < W * n_heads; wh += gridDim.x) {
+        const int w = wh / n_heads, h = wh - w * n_heads;
+        const int s0 = win_start[w];
+        const int T = win_start[w + 1] - s0;
+        const int nt = (T + 15) >> 4, Tp = nt * 16;
+        for (int t = lane; t < T; t += 64) toks[t] = win_tokens[s0 + t];
+        __syncthreads();
+        stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, Qt);
+        stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, Kt);
+        stage_head(qkv, 3 * C, 2 * C + h * kDh, toks, T, Tp, Vs, nullptr);
+        stage_head(dout, C, h * kDh, toks, T, Tp, dOs, dOt);
+        // delta_i = sum_d dO[i,d] * O[i,d] ; L_i
+        for (int t = lane; t < Tp; t += 64) {
+            float d = 0.0f, l = INFINITY;    // padded rows: P = exp(s - inf) = 0
+            if (t < T) {
+                const unsigned short* o = out + (int64_t)toks[t] * C + h * kDh;
+                const unsigned short* dp = dout + (int64_t)toks[t] * C + h * kDh;
+#pragma unroll
+                for (int k = 0; k < kDh; ++k) d += bf2f(o[k]) * bf2f(dp[k]);
+                l = lse[(int64_t)toks[t] * n_heads + h];
+            }
+            Ds[t] = d;
+            Ls[t] = l;
+        }
+        __syncthreads();
+        // ---- pass 1: dQ.  S^T orientation: lane holds query i = it*16 + c, keys j = jt*16 + 4g + r
+        for (int it = 0; it < nt; ++it) {
+            const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
+            const bf16x4 dob = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
+            const float Li = Ls[it * 16 + c], Di = Ds[it * 16 + c];
+            f32x4 dq = {0, 0, 0, 0};
+            for (int jt = 0; jt < nt; ++jt) {
+                const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
+                const bf16x4 va = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
+                f32x4 z = {0, 0, 0, 0};
+                const f32x4 s = mfma16(ka, qb, z);       // [j][i]
+                const f32x4 dp = mfma16(va, dob, z);     // dP^T[j][i] = sum_d V[j,d] dO[i,d]
+                bf16x4 dsa;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = jt * 16 + 4 * g + r;
+                    const float p = j < T ? __expf(s[r] * scale - Li) : 0.0f;
+                    dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
+                }
+                // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
+                const bf16x4 kb = lds4(Kt + c * Tp + jt * 16 + 4 * g);
+                dq = mfma16(dsa, kb, dq);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = it * 16 + 4 * g + r;
+                if (i < T) dqkv[(int64_t)toks[i] * 3 * C + h * kDh + c] = f2bf(dq[r]);
+            }
+        }
+        // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
+        for (int jt = 0; jt < nt; ++jt) {
+            const bf16x4 kb = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
+            const bf16x4 vb = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
+            const bool jvalid = (jt * 16 + c) < T;
+            f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
+            for (int it = 0; it < nt; ++it) {
+                const bf16x4 qa = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
+                const bf16x4 doa = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
+                f32x4 z = {0, 0, 0, 0};
+                const f32x4 s = mfma16(qa, kb, z);       // [i][j]
+                const f32x4 dp = mfma16(doa, vb, z);     // dP[i][j]
+                bf16x4 pa, dsa;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = it * 16 + 4 * g + r;
+                    const float p = jvalid ? __expf(s[r] * scale - Ls[i]) : 0.0f;
+                    pa[r] = (short)f2bf(p);
+                    dsa[r] = (short)f2bf(p * (dp[r] - Ds[i]) * scale);
+                }
+                // dV[j][d] += sum_i P[i][j] dO[i][d] : A = P^T (row j = c, k = i), B = dO[k=i][col=d] from dO^T
+                const bf16x4 dob = lds4(dOt + c * Tp + it * 16 + 4 * g);
+                dv = mfma16(pa, dob, dv);
+                // dK[j][d] += sum_i dS[i][j] Q[i][d]
+                const bf16x4 qb = lds4(Qt + c * Tp + it * 16 + 4 * g);
+                dk = mfma16(dsa, qb, dk);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = jt * 16 + 4 * g + r;
+                if (j < T) {
+                    dqkv[(int64_t)toks[j] * 3 * C + C + h * kDh + c] = f2bf(dk[r]);
+                    dqkv[(int64_t)toks[j] * 3 * C + 2 * C + h * kDh + c] = f2bf(dv[r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, int* slots_per_sample) {
+    GEOMAE_REQUIRE(cfg, "window: null config");
+    GEOMAE_REQUIRE(shift_index == 0 || shift_index == 1, "window: shift_index must be 0 or 1");
+    GEOMAE_REQUIRE(cfg->window_shape[0] >= 1 && cfg->window_shape[1] >= 1, "window: bad window_shape");
+    g->wx = cfg->window_shape[0];
+    g->wy = cfg->window_shape[1];
+    // bb.py:637-642: ceil(bev / win) + 1 windows per axis ("plus one to meet the needs of shift")
+    g->nwx = (cfg->bev_shape[0] + g->wx - 1) / g->wx + 1;
+    g->nwy = (cfg->bev_shape[1] + g->wy - 1) / g->wy + 1;
+    g->shift_x = shift_index ? cfg->shift[0] : 0;
+    g->shift_y = shift_index ? cfg->shift[1] : 0;
+    *slots_per_sample = g->nwx * g->nwy;
+    return GEOMAE_OK;
+}
+
+extern "C" int64_t geomae_window_build_workspace_bytes(int32_t num_tokens, int32_t batch_size,
+                                                       const GeomaeWindowConfig* cfg) {
+    WinGeom g;
+    int sps;
+    if (win_geom(cfg, 0, &g, &sps)) return -1;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return al((int64_t)batch_size * sps * 4) + al((int64_t)num_tokens * 4);
+}
+
+extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_size,
+                                   const GeomaeWindowConfig* cfg, int32_t shift_index, int32_t* win_start,
+                                   int32_t* win_tokens, int32_t* tok_win, int32_t* tok_pos,
+                                   int32_t* num_windows, void* workspace, int64_t workspace_bytes,
+                                   hipStream_t stream) {
+    WinGeom g;
+    int sps;
+    int rc = win_geom(cfg, shift_index, &g, &sps);
+    if (rc) return rc;
+    GEOMAE_REQUIRE(num_tokens >= 0 && batch_size >= 1, "window_build: bad sizes");
+    GEOMAE_REQUIRE(win_start && num_windows, "window_build: null output");
+    const int64_t need = geomae_window_build_workspace_bytes(num_tokens, batch_size, cfg);
+    if (workspace_bytes < need || !workspace) {
+        set_error("window_build: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    const int slots = batch_size * sps;
+    int32_t* table = (int32_t*)workspace;
+    int32_t* rank = (int32_t*)((char*)workspace + al((int64_t)slots * 4));
+    GEOMAE_HIP(hipMemsetAsync(table, 0, (size_t)slots * 4, stream));
+    if (num_tokens > 0) {
+        GEOMAE_REQUIRE(coors && win_tokens && tok_win && tok_pos, "window_build: null argument");
+        hipLaunchKernelGGL(win_hist_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream,
+                           (const int4*)coors, num_tokens, g, table, rank, tok_win, tok_pos);
+    }
+    hipLaunchKernelGGL(win_scan_kernel, dim3(1), dim3(1024), 0, stream, table, slots, win_start, num_windows,
+                       num_tokens);
+    if (num_tokens > 0) {
+        hipLaunchKernelGGL(win_place_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream, num_tokens,
+                           table, rank, win_start, tok_win, win_tokens);
+        const int max_w = num_tokens < slots ? num_tokens : slots;
+        hipLaunchKernelGGL(win_sort_kernel, dim3(max_w < 4096 ? max_w : 4096), dim3(64), 0, stream, win_start,
+                           num_windows, win_tokens);
+    }
+    return check_launch("window_build");
+}
+
+extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
+                                               int32_t head_dim, const int32_t* win_start,
+                                               const int32_t* win_tokens, const int32_t* num_windows,
+                                               int32_t max_windows, int32_t max_window_tokens, void* out_bf16,
+                                               float* lse, hipStream_t stream) {
+    if (num_tokens <= 0 || max_windows <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(qkv_bf16 && win_start && win_tokens && num_windows && out_bf16 && lse,
+                   "window_attention_forward: null argument");
+    GEOMAE_REQUIRE(head_dim == kDh, "window_attention_forward: head_dim must be %d", kDh);
+    GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_forward: windows hold at most %d tokens", kMaxT);
+    const int64_t items = (int64_t)max_windows * num_heads;
+    const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
+    hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
+                       num_heads, win_start, win_tokens, num_windows, 1.0f / sqrtf((float)head_dim),
+                       (unsigned short*)out_bf16, lse);
+    return check_launch("win_attn_fwd_kernel");
+}
+
+extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16,
+                                                const float* lse, int32_t num_tokens, int32_t num_heads,
+                                                int32_t head_dim, const int32_t* win_start,
+                                                const int32_t* win_tokens, const int32_t* num_windows,
+                                                int32_t max_windows, int32_t max_window_tokens, void* dqkv_bf16,
+                                                hipStream_t stream) {
+    if (num_tokens <= 0 || max_windows <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(qkv_bf16 && out_bf16 && dout_bf16 && lse && win_start && win_tokens && num_windows && dqkv_bf16,
+                   "window_attention_backward: null argument");
+    GEOMAE_REQUIRE(head_dim == kDh, "window_attention_backward: head_dim must be %d", kDh);
+    GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_backward: windows hold at most %d tokens", kMaxT);
+    const int64_t items = (int64_t)max_windows * num_heads;
+    const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
+    hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
+                       (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
+                       win_tokens, num_windows, 1.0f / sqrtf((float)head_dim), (unsigned short*)dqkv_bf16);
+    return check_launch("win_attn_bwd_kernel");
+}

@@ -1,0 +1,156 @@
+"""MultiSubVoxelDynamicVoxelNetSSL -- the GeoMAE pre-training detector (orchestration, random
+masking, geometric targets, six-term loss).
+
+Reference: mmdet3d/models/detectors/multi_sub_voxel_dynamic_voxelnet_ssl.py (forward_train :126-166,
+extract_feat :169-242, forward_loss :837-902).  Constructor kwargs are exactly those of
+configs/mae_sst/*.py (:60-161), including the ones the path never uses (hard_sub_voxel_layer_*,
+loss, nor_usr_sml1, ...).  The data flow is re-designed around one counting sort per batch:
+
+  points (list[B] of [N_i,5]) -> cat -> voxelize_batch3 (3 resolutions, 1 kernel)
+    -> pillar_segment (replaces 6x torch.unique(dim=0)) -> [the single D2H readback: pillars/sample]
+    -> DynamicScatterVFE (segment mean / max kernels) -> random_mask (device)
+    -> geometry_targets (centroids, occupancy, normal+curvature: 2 kernels, masked rows only)
+    -> MultiMAESSTSPChoose (CSR windows + MFMA window attention) -> forward_loss
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .registry import DETECTORS, build_backbone, build_loss, build_voxel_encoder
+
+
+@DETECTORS.register_module()
+class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
+    def __init__(self, loss, loss_ratio_low, loss_ratio_med, loss_ratio_top, loss_ratio_low_nor,
+                 loss_ratio_med_nor, loss_ratio_top_nor, hard_sub_voxel_layer_low, hard_sub_voxel_layer_med,
+                 hard_sub_voxel_layer_top, random_mask_ratio, grid_size, sub_voxel_ratio_low, sub_voxel_ratio_med,
+                 voxel_layer, sub_voxel_layer_low, sub_voxel_layer_med, voxel_encoder, backbone,
+                 spatial_shape=[1, 468, 468], nor_usr_sml1=None, cls_loss_ratio_low=None, cls_loss_ratio_med=None,
+                 vis=False, cls_sub_voxel=False, normalize_sub_voxel=None, use_focal_mask=None, norm_curv=True,
+                 mse_loss=None, neck=None, bbox_head=None, train_cfg=None, test_cfg=None, pretrained=None,
+                 init_cfg=None):
+        super().__init__()
+        if neck is not None or bbox_head is not None:
+            raise NotImplementedError("the pre-training detector has no neck / bbox head")
+        if use_focal_mask is not None:
+            raise NotImplementedError("use_focal_mask is dead code in the reference config (None)")
+        if not mse_loss or nor_usr_sml1 is not None or not normalize_sub_voxel or not cls_sub_voxel or not norm_curv:
+            raise NotImplementedError("only the mae_sst configuration (mse_loss, normalize_sub_voxel, "
+                                      "cls_sub_voxel, norm_curv) is implemented")
+        self.spatial_shape = spatial_shape
+        self.nor_usr_sml1, self.norm_curv = nor_usr_sml1, norm_curv
+        self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top = loss_ratio_low, loss_ratio_med, loss_ratio_top
+        self.loss_ratio_low_nor, self.loss_ratio_med_nor, self.loss_ratio_top_nor = \
+            loss_ratio_low_nor, loss_ratio_med_nor, loss_ratio_top_nor
+        self.cls_loss_ratio_low, self.cls_loss_ratio_med = cls_loss_ratio_low, cls_loss_ratio_med
+        self.cls_sub_voxel, self.vis = cls_sub_voxel, vis
+        self.random_mask_ratio = random_mask_ratio
+        self.point_cloud_range = voxel_layer["point_cloud_range"]
+        self.voxel_size = voxel_layer["voxel_size"]
+        self.grid_size = grid_size
+        self.sub_voxel_size_low = sub_voxel_layer_low["voxel_size"]
+        self.sub_voxel_size_med = sub_voxel_layer_med["voxel_size"]
+        self.sub_voxel_ratio_low, self.sub_voxel_ratio_med = sub_voxel_ratio_low, sub_voxel_ratio_med
+        self.sub_voxel_layer_low = ops.Voxelization(**sub_voxel_layer_low)
+        self.sub_voxel_layer_med = ops.Voxelization(**sub_voxel_layer_med)
+        self.hard_sub_voxel_layer_low = ops.Voxelization_with_flag(**hard_sub_voxel_layer_low)
+        self.hard_sub_voxel_layer_med = ops.Voxelization_with_flag(**hard_sub_voxel_layer_med)
+        self.hard_sub_voxel_layer_top = ops.Voxelization(**hard_sub_voxel_layer_top)
+        self.voxel_layer = ops.Voxelization(**voxel_layer)
+        self.voxel_encoder = build_voxel_encoder(voxel_encoder)
+        self.backbone = build_backbone(backbone)
+        self.reg_loss = build_loss(loss)
+        self.mse_loss, self.use_focal_mask, self.normalize_sub_voxel = mse_loss, use_focal_mask, normalize_sub_voxel
+        self.cls_loss = build_loss(dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0))
+        self._tcfg = ops.make_target_config(grid_size, sub_voxel_ratio_low, sub_voxel_ratio_med, self.voxel_size,
+                                            self.sub_voxel_size_med, self.sub_voxel_size_low, self.point_cloud_range)
+        self.mask_seed = 0
+        self._iter = 0
+
+    # ------------------------------------------------------------------ mmdet Base3DDetector surface
+    def forward(self, return_loss=True, **kwargs):
+        if return_loss:
+            return self.forward_train(**kwargs)
+        raise NotImplementedError("the SSL detector is train-only")
+
+    def init_weights(self):
+        pass
+
+    def forward_train(self, points, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_bboxes_ignore=None,
+                      ids_keep=None, ids_mask=None):
+        x, tgt = self.extract_feat(points, gt_bboxes_3d, gt_labels_3d, img_metas, ids_keep=ids_keep,
+                                   ids_mask=ids_mask)
+        reg_low, reg_med, reg_top, nor_low, nor_med, nor_top, cls_low, cls_med = x
+        return self.forward_loss(tgt["centroid_low"], tgt["mask_low"], tgt["centroid_med"], tgt["mask_med"],
+                                 tgt["centroid_top"], tgt["normal"], None, None, reg_low, reg_med, reg_top, nor_low,
+                                 nor_med, nor_top, cls_low, cls_med)
+
+    # ------------------------------------------------------------------ preprocessing
+    @torch.no_grad()
+    def voxelize_all(self, points):
+        """voxelize + sub_voxelize_low + sub_voxelize_med (ssl.py:307-377) in one kernel."""
+        sizes = [int(p.shape[0]) for p in points]
+        offs = [0]
+        for s in sizes:
+            offs.append(offs[-1] + s)
+        pts = torch.cat([p.float() for p in points], dim=0).contiguous() if len(points) > 1 else points[0].float().contiguous()
+        boffs = torch.tensor(offs, dtype=torch.int32, device=pts.device)
+        top, med, low = ops.voxelize_batch3(pts, boffs, len(points), self.voxel_size, self.sub_voxel_size_med,
+                                            self.sub_voxel_size_low, self.point_cloud_range)
+        return pts, top, med, low
+
+    def voxelize(self, points):
+        pts, top, _, _ = self.voxelize_all(points)
+        return pts, top
+
+    @torch.no_grad()
+    def get_vanilla_mask_index(self, seg):
+        self._iter += 1
+        return ops.random_mask(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
+
+    def extract_feat(self, points, gt_bboxes_3d=None, gt_labels_3d=None, img_metas=None, vis=False, ids_keep=None,
+                     ids_mask=None):
+        batch_size = len(points)
+        voxels, coors, sub_med, sub_low = self.voxelize_all(points)
+        seg = ops.pillar_segment(coors, batch_size, self.grid_size)
+        V = seg.V                                                     # the iteration's one host sync
+        voxel_features, feature_coors = self.voxel_encoder(voxels, coors, seg=seg)
+        if ids_keep is None:
+            ids_keep, ids_mask, token_row, counts = self.get_vanilla_mask_index(seg)
+        else:
+            ids_keep, ids_mask = ids_keep.int(), ids_mask.int()
+            token_row, counts = ops.token_rows_from_ids(ids_keep, ids_mask, V)
+        with torch.no_grad():
+            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts,
+                                       n_rows=int(ids_mask.numel()))
+        ik, im = ids_keep.long(), ids_mask.long()
+        mask_coors = feature_coors[im]
+        x = self.backbone(voxel_features[ik], feature_coors[ik], mask_coors, batch_size)
+        return x, tgt
+
+    # ------------------------------------------------------------------ losses (ssl.py:837-902)
+    def forward_loss(self, centroid_low, centroid_low_mask, centroid_med, centroid_med_mask, centroid_high,
+                     centroid_normal_low, centroid_normal_med, centroid_normal_high, reg_pred_low, reg_pred_med,
+                     reg_pred_high, nor_pred_low, nor_pred_med, nor_pred_high, cls_pred_low=None, cls_pred_med=None):
+        def masked_mse(pred, tgt, mask, ratio):
+            # == ((pred - tgt)[mask] ** 2).mean(-1).sum() / mask.sum(): no boolean indexing -> no host sync
+            m = mask.reshape(-1)
+            per = ((pred.reshape(-1, 3).float() - tgt.reshape(-1, 3)) ** 2).mean(dim=-1)
+            return (per * m).sum() / m.sum().clamp(min=1).to(per.dtype) * ratio
+
+        def mse(pred, tgt, ratio):
+            per = ((pred.float() - tgt) ** 2).mean(dim=-1)
+            return per.sum() / per.shape[0] * ratio
+
+        loss_reg_low = masked_mse(reg_pred_low, centroid_low, centroid_low_mask, self.loss_ratio_low)
+        loss_reg_med = masked_mse(reg_pred_med, centroid_med, centroid_med_mask, self.loss_ratio_med)
+        loss_reg_top = mse(reg_pred_high, centroid_high, self.loss_ratio_top)
+        nor_pred = nor_pred_high if (nor_pred_low is None and nor_pred_med is None) else nor_pred_low
+        loss_nor_low = mse(nor_pred, centroid_normal_low, self.loss_ratio_low_nor)
+        loss_cls_low = self.cls_loss(cls_pred_low.reshape(-1, 2).float(), centroid_low_mask.reshape(-1).long()) \
+            * self.cls_loss_ratio_low
+        loss_cls_med = self.cls_loss(cls_pred_med.reshape(-1, 2).float(), centroid_med_mask.reshape(-1).long()) \
+            * self.cls_loss_ratio_med
+        return dict(loss_curv_around=loss_nor_low, loss_centroid_low=loss_reg_low, loss_centroid_med=loss_reg_med,
+                    loss_centroid_top=loss_reg_top, loss_cls_low=loss_cls_low, loss_cls_med=loss_cls_med)

@@ -1,0 +1,363 @@
+"""Operator layer: the reference's `mmdet3d.ops` names for the pre-training hot path, backed by
+libgeomae_hip (hand-written gfx950 kernels) through the C ABI in include/geomae_hip.h.
+
+Mirrors (same names / argument meaning / error behaviour):
+  dynamic_voxelize, Voxelization      mmdet3d/ops/voxel/voxelize.py:14-121 (+ voxel_layer pybind)
+  scatter_v2                          mmdet3d/ops/sst/sst_ops.py:8-39
+PyTorch is used for device memory and streams only; every function raises if the HIP library is
+missing or a tensor is not a contiguous CUDA (ROCm) tensor -- there is no CPU fallback.
+"""
+import ctypes
+
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import GeomaeTargetConfig, GeomaeWindowConfig, check, f3
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _check_input(t, name, dtype=None):
+    # same contract as the reference's CHECK_INPUT (voxelization_cuda.cu:8-14)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (geomae_amd has no CPU path)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+# ------------------------------------------------------------------------------------ A1
+def grid_size(voxel_size, coors_range):
+    """fp32 grid size (x, y, z) exactly as the reference computes it (voxelization_cuda.cu:375-377)."""
+    out = (ctypes.c_int32 * 3)()
+    check(_lib.load().geomae_grid_size(f3(voxel_size), f3(coors_range), out), "geomae_grid_size")
+    return [int(v) for v in out]
+
+
+def dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3):
+    """Drop-in for voxel_layer.dynamic_voxelize: fills the pre-allocated coors [N,3] int32 (z,y,x)."""
+    if NDim != 3:
+        raise RuntimeError("only NDim == 3 is supported")
+    _check_input(points, "points", torch.float32)
+    _check_input(coors, "coors", torch.int32)
+    if points.dim() != 2 or coors.shape != (points.shape[0], 3):
+        raise RuntimeError("points must be [N, C] and coors [N, 3]")
+    check(_lib.load().geomae_dynamic_voxelize(_ptr(points), points.shape[0], points.shape[1], f3(voxel_size),
+                                              f3(coors_range), _ptr(coors), _stream()), "geomae_dynamic_voxelize")
+
+
+class Voxelization(nn.Module):
+    """mmdet3d.ops.Voxelization (voxelize.py:63-121).  Only the dynamic mode (max_num_points == -1 or
+    max_voxels == -1) is on the pre-training path; hard voxelization is constructed by the config
+    (hard_sub_voxel_layer_*) but never called, so calling it raises."""
+
+    def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
+        super().__init__()
+        self.voxel_size = voxel_size
+        self.point_cloud_range = point_cloud_range
+        self.max_num_points = max_num_points
+        self.max_voxels = max_voxels if isinstance(max_voxels, tuple) else (max_voxels, max_voxels)
+        pcr = torch.tensor(point_cloud_range, dtype=torch.float32)
+        vs = torch.tensor(voxel_size, dtype=torch.float32)
+        grid = torch.round((pcr[3:] - pcr[:3]) / vs).long()
+        self.grid_size = grid
+        self.pcd_shape = [*grid[:2].tolist(), 1][::-1]
+
+    def forward(self, input):
+        max_voxels = self.max_voxels[0] if self.training else self.max_voxels[1]
+        if self.max_num_points == -1 or max_voxels == -1:
+            coors = input.new_zeros(size=(input.size(0), 3), dtype=torch.int)
+            dynamic_voxelize(input.contiguous(), coors, self.voxel_size, self.point_cloud_range, 3)
+            return coors
+        raise NotImplementedError("hard voxelization is not part of the GeoMAE pre-training path")
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="
+                f"{self.point_cloud_range}, max_num_points={self.max_num_points}, max_voxels={self.max_voxels})")
+
+
+Voxelization_with_flag = Voxelization   # constructed by the config, never called on this path
+
+
+def voxelize_batch3(points, batch_offsets, batch_size, vs_top, vs_med, vs_low, coors_range):
+    """Three resolutions in one pass over the concatenated batch -> three [N,4] int32 (b,z,y,x)."""
+    _check_input(points, "points", torch.float32)
+    _check_input(batch_offsets, "batch_offsets", torch.int32)
+    n = points.shape[0]
+    out = [torch.empty((n, 4), dtype=torch.int32, device=points.device) for _ in range(3)]
+    check(_lib.load().geomae_voxelize_batch3(_ptr(points), n, points.shape[1], _ptr(batch_offsets), batch_size,
+                                             f3(vs_top), f3(vs_med), f3(vs_low), f3(coors_range), _ptr(out[0]),
+                                             _ptr(out[1]), _ptr(out[2]), _stream()), "geomae_voxelize_batch3")
+    return out
+
+
+# ------------------------------------------------------------------------------------ A2
+class PillarSegments:
+    """Result of the one counting sort per batch that replaces the reference's six unique(dim=0)."""
+    __slots__ = ("cell_table", "voxel_coors", "inv", "order", "seg_start", "sample_start", "num_pillars",
+                 "cap", "grid", "batch_size", "num_points", "_host")
+
+    def sync_counts(self):
+        """The one device->host readback of the iteration: pillar offsets per sample."""
+        if self._host is None:
+            self._host = self.sample_start.cpu().tolist()
+        return self._host
+
+    @property
+    def V(self):
+        return self.sync_counts()[-1]
+
+
+def pillar_segment(coors, batch_size, grid_zyx, cap=None):
+    _check_input(coors, "coors", torch.int32)
+    n = coors.shape[0]
+    gz, gy, gx = [int(g) for g in grid_zyx]
+    cells = batch_size * gz * gy * gx
+    cap = min(n, cells) if cap is None else cap
+    dev = coors.device
+    lib = _lib.load()
+    s = PillarSegments()
+    s.cell_table = torch.empty(cells, dtype=torch.int32, device=dev)
+    s.voxel_coors = torch.empty((max(cap, 1), 4), dtype=torch.int32, device=dev)
+    s.inv = torch.empty(n, dtype=torch.int32, device=dev)
+    s.order = torch.empty(n, dtype=torch.int32, device=dev)
+    s.seg_start = torch.empty(max(cap, 1) + 1, dtype=torch.int32, device=dev)
+    s.sample_start = torch.empty(batch_size + 1, dtype=torch.int32, device=dev)
+    s.num_pillars = torch.empty(1, dtype=torch.int32, device=dev)
+    s.cap, s.grid, s.batch_size, s.num_points, s._host = cap, (gz, gy, gx), batch_size, n, None
+    wsb = lib.geomae_pillar_segment_workspace_bytes(n, batch_size, gz, gy, gx)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.geomae_pillar_segment(_ptr(coors), n, batch_size, gz, gy, gx, _ptr(s.cell_table), _ptr(s.voxel_coors),
+                                    _ptr(s.inv), _ptr(s.order), _ptr(s.seg_start), _ptr(s.sample_start),
+                                    _ptr(s.num_pillars), _ptr(ws), wsb, _stream()), "geomae_pillar_segment")
+    return s
+
+
+def segment_mean_xyz(points, seg):
+    mean = torch.empty((max(seg.cap, 1), 3), dtype=torch.float32, device=points.device)
+    check(_lib.load().geomae_segment_mean_xyz(_ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start),
+                                              _ptr(seg.num_pillars), seg.cap, _ptr(mean), _stream()),
+          "geomae_segment_mean_xyz")
+    return mean
+
+
+class _SegmentMax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, seg, V):
+        feat = feat.contiguous()
+        _check_input(feat, "feat", torch.float32)
+        C = feat.shape[1]
+        out = torch.empty((V, C), dtype=torch.float32, device=feat.device)
+        arg = torch.empty((V, C), dtype=torch.int32, device=feat.device)
+        check(_lib.load().geomae_segment_max_forward(_ptr(feat), C, _ptr(seg.order), _ptr(seg.seg_start),
+                                                     _ptr(seg.num_pillars), V, _ptr(out), _ptr(arg), _stream()),
+              "geomae_segment_max_forward")
+        ctx.seg, ctx.n, ctx.C = seg, feat.shape[0], C
+        ctx.save_for_backward(arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (arg,) = ctx.saved_tensors
+        grad_out = grad_out.contiguous().float()
+        grad = torch.empty((ctx.n, ctx.C), dtype=torch.float32, device=grad_out.device)
+        check(_lib.load().geomae_segment_max_backward(_ptr(grad_out), _ptr(arg), _ptr(ctx.seg.inv), ctx.n, ctx.C,
+                                                      _ptr(grad), _stream()), "geomae_segment_max_backward")
+        return grad, None, None
+
+
+def segment_max(feat, seg, V=None):
+    return _SegmentMax.apply(feat, seg, seg.V if V is None else V)
+
+
+def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, new_coors=None, grid_zyx=None,
+               batch_size=None):
+    """mmdet3d.ops.scatter_v2 (sst_ops.py:8-39) on the pillar-segment kernels.
+
+    `coors` is [N,4] int32 (b,z,y,x).  The dense cell table needs the grid extent: pass grid_zyx /
+    batch_size, or they are taken from coors.max() (one extra sync -- fine for the operator API;
+    the fused detector path never calls this wrapper)."""
+    assert feat.size(0) == coors.size(0)
+    if mode == "avg":
+        mode = "mean"
+    if min_points > 0:
+        raise NotImplementedError("min_points > 0 is not on the pre-training path")
+    if isinstance(unq_inv, PillarSegments):
+        seg = unq_inv
+    else:
+        coors = coors.contiguous().int()
+        if grid_zyx is None:
+            mx = coors.max(0).values.tolist()
+            batch_size, grid_zyx = mx[0] + 1, (mx[1] + 1, mx[2] + 1, mx[3] + 1)
+        seg = pillar_segment(coors, batch_size, grid_zyx)
+    V = seg.V
+    if mode == "max":
+        new_feat = segment_max(feat.float(), seg, V)
+    elif mode == "mean":
+        if feat.shape[1] != 3:
+            raise NotImplementedError("segment mean is implemented for the xyz cluster centre (3 channels)")
+        new_feat = segment_mean_xyz(feat.contiguous().float(), seg)[:V]
+    else:
+        raise NotImplementedError(mode)
+    out_coors = seg.voxel_coors[:V]
+    if not return_inv:
+        return new_feat, out_coors
+    return new_feat, out_coors, seg.inv.long()
+
+
+# ------------------------------------------------------------------------------------ A6
+def random_mask(seg, keep_fraction, seed):
+    """-> ids_keep [n_keep], ids_mask [n_mask] (int64, ascending), token_row [V] int32, counts [2] int32."""
+    dev = seg.voxel_coors.device
+    starts = seg.sync_counts()
+    V = starts[-1]
+    n_keep = sum(int((starts[b + 1] - starts[b]) * keep_fraction) for b in range(seg.batch_size))
+    ids_keep = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+    ids_mask = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+    token_row = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+    counts = torch.empty(2, dtype=torch.int32, device=dev)
+    check(_lib.load().geomae_random_mask(_ptr(seg.sample_start), seg.batch_size, float(keep_fraction),
+                                         int(seed) & (2 ** 64 - 1), _ptr(ids_keep), _ptr(ids_mask), _ptr(token_row),
+                                         _ptr(counts), _stream()), "geomae_random_mask")
+    return ids_keep[:n_keep], ids_mask[:V - n_keep], token_row[:V], counts
+
+
+def token_rows_from_ids(ids_keep, ids_mask, V):
+    """token_row / counts for externally supplied ids (parity tests inject the reference's ids)."""
+    dev = ids_keep.device
+    token_row = torch.empty(V, dtype=torch.int32, device=dev)
+    token_row[ids_keep.long()] = torch.arange(ids_keep.numel(), dtype=torch.int32, device=dev)
+    token_row[ids_mask.long()] = torch.arange(ids_mask.numel(), dtype=torch.int32, device=dev) + ids_keep.numel()
+    counts = torch.tensor([ids_keep.numel(), ids_mask.numel()], dtype=torch.int32, device=dev)
+    return token_row, counts
+
+
+# ------------------------------------------------------------------------------------ A5, A7-A11
+def make_target_config(grid_size_zyx, ratio_low, ratio_med, vs_top, vs_med, vs_low, coors_range):
+    c = GeomaeTargetConfig()
+    c.grid_size[:] = [int(v) for v in grid_size_zyx]
+    c.ratio_low[:] = [int(v) for v in ratio_low]
+    c.ratio_med[:] = [int(v) for v in ratio_med]
+    c.voxel_size_top[:] = [float(v) for v in vs_top]
+    c.voxel_size_med[:] = [float(v) for v in vs_med]
+    c.voxel_size_low[:] = [float(v) for v in vs_low]
+    c.coors_range[:] = [float(v) for v in coors_range]
+    return c
+
+
+def geometry_targets(points, seg, coors_med, coors_low, cfg, token_row=None, counts=None, n_rows=None,
+                     want_cov=False):
+    """All geometric targets of extract_feat (ssl.py:185-219) in two kernels.  Rows = masked pillars in
+    ids_mask order when token_row/counts are given (n_rows = n_mask), else one row per pillar."""
+    dev = points.device
+    V = seg.V
+    M = V if token_row is None else n_rows
+    s_low = cfg.ratio_low[0] * cfg.ratio_low[1] * cfg.ratio_low[2]
+    s_med = cfg.ratio_med[0] * cfg.ratio_med[1] * cfg.ratio_med[2]
+    f32, u8 = torch.float32, torch.uint8
+    out = dict(
+        centroid_low=torch.empty((M, s_low, 3), dtype=f32, device=dev),
+        mask_low=torch.empty((M, s_low), dtype=u8, device=dev),
+        centroid_med=torch.empty((M, s_med, 3), dtype=f32, device=dev),
+        mask_med=torch.empty((M, s_med), dtype=u8, device=dev),
+        centroid_top=torch.empty((M, 3), dtype=f32, device=dev),
+        normal=torch.empty((M, 3), dtype=f32, device=dev),
+        curv=torch.empty((M, 3), dtype=torch.float64, device=dev),
+        top_raw=torch.empty((max(V, 1), 3), dtype=f32, device=dev),
+        med_raw=torch.empty((max(V, 1), s_med, 3), dtype=f32, device=dev),
+        med_raw_mask=torch.empty((max(V, 1), s_med), dtype=u8, device=dev),
+        cov=torch.empty((M, 6), dtype=f32, device=dev) if want_cov else None)
+    check(_lib.load().geomae_geometry_targets(
+        _ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start), _ptr(seg.num_pillars), V,
+        _ptr(seg.voxel_coors), _ptr(coors_med), _ptr(coors_low), _ptr(seg.cell_table), seg.batch_size,
+        _ptr(token_row), _ptr(counts), ctypes.byref(cfg), _ptr(out["centroid_low"]), _ptr(out["mask_low"]),
+        _ptr(out["centroid_med"]), _ptr(out["mask_med"]), _ptr(out["centroid_top"]), _ptr(out["normal"]),
+        _ptr(out["curv"]), _ptr(out["top_raw"]), _ptr(out["med_raw"]), _ptr(out["med_raw_mask"]), _ptr(out["cov"]),
+        _stream()), "geomae_geometry_targets")
+    out["mask_low"] = out["mask_low"].bool()
+    out["mask_med"] = out["mask_med"].bool()
+    return out
+
+
+# ------------------------------------------------------------------------------------ A12-A19
+def make_window_config(window_shape, shift, bev_shape):
+    c = GeomaeWindowConfig()
+    c.window_shape[:] = [int(v) for v in window_shape]
+    c.shift[:] = [int(v) for v in shift]
+    c.bev_shape[:] = [int(v) for v in bev_shape]
+    return c
+
+
+class WindowLayout:
+    """CSR grouping of tokens by window for one shift (replaces the flat2win index dictionaries)."""
+    __slots__ = ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "max_windows", "n", "max_tokens")
+
+
+def window_build(coors, batch_size, wcfg, shift_index):
+    coors = coors.contiguous()
+    _check_input(coors, "coors", torch.int32)
+    n = coors.shape[0]
+    dev = coors.device
+    lib = _lib.load()
+    nwx = (wcfg.bev_shape[0] + wcfg.window_shape[0] - 1) // wcfg.window_shape[0] + 1
+    nwy = (wcfg.bev_shape[1] + wcfg.window_shape[1] - 1) // wcfg.window_shape[1] + 1
+    slots = batch_size * nwx * nwy
+    L = WindowLayout()
+    L.n = n
+    L.max_windows = max(1, min(n, slots))
+    L.max_tokens = wcfg.window_shape[0] * wcfg.window_shape[1]
+    L.win_start = torch.empty(L.max_windows + 1, dtype=torch.int32, device=dev)
+    L.win_tokens = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    L.tok_win = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    L.tok_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    L.num_windows = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = lib.geomae_window_build_workspace_bytes(n, batch_size, ctypes.byref(wcfg))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.geomae_window_build(_ptr(coors), n, batch_size, ctypes.byref(wcfg), shift_index, _ptr(L.win_start),
+                                  _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.tok_pos), _ptr(L.num_windows),
+                                  _ptr(ws), wsb, _stream()), "geomae_window_build")
+    return L
+
+
+class _WindowAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, layout, num_heads):
+        qkv = qkv.contiguous()
+        _check_input(qkv, "qkv", torch.bfloat16)
+        n, c3 = qkv.shape
+        C = c3 // 3
+        out = torch.empty((n, C), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((n, num_heads), dtype=torch.float32, device=qkv.device)
+        check(_lib.load().geomae_window_attention_forward(
+            _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
+            _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+            "geomae_window_attention_forward")
+        ctx.layout, ctx.num_heads = layout, num_heads
+        ctx.save_for_backward(qkv, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        dout = dout.contiguous().to(torch.bfloat16)
+        n, c3 = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        L = ctx.layout
+        check(_lib.load().geomae_window_attention_backward(
+            _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), n, ctx.num_heads, c3 // 3 // ctx.num_heads,
+            _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv),
+            _stream()), "geomae_window_attention_backward")
+        return dqkv, None, None
+
+
+def window_attention(qkv_bf16, layout, num_heads):
+    """softmax(q k^T / sqrt(d)) v inside every window; qkv [n, 3C] bf16 -> [n, C] bf16."""
+    return _WindowAttention.apply(qkv_bf16, layout, num_heads)

@@ -1,0 +1,225 @@
+"""SST blocks and the MAE backbone of the mae_sst config.
+
+Reference: mmdet3d/models/sst/sst_basic_block.py:13-147 (WindowAttention / EncoderLayer /
+BasicShiftBlock) and mmdet3d/models/backbones/multi_mae_sst_spearate_top_only.py (registered as
+MultiMAESSTSPChoose).  Parameter names match the reference's state_dict
+(backbone.encoder_blocks.{i}.encoder_list.{j}.win_attn.self_attn.in_proj_weight, ...), so
+checkpoints interchange with the fine-tune configs.
+
+Differences in mechanism, not in math: windows are CSR segments built once per token set by
+libgeomae_hip (no zero-padded [W, 56|144, C] buckets, no .item() syncs, no per-layer
+flat2window/window2flat copies); the positional embedding is a 144 x 128 table gathered per token
+(it is a pure function of the in-window coordinate, bb.py:361-394); attention inside a window is
+the hand-written MFMA kernel (ops.window_attention).  The dense projections / FFN run as bf16 MFMA
+GEMMs with fp32 accumulation and an fp32 residual stream (compute_dtype='bf16', BASELINE config 2) or
+in fp32 (compute_dtype='fp32', used by the tight parity tests).
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from . import ops
+from .registry import BACKBONES
+
+
+def pos_embed_table(window_shape, d_model, temperature=10000):
+    """[wx*wy, d_model] fp32, row cx*wy + cy  (bb.py:361-394)."""
+    wx, wy = window_shape
+    cx = torch.arange(wx, dtype=torch.float32).repeat_interleave(wy)
+    cy = torch.arange(wy, dtype=torch.float32).repeat(wx)
+    x, y = cx - wx / 2, cy - wy / 2
+    pos_length = d_model // 2
+    inv_freq = torch.arange(pos_length, dtype=torch.float32)
+    inv_freq = temperature ** (2 * (inv_freq // 2) / pos_length)
+    ex = x[:, None] / inv_freq[None, :]
+    ey = y[:, None] / inv_freq[None, :]
+    ex = torch.stack([ex[:, ::2].sin(), ex[:, 1::2].cos()], dim=-1).flatten(1)
+    ey = torch.stack([ey[:, ::2].sin(), ey[:, 1::2].cos()], dim=-1).flatten(1)
+    return torch.cat([ex, ey], dim=-1)
+
+
+class WindowAttention(nn.Module):
+    def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None):
+        super().__init__()
+        assert dropout == 0.0, "the mae_sst config trains with dropout 0"
+        self.nhead = nhead
+        self.d_model = d_model
+        # parameter container only: in_proj_weight [3C, C], in_proj_bias, out_proj.{weight,bias}
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.layer_id = layer_id
+
+    def forward(self, x, pos, layout, compute_dtype):
+        C = self.d_model
+        a = self.self_attn
+        dt = compute_dtype
+        w, b = a.in_proj_weight.to(dt), a.in_proj_bias.to(dt)
+        qk_in = (x + pos).to(dt)
+        qk = F.linear(qk_in, w[:2 * C], b[:2 * C])
+        v = F.linear(x.to(dt), w[2 * C:], b[2 * C:])
+        qkv = torch.cat([qk, v], dim=1).to(torch.bfloat16)
+        o = ops.window_attention(qkv, layout, self.nhead).to(dt)
+        return F.linear(o, a.out_proj.weight.to(dt), a.out_proj.bias.to(dt)).float()
+
+
+class EncoderLayer(nn.Module):
+    """Post-norm transformer layer (sst_basic_block.py:63-102)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 layer_id=None, mlp_dropout=0):
+        super().__init__()
+        assert not batch_first
+        assert activation == "gelu", "the mae_sst config uses GELU"
+        self.win_attn = WindowAttention(d_model, nhead, dropout, layer_id=layer_id)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, layout, compute_dtype):
+        dt = compute_dtype
+        src2 = self.win_attn(src, pos, layout, dt)
+        src = self.norm1(src + src2)
+        h = F.gelu(F.linear(src.to(dt), self.linear1.weight.to(dt), self.linear1.bias.to(dt)))
+        src2 = F.linear(h, self.linear2.weight.to(dt), self.linear2.bias.to(dt)).float()
+        return self.norm2(src + src2)
+
+
+class BasicShiftBlock(nn.Module):
+    """Two encoder layers, the second on the shifted window layout (sst_basic_block.py:104-147)."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu", batch_first=False,
+                 block_id=-100):
+        super().__init__()
+        self.encoder_list = nn.ModuleList([
+            EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first, layer_id=block_id * 2 + i)
+            for i in range(2)])
+
+    def forward(self, src, pos_list, layout_list, compute_dtype):
+        num_shifts = len(layout_list)
+        assert num_shifts in (1, 2)
+        out = src
+        for i in range(2):
+            s = i % num_shifts
+            out = self.encoder_list[i](out, pos_list[s], layout_list[s], compute_dtype)
+        return out
+
+
+@BACKBONES.register_module()
+class MultiMAESSTSPChoose(nn.Module):
+    """MAE-style SST: 6 encoder blocks on visible pillars, mask-token insertion, two 2-block decoder
+    stacks (centroid / density) on all pillars, six linear heads on the masked rows
+    (multi_mae_sst_spearate_top_only.py:20-303)."""
+
+    def __init__(self, window_shape, shifts_list, point_cloud_range, voxel_size, shuffle_voxels=False, d_model=[],
+                 nhead=[], sub_voxel_ratio_low=[], sub_voxel_ratio_med=[], cls_sub_voxel=False,
+                 encoder_num_blocks=6, decoder_num_blocks=2, dim_feedforward=[], dropout=0.0, activation="gelu",
+                 output_shape=None, low=True, med=True, top=True, debug=True, drop_info=None, normalize_pos=False,
+                 pos_temperature=10000, in_channel=None, conv_kwargs=None, checkpoint_blocks=[],
+                 compute_dtype="bf16"):
+        super().__init__()
+        assert drop_info is not None
+        assert not shuffle_voxels and not normalize_pos and in_channel is None
+        self.shifts_list = shifts_list
+        self.point_cloud_range = point_cloud_range
+        self.voxel_size = voxel_size
+        self.meta_drop_info = drop_info
+        self.pos_temperature = pos_temperature
+        self.d_model = d_model
+        self.window_shape = tuple(window_shape)
+        self.nhead = nhead
+        self.cls_sub_voxel = cls_sub_voxel
+        self.low, self.med, self.top = low, med, top
+        self.debug = debug
+        self.output_shape = output_shape
+        self.compute_dtype = compute_dtype
+        assert len(set(d_model)) == 1
+
+        def blocks(n):
+            return nn.ModuleList([BasicShiftBlock(d_model[i], nhead[i], dim_feedforward[i], dropout, activation,
+                                                  batch_first=False, block_id=i) for i in range(n)])
+        self.encoder_blocks = blocks(encoder_num_blocks)
+        self.decoder_centroid_blocks = blocks(decoder_num_blocks)
+        self.decoder_density_blocks = blocks(decoder_num_blocks)
+        self.mask_token = nn.Parameter(torch.zeros(1, d_model[-1]))
+        self.per_sub_voxel_num_low = int(np.prod(sub_voxel_ratio_low))
+        self.per_sub_voxel_num_med = int(np.prod(sub_voxel_ratio_med))
+        D = d_model[-1]
+        self.decoder_pred_low = nn.Linear(D, self.per_sub_voxel_num_low * 3)
+        self.decoder_pred_med = nn.Linear(D, self.per_sub_voxel_num_med * 3)
+        self.decoder_pred_top = nn.Linear(D, 3)
+        if low:
+            self.decoder_pred_density_low = nn.Linear(D, self.per_sub_voxel_num_low * 3)
+        if med:
+            self.decoder_pred_density_med = nn.Linear(D, self.per_sub_voxel_num_med * 3)
+        if top:
+            self.decoder_pred_density_top = nn.Linear(D, 3)
+        if cls_sub_voxel:
+            self.cls_pred_low = nn.Linear(D, self.per_sub_voxel_num_low * 2)
+            self.cls_pred_med = nn.Linear(D, self.per_sub_voxel_num_med * 2)
+        self._reset_parameters()
+        self.register_buffer("pos_table", pos_embed_table(self.window_shape, d_model[0], pos_temperature),
+                             persistent=False)
+        bev_x = int(np.ceil((point_cloud_range[3] - point_cloud_range[0]) / voxel_size[0]))
+        bev_y = int(np.ceil((point_cloud_range[4] - point_cloud_range[1]) / voxel_size[1]))
+        shift = shifts_list[1] if len(shifts_list) > 1 else (0, 0)
+        self._wcfg = ops.make_window_config(self.window_shape, shift, (bev_x, bev_y))
+        # every window must fit its bucket, i.e. no token is ever dropped in training:
+        # the largest training bucket must hold a full window
+        info = drop_info[0] if isinstance(drop_info, tuple) else drop_info
+        assert max(v["max_tokens"] for v in info.values()) >= self.window_shape[0] * self.window_shape[1], \
+            "token dropping is not supported: the largest bucket must hold a full window"
+
+    def _reset_parameters(self):
+        for name, p in self.named_parameters():
+            if p.dim() > 1 and "scaler" not in name:
+                nn.init.xavier_uniform_(p)
+
+    def _dtype(self):
+        return torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+
+    def get_voxel_info(self, coors, batch_size):
+        """CSR window layouts for both shifts + gathered positional embeddings."""
+        coors = coors.int().contiguous()
+        layouts = [ops.window_build(coors, batch_size, self._wcfg, s) for s in range(len(self.shifts_list))]
+        pos = [self.pos_table[L.tok_pos[:L.n].long()] for L in layouts]
+        return layouts, pos
+
+    def forward(self, voxel_feat, coors, coors_mask, batch_size):
+        layouts, pos = self.get_voxel_info(coors, batch_size)
+        x = self.forward_encoder(voxel_feat.float(), layouts, pos)
+        return self.forward_decoder(x, coors, coors_mask, batch_size)
+
+    def forward_encoder(self, x, layouts, pos):
+        dt = self._dtype()
+        for block in self.encoder_blocks:
+            x = block(x, pos, layouts, dt)
+        return x
+
+    def forward_decoder(self, visible_voxel_feat, coors, coors_mask, batch_size):
+        dt = self._dtype()
+        masked_start_id = coors.shape[0]
+        mask_tokens = self.mask_token.repeat(coors_mask.shape[0], 1)
+        tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)
+        coors_all = torch.cat([coors, coors_mask], dim=0)
+        layouts, pos = self.get_voxel_info(coors_all, batch_size)
+        cen, den = tokens, tokens
+        for block in self.decoder_centroid_blocks:
+            cen = block(cen, pos, layouts, dt)
+        for block in self.decoder_density_blocks:
+            den = block(den, pos, layouts, dt)
+        cm = cen[masked_start_id:]
+        dm = den[masked_start_id:]
+        reg_pred_low = self.decoder_pred_low(cm).view(-1, self.per_sub_voxel_num_low, 3)
+        reg_pred_med = self.decoder_pred_med(cm).view(-1, self.per_sub_voxel_num_med, 3)
+        reg_pred_top = self.decoder_pred_top(cm)
+        nor_low = self.decoder_pred_density_low(dm).view(-1, self.per_sub_voxel_num_low, 3) if self.low else None
+        nor_med = self.decoder_pred_density_med(dm).view(-1, self.per_sub_voxel_num_med, 3) if self.med else None
+        nor_top = self.decoder_pred_density_top(dm) if self.top else None
+        if self.cls_sub_voxel:
+            cls_low = self.cls_pred_low(cm).view(-1, self.per_sub_voxel_num_low, 2)
+            cls_med = self.cls_pred_med(cm).view(-1, self.per_sub_voxel_num_med, 2)
+            return reg_pred_low, reg_pred_med, reg_pred_top, nor_low, nor_med, nor_top, cls_low, cls_med
+        return reg_pred_low, reg_pred_med, reg_pred_top, nor_low, nor_med, nor_top

@@ -1,0 +1,158 @@
+/* libgeomae_hip -- C ABI of the MI355X-native GeoMAE-SST pre-training hot path.
+ *
+ * Drop-in boundary: these entry points are what the reference's
+ * native bindings for this path would bind instead of its pybind module `voxel_layer`
+ * (mmdet3d/ops/voxel/src/voxelization.cpp:5-11, voxelization.h:58-154), torch_scatter
+ * (call sites mmdet3d/ops/sst/sst_ops.py:30,32) and spconv's index-pair generator
+ * (call site mmdet3d/models/detectors/multi_sub_voxel_dynamic_voxelnet_ssl.py:192-207).
+ *
+ * Conventions (same as the reference's native ops): the CALLER allocates every output and
+ * workspace (torch owns all memory); all pointers are DEVICE pointers unless marked host;
+ * row-major contiguous; work is enqueued on `stream` and nothing blocks the host; nothing is
+ * allocated and no global state is kept.  Return 0, or a negative GEOMAE_ERR_* code with a
+ * thread-local message in geomae_last_error().  Coordinates are int32 (b, z, y, x); geometric
+ * vectors are fp32 (z, y, x), as in the reference.
+ */
+#ifndef GEOMAE_HIP_H
+#define GEOMAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* geomaeStream_t; /* == hipStream_t */
+
+#define GEOMAE_ABI_VERSION 1
+
+const char* geomae_last_error(void);
+int32_t geomae_abi_version(void);
+
+/* ------------------------------------------------------------------ A1 dynamic voxelization
+ * replaces voxel_layer.dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3)
+ * (voxelization.h:97-109 -> voxelization_cuda.cu:22-63,352-393).  Bit-exact, including this
+ * fork's clamp of out-of-range points into the border cell.  coors: [N, 3] int32 (z, y, x). */
+int geomae_grid_size(const float* voxel_size /*host[3] x,y,z*/, const float* coors_range /*host[6]*/,
+                     int32_t* grid_xyz /*host[3]*/);
+int geomae_dynamic_voxelize(const float* points, int64_t num_points, int32_t num_features,
+                            const float* voxel_size /*host[3]*/, const float* coors_range /*host[6]*/,
+                            int32_t* coors, geomaeStream_t stream);
+
+/* Fused form of detector.voxelize / sub_voxelize_med / sub_voxelize_low (ssl.py:307-377): one pass
+ * over the concatenated batch, three resolutions, batch index prepended: coors_*: [N, 4] int32.
+ * batch_offsets: device int32 [B + 1] (row offsets of the samples in `points`). */
+int geomae_voxelize_batch3(const float* points, int64_t num_points, int32_t num_features,
+                           const int32_t* batch_offsets, int32_t batch_size,
+                           const float* voxel_size_top, const float* voxel_size_med,
+                           const float* voxel_size_low, const float* coors_range /*all host*/,
+                           int32_t* coors_top, int32_t* coors_med, int32_t* coors_low,
+                           geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A2 pillar segments
+ * replaces torch.unique(coors, dim=0, return_inverse=True) of scatter_v2 (sst_ops.py:8-39) and of
+ * get_centroid_per_voxel (ssl.py:749).  voxel_coors comes out in the same lexicographic
+ * (b, z, y, x) order.  Outputs sized for the worst case (V <= min(N, cells)):
+ *   cell_table  [B*gz*gy*gx]  pillar id of every cell or -1 (kept for neighbour lookups)
+ *   voxel_coors [cap, 4]      inv [N] (point -> pillar)      order [N] (points grouped by pillar)
+ *   seg_start   [cap + 1]     sample_start [B + 1] (pillar offsets per sample)    num_pillars [1] */
+int64_t geomae_pillar_segment_workspace_bytes(int64_t num_points, int32_t batch_size, int32_t gz,
+                                              int32_t gy, int32_t gx);
+int geomae_pillar_segment(const int32_t* coors /*[N,4]*/, int64_t num_points, int32_t batch_size,
+                          int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table,
+                          int32_t* voxel_coors, int32_t* inv, int32_t* order, int32_t* seg_start,
+                          int32_t* sample_start, int32_t* num_pillars, void* workspace,
+                          int64_t workspace_bytes, geomaeStream_t stream);
+
+/* torch_scatter.scatter(reduce='mean') of the xyz columns (voxel_encoder.py:375): mean [cap, 3] */
+int geomae_segment_mean_xyz(const float* points, int32_t num_features, const int32_t* order,
+                            const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
+                            float* mean, geomaeStream_t stream);
+/* torch_scatter.scatter_max (voxel_encoder.py:407): feat [N, C] in point order -> out [cap, C],
+ * argmax [cap, C] (point index); backward routes grad_out to the arg-max rows: grad_feat [N, C]. */
+int geomae_segment_max_forward(const float* feat, int32_t channels, const int32_t* order,
+                               const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
+                               float* out, int32_t* argmax, geomaeStream_t stream);
+int geomae_segment_max_backward(const float* grad_out, const int32_t* argmax, const int32_t* inv,
+                                int64_t num_points, int32_t channels, float* grad_feat,
+                                geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A6 random masking
+ * replaces get_vanilla_mask_index (ssl.py:287-304).  Per sample keeps int(L * keep_fraction)
+ * pillars chosen uniformly at random (counter-based RNG on `seed`).  ids_keep / ids_mask:
+ * ascending pillar ids, [cap] each; token_row [cap]: position of the pillar in the decoder's
+ * token list (kept tokens first, then masked); counts [2] = (n_keep, n_mask). */
+int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double keep_fraction,
+                       uint64_t seed, int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row,
+                       int32_t* counts, geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A5,A7-A11 geometric targets */
+typedef struct GeomaeTargetConfig {
+    int32_t grid_size[3];       /* top grid (z, y, x), z must be 1           (config grid_size)        */
+    int32_t ratio_low[3];       /* sub_voxel_ratio_low (z, y, x)                                      */
+    int32_t ratio_med[3];       /* sub_voxel_ratio_med (z, y, x)                                      */
+    float voxel_size_top[3];    /* (x, y, z)                                                          */
+    float voxel_size_med[3];
+    float voxel_size_low[3];
+    float coors_range[6];       /* point_cloud_range                                                  */
+} GeomaeTargetConfig;
+
+/* replaces get_centroid_per_voxel x3, get_multi_voxel_id_to_tensor_id_for_curv, the spconv 3x3
+ * neighbour table, cal_regular_voxel_nor_and_curv, normalize_centroid_sub_voxel x3 and
+ * get_multi_voxel_id_to_tensor_id_ori (ssl.py:575-768).  Rows of the first seven outputs are the
+ * masked pillars in ids_mask order (row = token_row[p] - counts[0]); pass token_row = mask_counts
+ * = NULL to get one row per pillar.  S_low / S_med = prod(ratio).
+ *   centroid_low [M,S_low,3] f32   mask_low [M,S_low] u8   centroid_med [M,S_med,3]   mask_med [M,S_med]
+ *   centroid_top [M,3]   normal [M,3] f32 (canonical sign)   curv [M,3] f64
+ *   top_raw [cap,3], med_raw [cap,S_med,3], med_raw_mask [cap,S_med]: un-normalised centroids of
+ *   every pillar (also scratch for the neighbourhood pass);  cov_out [M,6] optional (may be NULL) */
+int geomae_geometry_targets(const float* points, int32_t num_features, const int32_t* order,
+                            const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
+                            const int32_t* voxel_coors, const int32_t* coors_med,
+                            const int32_t* coors_low, const int32_t* cell_table, int32_t batch_size,
+                            const int32_t* token_row, const int32_t* mask_counts,
+                            const GeomaeTargetConfig* config /*host*/, float* centroid_low,
+                            uint8_t* mask_low, float* centroid_med, uint8_t* mask_med,
+                            float* centroid_top, float* normal, double* curv, float* top_raw,
+                            float* med_raw, uint8_t* med_raw_mask, float* cov_out,
+                            geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A12-A16 windows */
+typedef struct GeomaeWindowConfig {
+    int32_t window_shape[2];    /* (x, y) pillars per window, e.g. 12, 12                            */
+    int32_t shift[2];           /* second layout's shift, e.g. 6, 6 (shift_index 1)                   */
+    int32_t bev_shape[2];       /* pillars along (x, y), e.g. 400, 400                                */
+} GeomaeWindowConfig;
+
+/* replaces window_partition + get_voxel_keep_inds + get_flat2win_inds (bb.py:413-681): tokens
+ * grouped by window as CSR.  coors [n, 4] int32.  Outputs: win_start [min(n, slots) + 1],
+ * win_tokens [n] (token ids grouped by window, ascending inside a window), tok_win [n] (CSR window
+ * of each token), tok_pos [n] (in-window position cx * wy + cy, the pos-embed row), num_windows [1]. */
+int64_t geomae_window_build_workspace_bytes(int32_t num_tokens, int32_t batch_size,
+                                            const GeomaeWindowConfig* cfg);
+int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_size,
+                        const GeomaeWindowConfig* cfg /*host*/, int32_t shift_index, int32_t* win_start,
+                        int32_t* win_tokens, int32_t* tok_win, int32_t* tok_pos, int32_t* num_windows,
+                        void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A19 windowed attention core
+ * replaces flat2window -> nn.MultiheadAttention(key_padding_mask) -> window2flat
+ * (sst_basic_block.py:36-59) between the in-projection and the out-projection.
+ * qkv [n, 3*H*16] bf16 (q | k | v, already projected, q NOT pre-scaled); out [n, H*16] bf16;
+ * lse [n, H] fp32 (log-sum-exp of the scaled scores, kept for the backward pass). */
+int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
+                                    int32_t head_dim, const int32_t* win_start,
+                                    const int32_t* win_tokens, const int32_t* num_windows,
+                                    int32_t max_windows, int32_t max_window_tokens, void* out_bf16,
+                                    float* lse, geomaeStream_t stream);
+int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16,
+                                     const float* lse, int32_t num_tokens, int32_t num_heads,
+                                     int32_t head_dim, const int32_t* win_start,
+                                     const int32_t* win_tokens, const int32_t* num_windows,
+                                     int32_t max_windows, int32_t max_window_tokens, void* dqkv_bf16,
+                                     geomaeStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GEOMAE_HIP_H */

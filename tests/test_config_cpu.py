@@ -1,0 +1,64 @@
+"""Registry / config host logic (CPU)."""
+import os
+
+import pytest
+import torch
+
+import geomae_amd
+from geomae_amd import Config
+from geomae_amd.configs import mae_sst_model
+
+REF_CFG = "/root/reference/configs/mae_sst/m_sst_nus_singlestage_curv_07_ssl_dataset_wo_dbsampler_6x_1e-5.py"
+
+
+def _plain(v):
+    if isinstance(v, dict):
+        return {k: _plain(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_plain(x) for x in v]
+    return v
+
+
+@pytest.mark.skipif(not os.path.exists(REF_CFG), reason="reference not mounted (GPU box)")
+def test_reference_config_loads_unchanged_and_matches_restated_dict():
+    cfg = Config.fromfile(REF_CFG)
+    assert cfg.model.type == "MultiSubVoxelDynamicVoxelNetSSL"
+    assert cfg.optimizer.type == "AdamW" and cfg.optimizer_config.grad_clip.max_norm == 10
+    assert cfg.data.samples_per_gpu == 4 and cfg.runner.max_epochs == 72
+    assert _plain(cfg.model) == _plain(mae_sst_model())
+    model = geomae_amd.build_model(cfg.model)
+    assert sum(p.numel() for p in model.parameters()) == 2743382 + 17472
+
+
+def test_state_dict_keys_match_reference_names():
+    import geomae_oracle as O
+    model = geomae_amd.build_model(mae_sst_model())
+    keys = {k for k, _ in model.named_parameters()}
+    assert keys == {n for n, _ in O.param_shapes(6, 2)}
+    for n, shape in O.param_shapes(6, 2):
+        assert tuple(model.state_dict()[n].shape) == shape
+    assert "backbone.encoder_blocks.5.encoder_list.1.win_attn.self_attn.in_proj_weight" in keys
+
+
+def test_registry_errors():
+    with pytest.raises(KeyError):
+        geomae_amd.build_model(dict(type="NoSuchDetector"))
+    with pytest.raises(KeyError):
+        geomae_amd.build_norm_layer(dict(type="NoSuchNorm"), 8)
+    name, layer = geomae_amd.build_norm_layer(dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01), 8)
+    assert layer.eps == 1e-3 and layer.momentum == 0.01
+
+
+def test_config_inheritance_and_delete(tmp_path):
+    (tmp_path / "base.py").write_text("a = dict(x=1, y=dict(z=2, w=3))\nb = 5\n")
+    (tmp_path / "child.py").write_text("_base_ = ['base.py']\na = dict(y=dict(_delete_=True, q=9))\nc = [1, 2]\n")
+    cfg = Config.fromfile(str(tmp_path / "child.py"))
+    assert cfg.a.x == 1 and dict(cfg.a.y) == {"q": 9} and cfg.b == 5 and cfg.c == [1, 2]
+    cfg.merge_from_dict({"a.x": 7, "d.e": 1})
+    assert cfg.a.x == 7 and cfg.d.e == 1
+
+
+def test_pos_table_matches_oracle():
+    import geomae_oracle as O
+    from geomae_amd.sst import pos_embed_table
+    assert torch.equal(pos_embed_table((12, 12), 128), O.pos_embed_table((12, 12), 128))
