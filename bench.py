@@ -1,0 +1,159 @@
+"""GeoMAE-SST pre-training throughput on MI355X (BASELINE.json metric: pretrain frames/sec).
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver as `python -m torch.distributed.run --nproc-per-node N ... bench.py`
+(one rank per GPU, RCCL).  A step = forward_train + backward + gradient all-reduce + clip + AdamW on
+one batch of 4 synthetic nuScenes-like single-sweep frames per GPU (BASELINE config 2; weak scaling).
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+def cpu_baseline(seed=1000):
+    """The oracle (CPU restatement of the reference path, kind='port') timed on the host cores on a
+    bounded sample: ONE single-sweep frame, forward + backward (no optimizer)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import geomae_oracle as O
+    from geomae_amd import synth
+    cores = min(16, os.cpu_count() or 1)          # more threads only slow these small CPU ops down
+    torch.set_num_threads(cores)
+    cfg = O.mae_sst_cfg(6, 2)
+    params = {k: v.requires_grad_(True) for k, v in O.make_params(7, 6, 2, perturb=False).items()}
+    frame = synth.lidar_frame(seed)
+    g = torch.Generator().manual_seed(0)
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        losses, _ = O.forward_train(params, [frame], cfg, generator=g)
+        sum(losses.values()).backward()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > 10.0 or n >= 3:
+            break
+    return dict(value=round(n / dt, 4), unit="frames/s", cores=cores, kind="port",
+                sample=f"{n} x (1 single-sweep frame, {frame.shape[0]} pts, fwd+bwd, torch-CPU fp32)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames-per-gpu", type=int, default=4)
+    ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+
+    import geomae_amd
+    from geomae_amd import _lib, ops, synth
+    from geomae_amd.configs import mae_sst_model
+    from geomae_amd.train import Trainer
+    _lib.load()                                   # no fallback: fail here if the HIP library is missing
+
+    torch.manual_seed(1234)                       # identical initial weights on every rank (as DDP broadcast)
+    cfg = mae_sst_model()
+    cfg["backbone"]["compute_dtype"] = args.dtype
+    model = geomae_amd.build_model(cfg).to(dev).train()
+    trainer = Trainer(model)
+    B = args.frames_per_gpu
+    pool = []
+    for i in range(4):                            # 4 distinct batches per rank, cycled; resident in HBM
+        pool.append([torch.as_tensor(synth.lidar_frame(10_000 * (rank + 1) + i * B + b, sweeps=args.sweeps), device=dev)
+                     for b in range(B)])
+    n_pts = float(np.mean([sum(p.shape[0] for p in batch) for batch in pool]))
+
+    def step(i):
+        return trainer.train_step(pool[i % len(pool)])
+
+    for i in range(args.warmup):
+        step(i)
+    ops.KERNEL_EVENTS = {"win_attn_fwd_kernel": [], "win_attn_bwd_kernel": []}
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        losses, _ = step(args.warmup + i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    events, ops.KERNEL_EVENTS = ops.KERNEL_EVENTS, None
+    loss_val = float(sum(losses.values()))
+    assert np.isfinite(loss_val), "non-finite loss"
+
+    if rank == 0:
+        # roofline of the dominant hand-written kernel: windowed attention backward (MFMA bound):
+        # algorithmic FLOPs per launch = 10 * 16 * H * sum_w n_w^2  (5 n_w x n_w x 16 products per head;
+        # forward has 2).  sum_w n_w^2 is recomputed here from the layouts of the last batch.
+        def avg_ms(name):
+            ev = events[name]
+            return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+        with torch.no_grad():
+            sq = []
+            pts = pool[(args.warmup + args.steps - 1) % len(pool)]
+            voxels, coors, _, _ = model.voxelize_all(pts)
+            seg = ops.pillar_segment(coors, B, model.grid_size)
+            vc = seg.voxel_coors[:seg.V]
+            ids_keep, _, _, _ = ops.random_mask(seg, 1 - model.random_mask_ratio, 1)
+            for toks, layers in ((vc[ids_keep.long()], 12), (vc, 8)):
+                for s in (0, 1):
+                    L = ops.window_build(toks.contiguous(), B, model.backbone._wcfg, s)
+                    W = int(L.num_windows.item())
+                    nw = (L.win_start[1:W + 1] - L.win_start[:W]).double()
+                    sq += [float((nw * nw).sum())] * (layers // 2)
+        flops_bwd = 10 * 16 * 8 * float(np.mean(sq)) * 2          # 2 flops per MAC
+        ms_bwd, ms_fwd = avg_ms("win_attn_bwd_kernel"), avg_ms("win_attn_fwd_kernel")
+        peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
+        achieved = flops_bwd / (ms_bwd * 1e-3) / 1e12 if ms_bwd else None
+        out = {
+            "metric": "pretrain frames/sec (nuScenes SST-GeoMAE)",
+            "value": round(world * B * args.steps / elapsed, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"configs[1]: nuScenes-like {args.sweeps}-sweep GeoMAE-SST pretrain (mae_sst model "
+                                   f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
+                       "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}"},
+            "loss": round(loss_val, 4),
+            "roofline": {"bound": "mfma", "kernel": "win_attn_bwd_kernel", "achieved": achieved, "peak": peak,
+                         "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None, "traffic": None,
+                         "avg_launch_ms": ms_bwd, "fwd_avg_launch_ms": ms_fwd,
+                         "launches_timed": len(events["win_attn_bwd_kernel"])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,29 @@ from . import _lib
 from ._lib import GeomaeTargetConfig, GeomaeWindowConfig, check, f3
 
 
+# optional per-kernel timing (bench.py): name -> list of (start_event, end_event) recorded on the
+# stream the kernel is launched on (torch's current stream == the stream handed to the C ABI)
+KERNEL_EVENTS = None
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None and self.name in KERNEL_EVENTS:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if KERNEL_EVENTS is not None and self.name in KERNEL_EVENTS:
+            self.e1.record()
+            KERNEL_EVENTS[self.name].append((self.e0, self.e1))
+        return False
+
+
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -336,10 +359,11 @@ class _WindowAttention(torch.autograd.Function):
         C = c3 // 3
         out = torch.empty((n, C), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((n, num_heads), dtype=torch.float32, device=qkv.device)
-        check(_lib.load().geomae_window_attention_forward(
-            _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
-            _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
-            "geomae_window_attention_forward")
+        with _timed("win_attn_fwd_kernel"):
+            check(_lib.load().geomae_window_attention_forward(
+                _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
+                _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+                "geomae_window_attention_forward")
         ctx.layout, ctx.num_heads = layout, num_heads
         ctx.save_for_backward(qkv, out, lse)
         return out
@@ -351,10 +375,11 @@ class _WindowAttention(torch.autograd.Function):
         n, c3 = qkv.shape
         dqkv = torch.empty_like(qkv)
         L = ctx.layout
-        check(_lib.load().geomae_window_attention_backward(
-            _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), n, ctx.num_heads, c3 // 3 // ctx.num_heads,
-            _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv),
-            _stream()), "geomae_window_attention_backward")
+        with _timed("win_attn_bwd_kernel"):
+            check(_lib.load().geomae_window_attention_backward(
+                _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), n, ctx.num_heads, c3 // 3 // ctx.num_heads,
+                _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv),
+                _stream()), "geomae_window_attention_backward")
         return dqkv, None, None
 
 

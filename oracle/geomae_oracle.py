@@ -632,7 +632,7 @@ def make_params(seed, encoder_num_blocks=6, decoder_num_blocks=2, perturb=True):
                 a = 1.0 / math.sqrt(fan_in)
             v = rng.uniform(-a, a, shape)
         elif name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight"):
-            v = 1.0 + (0.1 * rng.standard_normal(shape) if perturb else 0.0)
+            v = np.ones(shape) + (0.1 * rng.standard_normal(shape) if perturb else 0.0)
         else:
             v = 0.05 * rng.standard_normal(shape) if perturb else np.zeros(shape)
         p[name] = torch.tensor(np.asarray(v, np.float32))

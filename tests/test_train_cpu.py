@@ -1,0 +1,105 @@
+"""Host logic of the training step on CPU: flat buffers, AdamW vs torch.optim.AdamW, clip, and the
+world_size-2 gradient exchange / naiveSyncBN1d over gloo."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+from torch import nn
+
+from geomae_amd.norm import NaiveSyncBatchNorm1d
+from geomae_amd.train import FlatAdamW, FlatParams, allreduce_gradients, clip_grad_norm
+
+
+class Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.lin = nn.Linear(6, 5)
+        self.norm = nn.LayerNorm(5)
+        self.out = nn.Linear(5, 3)
+
+    def forward(self, x):
+        return self.out(self.norm(torch.relu(self.lin(x))))
+
+
+def test_flat_adamw_matches_torch_adamw():
+    torch.manual_seed(0)
+    a, b = Toy(), Toy()
+    b.load_state_dict(a.state_dict())
+    flat = FlatParams(a, no_decay_keys=("norm",))
+    opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.05)
+    nd = [p for n, p in b.named_parameters() if "norm" in n]
+    dc = [p for n, p in b.named_parameters() if "norm" not in n]
+    ref = torch.optim.AdamW([dict(params=nd, weight_decay=0.0), dict(params=dc, weight_decay=0.05)], lr=1e-2)
+    assert flat.n_no_decay == sum(p.numel() for p in nd)
+    for it in range(5):
+        x = torch.randn(16, 6)
+        flat.zero_grad()
+        a(x).pow(2).sum().backward()
+        flat.check_views()
+        gn = clip_grad_norm(flat, 10.0)
+        opt.step()
+        ref.zero_grad()
+        b(x).pow(2).sum().backward()
+        gn_ref = torch.nn.utils.clip_grad_norm_(b.parameters(), 10.0)
+        ref.step()
+        assert torch.allclose(gn, gn_ref, rtol=1e-5)
+        for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (it, n)
+    # parameters still alias the flat buffer
+    assert all(p.data_ptr() >= flat.flat.data_ptr() for p in a.parameters())
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        m = Toy()
+        flat = FlatParams(m)
+        x = torch.randn(8, 6, generator=torch.Generator().manual_seed(100 + rank))
+        flat.zero_grad()
+        m(x).pow(2).sum().backward()
+        flat.check_views()
+        local = flat.grad.clone()
+        allreduce_gradients(flat)
+        gathered = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        assert torch.allclose(flat.grad, sum(gathered) / world, atol=1e-6)
+        # naiveSyncBN1d: equal weight per rank, different point counts per rank
+        bn = NaiveSyncBatchNorm1d(4, eps=1e-3, momentum=0.01).train()
+        xs = [torch.randn(10 + 7 * r, 4, generator=torch.Generator().manual_seed(r)) for r in range(world)]
+        xin = xs[rank].clone().requires_grad_(True)
+        y = bn(xin)
+        mean = sum(t.mean(0) for t in xs) / world
+        msq = sum((t * t).mean(0) for t in xs) / world
+        var = msq - mean * mean
+        want = (xs[rank] - mean) * torch.rsqrt(var + 1e-3)
+        assert torch.allclose(y, want, atol=1e-5)
+        assert torch.allclose(bn.running_var, 1 + 0.01 * (var - 1), atol=1e-6)
+        y.sum().backward()
+        assert torch.isfinite(xin.grad).all()
+        torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_gloo(tmp_path):
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}.pt") for r in range(2))
+
+
+def test_syncbn_single_process_is_plain_bn():
+    bn = NaiveSyncBatchNorm1d(4, eps=1e-3, momentum=0.01).train()
+    ref = nn.BatchNorm1d(4, eps=1e-3, momentum=0.01).train()
+    x = torch.randn(32, 4)
+    assert torch.allclose(bn(x), ref(x))
+    assert torch.allclose(bn.running_var, ref.running_var)

@@ -1,0 +1,9 @@
+#!/bin/bash
+# usage: tools_prof.sh <tag> <bench args...>   -- rocprofv3 kernel-trace stats of bench.py, summaries only
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/prof_$tag
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python /root/repo/bench.py "$@" > /root/repo/gpurun_out/prof_$tag.log 2>&1
+mkdir -p /root/repo/gpurun_out/prof_$tag
+find /tmp/prof_$tag -name '*stats*.csv' -exec cp {} /root/repo/gpurun_out/prof_$tag/ \;
+ls -la /root/repo/gpurun_out/prof_$tag
