@@ -26,6 +26,17 @@ class GeomaeWindowConfig(ctypes.Structure):
     _fields_ = [("window_shape", c_int32 * 2), ("shift", c_int32 * 2), ("bev_shape", c_int32 * 2)]
 
 
+class GeomaeSstLayerWeights(ctypes.Structure):
+    _fields_ = ([(n, c_void_p) for n in ("wqkv_p", "wqkT_p", "wvT_p", "wo_p", "woT_p", "w1_p", "w1T_p", "w2_p",
+                                         "w2T_p", "bqkv", "bo", "b1", "b2", "ln1_w", "ln1_b", "ln2_w", "ln2_b")]
+                + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float)])
+
+
+class GeomaeSstLayerGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "ln1_w", "ln1_b",
+                                        "ln2_w", "ln2_b")]
+
+
 F3 = POINTER(c_float)
 P = c_void_p
 # name -> (restype, argtypes).  Every symbol declared in include/geomae_hip.h is listed here;
@@ -52,6 +63,13 @@ SIGNATURES = {
                                                        P, P]),
     "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, c_int32,
                                                         c_int32, P, P]),
+    "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P]),
+    "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
+    "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
+    "geomae_sst_ffn_backward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P,
+                                               P, POINTER(GeomaeSstLayerGrads), P]),
+    "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
+    "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
 }
 
 _lib = None

@@ -1,0 +1,684 @@
+// Fused SST encoder-layer kernels for gfx950 (forward and backward), everything except the
+// in-window attention core (window.hip).
+//
+// Reference layer (mmdet3d/models/sst/sst_basic_block.py:63-102 EncoderLayer, :26-61 WindowAttention):
+//   q = k = (x + pos) W_qk^T + b ; v = x W_v^T + b ; a = MHA(q,k,v) W_o^T + b_o
+//   y = LN1(x + a) ; z = LN2(y + W_2 GELU(W_1 y + b_1) + b_2)
+// which the reference runs as ~30 small ATen/cuBLAS kernels per layer forward+backward with the
+// activations round-tripping HBM in fp32, and whose weight-gradient GEMMs (K = tokens, M x N = 128..384
+// wide) land on 4 workgroups in hipBLASLt (profiles/r01a).
+//
+// Design (every token row is independent outside attention, so no workgroup ever synchronises in the
+// forward/backward data path):
+//  * one WAVE owns 16 tokens and keeps them in registers in "T-layout": lane l holds token t = l & 15 and,
+//    for every 16-channel tile ct, channels 16*ct + 4*(l>>4) + {0,1,2,3}.  That is exactly the C/D layout
+//    of v_mfma_f32_16x16x32_bf16 when the product is computed TRANSPOSED (Y^T = W X^T: A = weights,
+//    B = activations), and -- with the contraction index permuted identically in the pre-packed weights --
+//    also its B-operand layout.  So projections, residuals, LayerNorm, GELU and their backward chain from
+//    registers to registers: fp32 residual stream, bf16 MFMA operands, fp32 accumulation.
+//  * weights are packed once per step to bf16 (plain and transposed, K-permuted) by pack_weights_kernel;
+//    a wave reads its A fragments as 16-byte lines straight from L2 (a layer's 512 KB of packed weights is
+//    L2 resident; there is nothing to stage, so no LDS and no barriers).
+//  * weight gradients are token-contractions: dW = dY^T X.  dw_kernel stages 32-token slabs of both
+//    operands transposed in LDS, accumulates 128 x 128 output blocks over a token chunk in MFMA
+//    accumulators and flushes them with coalesced fp32 atomics (~300 G atomics/s measured,
+//    profiles/r01_microbench_atomics.txt); bias gradients are the column sums of the same slabs.
+#include "common.h"
+#include "../../include/geomae_hip.h"
+
+namespace geomae {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+
+__device__ __forceinline__ f32x4 mfma32(uint4 a, uint4 b, f32x4 c) {
+    union { uint4 u; bf16x8_t v; } fa, fb;
+    fa.u = a;
+    fb.u = b;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned int f2bf_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf_bits(a) | (f2bf_bits(b) << 16); }
+__device__ __forceinline__ uint2 pack4(const f32x4 v) { return make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])); }
+__device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ f32x4 unpack4(const uint2 p) {
+    f32x4 v = {bf_lo(p.x), bf_hi(p.x), bf_lo(p.y), bf_hi(p.y)};
+    return v;
+}
+
+// packed position p (inside a row of K) <-> original contraction index k
+__host__ __device__ __forceinline__ int kperm(int p) { return (p & ~31) + 16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3); }
+
+// ------------------------------------------------------------------------------------------------
+// weight packing: desc[d] = {src_off, rows, cols, transpose, dst_off}; dst [R][K] bf16 with
+// dst[r][p] = W[r][kperm(p)] (K = cols) or, transposed, dst[j][p] = W[kperm(p)][j] (R = cols, K = rows)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ flat,
+                                                           const int64_t* __restrict__ desc,
+                                                           bf16_t* __restrict__ packed) {
+    const int64_t* d = desc + (int64_t)blockIdx.y * 5;
+    const int64_t src = d[0], rows = d[1], cols = d[2], tr = d[3], dst = d[4];
+    const int64_t total = rows * cols;
+    const int64_t K = tr ? rows : cols;
+    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / K;
+        const int p = (int)(e - r * K);
+        const int k = kperm(p);
+        const float v = tr ? flat[src + (int64_t)k * cols + r] : flat[src + r * cols + k];
+        packed[dst + e] = (bf16_t)f2bf_bits(v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Y^T[N x 16 tokens] += Wp[N x K] * X^T : acc[ot][r] = Y[t][16*ot + 4*g + r]  (T-layout in, T-layout out)
+// ------------------------------------------------------------------------------------------------
+template <int K, int N>
+__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, const uint2 (&xb)[K / 16],
+                                       f32x4 (&acc)[N / 16], int lane) {
+    const int o = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < N / 16; ++ot) {
+        const bf16_t* wrow = Wp + (size_t)(16 * ot + o) * K + 8 * g;
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) {
+            const uint4 a = *reinterpret_cast<const uint4*>(wrow + 32 * kk);
+            const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
+            acc[ot] = mfma32(a, b, acc[ot]);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&acc)[N / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < N / 16; ++ot) {
+        const float4 v = *reinterpret_cast<const float4*>(b + 16 * ot + 4 * g);
+        acc[ot][0] = v.x; acc[ot][1] = v.y; acc[ot][2] = v.z; acc[ot][3] = v.w;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int64_t tok, bool valid,
+                                              f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) t = *reinterpret_cast<const float4*>(src + tok * C + 16 * ct + 4 * g);
+        v[ct][0] = t.x; v[ct][1] = t.y; v[ct][2] = t.z; v[ct][3] = t.w;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int64_t tok, bool valid,
+                                               uint2 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) {
+        v[ct] = valid ? *reinterpret_cast<const uint2*>(src + tok * C + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int64_t tok, bool valid,
+                                               const f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+    if (!valid) return;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        *reinterpret_cast<float4*>(dst + tok * C + 16 * ct + 4 * g) = make_float4(v[ct][0], v[ct][1], v[ct][2], v[ct][3]);
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int64_t tok, int ld, int col0, bool valid,
+                                                const f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+    if (!valid) return;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        *reinterpret_cast<uint2*>(dst + tok * ld + col0 + 16 * ct + 4 * g) = pack4(v[ct]);
+}
+
+// sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)
+__device__ __forceinline__ float row_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// LayerNorm over 128 channels in T-layout; returns xhat in place, rstd out
+__device__ __forceinline__ void layer_norm_t(f32x4 (&u)[8], float eps, float* rstd_out) {
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) s += (u[ct][0] + u[ct][1]) + (u[ct][2] + u[ct][3]);
+    const float mean = row_sum(s) * (1.0f / 128.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = u[ct][r] - mean;
+            u[ct][r] = d;
+            q += d * d;
+        }
+    const float var = row_sum(q) * (1.0f / 128.0f);
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[ct][r] *= rstd;
+    *rstd_out = rstd;
+}
+
+__device__ __forceinline__ void affine_t(const f32x4 (&xhat)[8], const float* __restrict__ w,
+                                         const float* __restrict__ b, f32x4 (&y)[8], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
+        const float4 bv = *reinterpret_cast<const float4*>(b + 16 * ct + 4 * g);
+        y[ct][0] = xhat[ct][0] * wv.x + bv.x;
+        y[ct][1] = xhat[ct][1] * wv.y + bv.y;
+        y[ct][2] = xhat[ct][2] * wv.z + bv.z;
+        y[ct][3] = xhat[ct][3] * wv.w + bv.w;
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma     (in place on dy)
+__device__ __forceinline__ void layer_norm_bwd_t(f32x4 (&dy)[8], const f32x4 (&xhat)[8], const float* __restrict__ w,
+                                                 float rstd, int lane) {
+    const int g = lane >> 4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
+        dy[ct][0] *= wv.x; dy[ct][1] *= wv.y; dy[ct][2] *= wv.z; dy[ct][3] *= wv.w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dy[ct][r];
+            s2 += dy[ct][r] * xhat[ct][r];
+        }
+    }
+    const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy[ct][r] = rstd * (dy[ct][r] - m1 - xhat[ct][r] * m2);
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+// sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
+__device__ __forceinline__ float tok_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+constexpr int kLayerBlk = 256;   // 4 waves = 4 token tiles per workgroup
+
+struct LayerW {
+    const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
+    const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+};
+
+// ------------------------------------------------------------------------------------------------
+// F1: qkv = [(x + pos) Wqk^T + bqk | x Wv^T + bv]  ->  bf16 [n, 384]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLayerBlk) void sst_qkv_fwd_kernel(const float* __restrict__ x,
+                                                                const int32_t* __restrict__ tok_pos,
+                                                                const float* __restrict__ pos_table, LayerW W,
+                                                                int n, bf16_t* __restrict__ qkv) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
+    if (tile * 16 >= n) return;
+    const int t = lane & 15, g = lane >> 4;
+    const int64_t tok = (int64_t)tile * 16 + t;
+    const bool valid = tok < n;
+    const int64_t tc = valid ? tok : n - 1;
+    uint2 xb[8], xpb[8];
+    const int p = tok_pos[tc];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 xv = *reinterpret_cast<const float4*>(x + tc * 128 + 16 * ct + 4 * g);
+        const float4 pv = *reinterpret_cast<const float4*>(pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
+        xb[ct] = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
+        xpb[ct] = make_uint2(pack2(xv.x + pv.x, xv.y + pv.y), pack2(xv.z + pv.z, xv.w + pv.w));
+    }
+    {
+        f32x4 acc[16];
+        load_bias<256>(W.bqkv, acc, lane);
+        gemm_t<128, 256>(W.wqkv, xpb, acc, lane);
+        store_rows_bf16<256>(qkv, tok, 384, 0, valid, acc, lane);
+    }
+    {
+        f32x4 acc[8];
+        load_bias<128>(W.bqkv + 256, acc, lane);
+        gemm_t<128, 128>(W.wqkv + 256 * 128, xb, acc, lane);
+        store_rows_bf16<128>(qkv, tok, 384, 256, valid, acc, lane);
+    }
+}
+
+// shared forward chain of F3 / B3: from x and the attention output to (xhat1, rstd1, y, hp, xhat2, rstd2)
+__device__ __forceinline__ void ffn_forward_chain(const float* __restrict__ x, const bf16_t* __restrict__ attn,
+                                                  const LayerW& W, int64_t tok, bool valid, float eps, int lane,
+                                                  f32x4 (&xh1)[8], float* rstd1, f32x4 (&y)[8], f32x4 (&hp)[16],
+                                                  f32x4 (&xh2)[8], float* rstd2) {
+    uint2 ob[8];
+    load_rows_bf16<128>(attn, tok, valid, ob, lane);
+    load_bias<128>(W.bo, xh1, lane);
+    gemm_t<128, 128>(W.wo, ob, xh1, lane);
+    {
+        f32x4 xr[8];
+        load_rows_f32<128>(x, tok, valid, xr, lane);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) xh1[ct] += xr[ct];
+    }
+    layer_norm_t(xh1, eps, rstd1);
+    affine_t(xh1, W.g1, W.be1, y, lane);
+    uint2 yb[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
+    load_bias<256>(W.b1, hp, lane);
+    gemm_t<128, 256>(W.w1, yb, hp, lane);
+    uint2 hb[16];
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) {
+        f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
+        hb[ct] = pack4(h);
+    }
+    load_bias<128>(W.b2, xh2, lane);
+    gemm_t<256, 128>(W.w2, hb, xh2, lane);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) xh2[ct] += y[ct];
+    layer_norm_t(xh2, eps, rstd2);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F3: z = LN2(y + FFN(y)),  y = LN1(x + attn Wo^T + bo)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLayerBlk) void sst_ffn_fwd_kernel(const float* __restrict__ x,
+                                                                const bf16_t* __restrict__ attn, LayerW W, int n,
+                                                                float eps, float* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
+    if (tile * 16 >= n) return;
+    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
+    const bool valid = tok < n;
+    f32x4 xh1[8], y[8], hp[16], xh2[8];
+    float r1, r2;
+    ffn_forward_chain(x, attn, W, tok, valid, eps, lane, xh1, &r1, y, hp, xh2, &r2);
+    f32x4 out[8];
+    affine_t(xh2, W.g2, W.be2, out, lane);
+    store_rows_f32<128>(z, tok, valid, out, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// B3: backward of F3.  Recomputes the forward chain from (x, attn); emits
+//   dx_res [n,128] f32 (gradient reaching x through the residual = d(x + a)),  dattn [n,128] bf16,
+//   bf16 row-major operands of the weight-gradient GEMMs: du, dv, dhp [n,256], y, h [n,256]
+//   and the LayerNorm parameter gradients (atomics, one flush per workgroup).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLayerBlk) void sst_ffn_bwd_kernel(
+    const float* __restrict__ x, const bf16_t* __restrict__ attn, const float* __restrict__ dz, LayerW W, int n,
+    float eps, float* __restrict__ dx_res, bf16_t* __restrict__ dattn, bf16_t* __restrict__ du_b,
+    bf16_t* __restrict__ dv_b, bf16_t* __restrict__ dhp_b, bf16_t* __restrict__ y_b, bf16_t* __restrict__ h_b,
+    float* __restrict__ dg1, float* __restrict__ dbe1, float* __restrict__ dg2, float* __restrict__ dbe2) {
+    __shared__ float red[4][4][128];     // [wave][tensor][channel]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
+    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
+    const bool valid = tok < n;
+    f32x4 xh1[8], y[8], hp[16], xh2[8];
+    float r1, r2;
+    ffn_forward_chain(x, attn, W, tok, valid, eps, lane, xh1, &r1, y, hp, xh2, &r2);
+    store_rows_bf16<128>(y_b, tok, 128, 0, valid, y, lane);
+    {
+        f32x4 h[16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[ct][r] = gelu_f(hp[ct][r]);
+        store_rows_bf16<256>(h_b, tok, 256, 0, valid, h, lane);
+    }
+    // ---- LN2 backward
+    f32x4 dv[8];
+    load_rows_f32<128>(dz, tok, valid, dv, lane);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = tok_sum(dv[ct][r] * xh2[ct][r]);      // d gamma2
+            const float b = tok_sum(dv[ct][r]);                   // d beta2
+            if ((lane & 15) == 0) {
+                red[wave][0][16 * ct + 4 * g + r] = a;
+                red[wave][1][16 * ct + 4 * g + r] = b;
+            }
+        }
+    layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
+    store_rows_bf16<128>(dv_b, tok, 128, 0, valid, dv, lane);
+    // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
+    uint2 dvb[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
+    f32x4 dh[16];
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_t<128, 256>(W.w2T, dvb, dh, lane);
+    uint2 dhpb[16];
+#pragma unroll
+    for (int ct = 0; ct < 16; ++ct) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh[ct][r] *= gelu_grad(hp[ct][r]);
+        dhpb[ct] = pack4(dh[ct]);
+    }
+    store_rows_bf16<256>(dhp_b, tok, 256, 0, valid, dh, lane);
+    gemm_t<256, 128>(W.w1T, dhpb, dv, lane);                      // dv now holds dy
+    // ---- LN1 backward
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = tok_sum(dv[ct][r] * xh1[ct][r]);      // d gamma1
+            const float b = tok_sum(dv[ct][r]);                   // d beta1
+            if ((lane & 15) == 0) {
+                red[wave][2][16 * ct + 4 * g + r] = a;
+                red[wave][3][16 * ct + 4 * g + r] = b;
+            }
+        }
+    layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
+    store_rows_f32<128>(dx_res, tok, valid, dv, lane);
+    store_rows_bf16<128>(du_b, tok, 128, 0, valid, dv, lane);
+    uint2 dub[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) dub[ct] = pack4(dv[ct]);
+    f32x4 da[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    gemm_t<128, 128>(W.woT, dub, da, lane);
+    store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
+    // ---- flush LayerNorm parameter gradients (invalid rows contributed zeros: dz was loaded as 0)
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * 128; e += kLayerBlk) {
+        const int k = e >> 7, c = e & 127;
+        const float s = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+        float* dst = k == 0 ? dg2 : (k == 1 ? dbe2 : (k == 2 ? dg1 : dbe1));
+        atomicAdd(dst + c, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1: dx = dx_res + dqk Wqk + dv Wv   (+ bf16 copies of x + pos and x for the weight-gradient GEMMs)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
+                                                                const float* __restrict__ dx_res,
+                                                                const float* __restrict__ x,
+                                                                const int32_t* __restrict__ tok_pos,
+                                                                const float* __restrict__ pos_table, LayerW W, int n,
+                                                                float* __restrict__ dx, bf16_t* __restrict__ xp_b,
+                                                                bf16_t* __restrict__ x_b) {
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
+    if (tile * 16 >= n) return;
+    const int g = lane >> 4;
+    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
+    const bool valid = tok < n;
+    const int64_t tc = valid ? tok : n - 1;
+    f32x4 acc[8];
+    load_rows_f32<128>(dx_res, tok, valid, acc, lane);
+    {
+        uint2 d[16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct)
+            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+        gemm_t<256, 128>(W.wqkT, d, acc, lane);
+    }
+    {
+        uint2 d[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+        gemm_t<128, 128>(W.wvT, d, acc, lane);
+    }
+    store_rows_f32<128>(dx, tok, valid, acc, lane);
+    if (valid) {
+        const int p = tok_pos[tc];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + tc * 128 + 16 * ct + 4 * g);
+            const float4 pv = *reinterpret_cast<const float4*>(pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
+            *reinterpret_cast<uint2*>(x_b + tok * 128 + 16 * ct + 4 * g) = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
+            *reinterpret_cast<uint2*>(xp_b + tok * 128 + 16 * ct + 4 * g) =
+                make_uint2(pack2(xv.x + pv.x, xv.y + pv.y), pack2(xv.z + pv.z, xv.w + pv.w));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// DW: C[c_row0 + i][c_col0 + j] += sum_t A[t][a_col0 + i] * B[t][b_col0 + j],  i, j < 128
+//     dbias[c_row0 + i]         += sum_t A[t][a_col0 + i]                        (if dbias)
+// ------------------------------------------------------------------------------------------------
+struct DwTask {
+    const bf16_t* A; int lda, a_col0;
+    const bf16_t* B; int ldb, b_col0;
+    float* C; int ldc, c_row0, c_col0;
+    float* dbias;
+};
+struct DwTasks { DwTask t[8]; };
+
+constexpr int kDwTok = 32;          // tokens per slab (= MFMA K)
+constexpr int kDwLd = kDwTok + 8;   // padded LDS row (80 bytes: 16-byte aligned, conflict-free b128 reads)
+
+__global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk) {
+    __shared__ __attribute__((aligned(16))) bf16_t At[128 * kDwLd];
+    __shared__ __attribute__((aligned(16))) bf16_t Bt[128 * kDwLd];
+    const DwTask T = tasks.t[blockIdx.y];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int o = lane & 15, g = lane >> 4;
+    const int t_begin = blockIdx.x * chunk;
+    const int t_end = t_begin + chunk < n ? t_begin + chunk : n;
+    if (t_begin >= n) return;
+    f32x4 acc[2][8];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int st = threadIdx.x & 31, sc = threadIdx.x >> 5;      // staging: token, 16-channel group
+    float bsum[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) bsum[e] = 0.f;
+    for (int t0 = t_begin; t0 < t_end; t0 += kDwTok) {
+        const int tok = t0 + st;
+        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
+        if (tok < t_end) {
+            const bf16_t* ap = T.A + (int64_t)tok * T.lda + T.a_col0 + 16 * sc;
+            const bf16_t* bp = T.B + (int64_t)tok * T.ldb + T.b_col0 + 16 * sc;
+            a0 = *reinterpret_cast<const uint4*>(ap);
+            a1 = *reinterpret_cast<const uint4*>(ap + 8);
+            b0 = *reinterpret_cast<const uint4*>(bp);
+            b1 = *reinterpret_cast<const uint4*>(bp + 8);
+        }
+        __syncthreads();      // previous slab fully consumed
+        {
+            const unsigned int aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const unsigned int bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                At[(16 * sc + 2 * e) * kDwLd + st] = (bf16_t)(aw[e] & 0xffffu);
+                At[(16 * sc + 2 * e + 1) * kDwLd + st] = (bf16_t)(aw[e] >> 16);
+                Bt[(16 * sc + 2 * e) * kDwLd + st] = (bf16_t)(bw[e] & 0xffffu);
+                Bt[(16 * sc + 2 * e + 1) * kDwLd + st] = (bf16_t)(bw[e] >> 16);
+                bsum[2 * e] += bf_lo(aw[e]);
+                bsum[2 * e + 1] += bf_hi(aw[e]);
+            }
+        }
+        __syncthreads();
+        uint4 af[2];
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+            af[it] = *reinterpret_cast<const uint4*>(At + (32 * wave + 16 * it + o) * kDwLd + 8 * g);
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt) {
+            const uint4 bf = *reinterpret_cast<const uint4*>(Bt + (16 * jt + o) * kDwLd + 8 * g);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
+        }
+    }
+    // C layout: row i = 32*wave + 16*it + 4*g + r, col j = 16*jt + o
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 8; ++jt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 32 * wave + 16 * it + 4 * g + r, j = 16 * jt + o;
+                atomicAdd(T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j, acc[it][jt][r]);
+            }
+    if (T.dbias) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = bsum[e];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
+            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
+            if (st == 0) atomicAdd(T.dbias + T.c_row0 + 16 * sc + e, v);
+        }
+    }
+}
+
+static LayerW to_layer(const GeomaeSstLayerWeights* w) {
+    LayerW L;
+    L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;
+    L.wo = (const bf16_t*)w->wo_p; L.woT = (const bf16_t*)w->woT_p; L.w1 = (const bf16_t*)w->w1_p;
+    L.w1T = (const bf16_t*)w->w1T_p; L.w2 = (const bf16_t*)w->w2_p; L.w2T = (const bf16_t*)w->w2T_p;
+    L.bqkv = w->bqkv; L.bo = w->bo; L.b1 = w->b1; L.b2 = w->b2;
+    L.g1 = w->ln1_w; L.be1 = w->ln1_b; L.g2 = w->ln2_w; L.be2 = w->ln2_b;
+    return L;
+}
+
+static int check_weights(const GeomaeSstLayerWeights* w, const char* who) {
+    GEOMAE_REQUIRE(w, "%s: null weights", who);
+    GEOMAE_REQUIRE(w->wqkv_p && w->wqkT_p && w->wvT_p && w->wo_p && w->woT_p && w->w1_p && w->w1T_p && w->w2_p &&
+                   w->w2T_p && w->bqkv && w->bo && w->b1 && w->b2 && w->ln1_w && w->ln1_b && w->ln2_w && w->ln2_b,
+                   "%s: null weight pointer", who);
+    GEOMAE_REQUIRE(w->d_model == 128 && w->d_ffn == 256, "%s: kernels are built for d_model=128, d_ffn=256", who);
+    return GEOMAE_OK;
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc,
+                                   int64_t max_elems, void* packed_bf16, hipStream_t stream) {
+    if (num_desc <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(desc && packed_bf16 && max_elems > 0, "pack_weights: bad argument");
+    int gx = (int)((max_elems + 255) / 256);
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, num_desc), dim3(256), 0, stream, flat_params, desc,
+                       (bf16_t*)packed_bf16);
+    return check_launch("pack_weights_kernel");
+}
+
+extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
+                                      const GeomaeSstLayerWeights* w, int32_t num_tokens, void* qkv_bf16,
+                                      hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_weights(w, "sst_qkv_forward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(x && tok_pos && pos_table && qkv_bf16, "sst_qkv_forward: null argument");
+    const int tiles = cdiv(num_tokens, 16);
+    hipLaunchKernelGGL(sst_qkv_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x, tok_pos,
+                       pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16);
+    return check_launch("sst_qkv_fwd_kernel");
+}
+
+extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
+                                      int32_t num_tokens, float* z, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_weights(w, "sst_ffn_forward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(x && attn_bf16 && z, "sst_ffn_forward: null argument");
+    const int tiles = cdiv(num_tokens, 16);
+    hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
+                       (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z);
+    return check_launch("sst_ffn_fwd_kernel");
+}
+
+extern "C" int geomae_sst_ffn_backward(const float* x, const void* attn_bf16, const float* dz,
+                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx_res,
+                                       void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16, void* y_bf16,
+                                       void* h_bf16, const GeomaeSstLayerGrads* grads, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_weights(w, "sst_ffn_backward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(x && attn_bf16 && dz && dx_res && dattn_bf16 && du_bf16 && dv_bf16 && dhp_bf16 && y_bf16 && h_bf16,
+                   "sst_ffn_backward: null argument");
+    GEOMAE_REQUIRE(grads && grads->ln1_w && grads->ln1_b && grads->ln2_w && grads->ln2_b, "sst_ffn_backward: null grads");
+    const int tiles = cdiv(num_tokens, 16);
+    hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
+                       (const bf16_t*)attn_bf16, dz, to_layer(w), num_tokens, w->ln_eps, dx_res, (bf16_t*)dattn_bf16,
+                       (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16, (bf16_t*)h_bf16,
+                       grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b);
+    return check_launch("sst_ffn_bwd_kernel");
+}
+
+extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
+                                       const int32_t* tok_pos, const float* pos_table,
+                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx, void* xp_bf16,
+                                       void* x_bf16, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_weights(w, "sst_qkv_backward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(dqkv_bf16 && dx_res && x && tok_pos && pos_table && dx && xp_bf16 && x_bf16,
+                   "sst_qkv_backward: null argument");
+    const int tiles = cdiv(num_tokens, 16);
+    hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,
+                       (const bf16_t*)dqkv_bf16, dx_res, x, tok_pos, pos_table, to_layer(w), num_tokens, dx,
+                       (bf16_t*)xp_bf16, (bf16_t*)x_bf16);
+    return check_launch("sst_qkv_bwd_kernel");
+}
+
+extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16, const void* xp_bf16,
+                                      const void* x_bf16, const void* du_bf16, const void* attn_bf16,
+                                      const void* dhp_bf16, const void* y_bf16, const void* dv_bf16,
+                                      const void* h_bf16, const GeomaeSstLayerGrads* g, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(dqkv_bf16 && xp_bf16 && x_bf16 && du_bf16 && attn_bf16 && dhp_bf16 && y_bf16 && dv_bf16 && h_bf16,
+                   "sst_weight_grad: null argument");
+    GEOMAE_REQUIRE(g && g->wqkv && g->bqkv && g->wo && g->bo && g->w1 && g->b1 && g->w2 && g->b2,
+                   "sst_weight_grad: null grads");
+    const bf16_t *dqkv = (const bf16_t*)dqkv_bf16, *xp = (const bf16_t*)xp_bf16, *xb = (const bf16_t*)x_bf16,
+                 *du = (const bf16_t*)du_bf16, *at = (const bf16_t*)attn_bf16, *dhp = (const bf16_t*)dhp_bf16,
+                 *y = (const bf16_t*)y_bf16, *dv = (const bf16_t*)dv_bf16, *h = (const bf16_t*)h_bf16;
+    DwTasks T;
+    //          A     lda a0   B   ldb b0  C        ldc  r0   c0  dbias
+    T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv};   // dWq
+    T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv};   // dWk
+    T.t[2] = {dqkv, 384, 256, xb, 128, 0, g->wqkv, 128, 256, 0,  g->bqkv};   // dWv
+    T.t[3] = {du,   128, 0,   at, 128, 0, g->wo,   128, 0,   0,  g->bo};     // dWo
+    T.t[4] = {dhp,  256, 0,   y,  128, 0, g->w1,   128, 0,   0,  g->b1};     // dW1 rows 0..127
+    T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1};     // dW1 rows 128..255
+    T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2};    // dW2 cols 0..127
+    T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr};  // dW2 cols 128..255
+    int G = cdiv(num_tokens, 512);
+    if (G > 32) G = 32;
+    int chunk = cdiv(num_tokens, G);
+    chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
+    G = cdiv(num_tokens, chunk);
+    hipLaunchKernelGGL(dw_kernel, dim3(G, 8), dim3(256), 0, stream, T, num_tokens, chunk);
+    return check_launch("dw_kernel");
+}

@@ -386,3 +386,73 @@ class _WindowAttention(torch.autograd.Function):
 def window_attention(qkv_bf16, layout, num_heads):
     """softmax(q k^T / sqrt(d)) v inside every window; qkv [n, 3C] bf16 -> [n, C] bf16."""
     return _WindowAttention.apply(qkv_bf16, layout, num_heads)
+
+
+def window_attention_raw(qkv, layout, num_heads):
+    """Forward only (no autograd): -> (out [n,C] bf16, lse [n,H] fp32)."""
+    n, c3 = qkv.shape
+    C = c3 // 3
+    out = torch.empty((n, C), dtype=torch.bfloat16, device=qkv.device)
+    lse = torch.empty((n, num_heads), dtype=torch.float32, device=qkv.device)
+    with _timed("win_attn_fwd_kernel"):
+        check(_lib.load().geomae_window_attention_forward(
+            _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
+            _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+            "geomae_window_attention_forward")
+    return out, lse
+
+
+# ------------------------------------------------------------------------------------ fused SST layer
+def pack_weights(desc, num_desc, max_elems, packed):
+    check(_lib.load().geomae_pack_weights(ctypes.c_void_p(0), _ptr(desc), num_desc, max_elems, _ptr(packed),
+                                          _stream()), "geomae_pack_weights")
+
+
+def sst_qkv_forward(x, layout, pos_table, w):
+    _check_input(x, "x", torch.float32)
+    n = x.shape[0]
+    qkv = torch.empty((n, 384), dtype=torch.bfloat16, device=x.device)
+    check(_lib.load().geomae_sst_qkv_forward(_ptr(x), _ptr(layout.tok_pos), _ptr(pos_table), ctypes.byref(w), n,
+                                             _ptr(qkv), _stream()), "geomae_sst_qkv_forward")
+    return qkv
+
+
+def sst_ffn_forward(x, attn, w):
+    n = x.shape[0]
+    z = torch.empty_like(x)
+    check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _stream()),
+          "geomae_sst_ffn_forward")
+    return z
+
+
+def sst_layer_backward(x, qkv, attn, lse, dz, w, g, layout, pos_table, num_heads):
+    """ffn backward -> attention backward -> qkv backward -> weight gradients; returns dx [n,128] fp32."""
+    lib = _lib.load()
+    n = x.shape[0]
+    dev = x.device
+    dx_res = torch.empty_like(x)
+    cols = [128, 128, 128, 256, 128, 256, 128, 128, 384]
+    flat = torch.empty(n * sum(cols), dtype=torch.bfloat16, device=dev)          # one allocation, 9 slabs
+    bufs, o = [], 0
+    for c in cols:
+        bufs.append(flat[o:o + n * c].view(n, c))
+        o += n * c
+    dattn, du_b, dv_b, dhp_b, y_b, h_b, xp_b, x_b, dqkv = bufs
+    _check_input(dz, "dz", torch.float32)
+    check(lib.geomae_sst_ffn_backward(_ptr(x), _ptr(attn), _ptr(dz), ctypes.byref(w), n, _ptr(dx_res), _ptr(dattn),
+                                      _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b), _ptr(h_b), ctypes.byref(g),
+                                      _stream()), "geomae_sst_ffn_backward")
+    L = layout
+    with _timed("win_attn_bwd_kernel"):
+        check(lib.geomae_window_attention_backward(
+            _ptr(qkv), _ptr(attn), _ptr(dattn), _ptr(lse), n, num_heads, 128 // num_heads, _ptr(L.win_start),
+            _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv), _stream()),
+            "geomae_window_attention_backward")
+    dx = torch.empty_like(x)
+    check(lib.geomae_sst_qkv_backward(_ptr(dqkv), _ptr(dx_res), _ptr(x), _ptr(L.tok_pos), _ptr(pos_table),
+                                      ctypes.byref(w), n, _ptr(dx), _ptr(xp_b), _ptr(x_b), _stream()),
+          "geomae_sst_qkv_backward")
+    check(lib.geomae_sst_weight_grad(n, _ptr(dqkv), _ptr(xp_b), _ptr(x_b), _ptr(du_b), _ptr(attn), _ptr(dhp_b),
+                                     _ptr(y_b), _ptr(dv_b), _ptr(h_b), ctypes.byref(g), _stream()),
+          "geomae_sst_weight_grad")
+    return dx

@@ -41,6 +41,102 @@ def pos_embed_table(window_shape, d_model, temperature=10000):
     return torch.cat([ex, ey], dim=-1)
 
 
+class PackedLayers:
+    """bf16 MFMA-layout copies of every SST layer's matrices (geomae_pack_weights), refreshed once per
+    forward, plus the per-layer C structs handed to the fused kernels."""
+    PER_LAYER = 262144   # bf16 elements: wqkv 49152 | wqkT 32768 | wvT 16384 | wo, woT 16384 x2 | w1, w1T, w2, w2T 32768 x4
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self.key = None
+        self.packed = None
+
+    def _build(self, dev):
+        from ._lib import GeomaeSstLayerWeights
+        n = len(self.layers)
+        self.packed = torch.empty(n * self.PER_LAYER, dtype=torch.bfloat16, device=dev)
+        base = self.packed.data_ptr()
+        desc, self.structs = [], []
+
+        def f(t):
+            return t.data_ptr() // 4
+
+        for i, L in enumerate(self.layers):
+            a = L.win_attn.self_attn
+            win, wo, w1, w2 = a.in_proj_weight, a.out_proj.weight, L.linear1.weight, L.linear2.weight
+            off = i * self.PER_LAYER
+            o = dict(wqkv=off, wqkT=off + 49152, wvT=off + 81920, wo=off + 98304, woT=off + 114688, w1=off + 131072,
+                     w1T=off + 163840, w2=off + 196608, w2T=off + 229376)
+            desc += [[f(win), 384, 128, 0, o["wqkv"]], [f(win), 256, 128, 1, o["wqkT"]],
+                     [f(win) + 256 * 128, 128, 128, 1, o["wvT"]], [f(wo), 128, 128, 0, o["wo"]],
+                     [f(wo), 128, 128, 1, o["woT"]], [f(w1), 256, 128, 0, o["w1"]], [f(w1), 256, 128, 1, o["w1T"]],
+                     [f(w2), 128, 256, 0, o["w2"]], [f(w2), 128, 256, 1, o["w2T"]]]
+            st = GeomaeSstLayerWeights()
+            for k, v in o.items():
+                setattr(st, k + "_p", base + 2 * v)
+            st.bqkv, st.bo = a.in_proj_bias.data_ptr(), a.out_proj.bias.data_ptr()
+            st.b1, st.b2 = L.linear1.bias.data_ptr(), L.linear2.bias.data_ptr()
+            st.ln1_w, st.ln1_b = L.norm1.weight.data_ptr(), L.norm1.bias.data_ptr()
+            st.ln2_w, st.ln2_b = L.norm2.weight.data_ptr(), L.norm2.bias.data_ptr()
+            st.d_model, st.d_ffn, st.ln_eps = 128, 256, L.norm1.eps
+            self.structs.append(st)
+        self.desc = torch.tensor(desc, dtype=torch.int64, device=dev)
+        self.n_desc = len(desc)
+
+    def _key(self):
+        return tuple(p.data_ptr() for L in (self.layers[0], self.layers[-1]) for p in L.parameters()) + \
+            (self.layers[0].linear1.weight.device,)
+
+    def refresh(self):
+        """Re-pack from the current fp32 master weights (they change every optimizer step)."""
+        k = self._key()
+        if k != self.key:
+            self._build(k[-1])
+            self.key = k
+        ops.pack_weights(self.desc, self.n_desc, 384 * 128, self.packed)
+
+    def grads(self, layer_index):
+        """C struct of gradient pointers; allocates .grad where autograd has not yet."""
+        from ._lib import GeomaeSstLayerGrads
+        L = self.layers[layer_index]
+        a = L.win_attn.self_attn
+        ps = dict(wqkv=a.in_proj_weight, bqkv=a.in_proj_bias, wo=a.out_proj.weight, bo=a.out_proj.bias,
+                  w1=L.linear1.weight, b1=L.linear1.bias, w2=L.linear2.weight, b2=L.linear2.bias,
+                  ln1_w=L.norm1.weight, ln1_b=L.norm1.bias, ln2_w=L.norm2.weight, ln2_b=L.norm2.bias)
+        g = GeomaeSstLayerGrads()
+        for k, p in ps.items():
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            setattr(g, k, p.grad.data_ptr())
+        return g
+
+
+class _FusedLayer(torch.autograd.Function):
+    """One SST encoder layer: 3 kernels forward (qkv, window attention, out-proj+LN+FFN+LN), 4 backward
+    (ffn backward, attention backward, qkv backward, weight gradients).  Parameter gradients are
+    accumulated straight into .grad by the kernels (they are not autograd outputs of this Function)."""
+
+    @staticmethod
+    def forward(ctx, x, packed, index, layout, pos_table, nhead):
+        x = x.contiguous()
+        w = packed.structs[index]
+        qkv = ops.sst_qkv_forward(x, layout, pos_table, w)
+        attn, lse = ops.window_attention_raw(qkv, layout, nhead)
+        z = ops.sst_ffn_forward(x, attn, w)
+        ctx.packed, ctx.index, ctx.layout, ctx.pos_table, ctx.nhead = packed, index, layout, pos_table, nhead
+        ctx.save_for_backward(x, qkv, attn, lse)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, qkv, attn, lse = ctx.saved_tensors
+        w = ctx.packed.structs[ctx.index]
+        g = ctx.packed.grads(ctx.index)
+        dx = ops.sst_layer_backward(x, qkv, attn, lse, dz.contiguous().float(), w, g, ctx.layout, ctx.pos_table,
+                                    ctx.nhead)
+        return dx, None, None, None, None, None
+
+
 class WindowAttention(nn.Module):
     def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None):
         super().__init__()
@@ -79,6 +175,8 @@ class EncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
 
     def forward(self, src, pos, layout, compute_dtype):
+        """Composed (ATen/rocBLAS + window-attention kernel) form of the layer: kept as the A/B debugging
+        path for the fused kernels (`compute_dtype='fp32'`); the product path is _FusedLayer."""
         dt = compute_dtype
         src2 = self.win_attn(src, pos, layout, dt)
         src = self.norm1(src + src2)
@@ -97,13 +195,17 @@ class BasicShiftBlock(nn.Module):
             EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first, layer_id=block_id * 2 + i)
             for i in range(2)])
 
-    def forward(self, src, pos_list, layout_list, compute_dtype):
+    def forward(self, src, pos_list, layout_list, compute_dtype, fused=None):
         num_shifts = len(layout_list)
         assert num_shifts in (1, 2)
         out = src
         for i in range(2):
             s = i % num_shifts
-            out = self.encoder_list[i](out, pos_list[s], layout_list[s], compute_dtype)
+            if fused is not None:
+                packed, base, pos_table, nhead = fused
+                out = _FusedLayer.apply(out, packed, base + i, layout_list[s], pos_table, nhead)
+            else:
+                out = self.encoder_list[i](out, pos_list[s], layout_list[s], compute_dtype)
         return out
 
 
@@ -168,6 +270,11 @@ class MultiMAESSTSPChoose(nn.Module):
         self._wcfg = ops.make_window_config(self.window_shape, shift, (bev_x, bev_y))
         # every window must fit its bucket, i.e. no token is ever dropped in training:
         # the largest training bucket must hold a full window
+        all_layers = [l for stack in (self.encoder_blocks, self.decoder_centroid_blocks, self.decoder_density_blocks)
+                      for b in stack for l in b.encoder_list]
+        self._packed = PackedLayers(all_layers)
+        self._stack_base = {"enc": 0, "cen": 2 * encoder_num_blocks,
+                            "den": 2 * (encoder_num_blocks + decoder_num_blocks)}
         info = drop_info[0] if isinstance(drop_info, tuple) else drop_info
         assert max(v["max_tokens"] for v in info.values()) >= self.window_shape[0] * self.window_shape[1], \
             "token dropping is not supported: the largest bucket must hold a full window"
@@ -180,23 +287,33 @@ class MultiMAESSTSPChoose(nn.Module):
     def _dtype(self):
         return torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
 
+    @property
+    def fused(self):
+        return self.compute_dtype == "bf16"
+
     def get_voxel_info(self, coors, batch_size):
-        """CSR window layouts for both shifts + gathered positional embeddings."""
+        """CSR window layouts for both shifts (+ gathered positional embeddings for the composed path)."""
         coors = coors.int().contiguous()
         layouts = [ops.window_build(coors, batch_size, self._wcfg, s) for s in range(len(self.shifts_list))]
-        pos = [self.pos_table[L.tok_pos[:L.n].long()] for L in layouts]
+        pos = None if self.fused else [self.pos_table[L.tok_pos[:L.n].long()] for L in layouts]
         return layouts, pos
 
+    def _run_stack(self, blocks, name, x, pos, layouts):
+        dt = self._dtype()
+        for i, block in enumerate(blocks):
+            fused = (self._packed, self._stack_base[name] + 2 * i, self.pos_table, self.nhead[0]) if self.fused else None
+            x = block(x, pos, layouts, dt, fused)
+        return x
+
     def forward(self, voxel_feat, coors, coors_mask, batch_size):
+        if self.fused:
+            self._packed.refresh()
         layouts, pos = self.get_voxel_info(coors, batch_size)
         x = self.forward_encoder(voxel_feat.float(), layouts, pos)
         return self.forward_decoder(x, coors, coors_mask, batch_size)
 
     def forward_encoder(self, x, layouts, pos):
-        dt = self._dtype()
-        for block in self.encoder_blocks:
-            x = block(x, pos, layouts, dt)
-        return x
+        return self._run_stack(self.encoder_blocks, "enc", x, pos, layouts)
 
     def forward_decoder(self, visible_voxel_feat, coors, coors_mask, batch_size):
         dt = self._dtype()
@@ -205,11 +322,8 @@ class MultiMAESSTSPChoose(nn.Module):
         tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)
         coors_all = torch.cat([coors, coors_mask], dim=0)
         layouts, pos = self.get_voxel_info(coors_all, batch_size)
-        cen, den = tokens, tokens
-        for block in self.decoder_centroid_blocks:
-            cen = block(cen, pos, layouts, dt)
-        for block in self.decoder_density_blocks:
-            den = block(den, pos, layouts, dt)
+        cen = self._run_stack(self.decoder_centroid_blocks, "cen", tokens, pos, layouts)
+        den = self._run_stack(self.decoder_density_blocks, "den", tokens, pos, layouts)
         cm = cen[masked_start_id:]
         dm = den[masked_start_id:]
         reg_pred_low = self.decoder_pred_low(cm).view(-1, self.per_sub_voxel_num_low, 3)

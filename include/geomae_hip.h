@@ -152,6 +152,52 @@ int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16,
                                      int32_t max_windows, int32_t max_window_tokens, void* dqkv_bf16,
                                      geomaeStream_t stream);
 
+
+/* ------------------------------------------------------------------ A19-A22 fused SST encoder layer
+ * replaces EncoderLayer.forward (sst_basic_block.py:85-102) and its autograd: in-projection with the
+ * positional embedding folded in, out-projection + residual + LayerNorm + FFN(GELU) + residual +
+ * LayerNorm, forward and backward, for d_model = 128, d_ffn = 256.  Residual stream fp32, MFMA operands
+ * bf16, fp32 accumulation.  The attention core between qkv and attn is geomae_window_attention_*.
+ * Packed weights come from geomae_pack_weights (bf16, contraction index permuted for the MFMA B layout). */
+typedef struct GeomaeSstLayerWeights {
+    const void *wqkv_p, *wqkT_p, *wvT_p, *wo_p, *woT_p, *w1_p, *w1T_p, *w2_p, *w2T_p; /* packed bf16            */
+    const float *bqkv, *bo, *b1, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;                 /* the fp32 parameters   */
+    int32_t d_model, d_ffn;                                                           /* must be 128, 256       */
+    float ln_eps;
+} GeomaeSstLayerWeights;
+typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into (views of .grad) */
+    float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+} GeomaeSstLayerGrads;
+
+/* desc: device int64 [num_desc, 5] rows {src_offset, rows, cols, transpose, dst_offset} (elements);
+ * writes bf16 dst[r][p] = W[r][perm(p)] or, transposed, dst[c][p] = W[perm(p)][c].  src_offset is relative
+ * to flat_params; flat_params may be NULL with src_offset = (device address / 4) for scattered tensors. */
+int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
+                        void* packed_bf16, geomaeStream_t stream);
+/* qkv [n,384] bf16 = [(x + pos_table[tok_pos]) Wqk^T + b | x Wv^T + b];  x [n,128] fp32 */
+int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
+                           const GeomaeSstLayerWeights* w /*host*/, int32_t num_tokens, void* qkv_bf16,
+                           geomaeStream_t stream);
+/* z = LN2(y + W2 gelu(W1 y + b1) + b2), y = LN1(x + attn Wo^T + bo);  attn [n,128] bf16, z [n,128] fp32 */
+int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
+                           int32_t num_tokens, float* z, geomaeStream_t stream);
+/* backward of geomae_sst_ffn_forward (recomputes the forward chain): dx_res [n,128] f32, dattn [n,128]
+ * bf16, and the bf16 operands of the weight-gradient GEMMs du,dv,y [n,128], dhp,h [n,256];
+ * LayerNorm parameter gradients are accumulated into grads->ln*. */
+int geomae_sst_ffn_backward(const float* x, const void* attn_bf16, const float* dz,
+                            const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx_res,
+                            void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16, void* y_bf16,
+                            void* h_bf16, const GeomaeSstLayerGrads* grads, geomaeStream_t stream);
+/* dx = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv;  also xp = bf16(x + pos), xb = bf16(x) */
+int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
+                            const int32_t* tok_pos, const float* pos_table, const GeomaeSstLayerWeights* w,
+                            int32_t num_tokens, float* dx, void* xp_bf16, void* x_bf16, geomaeStream_t stream);
+/* all weight + bias gradients of the layer (token contractions), accumulated into grads */
+int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16, const void* xp_bf16, const void* x_bf16,
+                           const void* du_bf16, const void* attn_bf16, const void* dhp_bf16, const void* y_bf16,
+                           const void* dv_bf16, const void* h_bf16, const GeomaeSstLayerGrads* grads,
+                           geomaeStream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -375,3 +375,38 @@ def test_forward_train_random_mask_runs_and_is_finite(dev):
     total = sum(losses.values())
     total.backward()
     assert torch.isfinite(total) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_fused_layer_matches_composed_layer(dev):
+    """One BasicShiftBlock: fused kernels (bf16 MFMA) vs the composed fp32 layer, forward and backward."""
+    import copy
+    from geomae_amd import ops
+    model, _ = _build(dev, 1, 1, "bf16")
+    bb = model.backbone
+    frames = [synth.lidar_frame(21), synth.lidar_frame(22, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    x0 = torch.randn(n, 128, generator=torch.Generator().manual_seed(0)).to(dev)
+    w = torch.randn(n, 128, generator=torch.Generator().manual_seed(1)).to(dev)
+    outs, grads, pgrads = [], [], []
+    for mode in ("bf16", "fp32"):
+        bb.compute_dtype = mode
+        for p in bb.parameters():
+            p.grad = None
+        if bb.fused:
+            bb._packed.refresh()
+        layouts, pos = bb.get_voxel_info(vc, 2)
+        x = x0.clone().requires_grad_(True)
+        y = bb._run_stack(bb.encoder_blocks, "enc", x, pos, layouts)
+        (y * w).sum().backward()
+        outs.append(y.detach().float().cpu().numpy())
+        grads.append(x.grad.float().cpu().numpy())
+        pgrads.append({k: v.grad.float().cpu().numpy().copy() for k, v in bb.encoder_blocks.named_parameters()})
+
+    def rel(a, b):
+        return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+    assert rel(outs[0], outs[1]) < 1.5e-2, rel(outs[0], outs[1])
+    assert rel(grads[0], grads[1]) < 3e-2, rel(grads[0], grads[1])
+    bad = {k: rel(pgrads[0][k], pgrads[1][k]) for k in pgrads[0] if rel(pgrads[0][k], pgrads[1][k]) > 4e-2}
+    assert not bad, bad
