@@ -65,9 +65,9 @@ SIGNATURES = {
                                                         c_int32, P, P]),
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P]),
     "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
-    "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
-    "geomae_sst_ffn_backward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P,
-                                               P, POINTER(GeomaeSstLayerGrads), P]),
+    "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),
+    "geomae_sst_ffn_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P,
+                                               P, P, P, POINTER(GeomaeSstLayerGrads), P]),
     "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
     "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
 }

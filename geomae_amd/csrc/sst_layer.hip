@@ -31,6 +31,7 @@ namespace geomae {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 __device__ __forceinline__ f32x4 mfma32(uint4 a, uint4 b, f32x4 c) {
     union { uint4 u; bf16x8_t v; } fa, fb;
@@ -79,13 +80,39 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 // ------------------------------------------------------------------------------------------------
 // Y^T[N x 16 tokens] += Wp[N x K] * X^T : acc[ot][r] = Y[t][16*ot + 4*g + r]  (T-layout in, T-layout out)
 // ------------------------------------------------------------------------------------------------
+constexpr int kLayerBlk = 256;   // 4 waves = 4 token tiles (64 tokens) per workgroup
+constexpr int kPad = 8;          // bf16 elements (16 B) of row padding in LDS: b128 fragment reads conflict-free
+constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256][128] (also covers [128][256])
+
+// The workgroup's 4 waves share every weight matrix through LDS: one cooperative copy (L2 -> LDS, 16 B per
+// lane) per matrix per 64 tokens, then each wave reads its A fragments with ds_read_b128.  Without this
+// every wave pulled the whole matrix through its own vector-memory pipe with 1-2 loads in flight (the
+// kernels ran at ~260 cycles per MFMA, profiles/r01b).  All waves of the block must call this together.
 template <int K, int N>
-__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, const uint2 (&xb)[K / 16],
-                                       f32x4 (&acc)[N / 16], int lane) {
+__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
+                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane) {
+    constexpr int LD = K + kPad;
+    constexpr int CH = K / 8;                  // 16-byte chunks per row
+    constexpr int PASSES = N * CH / kLayerBlk;
+    static_assert(N * CH % kLayerBlk == 0, "matrix must tile over the block");
+    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
+    u32x4 stage[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = p * kLayerBlk + threadIdx.x;
+        stage[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
+    }
+    __syncthreads();                           // previous matrix fully consumed by every wave
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = p * kLayerBlk + threadIdx.x;
+        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = stage[p];
+    }
+    __syncthreads();
     const int o = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int ot = 0; ot < N / 16; ++ot) {
-        const bf16_t* wrow = Wp + (size_t)(16 * ot + o) * K + 8 * g;
+        const bf16_t* wrow = smem + (16 * ot + o) * LD + 8 * g;
 #pragma unroll
         for (int kk = 0; kk < K / 32; ++kk) {
             const uint4 a = *reinterpret_cast<const uint4*>(wrow + 32 * kk);
@@ -214,9 +241,26 @@ __device__ __forceinline__ void layer_norm_bwd_t(f32x4 (&dy)[8], const f32x4 (&x
         for (int r = 0; r < 4; ++r) dy[ct][r] = rstd * (dy[ct][r] - m1 - xhat[ct][r] * m2);
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// GELU (erf form, as F.gelu) and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one
+// exp + one rcp instead of libm erff (~60 instructions); exp(-x^2/2) is shared with the pdf term.
+__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    *cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    *pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float c, p;
+    gelu_parts(x, &c, &p);
+    return x * c;
+}
 __device__ __forceinline__ float gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+    float c, p;
+    gelu_parts(x, &c, &p);
+    return c + x * p;
 }
 
 // sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
@@ -228,7 +272,6 @@ __device__ __forceinline__ float tok_sum(float v) {
     return v;
 }
 
-constexpr int kLayerBlk = 256;   // 4 waves = 4 token tiles per workgroup
 
 struct LayerW {
     const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
@@ -242,9 +285,9 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_fwd_kernel(const float* __r
                                                                 const int32_t* __restrict__ tok_pos,
                                                                 const float* __restrict__ pos_table, LayerW W,
                                                                 int n, bf16_t* __restrict__ qkv) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    if (tile * 16 >= n) return;
     const int t = lane & 15, g = lane >> 4;
     const int64_t tok = (int64_t)tile * 16 + t;
     const bool valid = tok < n;
@@ -261,156 +304,181 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_fwd_kernel(const float* __r
     {
         f32x4 acc[16];
         load_bias<256>(W.bqkv, acc, lane);
-        gemm_t<128, 256>(W.wqkv, xpb, acc, lane);
+        gemm_t<128, 256>(W.wqkv, smem, xpb, acc, lane);
         store_rows_bf16<256>(qkv, tok, 384, 0, valid, acc, lane);
     }
     {
         f32x4 acc[8];
         load_bias<128>(W.bqkv + 256, acc, lane);
-        gemm_t<128, 128>(W.wqkv + 256 * 128, xb, acc, lane);
+        gemm_t<128, 128>(W.wqkv + 256 * 128, smem, xb, acc, lane);
         store_rows_bf16<128>(qkv, tok, 384, 256, valid, acc, lane);
     }
 }
 
-// shared forward chain of F3 / B3: from x and the attention output to (xhat1, rstd1, y, hp, xhat2, rstd2)
-__device__ __forceinline__ void ffn_forward_chain(const float* __restrict__ x, const bf16_t* __restrict__ attn,
-                                                  const LayerW& W, int64_t tok, bool valid, float eps, int lane,
-                                                  f32x4 (&xh1)[8], float* rstd1, f32x4 (&y)[8], f32x4 (&hp)[16],
-                                                  f32x4 (&xh2)[8], float* rstd2) {
-    uint2 ob[8];
-    load_rows_bf16<128>(attn, tok, valid, ob, lane);
-    load_bias<128>(W.bo, xh1, lane);
-    gemm_t<128, 128>(W.wo, ob, xh1, lane);
-    {
-        f32x4 xr[8];
-        load_rows_f32<128>(x, tok, valid, xr, lane);
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) xh1[ct] += xr[ct];
-    }
-    layer_norm_t(xh1, eps, rstd1);
-    affine_t(xh1, W.g1, W.be1, y, lane);
-    uint2 yb[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
-    load_bias<256>(W.b1, hp, lane);
-    gemm_t<128, 256>(W.w1, yb, hp, lane);
-    uint2 hb[16];
-#pragma unroll
-    for (int ct = 0; ct < 16; ++ct) {
-        f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
-        hb[ct] = pack4(h);
-    }
-    load_bias<128>(W.b2, xh2, lane);
-    gemm_t<256, 128>(W.w2, hb, xh2, lane);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) xh2[ct] += y[ct];
-    layer_norm_t(xh2, eps, rstd2);
-}
-
 // ------------------------------------------------------------------------------------------------
-// F3: z = LN2(y + FFN(y)),  y = LN1(x + attn Wo^T + bo)
+// F3: z = LN2(y + FFN(y)),  y = LN1(x + attn Wo^T + bo).  When training it also saves what the backward
+// needs instead of recomputing three GEMMs there: the two normalised residuals (fp32), the FFN
+// pre-activation (bf16) and the two 1/sigma per token.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kLayerBlk) void sst_ffn_fwd_kernel(const float* __restrict__ x,
                                                                 const bf16_t* __restrict__ attn, LayerW W, int n,
-                                                                float eps, float* __restrict__ z) {
+                                                                float eps, float* __restrict__ z,
+                                                                float* __restrict__ xh1_out,
+                                                                float* __restrict__ xh2_out,
+                                                                bf16_t* __restrict__ hp_out,
+                                                                float* __restrict__ rstd_out) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    if (tile * 16 >= n) return;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
-    f32x4 xh1[8], y[8], hp[16], xh2[8];
+    f32x4 u[8], y[8];
     float r1, r2;
-    ffn_forward_chain(x, attn, W, tok, valid, eps, lane, xh1, &r1, y, hp, xh2, &r2);
-    f32x4 out[8];
-    affine_t(xh2, W.g2, W.be2, out, lane);
-    store_rows_f32<128>(z, tok, valid, out, lane);
+    {
+        uint2 ob[8];
+        load_rows_bf16<128>(attn, tok, valid, ob, lane);
+        load_bias<128>(W.bo, u, lane);
+        gemm_t<128, 128>(W.wo, smem, ob, u, lane);
+        f32x4 xr[8];
+        load_rows_f32<128>(x, tok, valid, xr, lane);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
+    }
+    layer_norm_t(u, eps, &r1);
+    if (xh1_out) store_rows_f32<128>(xh1_out, tok, valid, u, lane);
+    affine_t(u, W.g1, W.be1, y, lane);
+    uint2 hb[16];
+    {
+        uint2 yb[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
+        f32x4 hp[16];
+        load_bias<256>(W.b1, hp, lane);
+        gemm_t<128, 256>(W.w1, smem, yb, hp, lane);
+        if (hp_out) store_rows_bf16<256>(hp_out, tok, 256, 0, valid, hp, lane);
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) {
+            f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
+            hb[ct] = pack4(h);
+        }
+    }
+    load_bias<128>(W.b2, u, lane);
+    gemm_t<256, 128>(W.w2, smem, hb, u, lane);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
+    layer_norm_t(u, eps, &r2);
+    if (xh2_out) store_rows_f32<128>(xh2_out, tok, valid, u, lane);
+    if (rstd_out && valid && (lane >> 4) == 0) {
+        rstd_out[tok * 2 + 0] = r1;
+        rstd_out[tok * 2 + 1] = r2;
+    }
+    affine_t(u, W.g2, W.be2, y, lane);
+    store_rows_f32<128>(z, tok, valid, y, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
-// B3: backward of F3.  Recomputes the forward chain from (x, attn); emits
+// B3: backward of F3 from the saved (xhat1, xhat2, hp, rstd).  Emits
 //   dx_res [n,128] f32 (gradient reaching x through the residual = d(x + a)),  dattn [n,128] bf16,
 //   bf16 row-major operands of the weight-gradient GEMMs: du, dv, dhp [n,256], y, h [n,256]
 //   and the LayerNorm parameter gradients (atomics, one flush per workgroup).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kLayerBlk) void sst_ffn_bwd_kernel(
-    const float* __restrict__ x, const bf16_t* __restrict__ attn, const float* __restrict__ dz, LayerW W, int n,
-    float eps, float* __restrict__ dx_res, bf16_t* __restrict__ dattn, bf16_t* __restrict__ du_b,
+    const float* __restrict__ xh1_in, const float* __restrict__ xh2_in, const bf16_t* __restrict__ hp_in,
+    const float* __restrict__ rstd_in, const float* __restrict__ dz, LayerW W, int n,
+    float* __restrict__ dx_res, bf16_t* __restrict__ dattn, bf16_t* __restrict__ du_b,
     bf16_t* __restrict__ dv_b, bf16_t* __restrict__ dhp_b, bf16_t* __restrict__ y_b, bf16_t* __restrict__ h_b,
     float* __restrict__ dg1, float* __restrict__ dbe1, float* __restrict__ dg2, float* __restrict__ dbe2) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ float red[4][4][128];     // [wave][tensor][channel]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
-    f32x4 xh1[8], y[8], hp[16], xh2[8];
-    float r1, r2;
-    ffn_forward_chain(x, attn, W, tok, valid, eps, lane, xh1, &r1, y, hp, xh2, &r2);
-    store_rows_bf16<128>(y_b, tok, 128, 0, valid, y, lane);
-    {
-        f32x4 h[16];
-#pragma unroll
-        for (int ct = 0; ct < 16; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) h[ct][r] = gelu_f(hp[ct][r]);
-        store_rows_bf16<256>(h_b, tok, 256, 0, valid, h, lane);
-    }
-    // ---- LN2 backward
+    const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
     f32x4 dv[8];
     load_rows_f32<128>(dz, tok, valid, dv, lane);
+    // ---- LN2 backward
+    {
+        f32x4 xh2[8];
+        load_rows_f32<128>(xh2_in, tok, valid, xh2, lane);
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = tok_sum(dv[ct][r] * xh2[ct][r]);      // d gamma2
-            const float b = tok_sum(dv[ct][r]);                   // d beta2
-            if ((lane & 15) == 0) {
-                red[wave][0][16 * ct + 4 * g + r] = a;
-                red[wave][1][16 * ct + 4 * g + r] = b;
+            for (int r = 0; r < 4; ++r) {
+                const float a = tok_sum(dv[ct][r] * xh2[ct][r]);      // d gamma2
+                const float b = tok_sum(dv[ct][r]);                   // d beta2
+                if ((lane & 15) == 0) {
+                    red[wave][0][16 * ct + 4 * g + r] = a;
+                    red[wave][1][16 * ct + 4 * g + r] = b;
+                }
             }
-        }
-    layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
+        layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
+    }
     store_rows_bf16<128>(dv_b, tok, 128, 0, valid, dv, lane);
     // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
-    uint2 dvb[8];
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
-    f32x4 dh[16];
-#pragma unroll
-    for (int ct = 0; ct < 16; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_t<128, 256>(W.w2T, dvb, dh, lane);
     uint2 dhpb[16];
+    {
+        uint2 dvb[8];
 #pragma unroll
-    for (int ct = 0; ct < 16; ++ct) {
+        for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
+        f32x4 dh[16];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dh[ct][r] *= gelu_grad(hp[ct][r]);
-        dhpb[ct] = pack4(dh[ct]);
-    }
-    store_rows_bf16<256>(dhp_b, tok, 256, 0, valid, dh, lane);
-    gemm_t<256, 128>(W.w1T, dhpb, dv, lane);                      // dv now holds dy
-    // ---- LN1 backward
+        for (int ct = 0; ct < 16; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_t<128, 256>(W.w2T, smem, dvb, dh, lane);
+        uint2 hpb[16];
+        load_rows_bf16<256>(hp_in, tok, valid, hpb, lane);
+        f32x4 h[16];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
+        for (int ct = 0; ct < 16; ++ct) {
+            const f32x4 hp = unpack4(hpb[ct]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = tok_sum(dv[ct][r] * xh1[ct][r]);      // d gamma1
-            const float b = tok_sum(dv[ct][r]);                   // d beta1
-            if ((lane & 15) == 0) {
-                red[wave][2][16 * ct + 4 * g + r] = a;
-                red[wave][3][16 * ct + 4 * g + r] = b;
+            for (int r = 0; r < 4; ++r) {
+                float c, p;
+                gelu_parts(hp[r], &c, &p);
+                h[ct][r] = hp[r] * c;
+                dh[ct][r] *= c + hp[r] * p;
             }
+            dhpb[ct] = pack4(dh[ct]);
         }
-    layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
+        store_rows_bf16<256>(h_b, tok, 256, 0, valid, h, lane);
+        store_rows_bf16<256>(dhp_b, tok, 256, 0, valid, dh, lane);
+    }
+    gemm_t<256, 128>(W.w1T, smem, dhpb, dv, lane);                    // dv now holds dy
+    // ---- LN1 backward
+    {
+        f32x4 xh1[8];
+        load_rows_f32<128>(xh1_in, tok, valid, xh1, lane);
+        {
+            f32x4 y[8];
+            affine_t(xh1, W.g1, W.be1, y, lane);
+            store_rows_bf16<128>(y_b, tok, 128, 0, valid, y, lane);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = tok_sum(dv[ct][r] * xh1[ct][r]);      // d gamma1
+                const float b = tok_sum(dv[ct][r]);                   // d beta1
+                if ((lane & 15) == 0) {
+                    red[wave][2][16 * ct + 4 * g + r] = a;
+                    red[wave][3][16 * ct + 4 * g + r] = b;
+                }
+            }
+        layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
+    }
     store_rows_f32<128>(dx_res, tok, valid, dv, lane);
     store_rows_bf16<128>(du_b, tok, 128, 0, valid, dv, lane);
-    uint2 dub[8];
+    {
+        uint2 dub[8];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) dub[ct] = pack4(dv[ct]);
-    f32x4 da[8];
+        for (int ct = 0; ct < 8; ++ct) dub[ct] = pack4(dv[ct]);
+        f32x4 da[8];
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-    gemm_t<128, 128>(W.woT, dub, da, lane);
-    store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
+        for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gemm_t<128, 128>(W.woT, smem, dub, da, lane);
+        store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
+    }
     // ---- flush LayerNorm parameter gradients (invalid rows contributed zeros: dz was loaded as 0)
     __syncthreads();
     for (int e = threadIdx.x; e < 4 * 128; e += kLayerBlk) {
@@ -431,9 +499,9 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __
                                                                 const float* __restrict__ pos_table, LayerW W, int n,
                                                                 float* __restrict__ dx, bf16_t* __restrict__ xp_b,
                                                                 bf16_t* __restrict__ x_b) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    if (tile * 16 >= n) return;
     const int g = lane >> 4;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
@@ -445,14 +513,14 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct)
             d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-        gemm_t<256, 128>(W.wqkT, d, acc, lane);
+        gemm_t<256, 128>(W.wqkT, smem, d, acc, lane);
     }
     {
         uint2 d[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
             d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-        gemm_t<128, 128>(W.wvT, d, acc, lane);
+        gemm_t<128, 128>(W.wvT, smem, d, acc, lane);
     }
     store_rows_f32<128>(dx, tok, valid, acc, lane);
     if (valid) {
@@ -607,30 +675,35 @@ extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, co
 }
 
 extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
-                                      int32_t num_tokens, float* z, hipStream_t stream) {
+                                      int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
+                                      float* rstd, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_forward");
     if (rc) return rc;
     GEOMAE_REQUIRE(x && attn_bf16 && z, "sst_ffn_forward: null argument");
+    const bool save = xhat1 || xhat2 || hp_bf16 || rstd;
+    GEOMAE_REQUIRE(!save || (xhat1 && xhat2 && hp_bf16 && rstd), "sst_ffn_forward: pass all four save buffers or none");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
-                       (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z);
+                       (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
+                       (bf16_t*)hp_bf16, rstd);
     return check_launch("sst_ffn_fwd_kernel");
 }
 
-extern "C" int geomae_sst_ffn_backward(const float* x, const void* attn_bf16, const float* dz,
-                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx_res,
-                                       void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16, void* y_bf16,
-                                       void* h_bf16, const GeomaeSstLayerGrads* grads, hipStream_t stream) {
+extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, const void* hp_bf16,
+                                       const float* rstd, const float* dz, const GeomaeSstLayerWeights* w,
+                                       int32_t num_tokens, float* dx_res, void* dattn_bf16, void* du_bf16,
+                                       void* dv_bf16, void* dhp_bf16, void* y_bf16, void* h_bf16,
+                                       const GeomaeSstLayerGrads* grads, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_backward");
     if (rc) return rc;
-    GEOMAE_REQUIRE(x && attn_bf16 && dz && dx_res && dattn_bf16 && du_bf16 && dv_bf16 && dhp_bf16 && y_bf16 && h_bf16,
-                   "sst_ffn_backward: null argument");
+    GEOMAE_REQUIRE(xhat1 && xhat2 && hp_bf16 && rstd && dz && dx_res && dattn_bf16 && du_bf16 && dv_bf16 &&
+                   dhp_bf16 && y_bf16 && h_bf16, "sst_ffn_backward: null argument");
     GEOMAE_REQUIRE(grads && grads->ln1_w && grads->ln1_b && grads->ln2_w && grads->ln2_b, "sst_ffn_backward: null grads");
     const int tiles = cdiv(num_tokens, 16);
-    hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
-                       (const bf16_t*)attn_bf16, dz, to_layer(w), num_tokens, w->ln_eps, dx_res, (bf16_t*)dattn_bf16,
+    hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, xhat1, xhat2,
+                       (const bf16_t*)hp_bf16, rstd, dz, to_layer(w), num_tokens, dx_res, (bf16_t*)dattn_bf16,
                        (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16, (bf16_t*)h_bf16,
                        grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b);
     return check_launch("sst_ffn_bwd_kernel");

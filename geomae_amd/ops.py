@@ -417,15 +417,22 @@ def sst_qkv_forward(x, layout, pos_table, w):
     return qkv
 
 
-def sst_ffn_forward(x, attn, w):
+def sst_ffn_forward(x, attn, w, save=True):
+    """-> z, saved = (xhat1, xhat2, hp, rstd) or None"""
     n = x.shape[0]
+    dev = x.device
     z = torch.empty_like(x)
-    check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _stream()),
-          "geomae_sst_ffn_forward")
-    return z
+    saved = None
+    if save:
+        saved = (torch.empty_like(x), torch.empty_like(x), torch.empty((n, 256), dtype=torch.bfloat16, device=dev),
+                 torch.empty((n, 2), dtype=torch.float32, device=dev))
+    s = saved or (None, None, None, None)
+    check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _ptr(s[0]), _ptr(s[1]),
+                                             _ptr(s[2]), _ptr(s[3]), _stream()), "geomae_sst_ffn_forward")
+    return z, saved
 
 
-def sst_layer_backward(x, qkv, attn, lse, dz, w, g, layout, pos_table, num_heads):
+def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, num_heads):
     """ffn backward -> attention backward -> qkv backward -> weight gradients; returns dx [n,128] fp32."""
     lib = _lib.load()
     n = x.shape[0]
@@ -439,9 +446,10 @@ def sst_layer_backward(x, qkv, attn, lse, dz, w, g, layout, pos_table, num_heads
         o += n * c
     dattn, du_b, dv_b, dhp_b, y_b, h_b, xp_b, x_b, dqkv = bufs
     _check_input(dz, "dz", torch.float32)
-    check(lib.geomae_sst_ffn_backward(_ptr(x), _ptr(attn), _ptr(dz), ctypes.byref(w), n, _ptr(dx_res), _ptr(dattn),
-                                      _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b), _ptr(h_b), ctypes.byref(g),
-                                      _stream()), "geomae_sst_ffn_backward")
+    xh1, xh2, hp, rstd = saved
+    check(lib.geomae_sst_ffn_backward(_ptr(xh1), _ptr(xh2), _ptr(hp), _ptr(rstd), _ptr(dz), ctypes.byref(w), n,
+                                      _ptr(dx_res), _ptr(dattn), _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b),
+                                      _ptr(h_b), ctypes.byref(g), _stream()), "geomae_sst_ffn_backward")
     L = layout
     with _timed("win_attn_bwd_kernel"):
         check(lib.geomae_window_attention_backward(

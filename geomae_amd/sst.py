@@ -122,18 +122,18 @@ class _FusedLayer(torch.autograd.Function):
         w = packed.structs[index]
         qkv = ops.sst_qkv_forward(x, layout, pos_table, w)
         attn, lse = ops.window_attention_raw(qkv, layout, nhead)
-        z = ops.sst_ffn_forward(x, attn, w)
+        z, saved = ops.sst_ffn_forward(x, attn, w, save=True)
         ctx.packed, ctx.index, ctx.layout, ctx.pos_table, ctx.nhead = packed, index, layout, pos_table, nhead
-        ctx.save_for_backward(x, qkv, attn, lse)
+        ctx.save_for_backward(x, qkv, attn, lse, *saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, qkv, attn, lse = ctx.saved_tensors
+        x, qkv, attn, lse, xh1, xh2, hp, rstd = ctx.saved_tensors
         w = ctx.packed.structs[ctx.index]
         g = ctx.packed.grads(ctx.index)
-        dx = ops.sst_layer_backward(x, qkv, attn, lse, dz.contiguous().float(), w, g, ctx.layout, ctx.pos_table,
-                                    ctx.nhead)
+        dx = ops.sst_layer_backward(x, qkv, attn, lse, (xh1, xh2, hp, rstd), dz.contiguous().float(), w, g,
+                                    ctx.layout, ctx.pos_table, ctx.nhead)
         return dx, None, None, None, None, None
 
 

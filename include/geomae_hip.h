@@ -178,16 +178,20 @@ int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t n
 int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                            const GeomaeSstLayerWeights* w /*host*/, int32_t num_tokens, void* qkv_bf16,
                            geomaeStream_t stream);
-/* z = LN2(y + W2 gelu(W1 y + b1) + b2), y = LN1(x + attn Wo^T + bo);  attn [n,128] bf16, z [n,128] fp32 */
+/* z = LN2(y + W2 gelu(W1 y + b1) + b2), y = LN1(x + attn Wo^T + bo);  attn [n,128] bf16, z [n,128] fp32.
+ * For training pass the four save buffers (else all NULL): xhat1, xhat2 [n,128] f32 (normalised residuals),
+ * hp [n,256] bf16 (FFN pre-activation), rstd [n,2] f32. */
 int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
-                           int32_t num_tokens, float* z, geomaeStream_t stream);
-/* backward of geomae_sst_ffn_forward (recomputes the forward chain): dx_res [n,128] f32, dattn [n,128]
- * bf16, and the bf16 operands of the weight-gradient GEMMs du,dv,y [n,128], dhp,h [n,256];
- * LayerNorm parameter gradients are accumulated into grads->ln*. */
-int geomae_sst_ffn_backward(const float* x, const void* attn_bf16, const float* dz,
-                            const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx_res,
-                            void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16, void* y_bf16,
-                            void* h_bf16, const GeomaeSstLayerGrads* grads, geomaeStream_t stream);
+                           int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
+                           float* rstd, geomaeStream_t stream);
+/* backward of geomae_sst_ffn_forward from its saved tensors: dx_res [n,128] f32, dattn [n,128] bf16, and the
+ * bf16 operands of the weight-gradient GEMMs du,dv,y [n,128], dhp,h [n,256]; LayerNorm parameter
+ * gradients are accumulated into grads->ln*. */
+int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, const void* hp_bf16, const float* rstd,
+                            const float* dz, const GeomaeSstLayerWeights* w, int32_t num_tokens,
+                            float* dx_res, void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16,
+                            void* y_bf16, void* h_bf16, const GeomaeSstLayerGrads* grads,
+                            geomaeStream_t stream);
 /* dx = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv;  also xp = bf16(x + pos), xb = bf16(x) */
 int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
                             const int32_t* tok_pos, const float* pos_table, const GeomaeSstLayerWeights* w,
