@@ -58,11 +58,11 @@ SIGNATURES = {
                                                POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P]),
     "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_window_build": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, P, P, P, P,
-                                           P, P, c_int64, P]),
-    "geomae_window_attention_forward": (ctypes.c_int, [P, c_int32, c_int32, c_int32, P, P, P, c_int32, c_int32, P,
-                                                       P, P]),
-    "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, c_int32,
-                                                        c_int32, P, P]),
+                                           P, P, P, P, c_int64, P]),
+    "geomae_window_attention_forward": (ctypes.c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32,
+                                                       c_int32, P, P, P]),
+    "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, P, P,
+                                                        c_int32, c_int32, P, P]),
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P]),
     "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
     "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),

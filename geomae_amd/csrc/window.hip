@@ -114,8 +114,50 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const int32_t* __restrict_
     }
 }
 
+// greedy packing of consecutive windows into bundles of at most `cap` tokens (cap >= the largest window):
+// most windows hold a handful of pillars, and one wavefront per (window, head) drowned in fixed
+// per-wave latency (profiles/r01d: 16k waves per launch).  One thread, sizes pipelined from LDS.
+__global__ __launch_bounds__(1024) void win_bundle_kernel(const int32_t* __restrict__ win_start,
+                                                          const int32_t* __restrict__ num_windows, int cap,
+                                                          int32_t* __restrict__ bun_start,
+                                                          int32_t* __restrict__ num_bundles,
+                                                          int32_t* __restrict__ nxt_ws) {
+    // nxt[w] = end (exclusive) of the greedy bundle that starts at window w: the largest e with
+    // win_start[e] - win_start[w] <= cap (binary search, all threads); then one thread follows the chain
+    // 0 -> nxt[0] -> ... (one dependent read per BUNDLE instead of per window).
+    __shared__ int ws[8192];
+    __shared__ int nx[8192];
+    const int W = num_windows[0];
+    const bool in_lds = W < 8192;
+    if (in_lds)
+        for (int t = threadIdx.x; t <= W; t += 1024) ws[t] = win_start[t];
+    __syncthreads();
+    for (int w = threadIdx.x; w < W; w += 1024) {
+        const int limit = (in_lds ? ws[w] : win_start[w]) + cap;
+        int lo = w + 1, hi = W;                          // answer in [w+1, W]: a window never exceeds cap
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            const int v = in_lds ? ws[mid] : win_start[mid];
+            if (v <= limit) lo = mid; else hi = mid - 1;
+        }
+        if (in_lds) nx[w] = lo; else nxt_ws[w] = lo;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nb = 0, w = 0;
+        while (w < W) {
+            bun_start[nb++] = w;
+            w = in_lds ? nx[w] : nxt_ws[w];
+        }
+        bun_start[nb] = W;
+        num_bundles[0] = nb;
+    }
+}
+
 // =====================================================================================
-// attention core: one wavefront per (window, head); d_head = 16
+// attention core: one wavefront per (bundle of windows, head); d_head = 16.  Attention is block
+// diagonal inside a bundle (a token attends to the tokens of its own window); tile pairs that no
+// window spans are skipped.
 // =====================================================================================
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -156,48 +198,83 @@ __device__ __forceinline__ void stage_head(const unsigned short* __restrict__ sr
 
 __device__ __forceinline__ bf16x4 lds4(const unsigned short* p) { return *reinterpret_cast<const bf16x4*>(p); }
 
+struct BundleCtx {
+    int s0, T, nt, Tp;
+};
+
+// loads the bundle's token list and each token's window (CSR index) into LDS
+__device__ __forceinline__ BundleCtx bundle_setup(int b, const int32_t* __restrict__ bun_start,
+                                                  const int32_t* __restrict__ win_start,
+                                                  const int32_t* __restrict__ win_tokens,
+                                                  const int32_t* __restrict__ tok_win, int* toks, int* wid) {
+    BundleCtx c;
+    c.s0 = win_start[bun_start[b]];
+    c.T = win_start[bun_start[b + 1]] - c.s0;
+    c.nt = (c.T + 15) >> 4;
+    c.Tp = c.nt * 16;
+    for (int t = threadIdx.x; t < c.Tp; t += 64) {
+        int tk = -1, w = -1 - t;                     // padded rows: a window id nothing else has
+        if (t < c.T) { tk = win_tokens[c.s0 + t]; w = tok_win[tk]; }
+        toks[t] = tk;
+        wid[t] = w;
+    }
+    return c;
+}
+
+// key-tile range [lo, hi] that the windows touching query tile `it` span
+__device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int* wid,
+                                           const int32_t* __restrict__ win_start, int* lo, int* hi) {
+    const int first = it * 16;
+    const int last = (first + 15 < c.T ? first + 15 : c.T - 1);
+    *lo = (win_start[wid[first]] - c.s0) >> 4;
+    *hi = (win_start[wid[last] + 1] - 1 - c.s0) >> 4;
+}
+
 // qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
 __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
                                                           const int32_t* __restrict__ win_start,
                                                           const int32_t* __restrict__ win_tokens,
-                                                          const int32_t* __restrict__ num_windows, float scale,
+                                                          const int32_t* __restrict__ tok_win,
+                                                          const int32_t* __restrict__ bun_start,
+                                                          const int32_t* __restrict__ num_bundles, float scale,
                                                           unsigned short* __restrict__ out,
                                                           float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[kDh * kMaxT];
-    __shared__ int toks[kMaxT];
+    __shared__ int toks[kMaxT], wid[kMaxT];
     const int lane = threadIdx.x;
     const int g = lane >> 4, c = lane & 15;
-    const int W = num_windows[0];
+    const int NB = num_bundles[0];
     const int C = n_heads * kDh;
-    for (int wh = blockIdx.x; wh < W * n_heads; wh += gridDim.x) {
-        const int w = wh / n_heads, h = wh - w * n_heads;
-        const int s0 = win_start[w];
-        const int T = win_start[w + 1] - s0;
-        const int nt = (T + 15) >> 4, Tp = nt * 16;
-        for (int t = lane; t < T; t += 64) toks[t] = win_tokens[s0 + t];
+    for (int bh = blockIdx.x; bh < NB * n_heads; bh += gridDim.x) {
+        const int b = bh / n_heads, h = bh - b * n_heads;
+        const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
+        const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
         stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, nullptr);
         stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, nullptr);
         stage_head(qkv, 3 * C, 2 * C + h * kDh, toks, T, Tp, nullptr, Vt);
         __syncthreads();
         for (int it = 0; it < nt; ++it) {
+            int jlo, jhi;
+            tile_range(B, it, wid, win_start, &jlo, &jhi);
             // S^T tiles: A = K rows (keys), B = Q^T (queries): lane holds query i = it*16 + c,
             // keys j = jt*16 + 4*g + r
             const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
+            const int wq = wid[it * 16 + c];
             f32x4 st[kMaxTiles];
             float m = -INFINITY;
 #pragma unroll
             for (int jt = 0; jt < kMaxTiles; ++jt) {
-                if (jt < nt) {
+                if (jt >= jlo && jt <= jhi) {
                     const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
                     f32x4 z = {0, 0, 0, 0};
                     st[jt] = mfma16(ka, qb, z);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int j = jt * 16 + 4 * g + r;
-                        st[jt][r] = j < T ? st[jt][r] * scale : -INFINITY;
+                        st[jt][r] = (wid[j] == wq) ? st[jt][r] * scale : -INFINITY;
                         m = fmaxf(m, st[jt][r]);
                     }
                 }
@@ -207,7 +284,7 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* 
             float sum = 0.0f;
 #pragma unroll
             for (int jt = 0; jt < kMaxTiles; ++jt) {
-                if (jt < nt) {
+                if (jt >= jlo && jt <= jhi) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float p = __expf(st[jt][r] - m);
@@ -222,7 +299,7 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* 
             f32x4 o = {0, 0, 0, 0};
 #pragma unroll
             for (int jt = 0; jt < kMaxTiles; ++jt) {
-                if (jt < nt) {
+                if (jt >= jlo && jt <= jhi) {
                     bf16x4 pa;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pa[r] = (short)f2bf(st[jt][r]);
@@ -252,22 +329,22 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
                                                           const float* __restrict__ lse, int n_heads,
                                                           const int32_t* __restrict__ win_start,
                                                           const int32_t* __restrict__ win_tokens,
-                                                          const int32_t* __restrict__ num_windows, float scale,
+                                                          const int32_t* __restrict__ tok_win,
+                                                          const int32_t* __restrict__ bun_start,
+                                                          const int32_t* __restrict__ num_bundles, float scale,
                                                           unsigned short* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
         dOs[kMaxT * kDh], Qt[kDh * kMaxT], Kt[kDh * kMaxT], dOt[kDh * kMaxT];
     __shared__ float Ls[kMaxT], Ds[kMaxT];
-    __shared__ int toks[kMaxT];
+    __shared__ int toks[kMaxT], wid[kMaxT];
     const int lane = threadIdx.x;
     const int g = lane >> 4, c = lane & 15;
-    const int W = num_windows[0];
+    const int NB = num_bundles[0];
     const int C = n_heads * kDh;
-    for (int wh = blockIdx.x; wh < W * n_heads; wh += gridDim.x) {
-        const int w = wh / n_heads, h = wh - w * n_heads;
-        const int s0 = win_start[w];
-        const int T = win_start[w + 1] - s0;
-        const int nt = (T + 15) >> 4, Tp = nt * 16;
-        for (int t = lane; t < T; t += 64) toks[t] = win_tokens[s0 + t];
+    for (int bh = blockIdx.x; bh < NB * n_heads; bh += gridDim.x) {
+        const int b = bh / n_heads, h = bh - b * n_heads;
+        const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
+        const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
         stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, Qt);
         stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, Kt);
@@ -289,11 +366,14 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
         __syncthreads();
         // ---- pass 1: dQ.  S^T orientation: lane holds query i = it*16 + c, keys j = jt*16 + 4g + r
         for (int it = 0; it < nt; ++it) {
+            int jlo, jhi;
+            tile_range(B, it, wid, win_start, &jlo, &jhi);
             const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
             const bf16x4 dob = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
             const float Li = Ls[it * 16 + c], Di = Ds[it * 16 + c];
+            const int wq = wid[it * 16 + c];
             f32x4 dq = {0, 0, 0, 0};
-            for (int jt = 0; jt < nt; ++jt) {
+            for (int jt = jlo; jt <= jhi; ++jt) {
                 const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
                 const bf16x4 va = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
@@ -303,7 +383,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int j = jt * 16 + 4 * g + r;
-                    const float p = j < T ? __expf(s[r] * scale - Li) : 0.0f;
+                    const float p = (wid[j] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
                     dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
                 }
                 // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
@@ -318,11 +398,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
         }
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
         for (int jt = 0; jt < nt; ++jt) {
+            int ilo, ihi;
+            tile_range(B, jt, wid, win_start, &ilo, &ihi);
             const bf16x4 kb = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
             const bf16x4 vb = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
-            const bool jvalid = (jt * 16 + c) < T;
+            const int wk = wid[jt * 16 + c];
             f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
-            for (int it = 0; it < nt; ++it) {
+            for (int it = ilo; it <= ihi; ++it) {
                 const bf16x4 qa = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
                 const bf16x4 doa = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
@@ -332,7 +414,7 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = it * 16 + 4 * g + r;
-                    const float p = jvalid ? __expf(s[r] * scale - Ls[i]) : 0.0f;
+                    const float p = (wid[i] == wk) ? __expf(s[r] * scale - Ls[i]) : 0.0f;
                     pa[r] = (short)f2bf(p);
                     dsa[r] = (short)f2bf(p * (dp[r] - Ds[i]) * scale);
                 }
@@ -387,14 +469,14 @@ extern "C" int64_t geomae_window_build_workspace_bytes(int32_t num_tokens, int32
 extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_size,
                                    const GeomaeWindowConfig* cfg, int32_t shift_index, int32_t* win_start,
                                    int32_t* win_tokens, int32_t* tok_win, int32_t* tok_pos,
-                                   int32_t* num_windows, void* workspace, int64_t workspace_bytes,
-                                   hipStream_t stream) {
+                                   int32_t* num_windows, int32_t* bun_start, int32_t* num_bundles,
+                                   void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     WinGeom g;
     int sps;
     int rc = win_geom(cfg, shift_index, &g, &sps);
     if (rc) return rc;
     GEOMAE_REQUIRE(num_tokens >= 0 && batch_size >= 1, "window_build: bad sizes");
-    GEOMAE_REQUIRE(win_start && num_windows, "window_build: null output");
+    GEOMAE_REQUIRE(win_start && num_windows && bun_start && num_bundles, "window_build: null output");
     const int64_t need = geomae_window_build_workspace_bytes(num_tokens, batch_size, cfg);
     if (workspace_bytes < need || !workspace) {
         set_error("window_build: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
@@ -419,42 +501,47 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
         hipLaunchKernelGGL(win_sort_kernel, dim3(max_w < 4096 ? max_w : 4096), dim3(64), 0, stream, win_start,
                            num_windows, win_tokens);
     }
+    hipLaunchKernelGGL(win_bundle_kernel, dim3(1), dim3(1024), 0, stream, win_start, num_windows, g.wx * g.wy,
+                       bun_start, num_bundles, rank /* reused: the window counting sort is done with it */);
     return check_launch("window_build");
 }
 
 extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
                                                int32_t head_dim, const int32_t* win_start,
-                                               const int32_t* win_tokens, const int32_t* num_windows,
-                                               int32_t max_windows, int32_t max_window_tokens, void* out_bf16,
+                                               const int32_t* win_tokens, const int32_t* tok_win,
+                                               const int32_t* bun_start, const int32_t* num_bundles,
+                                               int32_t max_bundles, int32_t max_window_tokens, void* out_bf16,
                                                float* lse, hipStream_t stream) {
-    if (num_tokens <= 0 || max_windows <= 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE(qkv_bf16 && win_start && win_tokens && num_windows && out_bf16 && lse,
+    if (num_tokens <= 0 || max_bundles <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(qkv_bf16 && win_start && win_tokens && tok_win && bun_start && num_bundles && out_bf16 && lse,
                    "window_attention_forward: null argument");
     GEOMAE_REQUIRE(head_dim == kDh, "window_attention_forward: head_dim must be %d", kDh);
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_forward: windows hold at most %d tokens", kMaxT);
-    const int64_t items = (int64_t)max_windows * num_heads;
+    const int64_t items = (int64_t)max_bundles * num_heads;
     const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
     hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
-                       num_heads, win_start, win_tokens, num_windows, 1.0f / sqrtf((float)head_dim),
-                       (unsigned short*)out_bf16, lse);
+                       num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
+                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse);
     return check_launch("win_attn_fwd_kernel");
 }
 
 extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16,
                                                 const float* lse, int32_t num_tokens, int32_t num_heads,
                                                 int32_t head_dim, const int32_t* win_start,
-                                                const int32_t* win_tokens, const int32_t* num_windows,
-                                                int32_t max_windows, int32_t max_window_tokens, void* dqkv_bf16,
+                                                const int32_t* win_tokens, const int32_t* tok_win,
+                                                const int32_t* bun_start, const int32_t* num_bundles,
+                                                int32_t max_bundles, int32_t max_window_tokens, void* dqkv_bf16,
                                                 hipStream_t stream) {
-    if (num_tokens <= 0 || max_windows <= 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE(qkv_bf16 && out_bf16 && dout_bf16 && lse && win_start && win_tokens && num_windows && dqkv_bf16,
-                   "window_attention_backward: null argument");
+    if (num_tokens <= 0 || max_bundles <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(qkv_bf16 && out_bf16 && dout_bf16 && lse && win_start && win_tokens && tok_win && bun_start &&
+                   num_bundles && dqkv_bf16, "window_attention_backward: null argument");
     GEOMAE_REQUIRE(head_dim == kDh, "window_attention_backward: head_dim must be %d", kDh);
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_backward: windows hold at most %d tokens", kMaxT);
-    const int64_t items = (int64_t)max_windows * num_heads;
+    const int64_t items = (int64_t)max_bundles * num_heads;
     const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
-                       win_tokens, num_windows, 1.0f / sqrtf((float)head_dim), (unsigned short*)dqkv_bf16);
+                       win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),
+                       (unsigned short*)dqkv_bf16);
     return check_launch("win_attn_bwd_kernel");
 }

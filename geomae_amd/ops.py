@@ -321,7 +321,8 @@ def make_window_config(window_shape, shift, bev_shape):
 
 class WindowLayout:
     """CSR grouping of tokens by window for one shift (replaces the flat2win index dictionaries)."""
-    __slots__ = ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "max_windows", "n", "max_tokens")
+    __slots__ = ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "max_windows", "n", "max_tokens",
+                 "bun_start", "num_bundles")
 
 
 def window_build(coors, batch_size, wcfg, shift_index):
@@ -342,11 +343,14 @@ def window_build(coors, batch_size, wcfg, shift_index):
     L.tok_win = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     L.tok_pos = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
     L.num_windows = torch.empty(1, dtype=torch.int32, device=dev)
+    L.bun_start = torch.empty(L.max_windows + 1, dtype=torch.int32, device=dev)
+    L.num_bundles = torch.empty(1, dtype=torch.int32, device=dev)
     wsb = lib.geomae_window_build_workspace_bytes(n, batch_size, ctypes.byref(wcfg))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
     check(lib.geomae_window_build(_ptr(coors), n, batch_size, ctypes.byref(wcfg), shift_index, _ptr(L.win_start),
                                   _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.tok_pos), _ptr(L.num_windows),
-                                  _ptr(ws), wsb, _stream()), "geomae_window_build")
+                                  _ptr(L.bun_start), _ptr(L.num_bundles), _ptr(ws), wsb, _stream()),
+          "geomae_window_build")
     return L
 
 
@@ -362,7 +366,8 @@ class _WindowAttention(torch.autograd.Function):
         with _timed("win_attn_fwd_kernel"):
             check(_lib.load().geomae_window_attention_forward(
                 _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
-                _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+                _ptr(layout.tok_win), _ptr(layout.bun_start), _ptr(layout.num_bundles), layout.max_windows,
+                layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
                 "geomae_window_attention_forward")
         ctx.layout, ctx.num_heads = layout, num_heads
         ctx.save_for_backward(qkv, out, lse)
@@ -378,8 +383,8 @@ class _WindowAttention(torch.autograd.Function):
         with _timed("win_attn_bwd_kernel"):
             check(_lib.load().geomae_window_attention_backward(
                 _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), n, ctx.num_heads, c3 // 3 // ctx.num_heads,
-                _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv),
-                _stream()), "geomae_window_attention_backward")
+                _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.bun_start), _ptr(L.num_bundles),
+                L.max_windows, L.max_tokens, _ptr(dqkv), _stream()), "geomae_window_attention_backward")
         return dqkv, None, None
 
 
@@ -397,7 +402,8 @@ def window_attention_raw(qkv, layout, num_heads):
     with _timed("win_attn_fwd_kernel"):
         check(_lib.load().geomae_window_attention_forward(
             _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
-            _ptr(layout.num_windows), layout.max_windows, layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+            _ptr(layout.tok_win), _ptr(layout.bun_start), _ptr(layout.num_bundles), layout.max_windows,
+            layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
             "geomae_window_attention_forward")
     return out, lse
 
@@ -454,7 +460,8 @@ def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, nu
     with _timed("win_attn_bwd_kernel"):
         check(lib.geomae_window_attention_backward(
             _ptr(qkv), _ptr(attn), _ptr(dattn), _ptr(lse), n, num_heads, 128 // num_heads, _ptr(L.win_start),
-            _ptr(L.win_tokens), _ptr(L.num_windows), L.max_windows, L.max_tokens, _ptr(dqkv), _stream()),
+            _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.bun_start), _ptr(L.num_bundles), L.max_windows,
+            L.max_tokens, _ptr(dqkv), _stream()),
             "geomae_window_attention_backward")
     dx = torch.empty_like(x)
     check(lib.geomae_sst_qkv_backward(_ptr(dqkv), _ptr(dx_res), _ptr(x), _ptr(L.tok_pos), _ptr(pos_table),

@@ -127,13 +127,16 @@ typedef struct GeomaeWindowConfig {
 /* replaces window_partition + get_voxel_keep_inds + get_flat2win_inds (bb.py:413-681): tokens
  * grouped by window as CSR.  coors [n, 4] int32.  Outputs: win_start [min(n, slots) + 1],
  * win_tokens [n] (token ids grouped by window, ascending inside a window), tok_win [n] (CSR window
- * of each token), tok_pos [n] (in-window position cx * wy + cy, the pos-embed row), num_windows [1]. */
+ * of each token), tok_pos [n] (in-window position cx * wy + cy, the pos-embed row), num_windows [1],
+ * and the packing of consecutive windows into bundles of <= wx*wy tokens that the attention kernels
+ * iterate over: bun_start [min(n, slots) + 1] (window index ranges), num_bundles [1]. */
 int64_t geomae_window_build_workspace_bytes(int32_t num_tokens, int32_t batch_size,
                                             const GeomaeWindowConfig* cfg);
 int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_size,
                         const GeomaeWindowConfig* cfg /*host*/, int32_t shift_index, int32_t* win_start,
                         int32_t* win_tokens, int32_t* tok_win, int32_t* tok_pos, int32_t* num_windows,
-                        void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
+                        int32_t* bun_start, int32_t* num_bundles, void* workspace, int64_t workspace_bytes,
+                        geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A19 windowed attention core
  * replaces flat2window -> nn.MultiheadAttention(key_padding_mask) -> window2flat
@@ -142,16 +145,17 @@ int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_
  * lse [n, H] fp32 (log-sum-exp of the scaled scores, kept for the backward pass). */
 int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
                                     int32_t head_dim, const int32_t* win_start,
-                                    const int32_t* win_tokens, const int32_t* num_windows,
-                                    int32_t max_windows, int32_t max_window_tokens, void* out_bf16,
+                                    const int32_t* win_tokens, const int32_t* tok_win,
+                                    const int32_t* bun_start, const int32_t* num_bundles,
+                                    int32_t max_bundles, int32_t max_window_tokens, void* out_bf16,
                                     float* lse, geomaeStream_t stream);
 int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16,
                                      const float* lse, int32_t num_tokens, int32_t num_heads,
                                      int32_t head_dim, const int32_t* win_start,
-                                     const int32_t* win_tokens, const int32_t* num_windows,
-                                     int32_t max_windows, int32_t max_window_tokens, void* dqkv_bf16,
+                                     const int32_t* win_tokens, const int32_t* tok_win,
+                                     const int32_t* bun_start, const int32_t* num_bundles,
+                                     int32_t max_bundles, int32_t max_window_tokens, void* dqkv_bf16,
                                      geomaeStream_t stream);
-
 
 /* ------------------------------------------------------------------ A19-A22 fused SST encoder layer
  * replaces EncoderLayer.forward (sst_basic_block.py:85-102) and its autograd: in-projection with the

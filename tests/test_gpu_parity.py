@@ -249,6 +249,13 @@ def test_window_build_matches_partition(dev):
         assert np.array_equal(L.tok_pos[:vc.shape[0]].cpu().numpy(), ciw[:, 0] * 12 + ciw[:, 1])
         assert np.array_equal(uniq[L.tok_win[:vc.shape[0]].cpu().numpy()], win)
         assert cnt.max() <= 144
+        # bundles: consecutive windows, <= 144 tokens each, greedy (the next window would overflow)
+        NB = int(L.num_bundles.item())
+        bs = L.bun_start[:NB + 1].cpu().numpy()
+        assert bs[0] == 0 and bs[-1] == W and (np.diff(bs) > 0).all()
+        btok = ws[bs[1:]] - ws[bs[:-1]]
+        assert btok.max() <= 144 and btok.min() >= 1
+        assert (btok[:-1] + cnt[bs[1:-1]] > 144).all()
 
 
 def _ref_window_attention(qkv, win, nhead):
