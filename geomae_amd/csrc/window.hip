@@ -177,23 +177,64 @@ __device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
-// stage the head slice [T, 16] of a [n, ld] bf16 matrix (columns col0..col0+15) into LDS,
-// row-major rm[Tp][16] and/or transposed tr[16][Tp]; rows >= T are zero
-__device__ __forceinline__ void stage_head(const unsigned short* __restrict__ src, int ld, int col0,
-                                           const int32_t* __restrict__ toks, int T, int Tp,
-                                           unsigned short* rm, unsigned short* tr) {
-    const int lane = threadIdx.x;
-    for (int t = lane; t < Tp * 2; t += 64) {
-        const int row = t >> 1, half = t & 1;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < T) v = *reinterpret_cast<const uint4*>(src + (int64_t)toks[row] * ld + col0 + half * 8);
-        if (rm) *reinterpret_cast<uint4*>(rm + row * kDh + half * 8) = v;
-        if (tr) {
-            const unsigned short* e = reinterpret_cast<const unsigned short*>(&v);
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr int kAttnBlk = 256;                           // 4 waves share one (bundle, head): query/key tiles round-robin
+constexpr int kStageIters = (kMaxT * 2 + kAttnBlk - 1) / kAttnBlk;   // 16-byte pieces per thread per [T,16] head slice (2)
+
+// Head slice [T, 16] of a [n, ld] bf16 matrix (columns col0..col0+15): lane handles (row, half) pieces.
+// Loads for ALL slices are issued before any LDS write so that their latencies overlap.
+__device__ __forceinline__ void stage_load(const unsigned short* __restrict__ src, int ld, int col0,
+                                           const int* toks, int T, u32x4 (&v)[kStageIters]) {
 #pragma unroll
-            for (int k = 0; k < 8; ++k) tr[(half * 8 + k) * Tp + row] = e[k];
+    for (int k = 0; k < kStageIters; ++k) {
+        const int t = k * kAttnBlk + threadIdx.x;
+        const int row = t >> 1, half = t & 1;
+        v[k] = u32x4{0u, 0u, 0u, 0u};
+        if (row < T) v[k] = *reinterpret_cast<const u32x4*>(src + (int64_t)toks[row] * ld + col0 + half * 8);
+    }
+}
+
+// row-major rm[Tp][16] and/or transposed tr[16][Tp]; rows in [T, Tp) are written as zeros
+__device__ __forceinline__ void stage_store(const u32x4 (&v)[kStageIters], int Tp, unsigned short* rm,
+                                            unsigned short* tr) {
+#pragma unroll
+    for (int k = 0; k < kStageIters; ++k) {
+        const int t = k * kAttnBlk + threadIdx.x;
+        const int row = t >> 1, half = t & 1;
+        if (row < Tp) {
+            if (rm) *reinterpret_cast<u32x4*>(rm + row * kDh + half * 8) = v[k];
+            if (tr) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    tr[(half * 8 + 2 * e) * Tp + row] = (unsigned short)(v[k][e] & 0xffffu);
+                    tr[(half * 8 + 2 * e + 1) * Tp + row] = (unsigned short)(v[k][e] >> 16);
+                }
+            }
         }
     }
+}
+
+// rows of an LDS tile rm[Tp][16] -> global [n, ld] at columns col0.. (16-byte stores)
+__device__ __forceinline__ void unstage_store(const unsigned short* rm, unsigned short* __restrict__ dst, int ld,
+                                              int col0, const int* toks, int T) {
+#pragma unroll
+    for (int k = 0; k < kStageIters; ++k) {
+        const int t = k * kAttnBlk + threadIdx.x;
+        const int row = t >> 1, half = t & 1;
+        if (row < T)
+            *reinterpret_cast<u32x4*>(dst + (int64_t)toks[row] * ld + col0 + half * 8) =
+                *reinterpret_cast<const u32x4*>(rm + row * kDh + half * 8);
+    }
+}
+
+__device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        s += __uint_as_float(a[e] << 16) * __uint_as_float(b[e] << 16);
+        s += __uint_as_float(a[e] & 0xffff0000u) * __uint_as_float(b[e] & 0xffff0000u);
+    }
+    return s;
 }
 
 __device__ __forceinline__ bf16x4 lds4(const unsigned short* p) { return *reinterpret_cast<const bf16x4*>(p); }
@@ -212,7 +253,7 @@ __device__ __forceinline__ BundleCtx bundle_setup(int b, const int32_t* __restri
     c.T = win_start[bun_start[b + 1]] - c.s0;
     c.nt = (c.T + 15) >> 4;
     c.Tp = c.nt * 16;
-    for (int t = threadIdx.x; t < c.Tp; t += 64) {
+    for (int t = threadIdx.x; t < c.Tp; t += kAttnBlk) {
         int tk = -1, w = -1 - t;                     // padded rows: a window id nothing else has
         if (t < c.T) { tk = win_tokens[c.s0 + t]; w = tok_win[tk]; }
         toks[t] = tk;
@@ -231,7 +272,7 @@ __device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int
 }
 
 // qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
-__global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
+__global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
                                                           const int32_t* __restrict__ win_start,
                                                           const int32_t* __restrict__ win_tokens,
                                                           const int32_t* __restrict__ tok_win,
@@ -242,8 +283,9 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* 
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Vt[kDh * kMaxT];
+    __shared__ __attribute__((aligned(16))) unsigned short Os[kMaxT * kDh];
     __shared__ int toks[kMaxT], wid[kMaxT];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
@@ -252,11 +294,17 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* 
         const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
-        stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, nullptr);
-        stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, nullptr);
-        stage_head(qkv, 3 * C, 2 * C + h * kDh, toks, T, Tp, nullptr, Vt);
+        {
+            u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters];
+            stage_load(qkv, 3 * C, h * kDh, toks, T, rq);
+            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
+            stage_store(rq, Tp, Qs, nullptr);
+            stage_store(rk, Tp, Ks, nullptr);
+            stage_store(rv, Tp, nullptr, Vt);
+        }
         __syncthreads();
-        for (int it = 0; it < nt; ++it) {
+        for (int it = wave; it < nt; it += kAttnBlk / 64) {
             int jlo, jhi;
             tile_range(B, it, wid, win_start, &jlo, &jhi);
             // S^T tiles: A = K rows (keys), B = Q^T (queries): lane holds query i = it*16 + c,
@@ -313,17 +361,19 @@ __global__ __launch_bounds__(64) void win_attn_fwd_kernel(const unsigned short* 
             for (int r = 0; r < 4; ++r) {
                 const int i = it * 16 + 4 * g + r;
                 const float inv_i = __shfl(inv, 4 * g + r, 64);
-                if (i < T) out[(int64_t)toks[i] * C + h * kDh + c] = f2bf(o[r] * inv_i);
+                Os[i * kDh + c] = f2bf(o[r] * inv_i);
             }
             const int iq = it * 16 + c;
             if (g == 0 && iq < T) lse[(int64_t)toks[iq] * n_heads + h] = m + __logf(sum);
         }
         __syncthreads();
+        unstage_store(Os, out, C, h * kDh, toks, T);
+        __syncthreads();
     }
 }
 
 // backward: dqkv [n, 3C] bf16 from dout [n, C] bf16, qkv, out, lse
-__global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* __restrict__ qkv,
+__global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                           const unsigned short* __restrict__ out,
                                                           const unsigned short* __restrict__ dout,
                                                           const float* __restrict__ lse, int n_heads,
@@ -335,9 +385,10 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
                                                           unsigned short* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
         dOs[kMaxT * kDh], Qt[kDh * kMaxT], Kt[kDh * kMaxT], dOt[kDh * kMaxT];
+    __shared__ __attribute__((aligned(16))) unsigned short G1[kMaxT * kDh], G2[kMaxT * kDh];   // dQ, then dK / dV
     __shared__ float Ls[kMaxT], Ds[kMaxT];
     __shared__ int toks[kMaxT], wid[kMaxT];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
@@ -346,26 +397,33 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
         const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
-        stage_head(qkv, 3 * C, h * kDh, toks, T, Tp, Qs, Qt);
-        stage_head(qkv, 3 * C, C + h * kDh, toks, T, Tp, Ks, Kt);
-        stage_head(qkv, 3 * C, 2 * C + h * kDh, toks, T, Tp, Vs, nullptr);
-        stage_head(dout, C, h * kDh, toks, T, Tp, dOs, dOt);
-        // delta_i = sum_d dO[i,d] * O[i,d] ; L_i
-        for (int t = lane; t < Tp; t += 64) {
-            float d = 0.0f, l = INFINITY;    // padded rows: P = exp(s - inf) = 0
-            if (t < T) {
-                const unsigned short* o = out + (int64_t)toks[t] * C + h * kDh;
-                const unsigned short* dp = dout + (int64_t)toks[t] * C + h * kDh;
+        {
+            u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters], rdo[kStageIters], ro[kStageIters];
+            stage_load(qkv, 3 * C, h * kDh, toks, T, rq);
+            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
+            stage_load(dout, C, h * kDh, toks, T, rdo);
+            stage_load(out, C, h * kDh, toks, T, ro);
+            stage_store(rq, Tp, Qs, Qt);
+            stage_store(rk, Tp, Ks, Kt);
+            stage_store(rv, Tp, Vs, nullptr);
+            stage_store(rdo, Tp, dOs, dOt);
+            // delta_i = sum_d dO[i,d] * O[i,d] (two 8-wide halves per row, adjacent lanes) ; L_i
 #pragma unroll
-                for (int k = 0; k < kDh; ++k) d += bf2f(o[k]) * bf2f(dp[k]);
-                l = lse[(int64_t)toks[t] * n_heads + h];
+            for (int k = 0; k < kStageIters; ++k) {
+                const int t = k * kAttnBlk + threadIdx.x;
+                const int row = t >> 1;
+                float d = dot8_bf16(rdo[k], ro[k]);
+                d += __shfl_xor(d, 1, 64);
+                if ((t & 1) == 0 && row < Tp) {
+                    Ds[row] = d;                                                    // zero for padded rows
+                    Ls[row] = row < T ? lse[(int64_t)toks[row] * n_heads + h] : INFINITY;   // P = exp(s - inf) = 0
+                }
             }
-            Ds[t] = d;
-            Ls[t] = l;
         }
         __syncthreads();
         // ---- pass 1: dQ.  S^T orientation: lane holds query i = it*16 + c, keys j = jt*16 + 4g + r
-        for (int it = 0; it < nt; ++it) {
+        for (int it = wave; it < nt; it += kAttnBlk / 64) {
             int jlo, jhi;
             tile_range(B, it, wid, win_start, &jlo, &jhi);
             const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
@@ -391,13 +449,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
                 dq = mfma16(dsa, kb, dq);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = it * 16 + 4 * g + r;
-                if (i < T) dqkv[(int64_t)toks[i] * 3 * C + h * kDh + c] = f2bf(dq[r]);
-            }
+            for (int r = 0; r < 4; ++r) G1[(it * 16 + 4 * g + r) * kDh + c] = f2bf(dq[r]);
         }
+        __syncthreads();
+        unstage_store(G1, dqkv, 3 * C, h * kDh, toks, T);
+        __syncthreads();
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
-        for (int jt = 0; jt < nt; ++jt) {
+        for (int jt = wave; jt < nt; jt += kAttnBlk / 64) {
             int ilo, ihi;
             tile_range(B, jt, wid, win_start, &ilo, &ihi);
             const bf16x4 kb = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
@@ -427,13 +485,13 @@ __global__ __launch_bounds__(64) void win_attn_bwd_kernel(const unsigned short* 
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int j = jt * 16 + 4 * g + r;
-                if (j < T) {
-                    dqkv[(int64_t)toks[j] * 3 * C + C + h * kDh + c] = f2bf(dk[r]);
-                    dqkv[(int64_t)toks[j] * 3 * C + 2 * C + h * kDh + c] = f2bf(dv[r]);
-                }
+                G1[(jt * 16 + 4 * g + r) * kDh + c] = f2bf(dk[r]);
+                G2[(jt * 16 + 4 * g + r) * kDh + c] = f2bf(dv[r]);
             }
         }
+        __syncthreads();
+        unstage_store(G1, dqkv, 3 * C, C + h * kDh, toks, T);
+        unstage_store(G2, dqkv, 3 * C, 2 * C + h * kDh, toks, T);
         __syncthreads();
     }
 }
@@ -519,7 +577,7 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_forward: windows hold at most %d tokens", kMaxT);
     const int64_t items = (int64_t)max_bundles * num_heads;
     const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
-    hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
+    hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
                        1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse);
     return check_launch("win_attn_fwd_kernel");
@@ -539,7 +597,7 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_backward: windows hold at most %d tokens", kMaxT);
     const int64_t items = (int64_t)max_bundles * num_heads;
     const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
-    hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(64), 0, stream, (const unsigned short*)qkv_bf16,
+    hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
                        win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),
                        (unsigned short*)dqkv_bf16);
