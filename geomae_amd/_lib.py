@@ -32,6 +32,11 @@ class GeomaeSstLayerWeights(ctypes.Structure):
                 + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float)])
 
 
+class GeomaeHeadGrads(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("reg_low_w", "reg_low_b", "cls_low_w", "cls_low_b", "reg_med_w", "reg_med_b",
+                                        "cls_med_w", "cls_med_b", "reg_top_w", "reg_top_b", "nor_top_w", "nor_top_b")]
+
+
 class GeomaeSstLayerGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "w1", "b1", "w2", "b2", "ln1_w", "ln1_b",
                                         "ln2_w", "ln2_b")]
@@ -55,7 +60,7 @@ SIGNATURES = {
     "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
     "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),
     "geomae_geometry_targets": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P, P, c_int32, P, P,
-                                               POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P]),
+                                               POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_window_build": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, P, P, P, P,
                                            P, P, P, P, c_int64, P]),
@@ -63,7 +68,9 @@ SIGNATURES = {
                                                        c_int32, P, P, P]),
     "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, P, P,
                                                         c_int32, c_int32, P, P]),
-    "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P]),
+    "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
+    "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
+    "geomae_heads_weight_grad": (ctypes.c_int, [c_int32, P, P, P, POINTER(GeomaeHeadGrads), P]),
     "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
     "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),
     "geomae_sst_ffn_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P,

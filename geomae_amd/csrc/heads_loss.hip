@@ -1,0 +1,264 @@
+// Fused decoder heads + the six GeoMAE losses + their backward (gfx950).
+//
+// Reference: the six nn.Linear heads on the masked rows of the two decoder outputs
+// (mmdet3d/models/backbones/multi_mae_sst_spearate_top_only.py:279-300) followed by forward_loss
+// (mmdet3d/models/detectors/multi_sub_voxel_dynamic_voxelnet_ssl.py:837-902): masked MSE on the
+// low / med / top sub-voxel centroids, MSE on the surface normal ("loss_curv_around"), and two
+// sigmoid cross-entropies on the occupancy logits (mmdet CrossEntropyLoss(use_sigmoid=True)).
+// That is ~18 GEMMs and ~60 elementwise / reduction / boolean-index launches per iteration (with host
+// syncs for the masked sizes).  Here: ONE kernel.  A wave owns 16 masked pillars in the T-layout of
+// sst_layer.hip; the 800 head outputs are produced 128 at a time from an LDS-staged weight chunk, turned
+// into loss terms and d(logit) in registers, and immediately contracted back through the SAME LDS tile
+// into d(decoder output) -- the [M,726] prediction tensors never exist.  Head weight gradients are the
+// token contraction dl^T x, done by dw_kernel from the bf16 dl / x copies this kernel writes.
+#include "common.h"
+#include "../../include/geomae_hip.h"
+#include "sst_device.h"
+
+namespace geomae {
+
+// output layout (rows of the packed head matrix, columns of dl):
+//   [0,384) reg_low | [384,640) cls_low | [640,688) reg_med | [688,720) cls_med | [720,723) reg_top |
+//   [723,768) zero  | [768,771) nor_top (input = density decoder) | [771,800) zero
+constexpr int kHeadRows = 800;
+constexpr int kDlLd = 896;          // leading dimension of dl (padded so 128-wide dw blocks never overrun)
+
+struct HeadArgs {
+    const float* cen; const float* den;       // [n,128] decoder outputs; masked rows start at n_keep
+    int n_keep, M;
+    const bf16_t* wp;                         // packed [800][128]
+    const float* bias;                        // [800]
+    const float* t_low; const uint8_t* m_low; // [M,384], [M,128]
+    const float* t_med; const uint8_t* m_med; // [M,48], [M,16]
+    const float* t_top; const float* t_nor;   // [M,3]
+    const int32_t* occ;                       // [2] occupied low / med cells over the M rows
+    float w_low, w_med, w_top, w_nor, w_cls_low, w_cls_med;
+    float* loss;                              // [6] curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med
+    float* d_cen; float* d_den;               // [n,128], rows >= n_keep written (others pre-zeroed by caller)
+    bf16_t* dl; bf16_t* cm_b; bf16_t* dm_b;   // [M,896], [M,128], [M,128]
+};
+
+__device__ __forceinline__ int kperm_inv(int k) { return (k & ~31) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3); }
+
+// BCE with logits against y in {0,1}: value and d/dx
+__device__ __forceinline__ void bce(float x, float y, float* l, float* d) {
+    const float e = __expf(-fabsf(x));
+    *l = fmaxf(x, 0.f) - x * y + __logf(1.f + e);
+    const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    *d = sig - y;
+}
+
+// dX (normal-orientation C layout: lane (c = l&15, g) holds tokens 4g+r of channel tile ct) +=
+//   dl[16 x 128 outputs] * W[128 outputs x 128 channels], W read from the staged chunk (K-permuted columns)
+__device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, const uint2 (&dlb)[8],
+                                              f32x4 (&acc)[8], int lane) {
+    constexpr int LD = 128 + kPad;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const uint4 a = make_uint4(dlb[2 * kk].x, dlb[2 * kk].y, dlb[2 * kk + 1].x, dlb[2 * kk + 1].y);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const int col = kperm_inv(16 * ct + c);
+            unsigned int w[4];
+#pragma unroll
+            for (int e2 = 0; e2 < 4; ++e2) {
+                // element e = 2*e2, 2*e2+1 of this lane's k-slice: output row o = 32kk + 16(e>>2) + 4g + (e&3)
+                const int o0 = 32 * kk + 16 * ((2 * e2) >> 2) + 4 * g + ((2 * e2) & 3);
+                const unsigned int lo = smem[o0 * LD + col], hi = smem[(o0 + 1) * LD + col];
+                w[e2] = lo | (hi << 16);
+            }
+            acc[ct] = mfma32(a, make_uint4(w[0], w[1], w[2], w[3]), acc[ct]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ float red[4][6];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
+    const int64_t row = (int64_t)tile * 16 + (lane & 15);     // masked-row index
+    const bool valid = row < A.M;
+    const int64_t tok = A.n_keep + row;
+    const float inv_low = A.w_low / fmaxf(1.f, (float)A.occ[0]);
+    const float inv_med = A.w_med / fmaxf(1.f, (float)A.occ[1]);
+    const float inv_top = A.w_top / (float)A.M, inv_nor = A.w_nor / (float)A.M;
+    const float inv_cl = A.w_cls_low / ((float)A.M * 256.f), inv_cm = A.w_cls_med / ((float)A.M * 32.f);
+    float l_nor = 0.f, l_low = 0.f, l_med = 0.f, l_top = 0.f, l_cl = 0.f, l_cm = 0.f;
+
+    uint2 xb[8];
+    {
+        f32x4 x[8];
+        load_rows_f32<128>(A.cen, tok, valid, x, lane);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) xb[ct] = pack4(x[ct]);
+        store_rows_bf16<128>(A.cm_b, row, 128, 0, valid, x, lane);
+    }
+    f32x4 dx[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int chunk = 0; chunk < 7; ++chunk) {
+        if (chunk == 6) {
+            // flush d_cen, switch the input to the density decoder
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
+                    if (rr < A.M) A.d_cen[(A.n_keep + rr) * 128 + 16 * ct + (lane & 15)] = dx[ct][r];
+                }
+            f32x4 x[8];
+            load_rows_f32<128>(A.den, tok, valid, x, lane);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                xb[ct] = pack4(x[ct]);
+                dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            store_rows_bf16<128>(A.dm_b, row, 128, 0, valid, x, lane);
+        }
+        const int row0 = chunk < 6 ? 128 * chunk : 768;         // first output row of this chunk
+        f32x4 z[8];
+        if (chunk < 6) {
+            load_bias<128>(A.bias + row0, z, lane);
+            gemm_t<128, 128>(A.wp + (size_t)row0 * 128, smem, xb, z, lane);
+        } else {
+            // last chunk holds 32 rows (nor_top + zero padding); the other 96 rows of the tile are stale
+            // weights multiplied by dl = 0 below
+            load_bias<32>(A.bias + row0, reinterpret_cast<f32x4(&)[2]>(z), lane);
+#pragma unroll
+            for (int ct = 2; ct < 8; ++ct) z[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            gemm_t<128, 32>(A.wp + (size_t)row0 * 128, smem, xb, reinterpret_cast<f32x4(&)[2]>(z), lane);
+        }
+        // ---- loss terms and d(logit) for the 32 outputs this lane holds
+        uint2 dlb[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            f32x4 d = {0.f, 0.f, 0.f, 0.f};
+            if (valid) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int o = 16 * ct + 4 * g + r;          // output within the chunk
+                    const float x = z[ct][r];
+                    if (chunk < 3) {
+                        const int og = 128 * chunk + o;
+                        if (A.m_low[row * 128 + og / 3]) {
+                            const float df = x - A.t_low[row * 384 + og];
+                            l_low += df * df * (1.f / 3.f);
+                            d[r] = df * (2.f / 3.f) * inv_low;
+                        }
+                    } else if (chunk < 5) {
+                        const int og = 128 * (chunk - 3) + o;
+                        const float y = ((int)A.m_low[row * 128 + (og >> 1)] == (og & 1)) ? 1.f : 0.f;
+                        float l, dd;
+                        bce(x, y, &l, &dd);
+                        l_cl += l;
+                        d[r] = dd * inv_cl;
+                    } else if (chunk == 5) {
+                        if (o < 48) {
+                            if (A.m_med[row * 16 + o / 3]) {
+                                const float df = x - A.t_med[row * 48 + o];
+                                l_med += df * df * (1.f / 3.f);
+                                d[r] = df * (2.f / 3.f) * inv_med;
+                            }
+                        } else if (o < 80) {
+                            const int og = o - 48;
+                            const float y = ((int)A.m_med[row * 16 + (og >> 1)] == (og & 1)) ? 1.f : 0.f;
+                            float l, dd;
+                            bce(x, y, &l, &dd);
+                            l_cm += l;
+                            d[r] = dd * inv_cm;
+                        } else if (o < 83) {
+                            const float df = x - A.t_top[row * 3 + (o - 80)];
+                            l_top += df * df * (1.f / 3.f);
+                            d[r] = df * (2.f / 3.f) * inv_top;
+                        }
+                    } else if (o < 3) {
+                        const float df = x - A.t_nor[row * 3 + o];
+                        l_nor += df * df * (1.f / 3.f);
+                        d[r] = df * (2.f / 3.f) * inv_nor;
+                    }
+                }
+            }
+            dlb[ct] = pack4(d);
+            if (valid && (chunk < 6 || ct < 2))
+                *reinterpret_cast<uint2*>(A.dl + row * kDlLd + row0 + 16 * ct + 4 * g) = dlb[ct];
+        }
+        accumulate_dx(smem, dlb, dx, lane);
+    }
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
+            if (rr < A.M) A.d_den[(A.n_keep + rr) * 128 + 16 * ct + (lane & 15)] = dx[ct][r];
+        }
+    // zero the padding columns of dl that dw_kernel will read: [771,896)
+    if (valid)
+        for (int cidx = 800 + 4 * g; cidx < kDlLd; cidx += 16)
+            *reinterpret_cast<uint2*>(A.dl + row * kDlLd + cidx) = make_uint2(0u, 0u);
+    // ---- losses: wave reduce, block reduce, one atomic per loss
+    float ls[6] = {l_nor * inv_nor, l_low * inv_low, l_med * inv_med, l_top * inv_top, l_cl * inv_cl, l_cm * inv_cm};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const float v = wave_sum(ls[k]);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) atomicAdd(A.loss + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] +
+                                                          red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                 const int32_t* occ_counts, const float* loss_weights, float* losses,
+                                 float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
+                                 void* dm_bf16, hipStream_t stream) {
+    if (num_mask <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(dec_centroid && dec_density && head_w_packed && head_bias && centroid_low && mask_low &&
+                   centroid_med && mask_med && centroid_top && normal && occ_counts && loss_weights && losses &&
+                   d_dec_centroid && d_dec_density && dlogits_bf16 && cm_bf16 && dm_bf16, "heads_loss: null argument");
+    HeadArgs A;
+    A.cen = dec_centroid; A.den = dec_density; A.n_keep = num_keep; A.M = num_mask;
+    A.wp = (const bf16_t*)head_w_packed; A.bias = head_bias;
+    A.t_low = centroid_low; A.m_low = mask_low; A.t_med = centroid_med; A.m_med = mask_med;
+    A.t_top = centroid_top; A.t_nor = normal; A.occ = occ_counts;
+    A.w_nor = loss_weights[0]; A.w_low = loss_weights[1]; A.w_med = loss_weights[2]; A.w_top = loss_weights[3];
+    A.w_cls_low = loss_weights[4]; A.w_cls_med = loss_weights[5];
+    A.loss = losses; A.d_cen = d_dec_centroid; A.d_den = d_dec_density;
+    A.dl = (bf16_t*)dlogits_bf16; A.cm_b = (bf16_t*)cm_bf16; A.dm_b = (bf16_t*)dm_bf16;
+    GEOMAE_HIP(hipMemsetAsync(losses, 0, 6 * sizeof(float), stream));
+    const int tiles = cdiv(num_mask, 16);
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, A);
+    return check_launch("heads_loss_kernel");
+}
+
+extern "C" int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const void* cm_bf16,
+                                        const void* dm_bf16, const GeomaeHeadGrads* g, hipStream_t stream) {
+    if (num_mask <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(dlogits_bf16 && cm_bf16 && dm_bf16 && g, "heads_weight_grad: null argument");
+    GEOMAE_REQUIRE(g->reg_low_w && g->reg_low_b && g->cls_low_w && g->cls_low_b && g->reg_med_w && g->reg_med_b &&
+                   g->cls_med_w && g->cls_med_b && g->reg_top_w && g->reg_top_b && g->nor_top_w && g->nor_top_b,
+                   "heads_weight_grad: null gradient pointer");
+    const bf16_t *dl = (const bf16_t*)dlogits_bf16, *cm = (const bf16_t*)cm_bf16, *dm = (const bf16_t*)dm_bf16;
+    DwTasks T;
+    //          A   lda    a0   B   ldb b0  C             ldc  r0   c0 dbias         rows
+    T.t[0] = {dl, kDlLd, 0,   cm, 128, 0, g->reg_low_w, 128, 0,   0, g->reg_low_b, 128};
+    T.t[1] = {dl, kDlLd, 128, cm, 128, 0, g->reg_low_w, 128, 128, 0, g->reg_low_b, 128};
+    T.t[2] = {dl, kDlLd, 256, cm, 128, 0, g->reg_low_w, 128, 256, 0, g->reg_low_b, 128};
+    T.t[3] = {dl, kDlLd, 384, cm, 128, 0, g->cls_low_w, 128, 0,   0, g->cls_low_b, 128};
+    T.t[4] = {dl, kDlLd, 512, cm, 128, 0, g->cls_low_w, 128, 128, 0, g->cls_low_b, 128};
+    T.t[5] = {dl, kDlLd, 640, cm, 128, 0, g->reg_med_w, 128, 0,   0, g->reg_med_b, 48};
+    T.t[6] = {dl, kDlLd, 688, cm, 128, 0, g->cls_med_w, 128, 0,   0, g->cls_med_b, 32};
+    T.t[7] = {dl, kDlLd, 720, cm, 128, 0, g->reg_top_w, 128, 0,   0, g->reg_top_b, 3};
+    T.t[8] = {dl, kDlLd, 768, dm, 128, 0, g->nor_top_w, 128, 0,   0, g->nor_top_b, 3};
+    return launch_dw(T, 9, num_mask, stream);
+}

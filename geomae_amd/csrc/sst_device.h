@@ -1,0 +1,246 @@
+// Device helpers shared by the fused SST layer kernels and the fused heads+loss kernel (gfx950).
+// See sst_layer.hip for the design notes (T-layout, K-permuted packed weights, LDS-shared weight tiles).
+#pragma once
+#include "common.h"
+
+namespace geomae {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+__device__ __forceinline__ f32x4 mfma32(uint4 a, uint4 b, f32x4 c) {
+    union { uint4 u; bf16x8_t v; } fa, fb;
+    fa.u = a;
+    fb.u = b;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ unsigned int f2bf_bits(float f) {
+    unsigned int u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf_bits(a) | (f2bf_bits(b) << 16); }
+__device__ __forceinline__ uint2 pack4(const f32x4 v) { return make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])); }
+__device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
+__device__ __forceinline__ f32x4 unpack4(const uint2 p) {
+    f32x4 v = {bf_lo(p.x), bf_hi(p.x), bf_lo(p.y), bf_hi(p.y)};
+    return v;
+}
+
+// packed position p (inside a row of K) <-> original contraction index k
+__host__ __device__ __forceinline__ int kperm(int p) { return (p & ~31) + 16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3); }
+
+// ------------------------------------------------------------------------------------------------
+// Y^T[N x 16 tokens] += Wp[N x K] * X^T : acc[ot][r] = Y[t][16*ot + 4*g + r]  (T-layout in, T-layout out)
+// ------------------------------------------------------------------------------------------------
+constexpr int kLayerBlk = 256;   // 4 waves = 4 token tiles (64 tokens) per workgroup
+constexpr int kPad = 8;          // bf16 elements (16 B) of row padding in LDS: b128 fragment reads conflict-free
+constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256][128] (also covers [128][256])
+
+// The workgroup's 4 waves share every weight matrix through LDS: one cooperative copy (L2 -> LDS, 16 B per
+// lane) per matrix per 64 tokens, then each wave reads its A fragments with ds_read_b128.  Without this
+// every wave pulled the whole matrix through its own vector-memory pipe with 1-2 loads in flight (the
+// kernels ran at ~260 cycles per MFMA, profiles/r01b).  All waves of the block must call this together.
+template <int K, int N>
+__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
+                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane) {
+    constexpr int LD = K + kPad;
+    constexpr int CH = K / 8;                  // 16-byte chunks per row
+    constexpr int PASSES = N * CH / kLayerBlk;
+    static_assert(N * CH % kLayerBlk == 0, "matrix must tile over the block");
+    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
+    u32x4 stage[PASSES];
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = p * kLayerBlk + threadIdx.x;
+        stage[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
+    }
+    __syncthreads();                           // previous matrix fully consumed by every wave
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = p * kLayerBlk + threadIdx.x;
+        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = stage[p];
+    }
+    __syncthreads();
+    const int o = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < N / 16; ++ot) {
+        const bf16_t* wrow = smem + (16 * ot + o) * LD + 8 * g;
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) {
+            const uint4 a = *reinterpret_cast<const uint4*>(wrow + 32 * kk);
+            const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
+            acc[ot] = mfma32(a, b, acc[ot]);
+        }
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&acc)[N / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < N / 16; ++ot) {
+        const float4 v = *reinterpret_cast<const float4*>(b + 16 * ot + 4 * g);
+        acc[ot][0] = v.x; acc[ot][1] = v.y; acc[ot][2] = v.z; acc[ot][3] = v.w;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int64_t tok, bool valid,
+                                              f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) t = *reinterpret_cast<const float4*>(src + tok * C + 16 * ct + 4 * g);
+        v[ct][0] = t.x; v[ct][1] = t.y; v[ct][2] = t.z; v[ct][3] = t.w;
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int64_t tok, bool valid,
+                                               uint2 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) {
+        v[ct] = valid ? *reinterpret_cast<const uint2*>(src + tok * C + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+    }
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int64_t tok, bool valid,
+                                               const f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+    if (!valid) return;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        *reinterpret_cast<float4*>(dst + tok * C + 16 * ct + 4 * g) = make_float4(v[ct][0], v[ct][1], v[ct][2], v[ct][3]);
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int64_t tok, int ld, int col0, bool valid,
+                                                const f32x4 (&v)[C / 16], int lane) {
+    const int g = lane >> 4;
+    if (!valid) return;
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        *reinterpret_cast<uint2*>(dst + tok * ld + col0 + 16 * ct + 4 * g) = pack4(v[ct]);
+}
+
+// sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)
+__device__ __forceinline__ float row_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// LayerNorm over 128 channels in T-layout; returns xhat in place, rstd out
+__device__ __forceinline__ void layer_norm_t(f32x4 (&u)[8], float eps, float* rstd_out) {
+    float s = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) s += (u[ct][0] + u[ct][1]) + (u[ct][2] + u[ct][3]);
+    const float mean = row_sum(s) * (1.0f / 128.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float d = u[ct][r] - mean;
+            u[ct][r] = d;
+            q += d * d;
+        }
+    const float var = row_sum(q) * (1.0f / 128.0f);
+    const float rstd = rsqrtf(var + eps);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) u[ct][r] *= rstd;
+    *rstd_out = rstd;
+}
+
+__device__ __forceinline__ void affine_t(const f32x4 (&xhat)[8], const float* __restrict__ w,
+                                         const float* __restrict__ b, f32x4 (&y)[8], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
+        const float4 bv = *reinterpret_cast<const float4*>(b + 16 * ct + 4 * g);
+        y[ct][0] = xhat[ct][0] * wv.x + bv.x;
+        y[ct][1] = xhat[ct][1] * wv.y + bv.y;
+        y[ct][2] = xhat[ct][2] * wv.z + bv.z;
+        y[ct][3] = xhat[ct][3] * wv.w + bv.w;
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma     (in place on dy)
+__device__ __forceinline__ void layer_norm_bwd_t(f32x4 (&dy)[8], const f32x4 (&xhat)[8], const float* __restrict__ w,
+                                                 float rstd, int lane) {
+    const int g = lane >> 4;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
+        dy[ct][0] *= wv.x; dy[ct][1] *= wv.y; dy[ct][2] *= wv.z; dy[ct][3] *= wv.w;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s1 += dy[ct][r];
+            s2 += dy[ct][r] * xhat[ct][r];
+        }
+    }
+    const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dy[ct][r] = rstd * (dy[ct][r] - m1 - xhat[ct][r] * m2);
+}
+
+// GELU (erf form, as F.gelu) and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one
+// exp + one rcp instead of libm erff (~60 instructions); exp(-x^2/2) is shared with the pdf term.
+__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float erf_abs = 1.0f - poly * e;
+    *cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    *pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float gelu_f(float x) {
+    float c, p;
+    gelu_parts(x, &c, &p);
+    return x * c;
+}
+__device__ __forceinline__ float gelu_grad(float x) {
+    float c, p;
+    gelu_parts(x, &c, &p);
+    return c + x * p;
+}
+
+// sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
+__device__ __forceinline__ float tok_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+
+
+// weight-gradient (token contraction) tasks, see dw_kernel in sst_layer.hip
+struct DwTask {
+    const bf16_t* A; int lda, a_col0;
+    const bf16_t* B; int ldb, b_col0;
+    float* C; int ldc, c_row0, c_col0;
+    float* dbias;
+    int rows_valid;          // only rows i < rows_valid of the 128-row block exist
+};
+constexpr int kMaxDwTasks = 12;
+struct DwTasks { DwTask t[kMaxDwTasks]; };
+int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t stream);
+
+}  // namespace geomae

@@ -26,36 +26,9 @@
 #include "common.h"
 #include "../../include/geomae_hip.h"
 
+#include "sst_device.h"
+
 namespace geomae {
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-typedef unsigned short bf16_t;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-
-__device__ __forceinline__ f32x4 mfma32(uint4 a, uint4 b, f32x4 c) {
-    union { uint4 u; bf16x8_t v; } fa, fb;
-    fa.u = a;
-    fb.u = b;
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ unsigned int f2bf_bits(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return u >> 16;
-}
-__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf_bits(a) | (f2bf_bits(b) << 16); }
-__device__ __forceinline__ uint2 pack4(const f32x4 v) { return make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])); }
-__device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
-__device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
-__device__ __forceinline__ f32x4 unpack4(const uint2 p) {
-    f32x4 v = {bf_lo(p.x), bf_hi(p.x), bf_lo(p.y), bf_hi(p.y)};
-    return v;
-}
-
-// packed position p (inside a row of K) <-> original contraction index k
-__host__ __device__ __forceinline__ int kperm(int p) { return (p & ~31) + 16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3); }
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: desc[d] = {src_off, rows, cols, transpose, dst_off}; dst [R][K] bf16 with
@@ -63,10 +36,14 @@ __host__ __device__ __forceinline__ int kperm(int p) { return (p & ~31) + 16 * (
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ flat,
                                                            const int64_t* __restrict__ desc,
-                                                           bf16_t* __restrict__ packed) {
+                                                           bf16_t* __restrict__ packed, float* __restrict__ aux) {
     const int64_t* d = desc + (int64_t)blockIdx.y * 5;
     const int64_t src = d[0], rows = d[1], cols = d[2], tr = d[3], dst = d[4];
     const int64_t total = rows * cols;
+    if (tr == 2) {        // plain fp32 gather into the aux vector (e.g. concatenated biases)
+        for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) aux[dst + e] = flat[src + e];
+        return;
+    }
     const int64_t K = tr ? rows : cols;
     for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t r = e / K;
@@ -76,202 +53,6 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         packed[dst + e] = (bf16_t)f2bf_bits(v);
     }
 }
-
-// ------------------------------------------------------------------------------------------------
-// Y^T[N x 16 tokens] += Wp[N x K] * X^T : acc[ot][r] = Y[t][16*ot + 4*g + r]  (T-layout in, T-layout out)
-// ------------------------------------------------------------------------------------------------
-constexpr int kLayerBlk = 256;   // 4 waves = 4 token tiles (64 tokens) per workgroup
-constexpr int kPad = 8;          // bf16 elements (16 B) of row padding in LDS: b128 fragment reads conflict-free
-constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256][128] (also covers [128][256])
-
-// The workgroup's 4 waves share every weight matrix through LDS: one cooperative copy (L2 -> LDS, 16 B per
-// lane) per matrix per 64 tokens, then each wave reads its A fragments with ds_read_b128.  Without this
-// every wave pulled the whole matrix through its own vector-memory pipe with 1-2 loads in flight (the
-// kernels ran at ~260 cycles per MFMA, profiles/r01b).  All waves of the block must call this together.
-template <int K, int N>
-__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
-                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane) {
-    constexpr int LD = K + kPad;
-    constexpr int CH = K / 8;                  // 16-byte chunks per row
-    constexpr int PASSES = N * CH / kLayerBlk;
-    static_assert(N * CH % kLayerBlk == 0, "matrix must tile over the block");
-    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
-    u32x4 stage[PASSES];
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int c = p * kLayerBlk + threadIdx.x;
-        stage[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
-    }
-    __syncthreads();                           // previous matrix fully consumed by every wave
-#pragma unroll
-    for (int p = 0; p < PASSES; ++p) {
-        const int c = p * kLayerBlk + threadIdx.x;
-        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = stage[p];
-    }
-    __syncthreads();
-    const int o = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int ot = 0; ot < N / 16; ++ot) {
-        const bf16_t* wrow = smem + (16 * ot + o) * LD + 8 * g;
-#pragma unroll
-        for (int kk = 0; kk < K / 32; ++kk) {
-            const uint4 a = *reinterpret_cast<const uint4*>(wrow + 32 * kk);
-            const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
-            acc[ot] = mfma32(a, b, acc[ot]);
-        }
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&acc)[N / 16], int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ot = 0; ot < N / 16; ++ot) {
-        const float4 v = *reinterpret_cast<const float4*>(b + 16 * ot + 4 * g);
-        acc[ot][0] = v.x; acc[ot][1] = v.y; acc[ot][2] = v.z; acc[ot][3] = v.w;
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int64_t tok, bool valid,
-                                              f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) t = *reinterpret_cast<const float4*>(src + tok * C + 16 * ct + 4 * g);
-        v[ct][0] = t.x; v[ct][1] = t.y; v[ct][2] = t.z; v[ct][3] = t.w;
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int64_t tok, bool valid,
-                                               uint2 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) {
-        v[ct] = valid ? *reinterpret_cast<const uint2*>(src + tok * C + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-    }
-}
-
-template <int C>
-__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int64_t tok, bool valid,
-                                               const f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-    if (!valid) return;
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct)
-        *reinterpret_cast<float4*>(dst + tok * C + 16 * ct + 4 * g) = make_float4(v[ct][0], v[ct][1], v[ct][2], v[ct][3]);
-}
-
-template <int C>
-__device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int64_t tok, int ld, int col0, bool valid,
-                                                const f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-    if (!valid) return;
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct)
-        *reinterpret_cast<uint2*>(dst + tok * ld + col0 + 16 * ct + 4 * g) = pack4(v[ct]);
-}
-
-// sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)
-__device__ __forceinline__ float row_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
-
-// LayerNorm over 128 channels in T-layout; returns xhat in place, rstd out
-__device__ __forceinline__ void layer_norm_t(f32x4 (&u)[8], float eps, float* rstd_out) {
-    float s = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) s += (u[ct][0] + u[ct][1]) + (u[ct][2] + u[ct][3]);
-    const float mean = row_sum(s) * (1.0f / 128.0f);
-    float q = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float d = u[ct][r] - mean;
-            u[ct][r] = d;
-            q += d * d;
-        }
-    const float var = row_sum(q) * (1.0f / 128.0f);
-    const float rstd = rsqrtf(var + eps);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) u[ct][r] *= rstd;
-    *rstd_out = rstd;
-}
-
-__device__ __forceinline__ void affine_t(const f32x4 (&xhat)[8], const float* __restrict__ w,
-                                         const float* __restrict__ b, f32x4 (&y)[8], int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
-        const float4 bv = *reinterpret_cast<const float4*>(b + 16 * ct + 4 * g);
-        y[ct][0] = xhat[ct][0] * wv.x + bv.x;
-        y[ct][1] = xhat[ct][1] * wv.y + bv.y;
-        y[ct][2] = xhat[ct][2] * wv.z + bv.z;
-        y[ct][3] = xhat[ct][3] * wv.w + bv.w;
-    }
-}
-
-// dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma     (in place on dy)
-__device__ __forceinline__ void layer_norm_bwd_t(f32x4 (&dy)[8], const f32x4 (&xhat)[8], const float* __restrict__ w,
-                                                 float rstd, int lane) {
-    const int g = lane >> 4;
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const float4 wv = *reinterpret_cast<const float4*>(w + 16 * ct + 4 * g);
-        dy[ct][0] *= wv.x; dy[ct][1] *= wv.y; dy[ct][2] *= wv.z; dy[ct][3] *= wv.w;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            s1 += dy[ct][r];
-            s2 += dy[ct][r] * xhat[ct][r];
-        }
-    }
-    const float m1 = row_sum(s1) * (1.0f / 128.0f), m2 = row_sum(s2) * (1.0f / 128.0f);
-#pragma unroll
-    for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dy[ct][r] = rstd * (dy[ct][r] - m1 - xhat[ct][r] * m2);
-}
-
-// GELU (erf form, as F.gelu) and its derivative.  erf by Abramowitz-Stegun 7.1.26 (|err| < 1.5e-7): one
-// exp + one rcp instead of libm erff (~60 instructions); exp(-x^2/2) is shared with the pdf term.
-__device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
-    const float e = __expf(-z * z);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float erf_abs = 1.0f - poly * e;
-    *cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
-    *pdf = 0.3989422804014327f * e;
-}
-__device__ __forceinline__ float gelu_f(float x) {
-    float c, p;
-    gelu_parts(x, &c, &p);
-    return x * c;
-}
-__device__ __forceinline__ float gelu_grad(float x) {
-    float c, p;
-    gelu_parts(x, &c, &p);
-    return c + x * p;
-}
-
-// sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
-__device__ __forceinline__ float tok_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
-
 
 struct LayerW {
     const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
@@ -540,14 +321,6 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __
 // DW: C[c_row0 + i][c_col0 + j] += sum_t A[t][a_col0 + i] * B[t][b_col0 + j],  i, j < 128
 //     dbias[c_row0 + i]         += sum_t A[t][a_col0 + i]                        (if dbias)
 // ------------------------------------------------------------------------------------------------
-struct DwTask {
-    const bf16_t* A; int lda, a_col0;
-    const bf16_t* B; int ldb, b_col0;
-    float* C; int ldc, c_row0, c_col0;
-    float* dbias;
-};
-struct DwTasks { DwTask t[8]; };
-
 constexpr int kDwTok = 32;          // tokens per slab (= MFMA K)
 constexpr int kDwLd = kDwTok + 8;   // padded LDS row (80 bytes: 16-byte aligned, conflict-free b128 reads)
 
@@ -614,7 +387,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 32 * wave + 16 * it + 4 * g + r, j = 16 * jt + o;
-                atomicAdd(T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j, acc[it][jt][r]);
+                if (i < T.rows_valid) atomicAdd(T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j, acc[it][jt][r]);
             }
     if (T.dbias) {
 #pragma unroll
@@ -622,7 +395,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
             float v = bsum[e];
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
             v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
-            if (st == 0) atomicAdd(T.dbias + T.c_row0 + 16 * sc + e, v);
+            if (st == 0 && 16 * sc + e < T.rows_valid) atomicAdd(T.dbias + T.c_row0 + 16 * sc + e, v);
         }
     }
 }
@@ -651,13 +424,13 @@ static int check_weights(const GeomaeSstLayerWeights* w, const char* who) {
 using namespace geomae;
 
 extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc,
-                                   int64_t max_elems, void* packed_bf16, hipStream_t stream) {
+                                   int64_t max_elems, void* packed_bf16, float* aux_f32, hipStream_t stream) {
     if (num_desc <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(desc && packed_bf16 && max_elems > 0, "pack_weights: bad argument");
     int gx = (int)((max_elems + 255) / 256);
     if (gx > 128) gx = 128;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, num_desc), dim3(256), 0, stream, flat_params, desc,
-                       (bf16_t*)packed_bf16);
+                       (bf16_t*)packed_bf16, aux_f32);
     return check_launch("pack_weights_kernel");
 }
 
@@ -738,20 +511,24 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
                  *du = (const bf16_t*)du_bf16, *at = (const bf16_t*)attn_bf16, *dhp = (const bf16_t*)dhp_bf16,
                  *y = (const bf16_t*)y_bf16, *dv = (const bf16_t*)dv_bf16, *h = (const bf16_t*)h_bf16;
     DwTasks T;
-    //          A     lda a0   B   ldb b0  C        ldc  r0   c0  dbias
-    T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv};   // dWq
-    T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv};   // dWk
-    T.t[2] = {dqkv, 384, 256, xb, 128, 0, g->wqkv, 128, 256, 0,  g->bqkv};   // dWv
-    T.t[3] = {du,   128, 0,   at, 128, 0, g->wo,   128, 0,   0,  g->bo};     // dWo
-    T.t[4] = {dhp,  256, 0,   y,  128, 0, g->w1,   128, 0,   0,  g->b1};     // dW1 rows 0..127
-    T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1};     // dW1 rows 128..255
-    T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2};    // dW2 cols 0..127
-    T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr};  // dW2 cols 128..255
+    //          A     lda a0   B   ldb b0  C        ldc  r0   c0  dbias     rows
+    T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv, 128};   // dWq
+    T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv, 128};   // dWk
+    T.t[2] = {dqkv, 384, 256, xb, 128, 0, g->wqkv, 128, 256, 0,  g->bqkv, 128};   // dWv
+    T.t[3] = {du,   128, 0,   at, 128, 0, g->wo,   128, 0,   0,  g->bo,   128};   // dWo
+    T.t[4] = {dhp,  256, 0,   y,  128, 0, g->w1,   128, 0,   0,  g->b1,   128};   // dW1 rows 0..127
+    T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1,   128};   // dW1 rows 128..255
+    T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2,   128};  // dW2 cols 0..127
+    T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
+    return launch_dw(T, 8, num_tokens, stream);
+}
+
+int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
     int G = cdiv(num_tokens, 512);
     if (G > 32) G = 32;
     int chunk = cdiv(num_tokens, G);
     chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
     G = cdiv(num_tokens, chunk);
-    hipLaunchKernelGGL(dw_kernel, dim3(G, 8), dim3(256), 0, stream, T, num_tokens, chunk);
+    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks), dim3(256), 0, stream, T, num_tokens, chunk);
     return check_launch("dw_kernel");
 }

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
     const int32_t* __restrict__ mask_counts, TargetCfg cfg, float* __restrict__ centroid_low,
     uint8_t* __restrict__ mask_low, float* __restrict__ centroid_med, uint8_t* __restrict__ mask_med,
     float* __restrict__ centroid_top, float* __restrict__ top_raw, float* __restrict__ med_raw,
-    uint8_t* __restrict__ med_raw_mask) {
+    uint8_t* __restrict__ med_raw_mask, int32_t* __restrict__ occ_counts) {
     __shared__ unsigned long long s_low[kLowMax * 3];
     __shared__ unsigned long long s_med[kMedMax * 3];
     __shared__ int c_low[kLowMax];
@@ -117,6 +117,14 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
                 med_raw[((int64_t)p * n_med + lane) * 3 + d] = c;
                 if (row >= 0) centroid_med[((int64_t)row * n_med + lane) * 3 + d] = nc;
             }
+        }
+        if (occ_counts && row >= 0) {      // occupied cells of this output row (loss normalisers)
+            int ol = 0;
+            for (int sl = lane; sl < n_low; sl += 64) ol += c_low[sl] > 0;
+            const int om = (lane < n_med && c_med[lane] > 0) ? 1 : 0;
+            ol = wave_sum(ol);
+            const int omt = wave_sum(om);
+            if (lane == 0) { atomicAdd(&occ_counts[0], ol); atomicAdd(&occ_counts[1], omt); }
         }
         // --- low sub-voxels (masked rows only)
         if (row >= 0) {
@@ -285,7 +293,7 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
                                        const GeomaeTargetConfig* config, float* centroid_low, uint8_t* mask_low,
                                        float* centroid_med, uint8_t* mask_med, float* centroid_top, float* normal,
                                        double* curv, float* top_raw, float* med_raw, uint8_t* med_raw_mask,
-                                       float* cov_out, hipStream_t stream) {
+                                       float* cov_out, int32_t* occ_counts, hipStream_t stream) {
     if (max_pillars <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(points && order && seg_start && num_pillars && voxel_coors && coors_med && coors_low && cell_table,
                    "geometry_targets: null input");
@@ -296,10 +304,11 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
     int rc = fill_cfg(c, config);
     if (rc) return rc;
     const int grid = max_pillars < 256 * 64 ? max_pillars : 256 * 64;
+    if (occ_counts) GEOMAE_HIP(hipMemsetAsync(occ_counts, 0, 2 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(centroid_targets_kernel, dim3(grid), dim3(64), 0, stream, points, num_features, order,
                        seg_start, num_pillars, (const int4*)voxel_coors, (const int4*)coors_med,
                        (const int4*)coors_low, token_row, mask_counts, c, centroid_low, mask_low, centroid_med,
-                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask);
+                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask, occ_counts);
     hipLaunchKernelGGL(normal_curv_kernel, dim3(grid), dim3(64), 0, stream, num_pillars, (const int4*)voxel_coors,
                        cell_table, token_row, mask_counts, c, batch_size, top_raw, med_raw, med_raw_mask, normal, curv,
                        cov_out);

@@ -79,12 +79,27 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
 
     def forward_train(self, points, img_metas=None, gt_bboxes_3d=None, gt_labels_3d=None, gt_bboxes_ignore=None,
                       ids_keep=None, ids_mask=None):
+        if getattr(self.backbone, "fused", False):
+            return self.forward_train_fused(points, ids_keep=ids_keep, ids_mask=ids_mask)
         x, tgt = self.extract_feat(points, gt_bboxes_3d, gt_labels_3d, img_metas, ids_keep=ids_keep,
                                    ids_mask=ids_mask)
         reg_low, reg_med, reg_top, nor_low, nor_med, nor_top, cls_low, cls_med = x
         return self.forward_loss(tgt["centroid_low"], tgt["mask_low"], tgt["centroid_med"], tgt["mask_med"],
                                  tgt["centroid_top"], tgt["normal"], None, None, reg_low, reg_med, reg_top, nor_low,
                                  nor_med, nor_top, cls_low, cls_med)
+
+    LOSS_KEYS = ("loss_curv_around", "loss_centroid_low", "loss_centroid_med", "loss_centroid_top", "loss_cls_low",
+                 "loss_cls_med")
+
+    def forward_train_fused(self, points, ids_keep=None, ids_mask=None):
+        """Same result as extract_feat + backbone heads + forward_loss, without materialising the eight
+        prediction tensors: the heads, the six losses and their gradients are one kernel."""
+        (voxel_features, feature_coors, ik, im, tgt), batch_size = self.prepare(points, ids_keep, ids_mask), len(points)
+        w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
+             self.cls_loss_ratio_low, self.cls_loss_ratio_med)
+        losses = self.backbone.forward_losses(voxel_features[ik], feature_coors[ik], feature_coors[im], batch_size,
+                                              tgt, w)
+        return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     # ------------------------------------------------------------------ preprocessing
     @torch.no_grad()
@@ -109,8 +124,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         self._iter += 1
         return ops.random_mask(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
 
-    def extract_feat(self, points, gt_bboxes_3d=None, gt_labels_3d=None, img_metas=None, vis=False, ids_keep=None,
-                     ids_mask=None):
+    def prepare(self, points, ids_keep=None, ids_mask=None):
+        """voxelize x3 -> pillar segments -> VFE -> mask -> geometric targets (ssl.py:172-231)."""
         batch_size = len(points)
         voxels, coors, sub_med, sub_low = self.voxelize_all(points)
         seg = ops.pillar_segment(coors, batch_size, self.grid_size)
@@ -124,9 +139,12 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         with torch.no_grad():
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts,
                                        n_rows=int(ids_mask.numel()))
-        ik, im = ids_keep.long(), ids_mask.long()
-        mask_coors = feature_coors[im]
-        x = self.backbone(voxel_features[ik], feature_coors[ik], mask_coors, batch_size)
+        return voxel_features, feature_coors, ids_keep.long(), ids_mask.long(), tgt
+
+    def extract_feat(self, points, gt_bboxes_3d=None, gt_labels_3d=None, img_metas=None, vis=False, ids_keep=None,
+                     ids_mask=None):
+        voxel_features, feature_coors, ik, im, tgt = self.prepare(points, ids_keep, ids_mask)
+        x = self.backbone(voxel_features[ik], feature_coors[ik], feature_coors[im], len(points))
         return x, tgt
 
     # ------------------------------------------------------------------ losses (ssl.py:837-902)

@@ -297,16 +297,18 @@ def geometry_targets(points, seg, coors_med, coors_low, cfg, token_row=None, cou
         top_raw=torch.empty((max(V, 1), 3), dtype=f32, device=dev),
         med_raw=torch.empty((max(V, 1), s_med, 3), dtype=f32, device=dev),
         med_raw_mask=torch.empty((max(V, 1), s_med), dtype=u8, device=dev),
-        cov=torch.empty((M, 6), dtype=f32, device=dev) if want_cov else None)
+        cov=torch.empty((M, 6), dtype=f32, device=dev) if want_cov else None,
+        occ_counts=torch.empty(2, dtype=torch.int32, device=dev))
     check(_lib.load().geomae_geometry_targets(
         _ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start), _ptr(seg.num_pillars), V,
         _ptr(seg.voxel_coors), _ptr(coors_med), _ptr(coors_low), _ptr(seg.cell_table), seg.batch_size,
         _ptr(token_row), _ptr(counts), ctypes.byref(cfg), _ptr(out["centroid_low"]), _ptr(out["mask_low"]),
         _ptr(out["centroid_med"]), _ptr(out["mask_med"]), _ptr(out["centroid_top"]), _ptr(out["normal"]),
         _ptr(out["curv"]), _ptr(out["top_raw"]), _ptr(out["med_raw"]), _ptr(out["med_raw_mask"]), _ptr(out["cov"]),
-        _stream()), "geomae_geometry_targets")
-    out["mask_low"] = out["mask_low"].bool()
-    out["mask_med"] = out["mask_med"].bool()
+        _ptr(out["occ_counts"]), _stream()), "geomae_geometry_targets")
+    out["mask_low_u8"], out["mask_med_u8"] = out["mask_low"], out["mask_med"]
+    out["mask_low"] = out["mask_low"].view(torch.bool)
+    out["mask_med"] = out["mask_med"].view(torch.bool)
     return out
 
 
@@ -409,9 +411,32 @@ def window_attention_raw(qkv, layout, num_heads):
 
 
 # ------------------------------------------------------------------------------------ fused SST layer
-def pack_weights(desc, num_desc, max_elems, packed):
+def pack_weights(desc, num_desc, max_elems, packed, aux=None):
     check(_lib.load().geomae_pack_weights(ctypes.c_void_p(0), _ptr(desc), num_desc, max_elems, _ptr(packed),
-                                          _stream()), "geomae_pack_weights")
+                                          _ptr(aux), _stream()), "geomae_pack_weights")
+
+
+def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights):
+    """-> losses [6] f32, d_cen, d_den [n,128] f32 (gradient of sum(losses)), saved = (dlogits, cm_b, dm_b)."""
+    dev = cen.device
+    n = cen.shape[0]
+    losses = torch.empty(6, dtype=torch.float32, device=dev)
+    d_cen = torch.zeros_like(cen)
+    d_den = torch.zeros_like(den)
+    dl = torch.empty((n_mask, 896), dtype=torch.bfloat16, device=dev)
+    cm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
+    dm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
+    check(_lib.load().geomae_heads_loss(
+        _ptr(cen), _ptr(den), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["centroid_low"]),
+        _ptr(tgt["mask_low_u8"]), _ptr(tgt["centroid_med"]), _ptr(tgt["mask_med_u8"]), _ptr(tgt["centroid_top"]),
+        _ptr(tgt["normal"]), _ptr(tgt["occ_counts"]), f3(weights), _ptr(losses), _ptr(d_cen), _ptr(d_den), _ptr(dl),
+        _ptr(cm_b), _ptr(dm_b), _stream()), "geomae_heads_loss")
+    return losses, d_cen, d_den, (dl, cm_b, dm_b)
+
+
+def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
+    check(_lib.load().geomae_heads_weight_grad(n_mask, _ptr(dl), _ptr(cm_b), _ptr(dm_b), ctypes.byref(grads),
+                                               _stream()), "geomae_heads_weight_grad")
 
 
 def sst_qkv_forward(x, layout, pos_table, w):

@@ -46,15 +46,21 @@ class PackedLayers:
     forward, plus the per-layer C structs handed to the fused kernels."""
     PER_LAYER = 262144   # bf16 elements: wqkv 49152 | wqkT 32768 | wvT 16384 | wo, woT 16384 x2 | w1, w1T, w2, w2T 32768 x4
 
-    def __init__(self, layers):
+    HEAD_ROWS = (("decoder_pred_low", 0), ("cls_pred_low", 384), ("decoder_pred_med", 640), ("cls_pred_med", 688),
+                 ("decoder_pred_top", 720), ("decoder_pred_density_top", 768))   # row offsets in the [800,128] block
+
+    def __init__(self, layers, backbone=None):
         self.layers = list(layers)
+        self.backbone = backbone          # owner of the six head Linears (None: layers only)
         self.key = None
         self.packed = None
 
     def _build(self, dev):
         from ._lib import GeomaeSstLayerWeights
         n = len(self.layers)
-        self.packed = torch.empty(n * self.PER_LAYER, dtype=torch.bfloat16, device=dev)
+        self.packed = torch.zeros(n * self.PER_LAYER + 800 * 128, dtype=torch.bfloat16, device=dev)
+        self.head_w = self.packed[n * self.PER_LAYER:]
+        self.head_bias = torch.zeros(800, dtype=torch.float32, device=dev)
         base = self.packed.data_ptr()
         desc, self.structs = [], []
 
@@ -80,11 +86,18 @@ class PackedLayers:
             st.ln2_w, st.ln2_b = L.norm2.weight.data_ptr(), L.norm2.bias.data_ptr()
             st.d_model, st.d_ffn, st.ln_eps = 128, 256, L.norm1.eps
             self.structs.append(st)
+        if self.backbone is not None:
+            for name, row0 in self.HEAD_ROWS:
+                lin = getattr(self.backbone, name)
+                desc.append([f(lin.weight), lin.weight.shape[0], 128, 0, n * self.PER_LAYER + row0 * 128])
+                desc.append([f(lin.bias), lin.bias.shape[0], 1, 2, row0])
         self.desc = torch.tensor(desc, dtype=torch.int64, device=dev)
         self.n_desc = len(desc)
 
     def _key(self):
-        return tuple(p.data_ptr() for L in (self.layers[0], self.layers[-1]) for p in L.parameters()) + \
+        heads = () if self.backbone is None else tuple(
+            getattr(self.backbone, n).weight.data_ptr() for n, _ in self.HEAD_ROWS)
+        return tuple(p.data_ptr() for L in (self.layers[0], self.layers[-1]) for p in L.parameters()) + heads + \
             (self.layers[0].linear1.weight.device,)
 
     def refresh(self):
@@ -93,7 +106,7 @@ class PackedLayers:
         if k != self.key:
             self._build(k[-1])
             self.key = k
-        ops.pack_weights(self.desc, self.n_desc, 384 * 128, self.packed)
+        ops.pack_weights(self.desc, self.n_desc, 384 * 128, self.packed, self.head_bias)
 
     def grads(self, layer_index):
         """C struct of gradient pointers; allocates .grad where autograd has not yet."""
@@ -109,6 +122,40 @@ class PackedLayers:
                 p.grad = torch.zeros_like(p)
             setattr(g, k, p.grad.data_ptr())
         return g
+
+
+    def head_grads(self):
+        from ._lib import GeomaeHeadGrads
+        g = GeomaeHeadGrads()
+        names = dict(reg_low="decoder_pred_low", cls_low="cls_pred_low", reg_med="decoder_pred_med",
+                     cls_med="cls_pred_med", reg_top="decoder_pred_top", nor_top="decoder_pred_density_top")
+        for k, attr in names.items():
+            lin = getattr(self.backbone, attr)
+            for suffix, p in (("_w", lin.weight), ("_b", lin.bias)):
+                if p.grad is None:
+                    p.grad = torch.zeros_like(p)
+                setattr(g, k + suffix, p.grad.data_ptr())
+        return g
+
+
+class _HeadsLoss(torch.autograd.Function):
+    """Six heads + six losses + their backward in one kernel (ops.heads_loss).  Returns the [6] loss vector
+    (curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med), each already multiplied by its
+    loss ratio; gradients assume the objective is their plain sum (as mmdet's _parse_losses forms it)."""
+
+    @staticmethod
+    def forward(ctx, cen, den, packed, n_keep, n_mask, tgt, weights):
+        losses, d_cen, d_den, saved = ops.heads_loss(cen.contiguous(), den.contiguous(), n_keep, n_mask, packed.head_w,
+                                                     packed.head_bias, tgt, weights)
+        ctx.packed, ctx.n_mask, ctx.saved = packed, n_mask, saved
+        ctx.save_for_backward(d_cen, d_den)
+        return losses
+
+    @staticmethod
+    def backward(ctx, dl):
+        d_cen, d_den = ctx.saved_tensors
+        ops.heads_weight_grad(ctx.n_mask, *ctx.saved, ctx.packed.head_grads())
+        return d_cen, d_den, None, None, None, None, None
 
 
 class _FusedLayer(torch.autograd.Function):
@@ -272,7 +319,7 @@ class MultiMAESSTSPChoose(nn.Module):
         # the largest training bucket must hold a full window
         all_layers = [l for stack in (self.encoder_blocks, self.decoder_centroid_blocks, self.decoder_density_blocks)
                       for b in stack for l in b.encoder_list]
-        self._packed = PackedLayers(all_layers)
+        self._packed = PackedLayers(all_layers, backbone=self)
         self._stack_base = {"enc": 0, "cen": 2 * encoder_num_blocks,
                             "den": 2 * (encoder_num_blocks + decoder_num_blocks)}
         info = drop_info[0] if isinstance(drop_info, tuple) else drop_info
@@ -315,15 +362,28 @@ class MultiMAESSTSPChoose(nn.Module):
     def forward_encoder(self, x, layouts, pos):
         return self._run_stack(self.encoder_blocks, "enc", x, pos, layouts)
 
-    def forward_decoder(self, visible_voxel_feat, coors, coors_mask, batch_size):
-        dt = self._dtype()
-        masked_start_id = coors.shape[0]
+    def forward_losses(self, voxel_feat, coors, coors_mask, batch_size, tgt, loss_weights):
+        """Fused training path: encoder, both decoder stacks, then heads + losses (+ their backward) in one
+        kernel -- the eight prediction tensors of forward() are never materialised.  Returns the [6] losses."""
+        assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
+        self._packed.refresh()
+        layouts, pos = self.get_voxel_info(coors, batch_size)
+        x = self.forward_encoder(voxel_feat.float(), layouts, pos)
+        cen, den = self.decode(x, coors, coors_mask, batch_size)
+        return _HeadsLoss.apply(cen, den, self._packed, coors.shape[0], coors_mask.shape[0], tgt, loss_weights)
+
+    def decode(self, visible_voxel_feat, coors, coors_mask, batch_size):
         mask_tokens = self.mask_token.repeat(coors_mask.shape[0], 1)
         tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)
         coors_all = torch.cat([coors, coors_mask], dim=0)
         layouts, pos = self.get_voxel_info(coors_all, batch_size)
         cen = self._run_stack(self.decoder_centroid_blocks, "cen", tokens, pos, layouts)
         den = self._run_stack(self.decoder_density_blocks, "den", tokens, pos, layouts)
+        return cen, den
+
+    def forward_decoder(self, visible_voxel_feat, coors, coors_mask, batch_size):
+        masked_start_id = coors.shape[0]
+        cen, den = self.decode(visible_voxel_feat, coors, coors_mask, batch_size)
         cm = cen[masked_start_id:]
         dm = den[masked_start_id:]
         reg_pred_low = self.decoder_pred_low(cm).view(-1, self.per_sub_voxel_num_low, 3)

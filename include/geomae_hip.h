@@ -115,6 +115,7 @@ int geomae_geometry_targets(const float* points, int32_t num_features, const int
                             uint8_t* mask_low, float* centroid_med, uint8_t* mask_med,
                             float* centroid_top, float* normal, double* curv, float* top_raw,
                             float* med_raw, uint8_t* med_raw_mask, float* cov_out,
+                            int32_t* occ_counts /* [2] occupied low / med cells over the output rows, may be NULL */,
                             geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A12-A16 windows */
@@ -177,7 +178,8 @@ typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into 
  * writes bf16 dst[r][p] = W[r][perm(p)] or, transposed, dst[c][p] = W[perm(p)][c].  src_offset is relative
  * to flat_params; flat_params may be NULL with src_offset = (device address / 4) for scattered tensors. */
 int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
-                        void* packed_bf16, geomaeStream_t stream);
+                        void* packed_bf16, float* aux_f32 /* target of transpose==2 rows: plain fp32 gather */,
+                        geomaeStream_t stream);
 /* qkv [n,384] bf16 = [(x + pos_table[tok_pos]) Wqk^T + b | x Wv^T + b];  x [n,128] fp32 */
 int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                            const GeomaeSstLayerWeights* w /*host*/, int32_t num_tokens, void* qkv_bf16,
@@ -205,6 +207,30 @@ int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16, const void
                            const void* du_bf16, const void* attn_bf16, const void* dhp_bf16, const void* y_bf16,
                            const void* dv_bf16, const void* h_bf16, const GeomaeSstLayerGrads* grads,
                            geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A22 heads + A23 losses, fused
+ * replaces the six decoder head Linears on the masked rows (bb.py:279-300) and forward_loss
+ * (ssl.py:837-902), forward AND backward, in one kernel.  dec_centroid / dec_density [n,128] f32 are the
+ * two decoder outputs (masked rows = num_keep .. num_keep + num_mask - 1).  head_w_packed [800,128] bf16
+ * (geomae_pack_weights, rows: reg_low 0.. | cls_low 384.. | reg_med 640.. | cls_med 688.. | reg_top 720.. |
+ * zeros | nor_top 768.. | zeros), head_bias [800] f32 in the same order.  Targets as produced by
+ * geomae_geometry_targets; occ_counts [2] = occupied low / med cells.  loss_weights (host) [6] and losses
+ * (device) [6] in the order curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med.
+ * Outputs: d_dec_* [n,128] f32 (masked rows written; caller zeroes the rest), and the bf16 operands of
+ * the head weight gradients: dlogits [M,896], cm, dm [M,128]. */
+int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep, int32_t num_mask,
+                      const void* head_w_packed, const float* head_bias, const float* centroid_low,
+                      const uint8_t* mask_low, const float* centroid_med, const uint8_t* mask_med,
+                      const float* centroid_top, const float* normal, const int32_t* occ_counts,
+                      const float* loss_weights /*host*/, float* losses, float* d_dec_centroid,
+                      float* d_dec_density, void* dlogits_bf16, void* cm_bf16, void* dm_bf16,
+                      geomaeStream_t stream);
+typedef struct GeomaeHeadGrads { /* fp32 gradient buffers of the six head Linears, accumulated into */
+    float *reg_low_w, *reg_low_b, *cls_low_w, *cls_low_b, *reg_med_w, *reg_med_b, *cls_med_w, *cls_med_b,
+          *reg_top_w, *reg_top_b, *nor_top_w, *nor_top_b;
+} GeomaeHeadGrads;
+int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const void* cm_bf16,
+                             const void* dm_bf16, const GeomaeHeadGrads* grads, geomaeStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -417,3 +417,35 @@ def test_fused_layer_matches_composed_layer(dev):
     assert rel(grads[0], grads[1]) < 3e-2, rel(grads[0], grads[1])
     bad = {k: rel(pgrads[0][k], pgrads[1][k]) for k in pgrads[0] if rel(pgrads[0][k], pgrads[1][k]) > 4e-2}
     assert not bad, bad
+
+
+def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
+    """forward_train (fused heads+loss kernel) vs extract_feat + forward_loss on the same model / mask:
+    losses and every gradient."""
+    g = np.load(os.path.join(golden_dir, "g_pipeline_tiny.npz"))
+    model, _ = _build(dev, 1, 1, "bf16")
+    pts = [torch.as_tensor(f, device=dev) for f in _frames()]
+    ik = torch.as_tensor(g["ids_keep"].astype(np.int64), device=dev)
+    im = torch.as_tensor(g["ids_mask"].astype(np.int64), device=dev)
+    res = []
+    for fused in (True, False):
+        for p in model.parameters():
+            p.grad = None
+        if fused:
+            losses = model.forward_train(pts, None, ids_keep=ik, ids_mask=im)
+        else:
+            x, tgt = model.extract_feat(pts, ids_keep=ik, ids_mask=im)
+            losses = model.forward_loss(tgt["centroid_low"], tgt["mask_low"], tgt["centroid_med"], tgt["mask_med"],
+                                        tgt["centroid_top"], tgt["normal"], None, None, *x)
+        sum(losses.values()).backward()
+        res.append(({k: float(v) for k, v in losses.items()},
+                    {k: p.grad.float().cpu().numpy().copy() for k, p in model.named_parameters()}))
+    (la, ga), (lb, gb) = res
+    for k in lb:
+        assert abs(la[k] - lb[k]) <= 5e-3 * max(1.0, abs(lb[k])), (k, la[k], lb[k])
+    bad = {}
+    for k in gb:
+        r = np.linalg.norm(ga[k] - gb[k]) / max(np.linalg.norm(gb[k]), 1e-9)
+        if r > 3e-2:
+            bad[k] = r
+    assert not bad, bad
