@@ -60,7 +60,7 @@ SIGNATURES = {
     "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
     "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),
     "geomae_geometry_targets": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P, P, c_int32, P, P,
-                                               POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P, P]),
+                                               POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P, c_int32, P]),
     "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_window_build": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, P, P, P, P,
                                            P, P, P, P, c_int64, P]),

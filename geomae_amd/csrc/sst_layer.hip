@@ -321,12 +321,25 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __
 // DW: C[c_row0 + i][c_col0 + j] += sum_t A[t][a_col0 + i] * B[t][b_col0 + j],  i, j < 128
 //     dbias[c_row0 + i]         += sum_t A[t][a_col0 + i]                        (if dbias)
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwTok = 32;          // tokens per slab (= MFMA K)
-constexpr int kDwLd = kDwTok + 8;   // padded LDS row (80 bytes: 16-byte aligned, conflict-free b128 reads)
+constexpr int kDwTok = 32;             // tokens per slab (= MFMA K)
+constexpr int kDwLd = 128 + 8;         // LDS row: 128 channels + 16 B pad (token-major, no transposition)
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+// ds_read_b64_tr_b16: within a 16-lane group, lane 4a+b receives element b of lanes a, 4+a, 8+a, 12+a.
+// With lane m pointing at row (m>>2), 4-element column chunk (m&3) of a row-major [4 x 16] block, lane c gets
+// column c of the block: 4 consecutive TOKENS of one channel -- the MFMA fragment of a token contraction,
+// read straight from the token-major slab (measured on gfx950, round 1).
+__device__ __forceinline__ uint2 tr_read(const bf16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    union { s16x4 s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
 
 __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk) {
-    __shared__ __attribute__((aligned(16))) bf16_t At[128 * kDwLd];
-    __shared__ __attribute__((aligned(16))) bf16_t Bt[128 * kDwLd];
+    __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
+    __shared__ float bred[4][128];
     const DwTask T = tasks.t[blockIdx.y];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = lane & 15, g = lane >> 4;
@@ -338,43 +351,52 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int st = threadIdx.x & 31, sc = threadIdx.x >> 5;      // staging: token, 16-channel group
-    float bsum[16];
+    // staging: 512 16-byte pieces per operand slab, two per thread: token = q >> 4, channel chunk = q & 15
+    const int cch = threadIdx.x & 15, tk0 = threadIdx.x >> 4;
+    float bsum[8];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) bsum[e] = 0.f;
-    for (int t0 = t_begin; t0 < t_end; t0 += kDwTok) {
-        const int tok = t0 + st;
-        uint4 a0 = make_uint4(0, 0, 0, 0), a1 = a0, b0 = a0, b1 = a0;
-        if (tok < t_end) {
-            const bf16_t* ap = T.A + (int64_t)tok * T.lda + T.a_col0 + 16 * sc;
-            const bf16_t* bp = T.B + (int64_t)tok * T.ldb + T.b_col0 + 16 * sc;
-            a0 = *reinterpret_cast<const uint4*>(ap);
-            a1 = *reinterpret_cast<const uint4*>(ap + 8);
-            b0 = *reinterpret_cast<const uint4*>(bp);
-            b1 = *reinterpret_cast<const uint4*>(bp + 8);
+    for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    u32x4 ra[2], rb[2];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int tok = t0 + tk0 + 16 * k;
+            ra[k] = u32x4{0u, 0u, 0u, 0u};
+            rb[k] = ra[k];
+            if (tok < t_end) {
+                ra[k] = *reinterpret_cast<const u32x4*>(T.A + (int64_t)tok * T.lda + T.a_col0 + 8 * cch);
+                rb[k] = *reinterpret_cast<const u32x4*>(T.B + (int64_t)tok * T.ldb + T.b_col0 + 8 * cch);
+            }
         }
+    };
+    fetch(t_begin);
+    for (int t0 = t_begin; t0 < t_end; t0 += kDwTok) {
         __syncthreads();      // previous slab fully consumed
-        {
-            const unsigned int aw[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            const unsigned int bw[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                At[(16 * sc + 2 * e) * kDwLd + st] = (bf16_t)(aw[e] & 0xffffu);
-                At[(16 * sc + 2 * e + 1) * kDwLd + st] = (bf16_t)(aw[e] >> 16);
-                Bt[(16 * sc + 2 * e) * kDwLd + st] = (bf16_t)(bw[e] & 0xffffu);
-                Bt[(16 * sc + 2 * e + 1) * kDwLd + st] = (bf16_t)(bw[e] >> 16);
-                bsum[2 * e] += bf_lo(aw[e]);
-                bsum[2 * e + 1] += bf_hi(aw[e]);
+        for (int k = 0; k < 2; ++k) {
+            *reinterpret_cast<u32x4*>(As + (tk0 + 16 * k) * kDwLd + 8 * cch) = ra[k];
+            *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = rb[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                bsum[2 * e] += bf_lo(ra[k][e]);
+                bsum[2 * e + 1] += bf_hi(ra[k][e]);
             }
         }
         __syncthreads();
+        if (t0 + kDwTok < t_end) fetch(t0 + kDwTok);     // next slab's loads fly under the MFMAs
+        const int m = o;
+        const bf16_t* arow = As + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
+        const bf16_t* brow = Bs + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
         uint4 af[2];
 #pragma unroll
-        for (int it = 0; it < 2; ++it)
-            af[it] = *reinterpret_cast<const uint4*>(At + (32 * wave + 16 * it + o) * kDwLd + 8 * g);
+        for (int it = 0; it < 2; ++it) {
+            const uint2 lo = tr_read(arow + 32 * wave + 16 * it), hi = tr_read(arow + 4 * kDwLd + 32 * wave + 16 * it);
+            af[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        }
 #pragma unroll
         for (int jt = 0; jt < 8; ++jt) {
-            const uint4 bf = *reinterpret_cast<const uint4*>(Bt + (16 * jt + o) * kDwLd + 8 * g);
+            const uint2 lo = tr_read(brow + 16 * jt), hi = tr_read(brow + 4 * kDwLd + 16 * jt);
+            const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
 #pragma unroll
             for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
         }
@@ -390,13 +412,18 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
                 if (i < T.rows_valid) atomicAdd(T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j, acc[it][jt][r]);
             }
     if (T.dbias) {
+        // column sums of A: thread holds 8 channels (chunk cch) of tokens tk0 + 16k (+32 per slab)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < 8; ++e) {
             float v = bsum[e];
-            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64);
-            v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 16, 64);
-            if (st == 0 && 16 * sc + e < T.rows_valid) atomicAdd(T.dbias + T.c_row0 + 16 * sc + e, v);
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (lane < 16) bred[wave][8 * cch + e] = v;
         }
+        __syncthreads();
+        if (threadIdx.x < 128 && threadIdx.x < T.rows_valid)
+            atomicAdd(T.dbias + T.c_row0 + threadIdx.x,
+                      bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
     }
 }
 

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
     const int32_t* __restrict__ mask_counts, TargetCfg cfg, float* __restrict__ centroid_low,
     uint8_t* __restrict__ mask_low, float* __restrict__ centroid_med, uint8_t* __restrict__ mask_med,
     float* __restrict__ centroid_top, float* __restrict__ top_raw, float* __restrict__ med_raw,
-    uint8_t* __restrict__ med_raw_mask, int32_t* __restrict__ occ_counts) {
+    uint8_t* __restrict__ med_raw_mask) {
     __shared__ unsigned long long s_low[kLowMax * 3];
     __shared__ unsigned long long s_med[kMedMax * 3];
     __shared__ int c_low[kLowMax];
@@ -118,14 +118,6 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
                 if (row >= 0) centroid_med[((int64_t)row * n_med + lane) * 3 + d] = nc;
             }
         }
-        if (occ_counts && row >= 0) {      // occupied cells of this output row (loss normalisers)
-            int ol = 0;
-            for (int sl = lane; sl < n_low; sl += 64) ol += c_low[sl] > 0;
-            const int om = (lane < n_med && c_med[lane] > 0) ? 1 : 0;
-            ol = wave_sum(ol);
-            const int omt = wave_sum(om);
-            if (lane == 0) { atomicAdd(&occ_counts[0], ol); atomicAdd(&occ_counts[1], omt); }
-        }
         // --- low sub-voxels (masked rows only)
         if (row >= 0) {
             for (int sl = lane; sl < n_low; sl += 64) {
@@ -147,6 +139,25 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
             }
         }
         __syncthreads();
+    }
+}
+
+// occupied cells over the output rows (the normalisers of the two masked-MSE losses): byte sums of the
+// 0/1 occupancy arrays; one atomic per workgroup (per-pillar atomics on two words serialise: 360 us)
+__global__ __launch_bounds__(256) void occ_count_kernel(const uint8_t* __restrict__ mask_low, int64_t n_low_bytes,
+                                                        const uint8_t* __restrict__ mask_med, int64_t n_med_bytes,
+                                                        int32_t* __restrict__ occ_counts) {
+    __shared__ int sm[2][4];
+    int a = 0, b = 0;
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n_low_bytes; i += (int64_t)gridDim.x * 256) a += mask_low[i];
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n_med_bytes; i += (int64_t)gridDim.x * 256) b += mask_med[i];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&occ_counts[0], sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
+        atomicAdd(&occ_counts[1], sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
     }
 }
 
@@ -293,7 +304,7 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
                                        const GeomaeTargetConfig* config, float* centroid_low, uint8_t* mask_low,
                                        float* centroid_med, uint8_t* mask_med, float* centroid_top, float* normal,
                                        double* curv, float* top_raw, float* med_raw, uint8_t* med_raw_mask,
-                                       float* cov_out, int32_t* occ_counts, hipStream_t stream) {
+                                       float* cov_out, int32_t* occ_counts, int32_t num_rows, hipStream_t stream) {
     if (max_pillars <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(points && order && seg_start && num_pillars && voxel_coors && coors_med && coors_low && cell_table,
                    "geometry_targets: null input");
@@ -308,9 +319,17 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
     hipLaunchKernelGGL(centroid_targets_kernel, dim3(grid), dim3(64), 0, stream, points, num_features, order,
                        seg_start, num_pillars, (const int4*)voxel_coors, (const int4*)coors_med,
                        (const int4*)coors_low, token_row, mask_counts, c, centroid_low, mask_low, centroid_med,
-                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask, occ_counts);
+                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask);
     hipLaunchKernelGGL(normal_curv_kernel, dim3(grid), dim3(64), 0, stream, num_pillars, (const int4*)voxel_coors,
                        cell_table, token_row, mask_counts, c, batch_size, top_raw, med_raw, med_raw_mask, normal, curv,
                        cov_out);
+    if (occ_counts) {
+        // rows: masked pillars (device count) or all pillars; the host-side upper bound is max_pillars,
+        // rows beyond the real count were never written, so count over the rows the caller allocated
+        GEOMAE_REQUIRE(num_rows >= 0, "geometry_targets: num_rows needed for occ_counts");
+        const int n_low = c.rl[0] * c.rl[1] * c.rl[2], n_med = c.rm[0] * c.rm[1] * c.rm[2];
+        hipLaunchKernelGGL(occ_count_kernel, dim3(128), dim3(256), 0, stream, mask_low, (int64_t)num_rows * n_low,
+                           mask_med, (int64_t)num_rows * n_med, occ_counts);
+    }
     return check_launch("geometry_targets");
 }

@@ -305,7 +305,7 @@ def geometry_targets(points, seg, coors_med, coors_low, cfg, token_row=None, cou
         _ptr(token_row), _ptr(counts), ctypes.byref(cfg), _ptr(out["centroid_low"]), _ptr(out["mask_low"]),
         _ptr(out["centroid_med"]), _ptr(out["mask_med"]), _ptr(out["centroid_top"]), _ptr(out["normal"]),
         _ptr(out["curv"]), _ptr(out["top_raw"]), _ptr(out["med_raw"]), _ptr(out["med_raw_mask"]), _ptr(out["cov"]),
-        _ptr(out["occ_counts"]), _stream()), "geomae_geometry_targets")
+        _ptr(out["occ_counts"]), M, _stream()), "geomae_geometry_targets")
     out["mask_low_u8"], out["mask_med_u8"] = out["mask_low"], out["mask_med"]
     out["mask_low"] = out["mask_low"].view(torch.bool)
     out["mask_med"] = out["mask_med"].view(torch.bool)

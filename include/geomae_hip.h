@@ -116,6 +116,7 @@ int geomae_geometry_targets(const float* points, int32_t num_features, const int
                             float* centroid_top, float* normal, double* curv, float* top_raw,
                             float* med_raw, uint8_t* med_raw_mask, float* cov_out,
                             int32_t* occ_counts /* [2] occupied low / med cells over the output rows, may be NULL */,
+                            int32_t num_rows /* rows of the M-sized outputs (needed with occ_counts) */,
                             geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A12-A16 windows */
