@@ -32,6 +32,17 @@ class GeomaeSstLayerWeights(ctypes.Structure):
                 + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float)])
 
 
+class GeomaeVfeArgs(ctypes.Structure):
+    _fields_ = [("points", c_void_p), ("num_features", c_int32), ("order", c_void_p), ("seg_start", c_void_p),
+                ("voxel_coors", c_void_p), ("pillar_mean", c_void_p), ("ranges", c_void_p), ("num_waves", c_int32),
+                ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p), ("scale1", c_void_p),
+                ("shift1", c_void_p), ("voxel_size", c_float * 3), ("center_offset", c_float * 3)]
+
+
+class GeomaeBnState(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("scale0", "shift0", "mean0", "invstd0", "scale1", "shift1", "mean1", "invstd1")]
+
+
 class GeomaeHeadGrads(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("reg_low_w", "reg_low_b", "cls_low_w", "cls_low_b", "reg_med_w", "reg_med_b",
                                         "cls_med_w", "cls_med_b", "reg_top_w", "reg_top_b", "nor_top_w", "nor_top_b")]
@@ -55,7 +66,17 @@ SIGNATURES = {
     "geomae_pillar_segment_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32]),
     "geomae_pillar_segment": (ctypes.c_int, [P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P,
                                              P, c_int64, P]),
-    "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P]),
+    "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, c_int32, P, P, P]),
+    "geomae_vfe_plan": (ctypes.c_int, [P, P, c_int32, c_int32, c_int32, P, P]),
+    "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P]),
+    "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),
+    "geomae_vfe_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
+    "geomae_vfe_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
+    "geomae_vfe_backward_stats": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, P]),
+    "geomae_vfe_backward_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, c_float,
+                                                  P, P, P, P, P, P, P]),
+    "geomae_vfe_backward_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, c_float, c_int64,
+                                                  P, P, P, P, P]),
     "geomae_segment_max_forward": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P]),
     "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
     "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),

@@ -165,30 +165,6 @@ __global__ __launch_bounds__(kBlk) void place_kernel(const int4* __restrict__ co
     }
 }
 
-// ---------------------------------------------------------------- segmented mean of xyz
-// one thread per pillar; 2^-32 fixed point (|x| < 2^20 m): order independent
-__global__ __launch_bounds__(kBlk) void seg_mean3_kernel(const float* __restrict__ pts, int stride,
-                                                         const int32_t* __restrict__ order,
-                                                         const int32_t* __restrict__ seg_start,
-                                                         const int32_t* __restrict__ num_pillars,
-                                                         float* __restrict__ mean) {
-    const int V = num_pillars[0];
-    for (int p = blockIdx.x * kBlk + threadIdx.x; p < V; p += gridDim.x * kBlk) {
-        const int s = seg_start[p], e = seg_start[p + 1];
-        long long sx = 0, sy = 0, sz = 0;
-        for (int j = s; j < e; ++j) {
-            const float* q = pts + (int64_t)order[j] * stride;
-            sx += __double2ll_rn((double)q[0] * 4294967296.0);
-            sy += __double2ll_rn((double)q[1] * 4294967296.0);
-            sz += __double2ll_rn((double)q[2] * 4294967296.0);
-        }
-        const double inv_n = 1.0 / (4294967296.0 * (double)(e - s));
-        mean[p * 3 + 0] = (float)((double)sx * inv_n);
-        mean[p * 3 + 1] = (float)((double)sy * inv_n);
-        mean[p * 3 + 2] = (float)((double)sz * inv_n);
-    }
-}
-
 // ---------------------------------------------------------------- segmented max (+argmax)
 // feat rows are given in ORIGINAL point order and read through `order`; one workgroup of C
 // lanes walks one pillar, every row read is a coalesced C*4-byte line.
@@ -275,16 +251,6 @@ extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, i
                            order);
     }
     return check_launch("pillar_segment");
-}
-
-extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features, const int32_t* order,
-                                       const int32_t* seg_start, const int32_t* num_pillars,
-                                       int32_t max_pillars, float* mean, hipStream_t stream) {
-    if (max_pillars <= 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE(points && order && seg_start && num_pillars && mean, "segment_mean_xyz: null argument");
-    hipLaunchKernelGGL(seg_mean3_kernel, dim3(stream_grid(max_pillars, kBlk)), dim3(kBlk), 0, stream, points,
-                       num_features, order, seg_start, num_pillars, mean);
-    return check_launch("seg_mean3_kernel");
 }
 
 extern "C" int geomae_segment_max_forward(const float* feat, int32_t channels, const int32_t* order,

@@ -1,0 +1,861 @@
+// Fused DynamicScatterVFE for gfx950, forward and backward.
+//
+// Reference: DynamicScatterVFE.forward (mmdet3d/models/voxel_encoders/voxel_encoder.py:358-419):
+//   f = [p(5) | xyz - pillar mean | xyz - pillar centre]                       (11 features)
+//   h0 = ReLU(BN64(W0 f)) ; m0 = scatter_max(h0) ; g = [h0 | m0[pillar]]      (128)
+//   h1 = ReLU(BN128(W1 g)) ; voxel_feats = scatter_max(h1)
+// run there as three torch.unique sorts + torch_scatter + cuBLAS + BatchNorm kernels with every [N, C]
+// intermediate in HBM (and ~100 autograd nodes in the backward).  Here the points are walked in pillar
+// order (geomae_pillar_segment), 16 at a time per wave in the transposed-product MFMA layout of
+// sst_device.h, in EXACT fp32 (v_mfma_f32_16x16x4_f32: raw coordinates do not survive bf16), and nothing
+// per-point is stored except what the weight-gradient contraction needs:
+//   * BatchNorm needs full-batch statistics before it can normalise, so each layer is two sweeps
+//     (statistics, then apply + segmented max); y = W f is recomputed instead of stored (11x64 and
+//     128x128 MACs per point are cheaper than a 256 / 512 B round trip per point);
+//   * a wave owns a RANGE OF WHOLE PILLARS (vfe_plan), so segmented max / sum never cross waves: a
+//     16 x C tile goes through LDS and lane c scans its channel over the 16 points, carrying the open
+//     pillar in registers -- no float atomics, deterministic;
+//   * the max-pool backward needs no arg-max: the forward value is recomputed bit-identically (same
+//     device function, same MFMA order) and the gradient is routed where h == max (ties at 0 are killed
+//     by ReLU'; exact duplicates of a point would both receive it);
+//   * statistics cross workgroups as fp64 atomics on 2C words; naiveSyncBN1d's cross-rank exchange
+//     (mmdet3d/ops/norm.py:54-86) happens between the kernels on those words (host side, RCCL).
+#include "common.h"
+#include "../../include/geomae_hip.h"
+#include "sst_device.h"
+
+namespace geomae {
+
+constexpr int kVfeBlk = 256;
+constexpr int kW1Ld = 128 + 4;          // fp32 LDS row of W1 (+16 B pad)
+constexpr int kTileLd = 128 + 4;        // fp32 LDS row of the per-wave [16 x C] tile
+
+__device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+struct VfeGeo {
+    const float* pts; int stride;
+    const int32_t* order; const int32_t* seg_start; const int4* voxel_coors; const float* mean;
+    float vx, vy, vz, xo, yo, zo;
+};
+
+struct WaveRange { int p_lo, p_hi, j_lo, j_hi; };
+
+__device__ __forceinline__ WaveRange wave_range(const int32_t* __restrict__ ranges, const int32_t* __restrict__ seg_start,
+                                                int wave_id, int n_waves) {
+    WaveRange r;
+    r.p_lo = wave_id < n_waves ? ranges[wave_id] : 0;
+    r.p_hi = wave_id < n_waves ? ranges[wave_id + 1] : 0;
+    r.j_lo = seg_start[r.p_lo];
+    r.j_hi = seg_start[r.p_hi];
+    return r;
+}
+
+// pillar id of sorted point j inside [p_lo, p_hi): binary search over seg_start
+__device__ __forceinline__ int pillar_of(const int32_t* __restrict__ seg_start, int p_lo, int p_hi, int j) {
+    int lo = p_lo, hi = p_hi - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (seg_start[mid] <= j) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+// the lane's 4 of the 16 (11 used) decorated features of its point, T-layout: feature index 4g + r
+__device__ __forceinline__ void build_features(const VfeGeo& G, int j, int pid, bool valid, int g, float (&f)[4]) {
+    f[0] = f[1] = f[2] = f[3] = 0.f;
+    if (!valid || g == 3) return;
+    const float* q = G.pts + (int64_t)G.order[j] * G.stride;
+    const float x = q[0], y = q[1], z = q[2];
+    if (g == 0) {
+        f[0] = x; f[1] = y; f[2] = z; f[3] = q[3];
+    } else if (g == 1) {
+        const float* m = G.mean + (int64_t)pid * 3;
+        f[0] = q[4]; f[1] = x - m[0]; f[2] = y - m[1]; f[3] = z - m[2];
+    } else {
+        // x - (coor * v + offset): every operation rounded separately, as the reference's tensor ops
+        const int4 c = G.voxel_coors[pid];
+        f[0] = __fsub_rn(x, __fadd_rn(__fmul_rn((float)c.w, G.vx), G.xo));
+        f[1] = __fsub_rn(y, __fadd_rn(__fmul_rn((float)c.z, G.vy), G.yo));
+        f[2] = __fsub_rn(z, __fadd_rn(__fmul_rn((float)c.y, G.vz), G.zo));
+    }
+}
+
+// y0[t][16*ot + 4g + r] = sum_k W0[.][k] f[t][k]; W0s: LDS [64][16] fp32 (columns >= 11 are zero)
+__device__ __forceinline__ void layer0_linear(const float* __restrict__ W0s, const float (&f)[4], f32x4 (&y)[4], int lane) {
+    const int o = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        const float4 a = *reinterpret_cast<const float4*>(W0s + (16 * ot + o) * 16 + 4 * g);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = mfma_f32(a.x, f[0], acc);
+        acc = mfma_f32(a.y, f[1], acc);
+        acc = mfma_f32(a.z, f[2], acc);
+        acc = mfma_f32(a.w, f[3], acc);
+        y[ot] = acc;
+    }
+}
+
+// y1[t][16*ot + 4g + r] = sum_k W1[.][k] gin[t][k]; W1s: LDS [128][kW1Ld] fp32 ; gin: 8 T-layout tiles
+__device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const f32x4 (&gin)[8], f32x4 (&y)[8], int lane) {
+    const int o = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* wrow = W1s + (16 * ot + o) * kW1Ld + 4 * g;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * ct);
+            acc = mfma_f32(a.x, gin[ct][0], acc);
+            acc = mfma_f32(a.y, gin[ct][1], acc);
+            acc = mfma_f32(a.z, gin[ct][2], acc);
+            acc = mfma_f32(a.w, gin[ct][3], acc);
+        }
+        y[ot] = acc;
+    }
+}
+
+// one 16-channel output tile of the same product (same MFMA order => bit-identical to layer1_linear)
+__device__ __forceinline__ f32x4 layer1_tile(const float* __restrict__ W1s, const f32x4 (&gin)[8], int ot, int lane) {
+    const int o = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const float* wrow = W1s + (16 * ot + o) * kW1Ld + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * ct);
+        acc = mfma_f32(a.x, gin[ct][0], acc);
+        acc = mfma_f32(a.y, gin[ct][1], acc);
+        acc = mfma_f32(a.z, gin[ct][2], acc);
+        acc = mfma_f32(a.w, gin[ct][3], acc);
+    }
+    return acc;
+}
+
+template <int NT>
+__device__ __forceinline__ void bn_relu(const f32x4 (&y)[NT], const float* __restrict__ scale,
+                                        const float* __restrict__ shift, f32x4 (&h)[NT], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + 16 * ot + 4 * g);
+        const float4 b = *reinterpret_cast<const float4*>(shift + 16 * ot + 4 * g);
+        h[ot][0] = fmaxf(y[ot][0] * s.x + b.x, 0.f);
+        h[ot][1] = fmaxf(y[ot][1] * s.y + b.y, 0.f);
+        h[ot][2] = fmaxf(y[ot][2] * s.z + b.z, 0.f);
+        h[ot][3] = fmaxf(y[ot][3] * s.w + b.w, 0.f);
+    }
+}
+
+__device__ __forceinline__ void stage_w0(const float* __restrict__ w0, float* W0s) {
+    for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
+        const int r = e >> 4, c = e & 15;
+        W0s[e] = c < 11 ? w0[r * 11 + c] : 0.f;
+    }
+}
+__device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1s, bool transpose) {
+    for (int e = threadIdx.x; e < 128 * 32; e += kVfeBlk) {
+        const int r = e >> 5, c4 = (e & 31) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(w1 + r * 128 + c4);
+        if (!transpose) {
+            *reinterpret_cast<float4*>(W1s + r * kW1Ld + c4) = v;
+        } else {
+            W1s[(c4 + 0) * kW1Ld + r] = v.x; W1s[(c4 + 1) * kW1Ld + r] = v.y;
+            W1s[(c4 + 2) * kW1Ld + r] = v.z; W1s[(c4 + 3) * kW1Ld + r] = v.w;
+        }
+    }
+}
+
+// per-wave tile helpers: T-layout registers -> LDS tile[t][c] (fp32)
+template <int NT>
+__device__ __forceinline__ void tile_store(float* tile, const f32x4 (&v)[NT], int lane) {
+    const int t = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot)
+        *reinterpret_cast<float4*>(tile + t * kTileLd + 16 * ot + 4 * g) = make_float4(v[ot][0], v[ot][1], v[ot][2], v[ot][3]);
+}
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+
+// Segmented reduction of a [16 x 64*CPL] tile over the tile's points, lane = channel (+64 per extra channel):
+// `cur_pid` / `cur` carry the open pillar across tiles; a finished pillar's row is stored to out[pid][c].
+template <int CPL, bool IS_MAX>
+__device__ __forceinline__ void seg_scan(const float* tile, const int* pids, int npts, int C, float* __restrict__ out,
+                                         int& cur_pid, float (&cur)[CPL], int lane) {
+    for (int t = 0; t < npts; ++t) {
+        const int p = pids[t];
+        if (p != cur_pid) {
+            if (cur_pid >= 0) {
+#pragma unroll
+                for (int k = 0; k < CPL; ++k) out[(int64_t)cur_pid * C + lane + 64 * k] = cur[k];
+            }
+            cur_pid = p;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) cur[k] = IS_MAX ? -INFINITY : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) {
+            const float v = tile[t * kTileLd + lane + 64 * k];
+            cur[k] = IS_MAX ? fmaxf(cur[k], v) : cur[k] + v;
+        }
+    }
+}
+template <int CPL>
+__device__ __forceinline__ void seg_flush(int C, float* __restrict__ out, int cur_pid, const float (&cur)[CPL], int lane) {
+    if (cur_pid >= 0) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) out[(int64_t)cur_pid * C + lane + 64 * k] = cur[k];
+    }
+}
+
+// sum over the 16 points of the tile and accumulate per-lane partials (kept until the end of the kernel)
+template <int NT>
+__device__ __forceinline__ void flush_channel_sums(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], double* __restrict__ out, int C,
+                                                   float* red /* LDS [4][2*C] */, int lane, int wave) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = tok_sum(s1[ot][r]), b = tok_sum(s2[ot][r]);
+            if ((lane & 15) == 0) {
+                red[wave * 2 * C + 16 * ot + 4 * g + r] = a;
+                red[wave * 2 * C + C + 16 * ot + 4 * g + r] = b;
+            }
+        }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 2 * C; e += kVfeBlk) {
+        const float s = red[e] + red[2 * C + e] + red[4 * C + e] + red[6 * C + e];
+        atomicAdd(out + e, (double)s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vfe_plan_kernel(const int32_t* __restrict__ seg_start,
+                                                       const int32_t* __restrict__ num_pillars, int n_points,
+                                                       int pts_per_wave, int n_waves, int32_t* __restrict__ ranges) {
+    const int V = num_pillars[0];
+    for (int w = blockIdx.x * 256 + threadIdx.x; w <= n_waves; w += gridDim.x * 256) {
+        // first pillar whose first point is at or after w * pts_per_wave
+        const int64_t target = (int64_t)w * pts_per_wave;
+        int lo = 0, hi = V;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_start[mid] >= target) hi = mid; else lo = mid + 1;
+        }
+        ranges[w] = (w == n_waves || target >= n_points) ? V : lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void vfe_mean_accum_kernel(const float* __restrict__ pts, int stride, int64_t n,
+                                                             const int32_t* __restrict__ inv,
+                                                             unsigned long long* __restrict__ sum64) {
+    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float* q = pts + i * stride;
+        unsigned long long* s = sum64 + (int64_t)inv[i] * 3;
+        atomicAdd(s + 0, (unsigned long long)__double2ll_rn((double)q[0] * 4294967296.0));
+        atomicAdd(s + 1, (unsigned long long)__double2ll_rn((double)q[1] * 4294967296.0));
+        atomicAdd(s + 2, (unsigned long long)__double2ll_rn((double)q[2] * 4294967296.0));
+    }
+}
+__global__ __launch_bounds__(256) void vfe_mean_final_kernel(const unsigned long long* __restrict__ sum64,
+                                                             const int32_t* __restrict__ seg_start,
+                                                             const int32_t* __restrict__ num_pillars,
+                                                             float* __restrict__ mean) {
+    const int V = num_pillars[0];
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < V * 3; e += gridDim.x * 256) {
+        const int p = e / 3;
+        const double inv_n = 1.0 / (4294967296.0 * (double)(seg_start[p + 1] - seg_start[p]));
+        mean[e] = (float)((double)(long long)sum64[e] * inv_n);
+    }
+}
+
+// BatchNorm bookkeeping, one workgroup.  moments (mean, mean of squares) come either from the local fp64
+// sums (single process) or from the caller (after the cross-rank average of naiveSyncBN1d).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ sums, double count,
+                                                          const float* __restrict__ moments_in, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, int unbiased_running,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          float* __restrict__ scale, float* __restrict__ shift,
+                                                          float* __restrict__ invstd_out, float* __restrict__ moments_out) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float mean, msq;
+        if (moments_in) { mean = moments_in[c]; msq = moments_in[C + c]; }
+        else { mean = (float)(sums[c] / count); msq = (float)(sums[C + c] / count); }
+        if (moments_out) { moments_out[c] = mean; moments_out[C + c] = msq; }
+        if (scale) {
+            float var = msq - mean * mean;
+            if (!moments_in) {   // single process: variance from fp64 sums (== nn.BatchNorm1d's two-pass value)
+                const double m = sums[c] / count;
+                var = (float)(sums[C + c] / count - m * m);
+            }
+            const float invstd = rsqrtf(var + eps);
+            const float s = gamma[c] * invstd;
+            scale[c] = s;
+            shift[c] = beta[c] - mean * s;
+            invstd_out[c] = invstd;
+            if (running_mean) {
+                const float rv = unbiased_running ? var * (float)(count / (count - 1.0)) : var;
+                running_mean[c] += momentum * (mean - running_mean[c]);
+                running_var[c] += momentum * (rv - running_var[c]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+struct VfeW {
+    const float *w0, *w1;                 // [64,11], [128,128]
+    const float *scale0, *shift0, *scale1, *shift1;   // BN folded: y * scale + shift
+};
+
+// sweep 1 of layer 0: per-channel sum / sum of squares of y0 = W0 f over all points
+__global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
+                                                             int n_waves, double* __restrict__ sums0) {
+    __shared__ float W0s[64 * 16];
+    __shared__ float red[4 * 2 * 64];
+    stage_w0(W.w0, W0s);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        float f[4];
+        build_features(G, j, pid, valid, g, f);
+        f32x4 y[4];
+        layer0_linear(W0s, f, y, lane);
+        if (valid) {
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) { s1[ot] += y[ot]; s2[ot] += y[ot] * y[ot]; }
+        }
+    }
+    flush_channel_sums<4>(s1, s2, sums0, 64, red, lane, wave);
+}
+
+// sweep 2 of layer 0 (h0, segmented max m0) fused with sweep 1 of layer 1 (statistics of y1 = W1 [h0 | m0])
+__global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
+                                                             int n_waves, float* __restrict__ m0,
+                                                             double* __restrict__ sums1) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
+    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
+    __shared__ int pids[4][16];
+    __shared__ float red[4 * 2 * 128];
+    stage_w0(W.w0, W0s);
+    stage_w1(W.w1, W1s, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    float* tile = tiles[wave];
+    // ---- pass A: h0 -> m0 (whole pillars, this wave only)
+    {
+        int cur_pid = -1;
+        float cur[1] = {0.f};
+        for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+            const int j = j0 + (lane & 15);
+            const bool valid = j < R.j_hi;
+            const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+            float f[4];
+            build_features(G, j, pid, valid, g, f);
+            f32x4 y[4], h[4];
+            layer0_linear(W0s, f, y, lane);
+            bn_relu<4>(y, W.scale0, W.shift0, h, lane);
+            tile_store<4>(tile, h, lane);
+            if (g == 0) pids[wave][lane & 15] = pid;
+            wave_sync();
+            const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
+            seg_scan<1, true>(tile, pids[wave], npts, 64, m0, cur_pid, cur, lane);
+            wave_sync();
+        }
+        seg_flush<1>(64, m0, cur_pid, cur, lane);
+    }
+    __threadfence_block();
+    wave_sync();
+    // ---- pass B: y1 statistics
+    f32x4 s1[8], s2[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        float f[4];
+        build_features(G, j, pid, valid, g, f);
+        f32x4 y0[4], gin[8];
+        layer0_linear(W0s, f, y0, lane);
+        bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+            float4 v = make_float4(0, 0, 0, 0);
+            if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
+            gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
+        }
+        f32x4 y1[8];
+        layer1_linear(W1s, gin, y1, lane);
+        if (valid) {
+#pragma unroll
+            for (int ot = 0; ot < 8; ++ot) { s1[ot] += y1[ot]; s2[ot] += y1[ot] * y1[ot]; }
+        }
+    }
+    flush_channel_sums<8>(s1, s2, sums1, 128, red, lane, wave);
+}
+
+// recompute h0 and g = [h0 | m0[pid]] for the lane's point (shared by every later sweep so that the values
+// are bit-identical to the forward's)
+__device__ __forceinline__ void recompute_g(const VfeGeo& G, const VfeW& W, const float* W0s, const float* __restrict__ m0,
+                                            int j, int pid, bool valid, int lane, f32x4 (&y0)[4], f32x4 (&gin)[8]) {
+    const int g = lane >> 4;
+    float f[4];
+    build_features(G, j, pid, valid, g, f);
+    layer0_linear(W0s, f, y0, lane);
+    bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
+        gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
+    }
+}
+
+// sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max
+__global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
+                                                             int n_waves, const float* __restrict__ m0,
+                                                             float* __restrict__ vf) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
+    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
+    __shared__ int pids[4][16];
+    stage_w0(W.w0, W0s);
+    stage_w1(W.w1, W1s, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    float* tile = tiles[wave];
+    int cur_pid = -1;
+    float cur[2] = {0.f, 0.f};
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        f32x4 y0[4], gin[8], y1[8], h1[8];
+        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
+        layer1_linear(W1s, gin, y1, lane);
+        bn_relu<8>(y1, W.scale1, W.shift1, h1, lane);
+        tile_store<8>(tile, h1, lane);
+        if (g == 0) pids[wave][lane & 15] = pid;
+        wave_sync();
+        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
+        seg_scan<2, true>(tile, pids[wave], npts, 128, vf, cur_pid, cur, lane);
+        wave_sync();
+    }
+    seg_flush<2>(128, vf, cur_pid, cur, lane);
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+// one output tile of the layer-1 backward inputs: dh[t][c] = dvf[pid][c] where h1[t][c] == vf[pid][c] > 0
+// (max-pool + ReLU routing on the recomputed, bit-identical forward value), yhat = (y1 - mean) * invstd
+struct Bn1 { const float *scale, *shift, *mean, *invstd; };
+__device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const float* __restrict__ vf,
+                                            const float* __restrict__ dvf, int pid, bool valid, int ot, int lane,
+                                            f32x4* dh, f32x4* yhat) {
+    const int g = lane >> 4, c0 = 16 * ot + 4 * g;
+    const float4 s = *reinterpret_cast<const float4*>(bn.scale + c0);
+    const float4 b = *reinterpret_cast<const float4*>(bn.shift + c0);
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c0);
+    const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c0);
+    float4 m = make_float4(0, 0, 0, 0), d = m;
+    if (valid) {
+        m = *reinterpret_cast<const float4*>(vf + (int64_t)pid * 128 + c0);
+        d = *reinterpret_cast<const float4*>(dvf + (int64_t)pid * 128 + c0);
+    }
+    const float sc[4] = {s.x, s.y, s.z, s.w}, sh[4] = {b.x, b.y, b.z, b.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w},
+                iv[4] = {is.x, is.y, is.z, is.w}, mx[4] = {m.x, m.y, m.z, m.w}, dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float h = fmaxf(y[r] * sc[r] + sh[r], 0.f);          // exactly bn_relu's expression
+        (*dh)[r] = (valid && h > 0.f && h == mx[r]) ? dd[r] : 0.f;
+        (*yhat)[r] = (y[r] - mn[r]) * iv[r];
+    }
+}
+
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
+                                                                 int n_waves, const float* __restrict__ m0,
+                                                                 const float* __restrict__ vf, const float* __restrict__ dvf,
+                                                                 Bn1 bn, double* __restrict__ bsums1) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
+    __shared__ float red[4 * 2 * 128];
+    stage_w0(W.w0, W0s);
+    stage_w1(W.w1, W1s, false);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    f32x4 s1[8], s2[8];
+#pragma unroll
+    for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        f32x4 y0[4], gin[8];
+        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) {
+            f32x4 dh, yh;
+            routed_tile(layer1_tile(W1s, gin, ot, lane), bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+            s1[ot] += dh;
+            s2[ot] += dh * yh;
+        }
+    }
+    flush_channel_sums<8>(s1, s2, bsums1, 128, red, lane, wave);
+}
+
+// layer-1 backward sweep + layer-0 routing/statistics sweep.
+//   dy1 = invstd1 * (dyh - S1/n - yhat * S2/n)  -> bf16 copy + g bf16 copy (operands of dW1 = dy1^T g)
+//   dg = dy1 W1 ; dh0_direct = dg[:, :64] (stored fp32) ; dm0 = segmented sum of dg[:, 64:]
+//   second pass: dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ; dyh0 = dh0 * gamma0 ; sums for BN0
+struct Bn0 { const float *scale, *shift, *mean, *invstd; };
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
+    VfeGeo G, VfeW W, const int32_t* __restrict__ ranges, int n_waves, const float* __restrict__ m0,
+    const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn, const double* __restrict__ bsums1, float n_eff,
+    Bn0 bn0, bf16_t* __restrict__ dy1_b, bf16_t* __restrict__ g_b, float* __restrict__ dy1_f, float* __restrict__ dh0,
+    float* __restrict__ dm0, double* __restrict__ bsums0) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
+    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
+    __shared__ int pids[4][16];
+    __shared__ float red[4 * 2 * 64];
+    __shared__ float bn1s[2][128];                                         // S1/n, S2/n
+    stage_w0(W.w0, W0s);
+    for (int c = threadIdx.x; c < 128; c += kVfeBlk) {
+        bn1s[0][c] = (float)(bsums1[c] / (double)n_eff);
+        bn1s[1][c] = (float)(bsums1[128 + c] / (double)n_eff);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    float* tile = tiles[wave];
+    // ---- pass A needs W1 (recompute y1) AND W1^T (dg = dy1 W1).  Two fp32 copies do not fit in LDS next to
+    // the tiles, so it is split: A1 computes dy1 with W1 and parks it in HBM (fp32); A2 re-reads it and
+    // multiplies by W1^T.
+    stage_w1(W.w1, W1s, false);
+    __syncthreads();
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        f32x4 y0[4], gin[8];
+        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
+        store_rows_bf16<128>(g_b, j, 128, 0, valid, gin, lane);
+#pragma unroll
+        for (int ot = 0; ot < 8; ++ot) {
+            f32x4 dh, yh, dy;
+            routed_tile(layer1_tile(W1s, gin, ot, lane), bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+            const int c0 = 16 * ot + 4 * g;
+            const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c0);     // gamma * invstd
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dy[r] = scv[r] * (dh[r] - bn1s[0][c0 + r] - yh[r] * bn1s[1][c0 + r]);
+            if (valid) {
+                *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy);      // operand of dW1 (dw_kernel)
+                *reinterpret_cast<float4*>(dy1_f + (int64_t)j * 128 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
+            }
+        }
+    }
+    __syncthreads();
+    stage_w1(W.w1, W1s, true);
+    __syncthreads();
+    {
+        int cur_pid = -1;
+        float cur[1] = {0.f};
+        for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+            const int j = j0 + (lane & 15);
+            const bool valid = j < R.j_hi;
+            const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+            f32x4 dy1[8], dg[8];
+            load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
+            layer1_linear(W1s, dy1, dg, lane);            // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]
+            if (valid) {
+#pragma unroll
+                for (int ct = 0; ct < 4; ++ct)
+                    *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + 16 * ct + 4 * g) =
+                        make_float4(dg[ct][0], dg[ct][1], dg[ct][2], dg[ct][3]);
+            }
+            tile_store<4>(tile, reinterpret_cast<f32x4(&)[4]>(dg[4]), lane);
+            if (g == 0) pids[wave][lane & 15] = pid;
+            wave_sync();
+            const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
+            seg_scan<1, false>(tile, pids[wave], npts, 64, dm0, cur_pid, cur, lane);
+            wave_sync();
+        }
+        seg_flush<1>(64, dm0, cur_pid, cur, lane);
+    }
+    __threadfence_block();
+    wave_sync();
+    // ---- pass B: total dh0, BN0 backward statistics
+    f32x4 s1[4], s2[4];
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        float f[4];
+        build_features(G, j, pid, valid, g, f);
+        f32x4 y0[4];
+        layer0_linear(W0s, f, y0, lane);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const int c0 = 16 * ot + 4 * g;
+            const float4 s = *reinterpret_cast<const float4*>(bn0.scale + c0);
+            const float4 b = *reinterpret_cast<const float4*>(bn0.shift + c0);
+            const float4 mu = *reinterpret_cast<const float4*>(bn0.mean + c0);
+            const float4 is = *reinterpret_cast<const float4*>(bn0.invstd + c0);
+            float4 m = make_float4(0, 0, 0, 0), dm = m, dd = m;
+            if (valid) {
+                m = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + c0);
+                dm = *reinterpret_cast<const float4*>(dm0 + (int64_t)pid * 64 + c0);
+                dd = *reinterpret_cast<const float4*>(dh0 + (int64_t)j * 64 + c0);
+            }
+            const float sc[4] = {s.x, s.y, s.z, s.w}, sh[4] = {b.x, b.y, b.z, b.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w},
+                        iv[4] = {is.x, is.y, is.z, is.w}, mx[4] = {m.x, m.y, m.z, m.w}, dmv[4] = {dm.x, dm.y, dm.z, dm.w},
+                        ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+            float outv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float h = fmaxf(y0[ot][r] * sc[r] + sh[r], 0.f);
+                float dh = 0.f;
+                if (valid && h > 0.f) dh = ddv[r] + (h == mx[r] ? dmv[r] : 0.f);
+                const float yh = (y0[ot][r] - mn[r]) * iv[r];
+                outv[r] = dh;
+                s1[ot][r] += dh;
+                s2[ot][r] += dh * yh;
+            }
+            if (valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + c0) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+        }
+    }
+    flush_channel_sums<4>(s1, s2, bsums0, 64, red, lane, wave);
+}
+
+// layer-0 backward: dy0 = invstd0 * (dyh0 - T1/n - yhat0 * T2/n) ; dW0 += dy0^T f   (64 x 11)
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
+                                                                 int n_waves, const float* __restrict__ dh0, Bn0 bn0,
+                                                                 const double* __restrict__ bsums0, float n_eff,
+                                                                 float* __restrict__ dw0) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];      // [t][0..63] dy0, [t][64..79] f
+    __shared__ float acc_s[64 * 16];
+    __shared__ float bn0s[2][64];
+    stage_w0(W.w0, W0s);
+    for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) acc_s[e] = 0.f;
+    for (int c = threadIdx.x; c < 64; c += kVfeBlk) {
+        bn0s[0][c] = (float)(bsums0[c] / (double)n_eff);
+        bn0s[1][c] = (float)(bsums0[64 + c] / (double)n_eff);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    float* tile = tiles[wave];
+    f32x4 dw[4];                                   // C layout: row = out channel 16*ot' ... see below
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) dw[ot] = f32x4{0, 0, 0, 0};
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        float f[4];
+        build_features(G, j, pid, valid, g, f);
+        f32x4 y0[4], dy0[4];
+        layer0_linear(W0s, f, y0, lane);
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const int c0 = 16 * ot + 4 * g;
+            const float4 s = *reinterpret_cast<const float4*>(bn0.scale + c0);
+            const float4 mu = *reinterpret_cast<const float4*>(bn0.mean + c0);
+            const float4 is = *reinterpret_cast<const float4*>(bn0.invstd + c0);
+            float4 dd = make_float4(0, 0, 0, 0);
+            if (valid) dd = *reinterpret_cast<const float4*>(dh0 + (int64_t)j * 64 + c0);
+            const float sc[4] = {s.x, s.y, s.z, s.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w},
+                        ddv[4] = {dd.x, dd.y, dd.z, dd.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float yh = (y0[ot][r] - mn[r]) * iv[r];
+                dy0[ot][r] = valid ? sc[r] * (ddv[r] - bn0s[0][c0 + r] - yh * bn0s[1][c0 + r]) : 0.f;
+            }
+        }
+        // dW0[o][k] += sum_t dy0[t][o] f[t][k]: token contraction -> tile through LDS, MFMA with k = t
+        tile_store<4>(tile, dy0, lane);
+        *reinterpret_cast<float4*>(tile + (lane & 15) * kTileLd + 64 + 4 * g) = make_float4(f[0], f[1], f[2], f[3]);
+        wave_sync();
+        const int o = lane & 15;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float a = tile[(4 * s + g) * kTileLd + 16 * ot + o];       // A[row = o][k = t = 4s + g]
+                const float b = tile[(4 * s + g) * kTileLd + 64 + o];            // B[k = t][col = feature o]
+                dw[ot] = mfma_f32(a, b, dw[ot]);
+            }
+        wave_sync();
+    }
+    // dw[ot][r] = dW0[16*ot + 4g + r][feature = lane & 15]
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(&acc_s[(16 * ot + 4 * g + r) * 16 + (lane & 15)], dw[ot][r]);
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
+        const int r = e >> 4, c = e & 15;
+        if (c < 11) atomicAdd(dw0 + r * 11 + c, acc_s[e]);
+    }
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+static int vfe_common(const GeomaeVfeArgs* a, VfeGeo* G, VfeW* W, const char* who) {
+    GEOMAE_REQUIRE(a, "%s: null args", who);
+    GEOMAE_REQUIRE(a->points && a->order && a->seg_start && a->voxel_coors && a->pillar_mean && a->ranges &&
+                   a->w0 && a->w1, "%s: null pointer in args", who);
+    GEOMAE_REQUIRE(a->num_features >= 5 && a->num_waves >= 1, "%s: bad sizes", who);
+    G->pts = a->points; G->stride = a->num_features; G->order = a->order; G->seg_start = a->seg_start;
+    G->voxel_coors = (const int4*)a->voxel_coors; G->mean = a->pillar_mean;
+    G->vx = a->voxel_size[0]; G->vy = a->voxel_size[1]; G->vz = a->voxel_size[2];
+    G->xo = a->center_offset[0]; G->yo = a->center_offset[1]; G->zo = a->center_offset[2];
+    W->w0 = a->w0; W->w1 = a->w1; W->scale0 = a->scale0; W->shift0 = a->shift0; W->scale1 = a->scale1; W->shift1 = a->shift1;
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,
+                               int32_t points_per_wave, int32_t num_waves, int32_t* ranges, hipStream_t stream) {
+    GEOMAE_REQUIRE(seg_start && num_pillars && ranges && points_per_wave >= 16 && num_waves >= 1, "vfe_plan: bad argument");
+    hipLaunchKernelGGL(vfe_plan_kernel, dim3(cdiv(num_waves + 1, 256)), dim3(256), 0, stream, seg_start, num_pillars,
+                       num_points, points_per_wave, num_waves, ranges);
+    return check_launch("vfe_plan_kernel");
+}
+
+extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features, int64_t num_points,
+                                       const int32_t* inv, const int32_t* seg_start, const int32_t* num_pillars,
+                                       int32_t max_pillars, void* sum_workspace, float* mean, hipStream_t stream) {
+    if (max_pillars <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(points && inv && seg_start && num_pillars && sum_workspace && mean, "segment_mean_xyz: null argument");
+    GEOMAE_HIP(hipMemsetAsync(sum_workspace, 0, (size_t)max_pillars * 3 * sizeof(unsigned long long), stream));
+    if (num_points > 0)
+        hipLaunchKernelGGL(vfe_mean_accum_kernel, dim3(stream_grid(num_points, 256)), dim3(256), 0, stream, points,
+                           num_features, num_points, inv, (unsigned long long*)sum_workspace);
+    hipLaunchKernelGGL(vfe_mean_final_kernel, dim3(stream_grid((int64_t)max_pillars * 3, 256)), dim3(256), 0, stream,
+                       (const unsigned long long*)sum_workspace, seg_start, num_pillars, mean);
+    return check_launch("segment_mean_xyz");
+}
+
+extern "C" int geomae_bn_finalize(const double* sums, double count, const float* moments_in, int32_t channels,
+                                  const float* gamma, const float* beta, float eps, float momentum,
+                                  int32_t unbiased_running_var, float* running_mean, float* running_var, float* scale,
+                                  float* shift, float* invstd, float* moments_out, hipStream_t stream) {
+    GEOMAE_REQUIRE((sums || moments_in) && channels >= 1 && channels <= 1024, "bn_finalize: bad argument");
+    GEOMAE_REQUIRE(!scale || (gamma && beta && shift && invstd), "bn_finalize: scale needs gamma, beta, shift, invstd");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, count, moments_in, channels, gamma, beta,
+                       eps, momentum, unbiased_running_var, running_mean, running_var, scale, shift, invstd, moments_out);
+    return check_launch("bn_finalize_kernel");
+}
+
+extern "C" int geomae_vfe_stats0(const GeomaeVfeArgs* a, double* sums0, hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_stats0");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(sums0, "vfe_stats0: null output");
+    GEOMAE_HIP(hipMemsetAsync(sums0, 0, 128 * sizeof(double), stream));
+    hipLaunchKernelGGL(vfe_stats0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, sums0);
+    return check_launch("vfe_stats0_kernel");
+}
+
+extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums1, hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_layer0");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(m0 && sums1 && a->scale0 && a->shift0, "vfe_layer0: null argument");
+    GEOMAE_HIP(hipMemsetAsync(sums1, 0, 256 * sizeof(double), stream));
+    hipLaunchKernelGGL(vfe_layer0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, m0, sums1);
+    return check_launch("vfe_layer0_kernel");
+}
+
+extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float* voxel_feats, hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_layer1");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
+    hipLaunchKernelGGL(vfe_layer1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, m0, voxel_feats);
+    return check_launch("vfe_layer1_kernel");
+}
+
+static int bn_of(const GeomaeBnState* b, int which, const float** scale, const float** shift, const float** mean,
+                 const float** invstd) {
+    GEOMAE_REQUIRE(b, "vfe backward: null bn state");
+    *scale = which ? b->scale1 : b->scale0; *shift = which ? b->shift1 : b->shift0;
+    *mean = which ? b->mean1 : b->mean0; *invstd = which ? b->invstd1 : b->invstd0;
+    GEOMAE_REQUIRE(*scale && *shift && *mean && *invstd, "vfe backward: null bn state pointer");
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnState* bnst, const float* m0,
+                                         const float* voxel_feats, const float* d_voxel_feats, double* bsums1,
+                                         hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_backward_stats");
+    if (rc) return rc;
+    Bn1 bn;
+    if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
+    GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1, "vfe_backward_stats: null argument");
+    GEOMAE_HIP(hipMemsetAsync(bsums1, 0, 256 * sizeof(double), stream));
+    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1);
+    return check_launch("vfe_bwd_stats1_kernel");
+}
+
+extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBnState* bnst, const float* m0,
+                                          const float* voxel_feats, const float* d_voxel_feats,
+                                          const double* bsums1_global, float n_eff, void* dy1_bf16, void* g_bf16,
+                                          float* dy1_f32, float* dh0, float* dm0, double* bsums0,
+                                          hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_backward_layer1");
+    if (rc) return rc;
+    Bn1 bn; Bn0 bn0;
+    if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
+    if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
+    GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dy1_f32 && dh0 && dm0 &&
+                   bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
+    GEOMAE_HIP(hipMemsetAsync(bsums0, 0, 128 * sizeof(double), stream));
+    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1_global, n_eff, bn0, (bf16_t*)dy1_bf16,
+                       (bf16_t*)g_bf16, dy1_f32, dh0, dm0, bsums0);
+    return check_launch("vfe_bwd_layer1_kernel");
+}
+
+extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBnState* bnst, const float* dh0,
+                                          const double* bsums0_global, float n_eff, int64_t num_points,
+                                          const void* dy1_bf16, const void* g_bf16, float* dw0, float* dw1,
+                                          hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_backward_layer0");
+    if (rc) return rc;
+    Bn0 bn0;
+    if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
+    GEOMAE_REQUIRE(dh0 && bsums0_global && dy1_bf16 && g_bf16 && dw0 && dw1 && n_eff > 0,
+                   "vfe_backward_layer0: null argument");
+    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+                       a->num_waves, dh0, bn0, bsums0_global, n_eff, dw0);
+    rc = check_launch("vfe_bwd_layer0_kernel");
+    if (rc) return rc;
+    DwTasks T;
+    T.t[0] = {(const bf16_t*)dy1_bf16, 128, 0, (const bf16_t*)g_bf16, 128, 0, dw1, 128, 0, 0, nullptr, 128};
+    return launch_dw(T, 1, (int)num_points, stream);
+}

@@ -166,9 +166,10 @@ def pillar_segment(coors, batch_size, grid_zyx, cap=None):
 
 def segment_mean_xyz(points, seg):
     mean = torch.empty((max(seg.cap, 1), 3), dtype=torch.float32, device=points.device)
-    check(_lib.load().geomae_segment_mean_xyz(_ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start),
-                                              _ptr(seg.num_pillars), seg.cap, _ptr(mean), _stream()),
-          "geomae_segment_mean_xyz")
+    ws = torch.empty(max(seg.cap, 1) * 3, dtype=torch.int64, device=points.device)
+    check(_lib.load().geomae_segment_mean_xyz(_ptr(points), points.shape[1], points.shape[0], _ptr(seg.inv),
+                                              _ptr(seg.seg_start), _ptr(seg.num_pillars), seg.cap, _ptr(ws), _ptr(mean),
+                                              _stream()), "geomae_segment_mean_xyz")
     return mean
 
 
@@ -496,3 +497,118 @@ def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, nu
                                      _ptr(y_b), _ptr(dv_b), _ptr(h_b), ctypes.byref(g), _stream()),
           "geomae_sst_weight_grad")
     return dx
+
+
+# ------------------------------------------------------------------------------------ fused VFE
+class VfePlan:
+    """Per-batch plan of the fused VFE sweeps: pillar mean, wave -> pillar ranges, the argument struct."""
+    POINTS_PER_WAVE = 128
+
+    def __init__(self, points, seg, w0, w1, voxel_size, center_offset):
+        from ._lib import GeomaeVfeArgs
+        lib = _lib.load()
+        dev = points.device
+        self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
+        self.mean = segment_mean_xyz(points, seg)
+        self.num_waves = max(1, (self.N + self.POINTS_PER_WAVE - 1) // self.POINTS_PER_WAVE)
+        self.ranges = torch.empty(self.num_waves + 1, dtype=torch.int32, device=dev)
+        check(lib.geomae_vfe_plan(_ptr(seg.seg_start), _ptr(seg.num_pillars), self.N, self.POINTS_PER_WAVE,
+                                  self.num_waves, _ptr(self.ranges), _stream()), "geomae_vfe_plan")
+        self.bn = torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)    # [layer][scale, shift, mean, invstd]
+        a = GeomaeVfeArgs()
+        a.points, a.num_features = points.data_ptr(), points.shape[1]
+        a.order, a.seg_start, a.voxel_coors = seg.order.data_ptr(), seg.seg_start.data_ptr(), seg.voxel_coors.data_ptr()
+        a.pillar_mean, a.ranges, a.num_waves = self.mean.data_ptr(), self.ranges.data_ptr(), self.num_waves
+        a.w0, a.w1 = w0.data_ptr(), w1.data_ptr()
+        a.scale0, a.shift0 = self.bn[0, 0].data_ptr(), self.bn[0, 1].data_ptr()
+        a.scale1, a.shift1 = self.bn[1, 0].data_ptr(), self.bn[1, 1].data_ptr()
+        a.voxel_size[:] = [float(v) for v in voxel_size]
+        a.center_offset[:] = [float(v) for v in center_offset]
+        self.args = a
+        self._keep = (w0, w1)
+
+    def bn_state(self):
+        from ._lib import GeomaeBnState
+        b = GeomaeBnState()
+        for layer in (0, 1):
+            for k, name in enumerate(("scale", "shift", "mean", "invstd")):
+                setattr(b, f"{name}{layer}", self.bn[layer, k].data_ptr())
+        return b
+
+
+def _bn_finalize(plan, layer, sums, norm, world, group):
+    """Training-mode statistics -> folded scale/shift (+ running stats), with naiveSyncBN1d's equal-weight
+    cross-rank average of (mean, mean of squares) when world > 1 (mmdet3d/ops/norm.py:64-76)."""
+    from torch import distributed as dist
+    lib = _lib.load()
+    C = 64 if layer == 0 else 128
+    bn = plan.bn[layer]
+    common = (C, _ptr(norm.weight), _ptr(norm.bias), float(norm.eps), float(norm.momentum))
+    if world == 1:
+        check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N), None, *common, 1, _ptr(norm.running_mean),
+                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), _ptr(bn[2]),
+                                     _stream()), "geomae_bn_finalize")
+    else:
+        mom = torch.empty(2 * C, dtype=torch.float32, device=sums.device)
+        check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N), None, C, None, None, 0.0, 0.0, 0, None, None, None, None,
+                                     None, _ptr(mom), _stream()), "geomae_bn_finalize")
+        dist.all_reduce(mom, group=group)
+        mom.mul_(1.0 / world)
+        check(lib.geomae_bn_finalize(None, float(plan.N), _ptr(mom), *common, 0, _ptr(norm.running_mean),
+                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), None, _stream()),
+              "geomae_bn_finalize")
+        bn[2, :C].copy_(mom[:C])
+    norm.num_batches_tracked += 1
+
+
+def vfe_forward(plan, norm0, norm1, world=1, group=None):
+    lib = _lib.load()
+    dev = plan.points.device
+    a = ctypes.byref(plan.args)
+    sums0 = torch.empty(128, dtype=torch.float64, device=dev)
+    check(lib.geomae_vfe_stats0(a, _ptr(sums0), _stream()), "geomae_vfe_stats0")
+    _bn_finalize(plan, 0, sums0, norm0, world, group)
+    m0 = torch.empty((max(plan.V, 1), 64), dtype=torch.float32, device=dev)
+    sums1 = torch.empty(256, dtype=torch.float64, device=dev)
+    check(lib.geomae_vfe_layer0(a, _ptr(m0), _ptr(sums1), _stream()), "geomae_vfe_layer0")
+    _bn_finalize(plan, 1, sums1, norm1, world, group)
+    vf = torch.empty((max(plan.V, 1), 128), dtype=torch.float32, device=dev)
+    check(lib.geomae_vfe_layer1(a, _ptr(m0), _ptr(vf), _stream()), "geomae_vfe_layer1")
+    return vf[:plan.V], m0
+
+
+def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
+    """params: dict w0, w1, g0, b0, g1, b1 -> nn.Parameters whose .grad is accumulated into."""
+    from torch import distributed as dist
+    lib = _lib.load()
+    dev = dvf.device
+    a, bn = ctypes.byref(plan.args), plan.bn_state()
+    N, V = plan.N, plan.V
+    for p in params.values():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    dvf = dvf.contiguous().float()
+    bs1 = torch.empty(256, dtype=torch.float64, device=dev)
+    check(lib.geomae_vfe_backward_stats(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), _stream()),
+          "geomae_vfe_backward_stats")
+    params["b1"].grad.add_(bs1[:128])
+    params["g1"].grad.add_(bs1[128:])
+    if world > 1:
+        dist.all_reduce(bs1, group=group)
+    n_eff = float(world * N)
+    dy1_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
+    g_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
+    dy1_f = torch.empty((N, 128), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((N, 64), dtype=torch.float32, device=dev)
+    dm0 = torch.empty((max(V, 1), 64), dtype=torch.float32, device=dev)
+    bs0 = torch.empty(128, dtype=torch.float64, device=dev)
+    check(lib.geomae_vfe_backward_layer1(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), n_eff,
+                                         _ptr(dy1_b), _ptr(g_b), _ptr(dy1_f), _ptr(dh0), _ptr(dm0), _ptr(bs0),
+                                         _stream()), "geomae_vfe_backward_layer1")
+    params["b0"].grad.add_(bs0[:64])
+    params["g0"].grad.add_(bs0[64:])
+    if world > 1:
+        dist.all_reduce(bs0, group=group)
+    check(lib.geomae_vfe_backward_layer0(a, ctypes.byref(bn), _ptr(dh0), _ptr(bs0), n_eff, N, _ptr(dy1_b), _ptr(g_b),
+                                         _ptr(params["w0"].grad), _ptr(params["w1"].grad), _stream()),
+          "geomae_vfe_backward_layer0")

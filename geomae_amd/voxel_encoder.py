@@ -28,6 +28,31 @@ class DynamicVFELayer(nn.Module):
         return F.relu(self.norm(self.linear(inputs)))
 
 
+class _FusedVFE(torch.autograd.Function):
+    """The whole encoder as seven sweeps forward / three backward (geomae_amd/csrc/vfe.hip).  The six
+    parameters enter as autograd inputs only so that the node is part of the graph; their gradients are
+    accumulated straight into .grad by the kernels."""
+
+    @staticmethod
+    def forward(ctx, points, enc, seg, w0, g0, b0, w1, g1, b1):
+        from torch import distributed as dist
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        sync = world > 1 and isinstance(enc.vfe_layers[0].norm, __import__("geomae_amd").norm.NaiveSyncBatchNorm1d)
+        world = world if sync else 1
+        plan = ops.VfePlan(points, seg, w0, w1, (enc.vx, enc.vy, enc.vz), (enc.x_offset, enc.y_offset, enc.z_offset))
+        vf, m0 = ops.vfe_forward(plan, enc.vfe_layers[0].norm, enc.vfe_layers[1].norm, world)
+        ctx.plan, ctx.world = plan, world
+        ctx.params = dict(w0=w0, g0=g0, b0=b0, w1=w1, g1=g1, b1=b1)
+        ctx.save_for_backward(m0, vf)
+        return vf
+
+    @staticmethod
+    def backward(ctx, dvf):
+        m0, vf = ctx.saved_tensors
+        ops.vfe_backward(ctx.plan, m0, vf, dvf, ctx.params, ctx.world)
+        return (None,) * 9
+
+
 @VOXEL_ENCODERS.register_module()
 class DynamicScatterVFE(nn.Module):
     def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
@@ -70,9 +95,22 @@ class DynamicScatterVFE(nn.Module):
         self.mode = mode
         self.unique_once = unique_once
 
+    use_fused = True      # set False to run the composed (ATen + segment kernels) form, kept for A/B tests
+
+    def fused_ok(self, features, seg, return_inv):
+        return (self.use_fused and seg is not None and self.training and features.is_cuda and not return_inv
+                and not self.return_point_feats and features.shape[1] == 5 and self._with_cluster_center
+                and self._with_voxel_center and not self._with_distance and self.rel_dist_scaler == 1.0
+                and [l.linear.out_features for l in self.vfe_layers] == [64, 128])
+
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, seg=None):
         """features [N, C_in] fp32, coors [N, 4] int32 (b, z, y, x)."""
         features = features.float()
+        if self.fused_ok(features, seg, return_inv):
+            l0, l1 = self.vfe_layers
+            vf = _FusedVFE.apply(features.contiguous(), self, seg, l0.linear.weight, l0.norm.weight, l0.norm.bias,
+                                 l1.linear.weight, l1.norm.weight, l1.norm.bias)
+            return vf, seg.voxel_coors[:seg.V]
         if seg is None:
             gx, gy, gz = ops.grid_size(self.voxel_size, self.point_cloud_range)
             batch_size = int(coors[:, 0].max().item()) + 1

@@ -64,10 +64,11 @@ int geomae_pillar_segment(const int32_t* coors /*[N,4]*/, int64_t num_points, in
                           int32_t* sample_start, int32_t* num_pillars, void* workspace,
                           int64_t workspace_bytes, geomaeStream_t stream);
 
-/* torch_scatter.scatter(reduce='mean') of the xyz columns (voxel_encoder.py:375): mean [cap, 3] */
-int geomae_segment_mean_xyz(const float* points, int32_t num_features, const int32_t* order,
+/* torch_scatter.scatter(reduce='mean') of the xyz columns (voxel_encoder.py:375): mean [cap, 3].
+ * 2^-32 fixed-point int64 atomics per point (order independent); sum_workspace: cap * 3 * 8 bytes. */
+int geomae_segment_mean_xyz(const float* points, int32_t num_features, int64_t num_points, const int32_t* inv,
                             const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
-                            float* mean, geomaeStream_t stream);
+                            void* sum_workspace, float* mean, geomaeStream_t stream);
 /* torch_scatter.scatter_max (voxel_encoder.py:407): feat [N, C] in point order -> out [cap, C],
  * argmax [cap, C] (point index); backward routes grad_out to the arg-max rows: grad_feat [N, C]. */
 int geomae_segment_max_forward(const float* feat, int32_t channels, const int32_t* order,
@@ -232,6 +233,56 @@ typedef struct GeomaeHeadGrads { /* fp32 gradient buffers of the six head Linear
 } GeomaeHeadGrads;
 int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const void* cm_bf16,
                              const void* dm_bf16, const GeomaeHeadGrads* grads, geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A3/A4 fused DynamicScatterVFE
+ * replaces DynamicScatterVFE.forward (voxel_encoder.py:358-419) + DynamicVFELayer (utils.py:130-144) and
+ * their autograd, for in_channels 5 (+3 cluster +3 centre), feat_channels [64, 128], mode 'max', in exact
+ * fp32.  BatchNorm is training-mode over all points: each layer is a statistics sweep, a host-visible
+ * [2C] fp64 sum vector (where naiveSyncBN1d's cross-rank average happens, ops/norm.py:64-70), and an apply
+ * sweep.  A wave owns whole pillars (geomae_vfe_plan: ranges [num_waves + 1], <= points_per_wave points each,
+ * more only for a pillar larger than that). */
+typedef struct GeomaeVfeArgs {
+    const float* points; int32_t num_features;       /* [N, C] fp32, original order                     */
+    const int32_t *order, *seg_start, *voxel_coors;  /* from geomae_pillar_segment                      */
+    const float* pillar_mean;                        /* [V, 3] from geomae_segment_mean_xyz              */
+    const int32_t* ranges; int32_t num_waves;        /* from geomae_vfe_plan                            */
+    const float *w0, *w1;                            /* vfe_layers.0.linear.weight [64,11], .1 [128,128] */
+    const float *scale0, *shift0, *scale1, *shift1;  /* folded BatchNorm (geomae_bn_finalize); may be NULL
+                                                        for the sweeps that do not need them            */
+    float voxel_size[3];                             /* vx, vy, vz                                      */
+    float center_offset[3];                          /* v/2 + range_min (x, y, z)                       */
+} GeomaeVfeArgs;
+int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,
+                    int32_t points_per_wave, int32_t num_waves, int32_t* ranges, geomaeStream_t stream);
+/* sums [2C] fp64 (sum, sum of squares) and count -> (mean, mean of squares) in moments_out [2C] and/or, when
+ * scale != NULL, the folded affine scale/shift, invstd and the running-stat update.  Pass moments_in [2C]
+ * instead of sums to finalize from externally averaged moments (naiveSyncBN1d). */
+int geomae_bn_finalize(const double* sums, double count, const float* moments_in, int32_t channels,
+                       const float* gamma, const float* beta, float eps, float momentum,
+                       int32_t unbiased_running_var, float* running_mean, float* running_var, float* scale,
+                       float* shift, float* invstd, float* moments_out, geomaeStream_t stream);
+int geomae_vfe_stats0(const GeomaeVfeArgs* args /*host*/, double* sums0 /*[128]*/, geomaeStream_t stream);
+int geomae_vfe_layer0(const GeomaeVfeArgs* args, float* m0 /*[V,64]*/, double* sums1 /*[256]*/, geomaeStream_t stream);
+int geomae_vfe_layer1(const GeomaeVfeArgs* args, const float* m0, float* voxel_feats /*[V,128]*/, geomaeStream_t stream);
+/* backward.  GeomaeBnState = what geomae_bn_finalize produced in the forward (scale = gamma * invstd,
+ * shift = beta - mean * scale, mean, invstd) for the two BatchNorms.  bsums [2C] fp64 = (sum dh, sum dh * yhat)
+ * over the local points: they ARE d beta and d gamma; for naiveSyncBN1d the caller all-reduces them before the
+ * next call and passes n_eff = world_size * N (ops/norm.py:21-24), else n_eff = N. */
+typedef struct GeomaeBnState {
+    const float *scale0, *shift0, *mean0, *invstd0, *scale1, *shift1, *mean1, *invstd1;
+} GeomaeBnState;
+int geomae_vfe_backward_stats(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* m0,
+                              const float* voxel_feats, const float* d_voxel_feats, double* bsums1 /*[256]*/,
+                              geomaeStream_t stream);
+int geomae_vfe_backward_layer1(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* m0,
+                               const float* voxel_feats, const float* d_voxel_feats, const double* bsums1_global,
+                               float n_eff, void* dy1_bf16 /*[N,128]*/, void* g_bf16 /*[N,128]*/,
+                               float* dy1_f32 /*[N,128] scratch*/, float* dh0 /*[N,64]*/, float* dm0 /*[V,64]*/,
+                               double* bsums0 /*[128]*/, geomaeStream_t stream);
+int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* dh0,
+                               const double* bsums0_global, float n_eff, int64_t num_points, const void* dy1_bf16,
+                               const void* g_bf16, float* dw0 /*[64,11] +=*/, float* dw1 /*[128,128] +=*/,
+                               geomaeStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -319,14 +319,21 @@ def _build(dev, enc, dec, compute_dtype):
     return model, params
 
 
-def test_vfe_forward_backward(dev, golden_dir):
+@pytest.mark.parametrize("fused", [True, False])
+def test_vfe_forward_backward(dev, golden_dir, fused):
     g = np.load(os.path.join(golden_dir, "g_pipeline_tiny.npz"))
     model, params = _build(dev, 1, 1, "fp32")
+    model.voxel_encoder.use_fused = fused
     frames = _frames()
     pts = [torch.as_tensor(f, device=dev) for f in frames]
     voxels, coors, _, _ = model.voxelize_all(pts)
-    vf, vc = model.voxel_encoder(voxels, coors)
+    from geomae_amd import ops
+    seg = ops.pillar_segment(coors, 2, (1, 400, 400))
+    vf, vc = model.voxel_encoder(voxels, coors, seg=seg)
     np.testing.assert_allclose(vf.detach().cpu().numpy(), g["voxel_feats"], rtol=1e-3, atol=2e-4)
+    # running statistics follow nn.BatchNorm1d (momentum 0.01, unbiased running variance)
+    bn = model.voxel_encoder.vfe_layers[1].norm
+    assert int(bn.num_batches_tracked) == 1 and float((bn.running_mean != 0).float().mean()) > 0.9
     assert np.array_equal(vc.cpu().numpy(), g["voxel_coors"].astype(np.int32))
     # backward against the oracle
     p = {k: v.clone().requires_grad_(True) for k, v in params.items() if k.startswith("voxel_encoder.")}
