@@ -33,10 +33,9 @@ class GeomaeSstLayerWeights(ctypes.Structure):
 
 
 class GeomaeVfeArgs(ctypes.Structure):
-    _fields_ = [("points", c_void_p), ("num_features", c_int32), ("order", c_void_p), ("seg_start", c_void_p),
-                ("voxel_coors", c_void_p), ("pillar_mean", c_void_p), ("ranges", c_void_p), ("num_waves", c_int32),
-                ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p), ("scale1", c_void_p),
-                ("shift1", c_void_p), ("voxel_size", c_float * 3), ("center_offset", c_float * 3)]
+    _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("ranges", c_void_p),
+                ("num_waves", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
+                ("scale1", c_void_p), ("shift1", c_void_p)]
 
 
 class GeomaeBnState(ctypes.Structure):
@@ -67,6 +66,7 @@ SIGNATURES = {
     "geomae_pillar_segment": (ctypes.c_int, [P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P,
                                              P, c_int64, P]),
     "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, c_int32, P, P, P]),
+    "geomae_vfe_prepare": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, P, F3, F3, P, P, P]),
     "geomae_vfe_plan": (ctypes.c_int, [P, P, c_int32, c_int32, c_int32, P, P]),
     "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P]),
     "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),

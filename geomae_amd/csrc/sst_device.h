@@ -67,14 +67,19 @@ __device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __
     }
     __syncthreads();
     const int o = lane & 15, g = lane >> 4;
+    // groups of 4 output tiles advance together over K: consecutive MFMAs hit independent accumulators, so the
+    // dependent-accumulator latency of a chain (kk inner loop: 38 % issue stalls in profiles/r01 PMC) is hidden
+    constexpr int GRP = (N / 16) < 4 ? (N / 16) : 4;
 #pragma unroll
-    for (int ot = 0; ot < N / 16; ++ot) {
-        const bf16_t* wrow = smem + (16 * ot + o) * LD + 8 * g;
+    for (int ot0 = 0; ot0 < N / 16; ot0 += GRP) {
 #pragma unroll
         for (int kk = 0; kk < K / 32; ++kk) {
-            const uint4 a = *reinterpret_cast<const uint4*>(wrow + 32 * kk);
             const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
-            acc[ot] = mfma32(a, b, acc[ot]);
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const uint4 a = *reinterpret_cast<const uint4*>(smem + (16 * (ot0 + u) + o) * LD + 8 * g + 32 * kk);
+                acc[ot0 + u] = mfma32(a, b, acc[ot0 + u]);
+            }
         }
     }
 }

@@ -35,9 +35,9 @@ __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
 }
 
 struct VfeGeo {
-    const float* pts; int stride;
-    const int32_t* order; const int32_t* seg_start; const int4* voxel_coors; const float* mean;
-    float vx, vy, vz, xo, yo, zo;
+    const float* feat;            // [N,16] decorated features of the points in pillar order (vfe_prepare)
+    const int32_t* pid;           // [N] pillar of each sorted point
+    const int32_t* seg_start;
 };
 
 struct WaveRange { int p_lo, p_hi, j_lo, j_hi; };
@@ -52,33 +52,41 @@ __device__ __forceinline__ WaveRange wave_range(const int32_t* __restrict__ rang
     return r;
 }
 
-// pillar id of sorted point j inside [p_lo, p_hi): binary search over seg_start
-__device__ __forceinline__ int pillar_of(const int32_t* __restrict__ seg_start, int p_lo, int p_hi, int j) {
-    int lo = p_lo, hi = p_hi - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (seg_start[mid] <= j) lo = mid; else hi = mid - 1;
-    }
-    return lo;
+__device__ __forceinline__ int pillar_of(const VfeGeo& G, int j) { return G.pid[j]; }
+
+// the lane's 4 of the 16 (11 used) decorated features of its point, T-layout: feature index 4g + r.
+// One coalesced 16-byte load: the gathers (order -> point -> pillar mean / centre) were hoisted into
+// vfe_prepare_kernel, because as per-tile dependent loads they cost ~5 us per tile in every sweep.
+__device__ __forceinline__ void build_features(const VfeGeo& G, int j, int pid, bool valid, int g, float (&f)[4]) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (valid) v = *reinterpret_cast<const float4*>(G.feat + (int64_t)j * 16 + 4 * g);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
 }
 
-// the lane's 4 of the 16 (11 used) decorated features of its point, T-layout: feature index 4g + r
-__device__ __forceinline__ void build_features(const VfeGeo& G, int j, int pid, bool valid, int g, float (&f)[4]) {
-    f[0] = f[1] = f[2] = f[3] = 0.f;
-    if (!valid || g == 3) return;
-    const float* q = G.pts + (int64_t)G.order[j] * G.stride;
-    const float x = q[0], y = q[1], z = q[2];
-    if (g == 0) {
-        f[0] = x; f[1] = y; f[2] = z; f[3] = q[3];
-    } else if (g == 1) {
-        const float* m = G.mean + (int64_t)pid * 3;
-        f[0] = q[4]; f[1] = x - m[0]; f[2] = y - m[1]; f[3] = z - m[2];
-    } else {
+// features of every point, written in pillar order: [x y z i | dt x-mx y-my z-mz | x-cx y-cy z-cz 0 | 0 0 0 0]
+__global__ __launch_bounds__(256) void vfe_prepare_kernel(const float* __restrict__ pts, int stride, int64_t n,
+                                                          const int32_t* __restrict__ order,
+                                                          const int32_t* __restrict__ inv,
+                                                          const float* __restrict__ mean,
+                                                          const int4* __restrict__ voxel_coors, float vx, float vy,
+                                                          float vz, float xo, float yo, float zo,
+                                                          float* __restrict__ feat, int32_t* __restrict__ pid_out) {
+    for (int64_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
+        const int i = order[j];
+        const int p = inv[i];
+        const float* q = pts + (int64_t)i * stride;
+        const float x = q[0], y = q[1], z = q[2];
+        const float* m = mean + (int64_t)p * 3;
+        const int4 c = voxel_coors[p];
+        float4* o = reinterpret_cast<float4*>(feat + j * 16);
+        o[0] = make_float4(x, y, z, q[3]);
+        o[1] = make_float4(q[4], x - m[0], y - m[1], z - m[2]);
         // x - (coor * v + offset): every operation rounded separately, as the reference's tensor ops
-        const int4 c = G.voxel_coors[pid];
-        f[0] = __fsub_rn(x, __fadd_rn(__fmul_rn((float)c.w, G.vx), G.xo));
-        f[1] = __fsub_rn(y, __fadd_rn(__fmul_rn((float)c.z, G.vy), G.yo));
-        f[2] = __fsub_rn(z, __fadd_rn(__fmul_rn((float)c.y, G.vz), G.zo));
+        o[2] = make_float4(__fsub_rn(x, __fadd_rn(__fmul_rn((float)c.w, vx), xo)),
+                           __fsub_rn(y, __fadd_rn(__fmul_rn((float)c.z, vy), yo)),
+                           __fsub_rn(z, __fadd_rn(__fmul_rn((float)c.y, vz), zo)), 0.f);
+        o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+        pid_out[j] = p;
     }
 }
 
@@ -97,39 +105,34 @@ __device__ __forceinline__ void layer0_linear(const float* __restrict__ W0s, con
     }
 }
 
-// y1[t][16*ot + 4g + r] = sum_k W1[.][k] gin[t][k]; W1s: LDS [128][kW1Ld] fp32 ; gin: 8 T-layout tiles
-__device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const f32x4 (&gin)[8], f32x4 (&y)[8], int lane) {
+// y1[t][16*ot + 4g + r] = sum_k W1[.][k] gin[t][k]; W1s: LDS [128][kW1Ld] fp32 ; gin: 8 T-layout tiles.
+// NG output tiles starting at ot0 advance together over k (independent accumulators back to back: the
+// 16x16x4 f32 MFMA has a 40-cycle dependent latency against a 32-cycle issue).  The k order inside every
+// accumulator is fixed (ct, then r), so any grouping gives bit-identical results.
+template <int NG>
+__device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, const f32x4 (&gin)[8], int ot0,
+                                             f32x4 (&y)[NG], int lane) {
     const int o = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int ot = 0; ot < 8; ++ot) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* wrow = W1s + (16 * ot + o) * kW1Ld + 4 * g;
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * ct);
-            acc = mfma_f32(a.x, gin[ct][0], acc);
-            acc = mfma_f32(a.y, gin[ct][1], acc);
-            acc = mfma_f32(a.z, gin[ct][2], acc);
-            acc = mfma_f32(a.w, gin[ct][3], acc);
-        }
-        y[ot] = acc;
-    }
-}
-
-// one 16-channel output tile of the same product (same MFMA order => bit-identical to layer1_linear)
-__device__ __forceinline__ f32x4 layer1_tile(const float* __restrict__ W1s, const f32x4 (&gin)[8], int ot, int lane) {
-    const int o = lane & 15, g = lane >> 4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float* wrow = W1s + (16 * ot + o) * kW1Ld + 4 * g;
+    for (int u = 0; u < NG; ++u) y[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
-        const float4 a = *reinterpret_cast<const float4*>(wrow + 16 * ct);
-        acc = mfma_f32(a.x, gin[ct][0], acc);
-        acc = mfma_f32(a.y, gin[ct][1], acc);
-        acc = mfma_f32(a.z, gin[ct][2], acc);
-        acc = mfma_f32(a.w, gin[ct][3], acc);
+        float4 a[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u)
+            a[u] = *reinterpret_cast<const float4*>(W1s + (16 * (ot0 + u) + o) * kW1Ld + 4 * g + 16 * ct);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].x, gin[ct][0], y[u]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].y, gin[ct][1], y[u]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].z, gin[ct][2], y[u]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].w, gin[ct][3], y[u]);
     }
-    return acc;
+}
+__device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const f32x4 (&gin)[8], f32x4 (&y)[8], int lane) {
+    layer1_group<8>(W1s, gin, 0, y, lane);
 }
 
 template <int NT>
@@ -174,7 +177,19 @@ __device__ __forceinline__ void tile_store(float* tile, const f32x4 (&v)[NT], in
     for (int ot = 0; ot < NT; ++ot)
         *reinterpret_cast<float4*>(tile + t * kTileLd + 16 * ot + 4 * g) = make_float4(v[ot][0], v[ot][1], v[ot][2], v[ot][3]);
 }
-__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+// LDS hand-off inside ONE wave (tile written by its lanes, scanned by its lanes): DS operations of a wave
+// execute in order, so it is enough to drain the LDS counter and stop the compiler from moving accesses
+// across.  (A workgroup-scope fence here also waited for the wave's outstanding global stores: ~1 us per tile.)
+__device__ __forceinline__ void wave_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// global hand-off inside one wave (rows stored in pass A, read back in pass B)
+__device__ __forceinline__ void wave_global_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 // Segmented reduction of a [16 x 64*CPL] tile over the tile's points, lane = channel (+64 per extra channel):
 // `cur_pid` / `cur` carry the open pillar across tiles; a finished pillar's row is stored to out[pid][c].
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, c
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y[4];
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
         for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
             const int j = j0 + (lane & 15);
             const bool valid = j < R.j_hi;
-            const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+            const int pid = valid ? pillar_of(G, j) : 0;
             float f[4];
             build_features(G, j, pid, valid, g, f);
             f32x4 y[4], h[4];
@@ -374,8 +389,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
         }
         seg_flush<1>(64, m0, cur_pid, cur, lane);
     }
-    __threadfence_block();
-    wave_sync();
+    wave_global_sync();
     // ---- pass B: y1 statistics
     f32x4 s1[8], s2[8];
 #pragma unroll
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y0[4], gin[8];
@@ -441,7 +455,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         f32x4 y0[4], gin[8], y1[8], h1[8];
         recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
         layer1_linear(W1s, gin, y1, lane);
@@ -501,15 +515,20 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         f32x4 y0[4], gin[8];
         recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
-            f32x4 dh, yh;
-            routed_tile(layer1_tile(W1s, gin, ot, lane), bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
-            s1[ot] += dh;
-            s2[ot] += dh * yh;
+        for (int ot0 = 0; ot0 < 8; ot0 += 4) {
+            f32x4 y4[4];
+            layer1_group<4>(W1s, gin, ot0, y4, lane);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                f32x4 dh, yh;
+                routed_tile(y4[u], bn, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
+                s1[ot0 + u] += dh;
+                s2[ot0 + u] += dh * yh;
+            }
         }
     }
     flush_channel_sums<8>(s1, s2, bsums1, 128, red, lane, wave);
@@ -547,14 +566,19 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         f32x4 y0[4], gin[8];
         recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
         store_rows_bf16<128>(g_b, j, 128, 0, valid, gin, lane);
 #pragma unroll
-        for (int ot = 0; ot < 8; ++ot) {
+        for (int ot0 = 0; ot0 < 8; ot0 += 4) {
+          f32x4 y4[4];
+          layer1_group<4>(W1s, gin, ot0, y4, lane);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int ot = ot0 + u;
             f32x4 dh, yh, dy;
-            routed_tile(layer1_tile(W1s, gin, ot, lane), bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+            routed_tile(y4[u], bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
             const int c0 = 16 * ot + 4 * g;
             const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c0);     // gamma * invstd
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
@@ -564,6 +588,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
                 *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy);      // operand of dW1 (dw_kernel)
                 *reinterpret_cast<float4*>(dy1_f + (int64_t)j * 128 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
             }
+          }
         }
     }
     __syncthreads();
@@ -575,7 +600,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
             const int j = j0 + (lane & 15);
             const bool valid = j < R.j_hi;
-            const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+            const int pid = valid ? pillar_of(G, j) : 0;
             f32x4 dy1[8], dg[8];
             load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
             layer1_linear(W1s, dy1, dg, lane);            // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]
@@ -594,8 +619,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         }
         seg_flush<1>(64, dm0, cur_pid, cur, lane);
     }
-    __threadfence_block();
-    wave_sync();
+    wave_global_sync();
     // ---- pass B: total dh0, BN0 backward statistics
     f32x4 s1[4], s2[4];
 #pragma unroll
@@ -603,7 +627,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y0[4];
@@ -666,7 +690,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G.seg_start, R.p_lo, R.p_hi, j) : 0;
+        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y0[4], dy0[4];
@@ -720,15 +744,26 @@ using namespace geomae;
 
 static int vfe_common(const GeomaeVfeArgs* a, VfeGeo* G, VfeW* W, const char* who) {
     GEOMAE_REQUIRE(a, "%s: null args", who);
-    GEOMAE_REQUIRE(a->points && a->order && a->seg_start && a->voxel_coors && a->pillar_mean && a->ranges &&
-                   a->w0 && a->w1, "%s: null pointer in args", who);
-    GEOMAE_REQUIRE(a->num_features >= 5 && a->num_waves >= 1, "%s: bad sizes", who);
-    G->pts = a->points; G->stride = a->num_features; G->order = a->order; G->seg_start = a->seg_start;
-    G->voxel_coors = (const int4*)a->voxel_coors; G->mean = a->pillar_mean;
-    G->vx = a->voxel_size[0]; G->vy = a->voxel_size[1]; G->vz = a->voxel_size[2];
-    G->xo = a->center_offset[0]; G->yo = a->center_offset[1]; G->zo = a->center_offset[2];
+    GEOMAE_REQUIRE(a->feat_sorted && a->pid_sorted && a->seg_start && a->ranges && a->w0 && a->w1,
+                   "%s: null pointer in args", who);
+    GEOMAE_REQUIRE(a->num_waves >= 1, "%s: bad sizes", who);
+    G->feat = a->feat_sorted; G->pid = a->pid_sorted; G->seg_start = a->seg_start;
     W->w0 = a->w0; W->w1 = a->w1; W->scale0 = a->scale0; W->shift0 = a->shift0; W->scale1 = a->scale1; W->shift1 = a->shift1;
     return GEOMAE_OK;
+}
+
+extern "C" int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
+                                  const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
+                                  const float* voxel_size, const float* center_offset, float* feat_sorted,
+                                  int32_t* pid_sorted, hipStream_t stream) {
+    if (num_points <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(points && order && inv && pillar_mean && voxel_coors && voxel_size && center_offset && feat_sorted &&
+                   pid_sorted, "vfe_prepare: null argument");
+    GEOMAE_REQUIRE(num_features >= 5, "vfe_prepare: points need 5 features (x, y, z, intensity, dt)");
+    hipLaunchKernelGGL(vfe_prepare_kernel, dim3(stream_grid(num_points, 256)), dim3(256), 0, stream, points, num_features,
+                       num_points, order, inv, pillar_mean, (const int4*)voxel_coors, voxel_size[0], voxel_size[1],
+                       voxel_size[2], center_offset[0], center_offset[1], center_offset[2], feat_sorted, pid_sorted);
+    return check_launch("vfe_prepare_kernel");
 }
 
 extern "C" int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,

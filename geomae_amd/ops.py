@@ -515,15 +515,17 @@ class VfePlan:
         check(lib.geomae_vfe_plan(_ptr(seg.seg_start), _ptr(seg.num_pillars), self.N, self.POINTS_PER_WAVE,
                                   self.num_waves, _ptr(self.ranges), _stream()), "geomae_vfe_plan")
         self.bn = torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)    # [layer][scale, shift, mean, invstd]
+        self.feat = torch.empty((max(self.N, 1), 16), dtype=torch.float32, device=dev)
+        self.pid = torch.empty(max(self.N, 1), dtype=torch.int32, device=dev)
+        check(lib.geomae_vfe_prepare(_ptr(points), points.shape[1], self.N, _ptr(seg.order), _ptr(seg.inv),
+                                     _ptr(self.mean), _ptr(seg.voxel_coors), f3(voxel_size), f3(center_offset),
+                                     _ptr(self.feat), _ptr(self.pid), _stream()), "geomae_vfe_prepare")
         a = GeomaeVfeArgs()
-        a.points, a.num_features = points.data_ptr(), points.shape[1]
-        a.order, a.seg_start, a.voxel_coors = seg.order.data_ptr(), seg.seg_start.data_ptr(), seg.voxel_coors.data_ptr()
-        a.pillar_mean, a.ranges, a.num_waves = self.mean.data_ptr(), self.ranges.data_ptr(), self.num_waves
+        a.feat_sorted, a.pid_sorted, a.seg_start = self.feat.data_ptr(), self.pid.data_ptr(), seg.seg_start.data_ptr()
+        a.ranges, a.num_waves = self.ranges.data_ptr(), self.num_waves
         a.w0, a.w1 = w0.data_ptr(), w1.data_ptr()
         a.scale0, a.shift0 = self.bn[0, 0].data_ptr(), self.bn[0, 1].data_ptr()
         a.scale1, a.shift1 = self.bn[1, 0].data_ptr(), self.bn[1, 1].data_ptr()
-        a.voxel_size[:] = [float(v) for v in voxel_size]
-        a.center_offset[:] = [float(v) for v in center_offset]
         self.args = a
         self._keep = (w0, w1)
 

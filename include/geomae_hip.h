@@ -242,16 +242,20 @@ int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const v
  * sweep.  A wave owns whole pillars (geomae_vfe_plan: ranges [num_waves + 1], <= points_per_wave points each,
  * more only for a pillar larger than that). */
 typedef struct GeomaeVfeArgs {
-    const float* points; int32_t num_features;       /* [N, C] fp32, original order                     */
-    const int32_t *order, *seg_start, *voxel_coors;  /* from geomae_pillar_segment                      */
-    const float* pillar_mean;                        /* [V, 3] from geomae_segment_mean_xyz              */
-    const int32_t* ranges; int32_t num_waves;        /* from geomae_vfe_plan                            */
+    const float* feat_sorted;                        /* [N,16] from geomae_vfe_prepare                   */
+    const int32_t* pid_sorted;                       /* [N]                                              */
+    const int32_t* seg_start;                        /* from geomae_pillar_segment                       */
+    const int32_t* ranges; int32_t num_waves;        /* from geomae_vfe_plan                             */
     const float *w0, *w1;                            /* vfe_layers.0.linear.weight [64,11], .1 [128,128] */
     const float *scale0, *shift0, *scale1, *shift1;  /* folded BatchNorm (geomae_bn_finalize); may be NULL
                                                         for the sweeps that do not need them            */
-    float voxel_size[3];                             /* vx, vy, vz                                      */
-    float center_offset[3];                          /* v/2 + range_min (x, y, z)                       */
 } GeomaeVfeArgs;
+/* decorated point features [x y z i dt | xyz - pillar mean | xyz - pillar centre | 0...] in pillar order
+ * (voxel_encoder.py:372-397); voxel_size (vx,vy,vz) and center_offset = v/2 + range_min are host arrays */
+int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
+                       const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
+                       const float* voxel_size, const float* center_offset, float* feat_sorted,
+                       int32_t* pid_sorted, geomaeStream_t stream);
 int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,
                     int32_t points_per_wave, int32_t num_waves, int32_t* ranges, geomaeStream_t stream);
 /* sums [2C] fp64 (sum, sum of squares) and count -> (mean, mean of squares) in moments_out [2C] and/or, when
