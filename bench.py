@@ -90,7 +90,9 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    ops.KERNEL_EVENTS = {"win_attn_fwd_kernel": [], "win_attn_bwd_kernel": []}
+    TIMED = ("sst_ffn_bwd_kernel", "win_attn_bwd_kernel", "dw_kernel", "sst_ffn_fwd_kernel", "sst_qkv_bwd_kernel",
+             "win_attn_fwd_kernel", "sst_qkv_fwd_kernel")
+    ops.KERNEL_EVENTS = {k: [] for k in TIMED}
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -110,29 +112,45 @@ def main():
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:
-        # roofline of the dominant hand-written kernel: windowed attention backward (MFMA bound):
-        # algorithmic FLOPs per launch = 10 * 16 * H * sum_w n_w^2  (5 n_w x n_w x 16 products per head;
-        # forward has 2).  sum_w n_w^2 is recomputed here from the layouts of the last batch.
-        def avg_ms(name):
-            ev = events[name]
-            return float(np.mean([a.elapsed_time(b) for a, b in ev])) if ev else None
+        # Per-launch roofline of the hand-written layer kernels.  Durations: HIP events recorded on the launch
+        # stream around every launch of the timed region.  Algorithmic FLOPs per launch (2 per MAC, DESIGN.md
+        # section 3): projections 2*n*K*N over the tokens n of the layer; attention 2*{2,5}*16*H*sum_w n_w^2.
+        def total_ms(name):
+            return float(np.sum([a.elapsed_time(b) for a, b in events[name]])) if events[name] else 0.0
         with torch.no_grad():
-            sq = []
             pts = pool[(args.warmup + args.steps - 1) % len(pool)]
             voxels, coors, _, _ = model.voxelize_all(pts)
             seg = ops.pillar_segment(coors, B, model.grid_size)
             vc = seg.voxel_coors[:seg.V]
             ids_keep, _, _, _ = ops.random_mask(seg, 1 - model.random_mask_ratio, 1)
+            n_tok, sq = [], []
             for toks, layers in ((vc[ids_keep.long()], 12), (vc, 8)):
-                for s in (0, 1):
-                    L = ops.window_build(toks.contiguous(), B, model.backbone._wcfg, s)
+                for s_ in (0, 1):
+                    L = ops.window_build(toks.contiguous(), B, model.backbone._wcfg, s_)
                     W = int(L.num_windows.item())
                     nw = (L.win_start[1:W + 1] - L.win_start[:W]).double()
                     sq += [float((nw * nw).sum())] * (layers // 2)
-        flops_bwd = 10 * 16 * 8 * float(np.mean(sq)) * 2          # 2 flops per MAC
-        ms_bwd, ms_fwd = avg_ms("win_attn_bwd_kernel"), avg_ms("win_attn_fwd_kernel")
+                    n_tok += [int(toks.shape[0])] * (layers // 2)
+        n_sum, sq_sum = float(np.sum(n_tok)), float(np.sum(sq))          # over the 20 layers of one step
+        flops_step = {"sst_ffn_bwd_kernel": 2 * 81920 * n_sum, "sst_ffn_fwd_kernel": 2 * 81920 * n_sum,
+                      "sst_qkv_fwd_kernel": 2 * 49152 * n_sum, "sst_qkv_bwd_kernel": 2 * 49152 * n_sum,
+                      "dw_kernel": 2 * 131072 * n_sum, "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum,
+                      "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum}
         peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
-        achieved = flops_bwd / (ms_bwd * 1e-3) / 1e12 if ms_bwd else None
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath))
+        kern = {}
+        for k in TIMED:
+            ms = total_ms(k)
+            if ms > 0:
+                ach = flops_step[k] * args.steps / (ms * 1e-3) / 1e12
+                kern[k] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
+                           "frac": round(ach / peak, 5), "traffic": traffic.get(k),
+                           "avg_launch_ms": round(ms / len(events[k]), 5), "launches_timed": len(events[k]),
+                           "ms_per_step": round(ms / args.steps, 4)}
+        dominant = max(kern, key=lambda k: kern[k]["ms_per_step"])
         out = {
             "metric": "pretrain frames/sec (nuScenes SST-GeoMAE)",
             "value": round(world * B * args.steps / elapsed, 3), "unit": "frames/s",
@@ -143,10 +161,8 @@ def main():
                                    f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": round(loss_val, 4),
-            "roofline": {"bound": "mfma", "kernel": "win_attn_bwd_kernel", "achieved": achieved, "peak": peak,
-                         "unit": "TFLOP/s", "frac": (achieved / peak) if achieved else None, "traffic": None,
-                         "avg_launch_ms": ms_bwd, "fwd_avg_launch_ms": ms_fwd,
-                         "launches_timed": len(events["win_attn_bwd_kernel"])},
+            "roofline": dict(kernel=dominant, **kern[dominant]),
+            "roofline_other_kernels": {k: v for k, v in kern.items() if k != dominant},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -444,8 +444,9 @@ def sst_qkv_forward(x, layout, pos_table, w):
     _check_input(x, "x", torch.float32)
     n = x.shape[0]
     qkv = torch.empty((n, 384), dtype=torch.bfloat16, device=x.device)
-    check(_lib.load().geomae_sst_qkv_forward(_ptr(x), _ptr(layout.tok_pos), _ptr(pos_table), ctypes.byref(w), n,
-                                             _ptr(qkv), _stream()), "geomae_sst_qkv_forward")
+    with _timed("sst_qkv_fwd_kernel"):
+        check(_lib.load().geomae_sst_qkv_forward(_ptr(x), _ptr(layout.tok_pos), _ptr(pos_table), ctypes.byref(w), n,
+                                                 _ptr(qkv), _stream()), "geomae_sst_qkv_forward")
     return qkv
 
 
@@ -459,8 +460,10 @@ def sst_ffn_forward(x, attn, w, save=True):
         saved = (torch.empty_like(x), torch.empty_like(x), torch.empty((n, 256), dtype=torch.bfloat16, device=dev),
                  torch.empty((n, 2), dtype=torch.float32, device=dev))
     s = saved or (None, None, None, None)
-    check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _ptr(s[0]), _ptr(s[1]),
-                                             _ptr(s[2]), _ptr(s[3]), _stream()), "geomae_sst_ffn_forward")
+    with _timed("sst_ffn_fwd_kernel"):
+        check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _ptr(s[0]),
+                                                 _ptr(s[1]), _ptr(s[2]), _ptr(s[3]), _stream()),
+              "geomae_sst_ffn_forward")
     return z, saved
 
 
@@ -479,9 +482,10 @@ def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, nu
     dattn, du_b, dv_b, dhp_b, y_b, h_b, xp_b, x_b, dqkv = bufs
     _check_input(dz, "dz", torch.float32)
     xh1, xh2, hp, rstd = saved
-    check(lib.geomae_sst_ffn_backward(_ptr(xh1), _ptr(xh2), _ptr(hp), _ptr(rstd), _ptr(dz), ctypes.byref(w), n,
-                                      _ptr(dx_res), _ptr(dattn), _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b),
-                                      _ptr(h_b), ctypes.byref(g), _stream()), "geomae_sst_ffn_backward")
+    with _timed("sst_ffn_bwd_kernel"):
+        check(lib.geomae_sst_ffn_backward(_ptr(xh1), _ptr(xh2), _ptr(hp), _ptr(rstd), _ptr(dz), ctypes.byref(w), n,
+                                          _ptr(dx_res), _ptr(dattn), _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b),
+                                          _ptr(h_b), ctypes.byref(g), _stream()), "geomae_sst_ffn_backward")
     L = layout
     with _timed("win_attn_bwd_kernel"):
         check(lib.geomae_window_attention_backward(
@@ -490,12 +494,14 @@ def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, nu
             L.max_tokens, _ptr(dqkv), _stream()),
             "geomae_window_attention_backward")
     dx = torch.empty_like(x)
-    check(lib.geomae_sst_qkv_backward(_ptr(dqkv), _ptr(dx_res), _ptr(x), _ptr(L.tok_pos), _ptr(pos_table),
-                                      ctypes.byref(w), n, _ptr(dx), _ptr(xp_b), _ptr(x_b), _stream()),
-          "geomae_sst_qkv_backward")
-    check(lib.geomae_sst_weight_grad(n, _ptr(dqkv), _ptr(xp_b), _ptr(x_b), _ptr(du_b), _ptr(attn), _ptr(dhp_b),
-                                     _ptr(y_b), _ptr(dv_b), _ptr(h_b), ctypes.byref(g), _stream()),
-          "geomae_sst_weight_grad")
+    with _timed("sst_qkv_bwd_kernel"):
+        check(lib.geomae_sst_qkv_backward(_ptr(dqkv), _ptr(dx_res), _ptr(x), _ptr(L.tok_pos), _ptr(pos_table),
+                                          ctypes.byref(w), n, _ptr(dx), _ptr(xp_b), _ptr(x_b), _stream()),
+              "geomae_sst_qkv_backward")
+    with _timed("dw_kernel"):
+        check(lib.geomae_sst_weight_grad(n, _ptr(dqkv), _ptr(xp_b), _ptr(x_b), _ptr(du_b), _ptr(attn), _ptr(dhp_b),
+                                         _ptr(y_b), _ptr(dv_b), _ptr(h_b), ctypes.byref(g), _stream()),
+              "geomae_sst_weight_grad")
     return dx
 
 
