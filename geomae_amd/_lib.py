@@ -32,6 +32,11 @@ class GeomaeSstLayerWeights(ctypes.Structure):
                 + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float)])
 
 
+class GeomaeSstStackLayout(ctypes.Structure):
+    _fields_ = [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "bun_start", "num_bundles")] + \
+               [("max_bundles", c_int32)]
+
+
 class GeomaeVfeArgs(ctypes.Structure):
     _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("ranges", c_void_p),
                 ("num_waves", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
@@ -98,6 +103,14 @@ SIGNATURES = {
                                                P, P, P, POINTER(GeomaeSstLayerGrads), P]),
     "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
     "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
+    "geomae_sst_stack_saved_bytes": (c_int64, [c_int32, c_int32, c_int32]),
+    "geomae_sst_stack_scratch_bytes": (c_int64, [c_int32]),
+    "geomae_sst_stack_forward": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, c_int32, c_int32, P, c_int64, P, P, P]),
+    "geomae_sst_stack_backward": (ctypes.c_int, [P, c_int32, P, P, c_int32, P, P, c_int32, c_int32, P, P, c_int64, P,
+                                                 P, P]),
+    "geomae_profiler_create": (c_void_p, [c_int32, c_int32]),
+    "geomae_profiler_read": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
+    "geomae_profiler_destroy": (None, [c_void_p]),
 }
 
 _lib = None

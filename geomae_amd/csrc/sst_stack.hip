@@ -1,0 +1,218 @@
+// Host-side orchestration of a stack of fused SST layers (encoder: 12, each decoder: 4) in ONE C call.
+//
+// Reference: BasicShiftBlock / the block loops of MultiMAESSTSPChoose.forward_encoder / forward_decoder
+// (mmdet3d/models/sst/sst_basic_block.py:119-147; backbones/multi_mae_sst_spearate_top_only.py:227-277),
+// which Python drives layer by layer (and the autograd engine node by node).  With the kernels at 13-60 us
+// the per-layer Python / ctypes / allocator work (~100 us a layer) had become the bottleneck of the step, so
+// the layer loop lives here: one call enqueues 3 kernels per layer forward, 4 per layer backward, on the
+// caller's stream, carving every intermediate out of two caller-provided buffers (no allocation, no sync).
+//
+// saved   (kept from forward to backward), per layer, 256-byte aligned pieces:
+//           x_in f32 [n,128] | qkv bf16 [n,384] | attn bf16 [n,128] | lse f32 [n,H] |
+//           xhat1 f32 [n,128] | xhat2 f32 [n,128] | hp bf16 [n,256] | rstd f32 [n,2]
+// scratch (backward only, reused by every layer): dx_res f32 [n,128] | dx ping-pong f32 2x[n,128] |
+//           bf16 slabs dattn, du, dv, y, xp, xb [n,128] each, dhp, h [n,256] each, dqkv [n,384]
+#include "common.h"
+#include "../../include/geomae_hip.h"
+#include <vector>
+
+namespace geomae {
+
+static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
+
+struct SavedOffsets {
+    int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, stride;
+};
+static SavedOffsets saved_offsets(int64_t n, int heads) {
+    SavedOffsets o;
+    int64_t p = 0;
+    o.x = p;    p += al256(n * 128 * 4);
+    o.qkv = p;  p += al256(n * 384 * 2);
+    o.attn = p; p += al256(n * 128 * 2);
+    o.lse = p;  p += al256(n * heads * 4);
+    o.xh1 = p;  p += al256(n * 128 * 4);
+    o.xh2 = p;  p += al256(n * 128 * 4);
+    o.hp = p;   p += al256(n * 256 * 2);
+    o.rstd = p; p += al256(n * 2 * 4);
+    o.stride = p;
+    return o;
+}
+
+struct ScratchOffsets {
+    int64_t dx_res, dxa, dxb, dattn, du, dv, y, xp, xb, dhp, h, dqkv, total;
+};
+static ScratchOffsets scratch_offsets(int64_t n) {
+    ScratchOffsets o;
+    int64_t p = 0;
+    o.dx_res = p; p += al256(n * 128 * 4);
+    o.dxa = p;    p += al256(n * 128 * 4);
+    o.dxb = p;    p += al256(n * 128 * 4);
+    o.dattn = p;  p += al256(n * 128 * 2);
+    o.du = p;     p += al256(n * 128 * 2);
+    o.dv = p;     p += al256(n * 128 * 2);
+    o.y = p;      p += al256(n * 128 * 2);
+    o.xp = p;     p += al256(n * 128 * 2);
+    o.xb = p;     p += al256(n * 128 * 2);
+    o.dhp = p;    p += al256(n * 256 * 2);
+    o.h = p;      p += al256(n * 256 * 2);
+    o.dqkv = p;   p += al256(n * 384 * 2);
+    o.total = p;
+    return o;
+}
+
+// optional per-kernel timing with HIP events recorded on the launch stream (bench.py's roofline)
+struct Profiler {
+    int kernel_id;
+    std::vector<hipEvent_t> ev;     // pairs
+    int used = 0;
+};
+struct Timed {
+    Profiler* p; hipStream_t s; bool on;
+    Timed(void* prof, int id, hipStream_t st) : p((Profiler*)prof), s(st) {
+        on = p && p->kernel_id == id && p->used + 2 <= (int)p->ev.size();
+        if (on) hipEventRecord(p->ev[p->used], s);
+    }
+    ~Timed() {
+        if (on) { hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
+    }
+};
+
+}  // namespace geomae
+
+using namespace geomae;
+
+extern "C" void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches) {
+    Profiler* p = new Profiler();
+    p->kernel_id = kernel_id;
+    p->ev.resize((size_t)max_launches * 2);
+    for (auto& e : p->ev)
+        if (hipEventCreate(&e) != hipSuccess) { delete p; set_error("profiler_create: hipEventCreate failed"); return nullptr; }
+    return p;
+}
+extern "C" int32_t geomae_profiler_read(void* prof, float* ms_out, int32_t capacity) {
+    Profiler* p = (Profiler*)prof;
+    if (!p) return 0;
+    const int n = p->used / 2 < capacity ? p->used / 2 : capacity;
+    for (int i = 0; i < n; ++i) {
+        hipEventSynchronize(p->ev[2 * i + 1]);
+        hipEventElapsedTime(&ms_out[i], p->ev[2 * i], p->ev[2 * i + 1]);
+    }
+    p->used = 0;
+    return n;
+}
+extern "C" void geomae_profiler_destroy(void* prof) {
+    Profiler* p = (Profiler*)prof;
+    if (!p) return;
+    for (auto& e : p->ev) hipEventDestroy(e);
+    delete p;
+}
+
+extern "C" int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads) {
+    return saved_offsets(num_tokens, num_heads).stride * num_layers;
+}
+extern "C" int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens) { return scratch_offsets(num_tokens).total; }
+
+static int check_stack(const GeomaeSstLayerWeights* layers, int n_layers, const GeomaeSstStackLayout* lay, const char* who) {
+    GEOMAE_REQUIRE(layers && n_layers >= 1 && lay, "%s: null layers / layouts", who);
+    for (int s = 0; s < 2; ++s)
+        GEOMAE_REQUIRE(lay[s].win_start && lay[s].win_tokens && lay[s].tok_win && lay[s].tok_pos && lay[s].bun_start &&
+                       lay[s].num_bundles && lay[s].max_bundles >= 1, "%s: incomplete window layout %d", who, s);
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+                                        int32_t num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table,
+                                        int32_t num_heads, int32_t max_window_tokens, void* saved, int64_t saved_bytes,
+                                        float* z_out, void* profiler, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_stack(layers, num_layers, layouts, "sst_stack_forward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(x_in && pos_table && saved && z_out, "sst_stack_forward: null argument");
+    const SavedOffsets so = saved_offsets(num_tokens, num_heads);
+    if (saved_bytes < so.stride * num_layers) {
+        set_error("sst_stack_forward: saved buffer %lld < %lld bytes", (long long)saved_bytes, (long long)(so.stride * num_layers));
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    char* base = (char*)saved;
+    GEOMAE_HIP(hipMemcpyAsync(base + so.x, x_in, (size_t)num_tokens * 128 * 4, hipMemcpyDeviceToDevice, stream));
+    for (int l = 0; l < num_layers; ++l) {
+        char* sv = base + so.stride * l;
+        const GeomaeSstStackLayout& L = layouts[l & 1];
+        const float* x = (const float*)(sv + so.x);
+        float* z = (l + 1 < num_layers) ? (float*)(sv + so.stride + so.x) : z_out;
+        {
+            Timed t(profiler, GEOMAE_KERNEL_QKV_FWD, stream);
+            if ((rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, stream))) return rc;
+        }
+        {
+            Timed t(profiler, GEOMAE_KERNEL_ATTN_FWD, stream);
+            if ((rc = geomae_window_attention_forward(sv + so.qkv, num_tokens, num_heads, 128 / num_heads, L.win_start,
+                                                      L.win_tokens, L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
+                                                      max_window_tokens, sv + so.attn, (float*)(sv + so.lse), stream)))
+                return rc;
+        }
+        {
+            Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
+            if ((rc = geomae_sst_ffn_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
+                                             (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd), stream)))
+                return rc;
+        }
+    }
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+                                         const GeomaeSstLayerGrads* grads, int32_t num_layers,
+                                         const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
+                                         int32_t max_window_tokens, const void* saved, void* scratch,
+                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(dz && grads && pos_table && saved && scratch && dx_out, "sst_stack_backward: null argument");
+    const SavedOffsets so = saved_offsets(num_tokens, num_heads);
+    const ScratchOffsets sc = scratch_offsets(num_tokens);
+    if (scratch_bytes < sc.total) {
+        set_error("sst_stack_backward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)sc.total);
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    const char* base = (const char*)saved;
+    char* w = (char*)scratch;
+    const float* dcur = dz;
+    for (int l = num_layers - 1; l >= 0; --l) {
+        const char* sv = base + so.stride * l;
+        const GeomaeSstStackLayout& L = layouts[l & 1];
+        float* dnext = (l == 0) ? dx_out : (float*)(w + ((l & 1) ? sc.dxa : sc.dxb));
+        {
+            Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
+            if ((rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
+                                              (const float*)(sv + so.rstd), dcur, &layers[l], num_tokens,
+                                              (float*)(w + sc.dx_res), w + sc.dattn, w + sc.du, w + sc.dv, w + sc.dhp,
+                                              w + sc.y, w + sc.h, &grads[l], stream)))
+                return rc;
+        }
+        {
+            Timed t(profiler, GEOMAE_KERNEL_ATTN_BWD, stream);
+            if ((rc = geomae_window_attention_backward(sv + so.qkv, sv + so.attn, w + sc.dattn, (const float*)(sv + so.lse),
+                                                       num_tokens, num_heads, 128 / num_heads, L.win_start, L.win_tokens,
+                                                       L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
+                                                       max_window_tokens, w + sc.dqkv, stream)))
+                return rc;
+        }
+        {
+            Timed t(profiler, GEOMAE_KERNEL_QKV_BWD, stream);
+            if ((rc = geomae_sst_qkv_backward(w + sc.dqkv, (const float*)(w + sc.dx_res), (const float*)(sv + so.x),
+                                              L.tok_pos, pos_table, &layers[l], num_tokens, dnext, w + sc.xp, w + sc.xb,
+                                              stream)))
+                return rc;
+        }
+        {
+            Timed t(profiler, GEOMAE_KERNEL_DW, stream);
+            if ((rc = geomae_sst_weight_grad(num_tokens, w + sc.dqkv, w + sc.xp, w + sc.xb, w + sc.du, sv + so.attn,
+                                             w + sc.dhp, w + sc.y, w + sc.dv, w + sc.h, &grads[l], stream)))
+                return rc;
+        }
+        dcur = dnext;
+    }
+    return GEOMAE_OK;
+}

@@ -396,21 +396,6 @@ def window_attention(qkv_bf16, layout, num_heads):
     return _WindowAttention.apply(qkv_bf16, layout, num_heads)
 
 
-def window_attention_raw(qkv, layout, num_heads):
-    """Forward only (no autograd): -> (out [n,C] bf16, lse [n,H] fp32)."""
-    n, c3 = qkv.shape
-    C = c3 // 3
-    out = torch.empty((n, C), dtype=torch.bfloat16, device=qkv.device)
-    lse = torch.empty((n, num_heads), dtype=torch.float32, device=qkv.device)
-    with _timed("win_attn_fwd_kernel"):
-        check(_lib.load().geomae_window_attention_forward(
-            _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
-            _ptr(layout.tok_win), _ptr(layout.bun_start), _ptr(layout.num_bundles), layout.max_windows,
-            layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
-            "geomae_window_attention_forward")
-    return out, lse
-
-
 # ------------------------------------------------------------------------------------ fused SST layer
 def pack_weights(desc, num_desc, max_elems, packed, aux=None):
     check(_lib.load().geomae_pack_weights(ctypes.c_void_p(0), _ptr(desc), num_desc, max_elems, _ptr(packed),
@@ -438,71 +423,6 @@ def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights):
 def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
     check(_lib.load().geomae_heads_weight_grad(n_mask, _ptr(dl), _ptr(cm_b), _ptr(dm_b), ctypes.byref(grads),
                                                _stream()), "geomae_heads_weight_grad")
-
-
-def sst_qkv_forward(x, layout, pos_table, w):
-    _check_input(x, "x", torch.float32)
-    n = x.shape[0]
-    qkv = torch.empty((n, 384), dtype=torch.bfloat16, device=x.device)
-    with _timed("sst_qkv_fwd_kernel"):
-        check(_lib.load().geomae_sst_qkv_forward(_ptr(x), _ptr(layout.tok_pos), _ptr(pos_table), ctypes.byref(w), n,
-                                                 _ptr(qkv), _stream()), "geomae_sst_qkv_forward")
-    return qkv
-
-
-def sst_ffn_forward(x, attn, w, save=True):
-    """-> z, saved = (xhat1, xhat2, hp, rstd) or None"""
-    n = x.shape[0]
-    dev = x.device
-    z = torch.empty_like(x)
-    saved = None
-    if save:
-        saved = (torch.empty_like(x), torch.empty_like(x), torch.empty((n, 256), dtype=torch.bfloat16, device=dev),
-                 torch.empty((n, 2), dtype=torch.float32, device=dev))
-    s = saved or (None, None, None, None)
-    with _timed("sst_ffn_fwd_kernel"):
-        check(_lib.load().geomae_sst_ffn_forward(_ptr(x), _ptr(attn), ctypes.byref(w), n, _ptr(z), _ptr(s[0]),
-                                                 _ptr(s[1]), _ptr(s[2]), _ptr(s[3]), _stream()),
-              "geomae_sst_ffn_forward")
-    return z, saved
-
-
-def sst_layer_backward(x, qkv, attn, lse, saved, dz, w, g, layout, pos_table, num_heads):
-    """ffn backward -> attention backward -> qkv backward -> weight gradients; returns dx [n,128] fp32."""
-    lib = _lib.load()
-    n = x.shape[0]
-    dev = x.device
-    dx_res = torch.empty_like(x)
-    cols = [128, 128, 128, 256, 128, 256, 128, 128, 384]
-    flat = torch.empty(n * sum(cols), dtype=torch.bfloat16, device=dev)          # one allocation, 9 slabs
-    bufs, o = [], 0
-    for c in cols:
-        bufs.append(flat[o:o + n * c].view(n, c))
-        o += n * c
-    dattn, du_b, dv_b, dhp_b, y_b, h_b, xp_b, x_b, dqkv = bufs
-    _check_input(dz, "dz", torch.float32)
-    xh1, xh2, hp, rstd = saved
-    with _timed("sst_ffn_bwd_kernel"):
-        check(lib.geomae_sst_ffn_backward(_ptr(xh1), _ptr(xh2), _ptr(hp), _ptr(rstd), _ptr(dz), ctypes.byref(w), n,
-                                          _ptr(dx_res), _ptr(dattn), _ptr(du_b), _ptr(dv_b), _ptr(dhp_b), _ptr(y_b),
-                                          _ptr(h_b), ctypes.byref(g), _stream()), "geomae_sst_ffn_backward")
-    L = layout
-    with _timed("win_attn_bwd_kernel"):
-        check(lib.geomae_window_attention_backward(
-            _ptr(qkv), _ptr(attn), _ptr(dattn), _ptr(lse), n, num_heads, 128 // num_heads, _ptr(L.win_start),
-            _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.bun_start), _ptr(L.num_bundles), L.max_windows,
-            L.max_tokens, _ptr(dqkv), _stream()),
-            "geomae_window_attention_backward")
-    dx = torch.empty_like(x)
-    with _timed("sst_qkv_bwd_kernel"):
-        check(lib.geomae_sst_qkv_backward(_ptr(dqkv), _ptr(dx_res), _ptr(x), _ptr(L.tok_pos), _ptr(pos_table),
-                                          ctypes.byref(w), n, _ptr(dx), _ptr(xp_b), _ptr(x_b), _stream()),
-              "geomae_sst_qkv_backward")
-    with _timed("dw_kernel"):
-        check(lib.geomae_sst_weight_grad(n, _ptr(dqkv), _ptr(xp_b), _ptr(x_b), _ptr(du_b), _ptr(attn), _ptr(dhp_b),
-                                         _ptr(y_b), _ptr(dv_b), _ptr(h_b), ctypes.byref(g), _stream()),
-              "geomae_sst_weight_grad")
-    return dx
 
 
 # ------------------------------------------------------------------------------------ fused VFE
@@ -620,3 +540,50 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
     check(lib.geomae_vfe_backward_layer0(a, ctypes.byref(bn), _ptr(dh0), _ptr(bs0), n_eff, N, _ptr(dy1_b), _ptr(g_b),
                                          _ptr(params["w0"].grad), _ptr(params["w1"].grad), _stream()),
           "geomae_vfe_backward_layer0")
+
+
+# ------------------------------------------------------------------------------------ SST layer stacks
+PROFILER = None        # bench.py: handle from geomae_profiler_create, passed to every stack call
+KERNEL_IDS = dict(sst_qkv_fwd_kernel=1, win_attn_fwd_kernel=2, sst_ffn_fwd_kernel=3, sst_ffn_bwd_kernel=4,
+                  win_attn_bwd_kernel=5, sst_qkv_bwd_kernel=6, dw_kernel=7)
+
+
+def _stack_layouts(layouts):
+    from ._lib import GeomaeSstStackLayout
+    arr = (GeomaeSstStackLayout * 2)()
+    for i in range(2):
+        L = layouts[i % len(layouts)]
+        a = arr[i]
+        a.win_start, a.win_tokens, a.tok_win = L.win_start.data_ptr(), L.win_tokens.data_ptr(), L.tok_win.data_ptr()
+        a.tok_pos, a.bun_start, a.num_bundles = L.tok_pos.data_ptr(), L.bun_start.data_ptr(), L.num_bundles.data_ptr()
+        a.max_bundles = L.max_windows
+    return arr
+
+
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads):
+    """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8)."""
+    lib = _lib.load()
+    _check_input(x, "x", torch.float32)
+    n, nl = x.shape[0], len(weights)
+    sb = lib.geomae_sst_stack_saved_bytes(n, nl, num_heads)
+    saved = torch.empty(max(sb, 1), dtype=torch.uint8, device=x.device)
+    z = torch.empty_like(x)
+    check(lib.geomae_sst_stack_forward(_ptr(x), n, weights, nl, _stack_layouts(layouts), _ptr(pos_table), num_heads,
+                                       layouts[0].max_tokens, _ptr(saved), sb, _ptr(z),
+                                       ctypes.c_void_p(PROFILER) if PROFILER else None, _stream()),
+          "geomae_sst_stack_forward")
+    return z, saved
+
+
+def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved):
+    lib = _lib.load()
+    _check_input(dz, "dz", torch.float32)
+    nl = len(weights)
+    wb = lib.geomae_sst_stack_scratch_bytes(n)
+    scratch = torch.empty(max(wb, 1), dtype=torch.uint8, device=dz.device)
+    dx = torch.empty_like(dz)
+    check(lib.geomae_sst_stack_backward(_ptr(dz), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
+                                        num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
+                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream()),
+          "geomae_sst_stack_backward")
+    return dx

@@ -124,6 +124,14 @@ class PackedLayers:
         return g
 
 
+    def weight_array(self, first, count):
+        from ._lib import GeomaeSstLayerWeights
+        return (GeomaeSstLayerWeights * count)(*self.structs[first:first + count])
+
+    def grad_array(self, first, count):
+        from ._lib import GeomaeSstLayerGrads
+        return (GeomaeSstLayerGrads * count)(*[self.grads(i) for i in range(first, first + count)])
+
     def head_grads(self):
         from ._lib import GeomaeHeadGrads
         g = GeomaeHeadGrads()
@@ -158,30 +166,28 @@ class _HeadsLoss(torch.autograd.Function):
         return d_cen, d_den, None, None, None, None, None
 
 
-class _FusedLayer(torch.autograd.Function):
-    """One SST encoder layer: 3 kernels forward (qkv, window attention, out-proj+LN+FFN+LN), 4 backward
-    (ffn backward, attention backward, qkv backward, weight gradients).  Parameter gradients are
-    accumulated straight into .grad by the kernels (they are not autograd outputs of this Function)."""
+class _FusedStack(torch.autograd.Function):
+    """A run of consecutive SST layers (the encoder, or one decoder) as ONE C call forward and ONE backward:
+    3 kernels per layer forward (qkv, window attention, out-proj+LN+FFN+LN), 4 backward (ffn backward,
+    attention backward, qkv backward, weight gradients).  Parameter gradients are accumulated straight into
+    .grad by the kernels (they are not autograd outputs of this Function)."""
 
     @staticmethod
-    def forward(ctx, x, packed, index, layout, pos_table, nhead):
-        x = x.contiguous()
-        w = packed.structs[index]
-        qkv = ops.sst_qkv_forward(x, layout, pos_table, w)
-        attn, lse = ops.window_attention_raw(qkv, layout, nhead)
-        z, saved = ops.sst_ffn_forward(x, attn, w, save=True)
-        ctx.packed, ctx.index, ctx.layout, ctx.pos_table, ctx.nhead = packed, index, layout, pos_table, nhead
-        ctx.save_for_backward(x, qkv, attn, lse, *saved)
+    def forward(ctx, x, packed, first, count, layouts, pos_table, nhead):
+        weights = packed.weight_array(first, count)
+        z, saved = ops.sst_stack_forward(x.contiguous(), weights, layouts, pos_table, nhead)
+        ctx.packed, ctx.first, ctx.count, ctx.layouts, ctx.pos_table, ctx.nhead = packed, first, count, layouts, pos_table, nhead
+        ctx.weights, ctx.n = weights, x.shape[0]
+        ctx.save_for_backward(saved)
         return z
 
     @staticmethod
     def backward(ctx, dz):
-        x, qkv, attn, lse, xh1, xh2, hp, rstd = ctx.saved_tensors
-        w = ctx.packed.structs[ctx.index]
-        g = ctx.packed.grads(ctx.index)
-        dx = ops.sst_layer_backward(x, qkv, attn, lse, (xh1, xh2, hp, rstd), dz.contiguous().float(), w, g,
-                                    ctx.layout, ctx.pos_table, ctx.nhead)
-        return dx, None, None, None, None, None
+        (saved,) = ctx.saved_tensors
+        grads = ctx.packed.grad_array(ctx.first, ctx.count)
+        dx = ops.sst_stack_backward(dz.contiguous().float(), ctx.n, ctx.weights, grads, ctx.layouts, ctx.pos_table,
+                                    ctx.nhead, saved)
+        return dx, None, None, None, None, None, None
 
 
 class WindowAttention(nn.Module):
@@ -242,17 +248,13 @@ class BasicShiftBlock(nn.Module):
             EncoderLayer(d_model, nhead, dim_feedforward, dropout, activation, batch_first, layer_id=block_id * 2 + i)
             for i in range(2)])
 
-    def forward(self, src, pos_list, layout_list, compute_dtype, fused=None):
+    def forward(self, src, pos_list, layout_list, compute_dtype):
         num_shifts = len(layout_list)
         assert num_shifts in (1, 2)
         out = src
         for i in range(2):
             s = i % num_shifts
-            if fused is not None:
-                packed, base, pos_table, nhead = fused
-                out = _FusedLayer.apply(out, packed, base + i, layout_list[s], pos_table, nhead)
-            else:
-                out = self.encoder_list[i](out, pos_list[s], layout_list[s], compute_dtype)
+            out = self.encoder_list[i](out, pos_list[s], layout_list[s], compute_dtype)
         return out
 
 
@@ -346,10 +348,12 @@ class MultiMAESSTSPChoose(nn.Module):
         return layouts, pos
 
     def _run_stack(self, blocks, name, x, pos, layouts):
+        if self.fused:
+            return _FusedStack.apply(x, self._packed, self._stack_base[name], 2 * len(blocks), layouts, self.pos_table,
+                                     self.nhead[0])
         dt = self._dtype()
-        for i, block in enumerate(blocks):
-            fused = (self._packed, self._stack_base[name] + 2 * i, self.pos_table, self.nhead[0]) if self.fused else None
-            x = block(x, pos, layouts, dt, fused)
+        for block in blocks:
+            x = block(x, pos, layouts, dt)
         return x
 
     def forward(self, voxel_feat, coors, coors_mask, batch_size):

@@ -288,6 +288,36 @@ int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* b
                                const void* g_bf16, float* dw0 /*[64,11] +=*/, float* dw1 /*[128,128] +=*/,
                                geomaeStream_t stream);
 
+/* ------------------------------------------------------------------ a stack of SST layers in one call
+ * replaces the Python block loops of forward_encoder / forward_decoder (bb.py:227-277) and their autograd
+ * graph: one call enqueues every kernel of `num_layers` consecutive layers (layer i uses layouts[i & 1]: the
+ * unshifted / shifted windows alternate, sst_basic_block.py:133-145).  `saved` (geomae_sst_stack_saved_bytes)
+ * carries the activations from forward to backward; `scratch` (geomae_sst_stack_scratch_bytes) is reused by
+ * every layer of the backward.  layers / grads are HOST arrays of structs. */
+typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_build for one shift */
+    const int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *bun_start, *num_bundles;
+    int32_t max_bundles;
+} GeomaeSstStackLayout;
+int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
+int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
+int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+                             int32_t num_layers, const GeomaeSstStackLayout* layouts /*[2]*/,
+                             const float* pos_table, int32_t num_heads, int32_t max_window_tokens, void* saved,
+                             int64_t saved_bytes, float* z_out, void* profiler /*or NULL*/, geomaeStream_t stream);
+int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+                              const GeomaeSstLayerGrads* grads, int32_t num_layers,
+                              const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
+                              int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
+                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream);
+
+/* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
+ * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
+enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_FWD = 3, GEOMAE_KERNEL_FFN_BWD = 4,
+       GEOMAE_KERNEL_ATTN_BWD = 5, GEOMAE_KERNEL_QKV_BWD = 6, GEOMAE_KERNEL_DW = 7 };
+void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches);
+int32_t geomae_profiler_read(void* profiler, float* ms_out, int32_t capacity);
+void geomae_profiler_destroy(void* profiler);
+
 #ifdef __cplusplus
 }
 #endif
