@@ -62,7 +62,7 @@ struct LayerW {
 // ------------------------------------------------------------------------------------------------
 // F1: qkv = [(x + pos) Wqk^T + bqk | x Wv^T + bv]  ->  bf16 [n, 384]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlk) void sst_qkv_fwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* __restrict__ x,
                                                                 const int32_t* __restrict__ tok_pos,
                                                                 const float* __restrict__ pos_table, LayerW W,
                                                                 int n, bf16_t* __restrict__ qkv) {
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_fwd_kernel(const float* __r
 // needs instead of recomputing three GEMMs there: the two normalised residuals (fp32), the FFN
 // pre-activation (bf16) and the two 1/sigma per token.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlk) void sst_ffn_fwd_kernel(const float* __restrict__ x,
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* __restrict__ x,
                                                                 const bf16_t* __restrict__ attn, LayerW W, int n,
                                                                 float eps, float* __restrict__ z,
                                                                 float* __restrict__ xh1_out,
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(kLayerBlk) void sst_ffn_fwd_kernel(const float* __r
 //   bf16 row-major operands of the weight-gradient GEMMs: du, dv, dhp [n,256], y, h [n,256]
 //   and the LayerNorm parameter gradients (atomics, one flush per workgroup).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlk) void sst_ffn_bwd_kernel(
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
     const float* __restrict__ xh1_in, const float* __restrict__ xh2_in, const bf16_t* __restrict__ hp_in,
     const float* __restrict__ rstd_in, const float* __restrict__ dz, LayerW W, int n,
     float* __restrict__ dx_res, bf16_t* __restrict__ dattn, bf16_t* __restrict__ du_b,
