@@ -560,8 +560,13 @@ def _stack_layouts(layouts):
     return arr
 
 
-def sst_stack_forward(x, weights, layouts, pos_table, num_heads):
-    """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8)."""
+def _stream_of(stream):
+    return _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
+
+
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None):
+    """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8).
+    Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current)."""
     lib = _lib.load()
     _check_input(x, "x", torch.float32)
     n, nl = x.shape[0], len(weights)
@@ -570,12 +575,12 @@ def sst_stack_forward(x, weights, layouts, pos_table, num_heads):
     z = torch.empty_like(x)
     check(lib.geomae_sst_stack_forward(_ptr(x), n, weights, nl, _stack_layouts(layouts), _ptr(pos_table), num_heads,
                                        layouts[0].max_tokens, _ptr(saved), sb, _ptr(z),
-                                       ctypes.c_void_p(PROFILER) if PROFILER else None, _stream()),
+                                       ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
           "geomae_sst_stack_forward")
     return z, saved
 
 
-def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved):
+def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None):
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
@@ -584,6 +589,7 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
     dx = torch.empty_like(dz)
     check(lib.geomae_sst_stack_backward(_ptr(dz), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream()),
+                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
           "geomae_sst_stack_backward")
-    return dx
+    # `scratch` must outlive the kernels: with a side stream the caller keeps it until the streams are joined
+    return (dx, scratch) if stream is not None else dx

@@ -190,6 +190,47 @@ class _FusedStack(torch.autograd.Function):
         return dx, None, None, None, None, None, None
 
 
+class _FusedDecoderPair(torch.autograd.Function):
+    """The two decoder stacks (centroid / density) read the same tokens and are independent of each other
+    (bb.py:269-277): run them concurrently on two HIP streams, forward and backward -- each stack alone is a
+    chain of 13-50 us kernels that leaves most CUs idle.  Buffers are allocated on the current stream before
+    the fork and both streams are joined before returning, so the caching allocator never sees them."""
+
+    @staticmethod
+    def forward(ctx, x, packed, first_a, first_b, count, layouts, pos_table, nhead, streams):
+        x = x.contiguous()
+        cur = torch.cuda.current_stream()
+        wa, wb = packed.weight_array(first_a, count), packed.weight_array(first_b, count)
+        for s in streams:
+            s.wait_stream(cur)
+        za, sa = ops.sst_stack_forward(x, wa, layouts, pos_table, nhead, stream=streams[0])
+        zb, sb = ops.sst_stack_forward(x, wb, layouts, pos_table, nhead, stream=streams[1])
+        for s in streams:
+            cur.wait_stream(s)
+        ctx.packed, ctx.firsts, ctx.count, ctx.layouts, ctx.pos_table, ctx.nhead = packed, (first_a, first_b), count, layouts, pos_table, nhead
+        ctx.weights, ctx.n, ctx.streams = (wa, wb), x.shape[0], streams
+        ctx.save_for_backward(sa, sb)
+        return za, zb
+
+    @staticmethod
+    def backward(ctx, dza, dzb):
+        sa, sb = ctx.saved_tensors
+        cur = torch.cuda.current_stream()
+        ga, gb = (ctx.packed.grad_array(f, ctx.count) for f in ctx.firsts)
+        dza, dzb = dza.contiguous().float(), dzb.contiguous().float()
+        for s in ctx.streams:
+            s.wait_stream(cur)
+        dxa, keep_a = ops.sst_stack_backward(dza, ctx.n, ctx.weights[0], ga, ctx.layouts, ctx.pos_table, ctx.nhead, sa,
+                                             stream=ctx.streams[0])
+        dxb, keep_b = ops.sst_stack_backward(dzb, ctx.n, ctx.weights[1], gb, ctx.layouts, ctx.pos_table, ctx.nhead, sb,
+                                             stream=ctx.streams[1])
+        for s in ctx.streams:
+            cur.wait_stream(s)
+        dx = dxa + dxb
+        del keep_a, keep_b          # scratch buffers: released only after both streams were joined
+        return dx, None, None, None, None, None, None, None, None
+
+
 class WindowAttention(nn.Module):
     def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None):
         super().__init__()
@@ -322,6 +363,8 @@ class MultiMAESSTSPChoose(nn.Module):
         all_layers = [l for stack in (self.encoder_blocks, self.decoder_centroid_blocks, self.decoder_density_blocks)
                       for b in stack for l in b.encoder_list]
         self._packed = PackedLayers(all_layers, backbone=self)
+        self.concurrent_decoders = True
+        self._streams = None
         self._stack_base = {"enc": 0, "cen": 2 * encoder_num_blocks,
                             "den": 2 * (encoder_num_blocks + decoder_num_blocks)}
         info = drop_info[0] if isinstance(drop_info, tuple) else drop_info
@@ -381,6 +424,13 @@ class MultiMAESSTSPChoose(nn.Module):
         tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)
         coors_all = torch.cat([coors, coors_mask], dim=0)
         layouts, pos = self.get_voxel_info(coors_all, batch_size)
+        if self.fused and self.concurrent_decoders:
+            if self._streams is None:
+                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            cen, den = _FusedDecoderPair.apply(tokens, self._packed, self._stack_base["cen"], self._stack_base["den"],
+                                               2 * len(self.decoder_centroid_blocks), layouts, self.pos_table,
+                                               self.nhead[0], self._streams)
+            return cen, den
         cen = self._run_stack(self.decoder_centroid_blocks, "cen", tokens, pos, layouts)
         den = self._run_stack(self.decoder_density_blocks, "den", tokens, pos, layouts)
         return cen, den
