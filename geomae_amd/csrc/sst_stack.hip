@@ -39,7 +39,10 @@ static SavedOffsets saved_offsets(int64_t n, int heads) {
 }
 
 struct ScratchOffsets {
-    int64_t dx_res, dxa, dxb, dattn, du, dv, y, xp, xb, dhp, h, dqkv, total;
+    int64_t dx_res, dxa, dxb, dattn;
+    int64_t set0;                               // first of two identical slab sets read by the weight-gradient kernel
+    int64_t du, dv, y, xp, xb, dhp, h, dqkv;    // offsets inside a set
+    int64_t set_bytes, total;
 };
 static ScratchOffsets scratch_offsets(int64_t n) {
     ScratchOffsets o;
@@ -48,15 +51,18 @@ static ScratchOffsets scratch_offsets(int64_t n) {
     o.dxa = p;    p += al256(n * 128 * 4);
     o.dxb = p;    p += al256(n * 128 * 4);
     o.dattn = p;  p += al256(n * 128 * 2);
-    o.du = p;     p += al256(n * 128 * 2);
-    o.dv = p;     p += al256(n * 128 * 2);
-    o.y = p;      p += al256(n * 128 * 2);
-    o.xp = p;     p += al256(n * 128 * 2);
-    o.xb = p;     p += al256(n * 128 * 2);
-    o.dhp = p;    p += al256(n * 256 * 2);
-    o.h = p;      p += al256(n * 256 * 2);
-    o.dqkv = p;   p += al256(n * 384 * 2);
-    o.total = p;
+    o.set0 = p;
+    int64_t q = 0;
+    o.du = q;     q += al256(n * 128 * 2);
+    o.dv = q;     q += al256(n * 128 * 2);
+    o.y = q;      q += al256(n * 128 * 2);
+    o.xp = q;     q += al256(n * 128 * 2);
+    o.xb = q;     q += al256(n * 128 * 2);
+    o.dhp = q;    q += al256(n * 256 * 2);
+    o.h = q;      q += al256(n * 256 * 2);
+    o.dqkv = q;   q += al256(n * 384 * 2);
+    o.set_bytes = q;
+    o.total = p + 2 * q;
     return o;
 }
 
@@ -165,7 +171,8 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
                                          const GeomaeSstLayerGrads* grads, int32_t num_layers,
                                          const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                                          int32_t max_window_tokens, const void* saved, void* scratch,
-                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream) {
+                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream,
+                                         hipStream_t side_stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -176,43 +183,74 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         set_error("sst_stack_backward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)sc.total);
         return GEOMAE_ERR_WORKSPACE;
     }
+    // The weight-gradient kernel of layer l only feeds .grad, so it runs on `side_stream` (if given) under the
+    // data-path kernels of layer l-1; its operand slabs are double-buffered and fenced with events.
+    const bool overlap = side_stream != nullptr && side_stream != stream;
+    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
+    bool done_pending[2] = {false, false};
+    if (overlap)
+        for (int k = 0; k < 2; ++k) {
+            GEOMAE_HIP(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
+            GEOMAE_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
+        }
     const char* base = (const char*)saved;
     char* w = (char*)scratch;
     const float* dcur = dz;
-    for (int l = num_layers - 1; l >= 0; --l) {
+    for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
+        const int set = l & 1;
+        char* ws = w + sc.set0 + (overlap ? set * sc.set_bytes : 0);
         float* dnext = (l == 0) ? dx_out : (float*)(w + ((l & 1) ? sc.dxa : sc.dxb));
+        if (overlap && done_pending[set]) {            // slab set still being read by the dw of layer l+2
+            GEOMAE_HIP(hipStreamWaitEvent(stream, done[set], 0));
+            done_pending[set] = false;
+        }
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
-            if ((rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
-                                              (const float*)(sv + so.rstd), dcur, &layers[l], num_tokens,
-                                              (float*)(w + sc.dx_res), w + sc.dattn, w + sc.du, w + sc.dv, w + sc.dhp,
-                                              w + sc.y, w + sc.h, &grads[l], stream)))
-                return rc;
+            rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
+                                         (const float*)(sv + so.rstd), dcur, &layers[l], num_tokens,
+                                         (float*)(w + sc.dx_res), w + sc.dattn, ws + sc.du, ws + sc.dv, ws + sc.dhp,
+                                         ws + sc.y, ws + sc.h, &grads[l], stream);
         }
+        if (rc) break;
         {
             Timed t(profiler, GEOMAE_KERNEL_ATTN_BWD, stream);
-            if ((rc = geomae_window_attention_backward(sv + so.qkv, sv + so.attn, w + sc.dattn, (const float*)(sv + so.lse),
-                                                       num_tokens, num_heads, 128 / num_heads, L.win_start, L.win_tokens,
-                                                       L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
-                                                       max_window_tokens, w + sc.dqkv, stream)))
-                return rc;
+            rc = geomae_window_attention_backward(sv + so.qkv, sv + so.attn, w + sc.dattn, (const float*)(sv + so.lse),
+                                                  num_tokens, num_heads, 128 / num_heads, L.win_start, L.win_tokens,
+                                                  L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
+                                                  max_window_tokens, ws + sc.dqkv, stream);
         }
+        if (rc) break;
         {
             Timed t(profiler, GEOMAE_KERNEL_QKV_BWD, stream);
-            if ((rc = geomae_sst_qkv_backward(w + sc.dqkv, (const float*)(w + sc.dx_res), (const float*)(sv + so.x),
-                                              L.tok_pos, pos_table, &layers[l], num_tokens, dnext, w + sc.xp, w + sc.xb,
-                                              stream)))
-                return rc;
+            rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), (const float*)(sv + so.x), L.tok_pos,
+                                         pos_table, &layers[l], num_tokens, dnext, ws + sc.xp, ws + sc.xb, stream);
+        }
+        if (rc) break;
+        hipStream_t ds = stream;
+        if (overlap) {
+            GEOMAE_HIP(hipEventRecord(ready[set], stream));
+            GEOMAE_HIP(hipStreamWaitEvent(side_stream, ready[set], 0));
+            ds = side_stream;
         }
         {
-            Timed t(profiler, GEOMAE_KERNEL_DW, stream);
-            if ((rc = geomae_sst_weight_grad(num_tokens, w + sc.dqkv, w + sc.xp, w + sc.xb, w + sc.du, sv + so.attn,
-                                             w + sc.dhp, w + sc.y, w + sc.dv, w + sc.h, &grads[l], stream)))
-                return rc;
+            Timed t(profiler, GEOMAE_KERNEL_DW, ds);
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, ws + sc.xp, ws + sc.xb, ws + sc.du, sv + so.attn,
+                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
+        }
+        if (overlap && rc == GEOMAE_OK) {
+            GEOMAE_HIP(hipEventRecord(done[set], side_stream));
+            done_pending[set] = true;
         }
         dcur = dnext;
     }
-    return GEOMAE_OK;
+    if (overlap) {
+        for (int k = 0; k < 2; ++k) {
+            if (done_pending[k]) hipStreamWaitEvent(stream, done[k], 0);      // join: the caller sees one stream
+            hipEventDestroy(ready[k]);
+            hipEventDestroy(done[k]);
+        }
+    }
+    return rc;
 }

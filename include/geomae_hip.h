@@ -308,7 +308,8 @@ int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeS
                               const GeomaeSstLayerGrads* grads, int32_t num_layers,
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
-                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream);
+                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream,
+                              geomaeStream_t side_stream /* or NULL: weight-gradient kernels overlap on it */);
 
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
