@@ -26,7 +26,8 @@
 
 namespace geomae {
 
-constexpr int kVfeBlk = 256;
+constexpr int kVfeBlk = 512;            // 8 waves share one LDS copy of W1: 2 waves per SIMD hide each other's latency
+constexpr int kVfeWaves = kVfeBlk / 64;
 constexpr int kW1Ld = 128 + 4;          // fp32 LDS row of W1 (+16 B pad)
 constexpr int kTileLd = 128 + 4;        // fp32 LDS row of the per-wave [16 x C] tile
 
@@ -50,6 +51,15 @@ __device__ __forceinline__ WaveRange wave_range(const int32_t* __restrict__ rang
     r.j_lo = seg_start[r.p_lo];
     r.j_hi = seg_start[r.p_hi];
     return r;
+}
+
+// A zero the optimiser cannot see through.  Added to the weight / BN-parameter addresses inside the point
+// loops so that LICM does not hoist ~250 registers of loop-invariant operands out of them (that hoisting is
+// what pinned these kernels at 1 wave/SIMD).
+__device__ __forceinline__ int opaque_zero() {
+    int z = 0;
+    asm volatile("" : "+s"(z));
+    return z;
 }
 
 __device__ __forceinline__ int pillar_of(const VfeGeo& G, int j) { return G.pid[j]; }
@@ -225,7 +235,7 @@ __device__ __forceinline__ void seg_flush(int C, float* __restrict__ out, int cu
 // sum over the 16 points of the tile and accumulate per-lane partials (kept until the end of the kernel)
 template <int NT>
 __device__ __forceinline__ void flush_channel_sums(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], double* __restrict__ out, int C,
-                                                   float* red /* LDS [4][2*C] */, int lane, int wave) {
+                                                   float* red /* LDS [waves][2*C] */, int lane, int wave) {
     const int g = lane >> 4;
 #pragma unroll
     for (int ot = 0; ot < NT; ++ot)
@@ -239,7 +249,9 @@ __device__ __forceinline__ void flush_channel_sums(const f32x4 (&s1)[NT], const 
         }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * C; e += kVfeBlk) {
-        const float s = red[e] + red[2 * C + e] + red[4 * C + e] + red[6 * C + e];
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < kVfeWaves; ++w) s += red[w * 2 * C + e];
         atomicAdd(out + e, (double)s);
     }
 }
@@ -324,15 +336,25 @@ struct VfeW {
     const float *scale0, *shift0, *scale1, *shift1;   // BN folded: y * scale + shift
 };
 
+__device__ __forceinline__ VfeW shifted(const VfeW& W, int z) {
+    VfeW o = W;
+    o.scale0 += z; o.shift0 += z; o.scale1 += z; o.shift1 += z;
+    return o;
+}
+struct Bn1 { const float *scale, *shift, *mean, *invstd; };
+struct Bn0 { const float *scale, *shift, *mean, *invstd; };
+__device__ __forceinline__ Bn1 shifted(const Bn1& b, int z) { return Bn1{b.scale + z, b.shift + z, b.mean + z, b.invstd + z}; }
+__device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale + z, b.shift + z, b.mean + z, b.invstd + z}; }
+
 // sweep 1 of layer 0: per-channel sum / sum of squares of y0 = W0 f over all points
 __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
                                                              int n_waves, double* __restrict__ sums0) {
     __shared__ float W0s[64 * 16];
-    __shared__ float red[4 * 2 * 64];
+    __shared__ float red[kVfeWaves * 2 * 64];
     stage_w0(W.w0, W0s);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     f32x4 s1[4], s2[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
@@ -358,14 +380,14 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
                                                              double* __restrict__ sums1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
-    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
-    __shared__ int pids[4][16];
-    __shared__ float red[4 * 2 * 128];
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
+    __shared__ int pids[kVfeWaves][16];
+    __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     float* tile = tiles[wave];
     // ---- pass A: h0 -> m0 (whole pillars, this wave only)
     {
@@ -398,22 +420,27 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int oz = opaque_zero();
+        const float* W1l = W1s + oz;
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y0[4], gin[8];
-        layer0_linear(W0s, f, y0, lane);
-        bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
+        layer0_linear(W0s + oz, f, y0, lane);
+        bn_relu<4>(y0, W.scale0 + oz, W.shift0 + oz, reinterpret_cast<f32x4(&)[4]>(gin), lane);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
             float4 v = make_float4(0, 0, 0, 0);
             if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
             gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
         }
-        f32x4 y1[8];
-        layer1_linear(W1s, gin, y1, lane);
-        if (valid) {
 #pragma unroll
-            for (int ot = 0; ot < 8; ++ot) { s1[ot] += y1[ot]; s2[ot] += y1[ot] * y1[ot]; }
+        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+            f32x4 y2[2];
+            layer1_group<2>(W1l, gin, ot0, y2, lane);
+            if (valid) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) { s1[ot0 + u] += y2[u]; s2[ot0 + u] += y2[u] * y2[u]; }
+            }
         }
     }
     flush_channel_sums<8>(s1, s2, sums1, 128, red, lane, wave);
@@ -442,13 +469,13 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
                                                              float* __restrict__ vf) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
-    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
-    __shared__ int pids[4][16];
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
+    __shared__ int pids[kVfeWaves][16];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     float* tile = tiles[wave];
     int cur_pid = -1;
     float cur[2] = {0.f, 0.f};
@@ -456,10 +483,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int oz = opaque_zero();
+        const VfeW Wl = shifted(W, oz);
         f32x4 y0[4], gin[8], y1[8], h1[8];
-        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
-        layer1_linear(W1s, gin, y1, lane);
-        bn_relu<8>(y1, W.scale1, W.shift1, h1, lane);
+        recompute_g(G, Wl, W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        layer1_linear(W1s + oz, gin, y1, lane);
+        bn_relu<8>(y1, Wl.scale1, Wl.shift1, h1, lane);
         tile_store<8>(tile, h1, lane);
         if (g == 0) pids[wave][lane & 15] = pid;
         wave_sync();
@@ -473,7 +502,6 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
 // ------------------------------------------------------------------------------------------------ backward
 // one output tile of the layer-1 backward inputs: dh[t][c] = dvf[pid][c] where h1[t][c] == vf[pid][c] > 0
 // (max-pool + ReLU routing on the recomputed, bit-identical forward value), yhat = (y1 - mean) * invstd
-struct Bn1 { const float *scale, *shift, *mean, *invstd; };
 __device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const float* __restrict__ vf,
                                             const float* __restrict__ dvf, int pid, bool valid, int ot, int lane,
                                             f32x4* dh, f32x4* yhat) {
@@ -503,12 +531,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
                                                                  Bn1 bn, double* __restrict__ bsums1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
-    __shared__ float red[4 * 2 * 128];
+    __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     f32x4 s1[8], s2[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
@@ -516,16 +544,18 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int oz = opaque_zero();
+        const Bn1 bnl = shifted(bn, oz);
         f32x4 y0[4], gin[8];
-        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
+        recompute_g(G, shifted(W, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
 #pragma unroll
-        for (int ot0 = 0; ot0 < 8; ot0 += 4) {
-            f32x4 y4[4];
-            layer1_group<4>(W1s, gin, ot0, y4, lane);
+        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+            f32x4 y4[2];
+            layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 2; ++u) {
                 f32x4 dh, yh;
-                routed_tile(y4[u], bn, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
+                routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
                 s1[ot0 + u] += dh;
                 s2[ot0 + u] += dh * yh;
             }
@@ -538,7 +568,6 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
 //   dy1 = invstd1 * (dyh - S1/n - yhat * S2/n)  -> bf16 copy + g bf16 copy (operands of dW1 = dy1^T g)
 //   dg = dy1 W1 ; dh0_direct = dg[:, :64] (stored fp32) ; dm0 = segmented sum of dg[:, 64:]
 //   second pass: dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ; dyh0 = dh0 * gamma0 ; sums for BN0
-struct Bn0 { const float *scale, *shift, *mean, *invstd; };
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     VfeGeo G, VfeW W, const int32_t* __restrict__ ranges, int n_waves, const float* __restrict__ m0,
     const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn, const double* __restrict__ bsums1, float n_eff,
@@ -546,9 +575,9 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     float* __restrict__ dm0, double* __restrict__ bsums0) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
-    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];
-    __shared__ int pids[4][16];
-    __shared__ float red[4 * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
+    __shared__ int pids[kVfeWaves][16];
+    __shared__ float red[kVfeWaves * 2 * 64];
     __shared__ float bn1s[2][128];                                         // S1/n, S2/n
     stage_w0(W.w0, W0s);
     for (int c = threadIdx.x; c < 128; c += kVfeBlk) {
@@ -556,7 +585,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         bn1s[1][c] = (float)(bsums1[128 + c] / (double)n_eff);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     float* tile = tiles[wave];
     // ---- pass A needs W1 (recompute y1) AND W1^T (dg = dy1 W1).  Two fp32 copies do not fit in LDS next to
     // the tiles, so it is split: A1 computes dy1 with W1 and parks it in HBM (fp32); A2 re-reads it and
@@ -567,23 +596,27 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int oz = opaque_zero();
+        const Bn1 bnl = shifted(bn, oz);
+        const float* bs0 = bn1s[0] + oz;
+        const float* bs1 = bn1s[1] + oz;
         f32x4 y0[4], gin[8];
-        recompute_g(G, W, W0s, m0, j, pid, valid, lane, y0, gin);
+        recompute_g(G, shifted(W, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
         store_rows_bf16<128>(g_b, j, 128, 0, valid, gin, lane);
 #pragma unroll
-        for (int ot0 = 0; ot0 < 8; ot0 += 4) {
-          f32x4 y4[4];
-          layer1_group<4>(W1s, gin, ot0, y4, lane);
+        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+          f32x4 y4[2];
+          layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 2; ++u) {
             const int ot = ot0 + u;
             f32x4 dh, yh, dy;
-            routed_tile(y4[u], bn, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+            routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot, lane, &dh, &yh);
             const int c0 = 16 * ot + 4 * g;
-            const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c0);     // gamma * invstd
+            const float4 sc = *reinterpret_cast<const float4*>(bnl.scale + c0);    // gamma * invstd
             const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
-            for (int r = 0; r < 4; ++r) dy[r] = scv[r] * (dh[r] - bn1s[0][c0 + r] - yh[r] * bn1s[1][c0 + r]);
+            for (int r = 0; r < 4; ++r) dy[r] = scv[r] * (dh[r] - bs0[c0 + r] - yh[r] * bs1[c0 + r]);
             if (valid) {
                 *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy);      // operand of dW1 (dw_kernel)
                 *reinterpret_cast<float4*>(dy1_f + (int64_t)j * 128 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
@@ -601,16 +634,26 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
             const int j = j0 + (lane & 15);
             const bool valid = j < R.j_hi;
             const int pid = valid ? pillar_of(G, j) : 0;
-            f32x4 dy1[8], dg[8];
+            const float* W1l = W1s + opaque_zero();
+            f32x4 dy1[8];
             load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
-            layer1_linear(W1s, dy1, dg, lane);            // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]
-            if (valid) {
+            // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct)
-                    *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + 16 * ct + 4 * g) =
-                        make_float4(dg[ct][0], dg[ct][1], dg[ct][2], dg[ct][3]);
+            for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+                f32x4 d2[2];
+                layer1_group<2>(W1l, dy1, ot0, d2, lane);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ct = ot0 + u;
+                    if (ct < 4) {
+                        if (valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + 16 * ct + 4 * g) =
+                                       make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
+                    } else {
+                        *reinterpret_cast<float4*>(tile + (lane & 15) * kTileLd + 16 * (ct - 4) + 4 * g) =
+                            make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
+                    }
+                }
             }
-            tile_store<4>(tile, reinterpret_cast<f32x4(&)[4]>(dg[4]), lane);
             if (g == 0) pids[wave][lane & 15] = pid;
             wave_sync();
             const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
@@ -628,17 +671,19 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int oz = opaque_zero();
+        const Bn0 b0 = shifted(bn0, oz);
         float f[4];
         build_features(G, j, pid, valid, g, f);
         f32x4 y0[4];
-        layer0_linear(W0s, f, y0, lane);
+        layer0_linear(W0s + oz, f, y0, lane);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
             const int c0 = 16 * ot + 4 * g;
-            const float4 s = *reinterpret_cast<const float4*>(bn0.scale + c0);
-            const float4 b = *reinterpret_cast<const float4*>(bn0.shift + c0);
-            const float4 mu = *reinterpret_cast<const float4*>(bn0.mean + c0);
-            const float4 is = *reinterpret_cast<const float4*>(bn0.invstd + c0);
+            const float4 s = *reinterpret_cast<const float4*>(b0.scale + c0);
+            const float4 b = *reinterpret_cast<const float4*>(b0.shift + c0);
+            const float4 mu = *reinterpret_cast<const float4*>(b0.mean + c0);
+            const float4 is = *reinterpret_cast<const float4*>(b0.invstd + c0);
             float4 m = make_float4(0, 0, 0, 0), dm = m, dd = m;
             if (valid) {
                 m = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + c0);
@@ -671,7 +716,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
                                                                  const double* __restrict__ bsums0, float n_eff,
                                                                  float* __restrict__ dw0) {
     __shared__ float W0s[64 * 16];
-    __shared__ __attribute__((aligned(16))) float tiles[4][16 * kTileLd];      // [t][0..63] dy0, [t][64..79] f
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];      // [t][0..63] dy0, [t][64..79] f
     __shared__ float acc_s[64 * 16];
     __shared__ float bn0s[2][64];
     stage_w0(W.w0, W0s);
@@ -682,7 +727,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * 4 + wave, n_waves);
+    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
     float* tile = tiles[wave];
     f32x4 dw[4];                                   // C layout: row = out channel 16*ot' ... see below
 #pragma unroll
@@ -805,7 +850,7 @@ extern "C" int geomae_vfe_stats0(const GeomaeVfeArgs* a, double* sums0, hipStrea
     if (rc) return rc;
     GEOMAE_REQUIRE(sums0, "vfe_stats0: null output");
     GEOMAE_HIP(hipMemsetAsync(sums0, 0, 128 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_stats0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_stats0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, sums0);
     return check_launch("vfe_stats0_kernel");
 }
@@ -816,7 +861,7 @@ extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && sums1 && a->scale0 && a->shift0, "vfe_layer0: null argument");
     GEOMAE_HIP(hipMemsetAsync(sums1, 0, 256 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_layer0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_layer0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, m0, sums1);
     return check_launch("vfe_layer0_kernel");
 }
@@ -826,7 +871,7 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     int rc = vfe_common(a, &G, &W, "vfe_layer1");
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
-    hipLaunchKernelGGL(vfe_layer1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_layer1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, m0, voxel_feats);
     return check_launch("vfe_layer1_kernel");
 }
@@ -850,7 +895,7 @@ extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnS
     if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1, "vfe_backward_stats: null argument");
     GEOMAE_HIP(hipMemsetAsync(bsums1, 0, 256 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1);
     return check_launch("vfe_bwd_stats1_kernel");
 }
@@ -869,7 +914,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dy1_f32 && dh0 && dm0 &&
                    bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
     GEOMAE_HIP(hipMemsetAsync(bsums0, 0, 128 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1_global, n_eff, bn0, (bf16_t*)dy1_bf16,
                        (bf16_t*)g_bf16, dy1_f32, dh0, dm0, bsums0);
     return check_launch("vfe_bwd_layer1_kernel");
@@ -886,7 +931,7 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
     GEOMAE_REQUIRE(dh0 && bsums0_global && dy1_bf16 && g_bf16 && dw0 && dw1 && n_eff > 0,
                    "vfe_backward_layer0: null argument");
-    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, dim3(cdiv(a->num_waves, 4)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
+    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
                        a->num_waves, dh0, bn0, bsums0_global, n_eff, dw0);
     rc = check_launch("vfe_bwd_layer0_kernel");
     if (rc) return rc;

@@ -428,7 +428,7 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 # ------------------------------------------------------------------------------------ fused VFE
 class VfePlan:
     """Per-batch plan of the fused VFE sweeps: pillar mean, wave -> pillar ranges, the argument struct."""
-    POINTS_PER_WAVE = 128
+    POINTS_PER_WAVE = 64
 
     def __init__(self, points, seg, w0, w1, voxel_size, center_offset):
         from ._lib import GeomaeVfeArgs
