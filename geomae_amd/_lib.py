@@ -38,8 +38,8 @@ class GeomaeSstStackLayout(ctypes.Structure):
 
 
 class GeomaeVfeArgs(ctypes.Structure):
-    _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("ranges", c_void_p),
-                ("num_waves", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
+    _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("num_points", c_int64),
+                ("max_pillars", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
                 ("scale1", c_void_p), ("shift1", c_void_p)]
 
 
@@ -72,7 +72,6 @@ SIGNATURES = {
                                              P, c_int64, P]),
     "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, c_int32, P, P, P]),
     "geomae_vfe_prepare": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, P, F3, F3, P, P, P]),
-    "geomae_vfe_plan": (ctypes.c_int, [P, P, c_int32, c_int32, c_int32, P, P]),
     "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P]),
     "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),
     "geomae_vfe_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),

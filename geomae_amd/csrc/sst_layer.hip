@@ -551,8 +551,10 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
 }
 
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
+    // enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
     int G = cdiv(num_tokens, 512);
-    if (G > 32) G = 32;
+    const int cap = num_tasks >= 8 ? 32 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
+    if (G > cap) G = cap;
     int chunk = cdiv(num_tokens, G);
     chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
     G = cdiv(num_tokens, chunk);

@@ -12,9 +12,10 @@
 //   * BatchNorm needs full-batch statistics before it can normalise, so each layer is two sweeps
 //     (statistics, then apply + segmented max); y = W f is recomputed instead of stored (11x64 and
 //     128x128 MACs per point are cheaper than a 256 / 512 B round trip per point);
-//   * a wave owns a RANGE OF WHOLE PILLARS (vfe_plan), so segmented max / sum never cross waves: a
-//     16 x C tile goes through LDS and lane c scans its channel over the 16 points, carrying the open
-//     pillar in registers -- no float atomics, deterministic;
+//   * a wave owns 64 consecutive points of the pillar-sorted order; a 16 x C tile goes through LDS and lane c
+//     scans its channel over the 16 points, carrying the open pillar in registers.  Pillars inside the
+//     wave's range are plain stores; the (at most two) pillars cut by the range boundaries are combined
+//     across waves with atomics, and every consumer of a pooled row is a later kernel;
 //   * the max-pool backward needs no arg-max: the forward value is recomputed bit-identically (same
 //     device function, same MFMA order) and the gradient is routed where h == max (ties at 0 are killed
 //     by ReLU'; exact duplicates of a point would both receive it);
@@ -29,7 +30,9 @@ namespace geomae {
 constexpr int kVfeBlk = 512;            // 8 waves share one LDS copy of W1: 2 waves per SIMD hide each other's latency
 constexpr int kVfeWaves = kVfeBlk / 64;
 constexpr int kW1Ld = 128 + 4;          // fp32 LDS row of W1 (+16 B pad)
-constexpr int kTileLd = 128 + 4;        // fp32 LDS row of the per-wave [16 x C] tile
+constexpr int kTileLd = 128 + 4;        // fp32 LDS row of the per-wave [16 x 128] tile
+constexpr int kTile0Ld = 80 + 4;        // ... of the [16 x 64 (+16 features)] tile
+constexpr int kVfePts = 64;             // points per wave: 4 tiles of 16
 
 __device__ __forceinline__ f32x4 mfma_f32(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -39,17 +42,19 @@ struct VfeGeo {
     const float* feat;            // [N,16] decorated features of the points in pillar order (vfe_prepare)
     const int32_t* pid;           // [N] pillar of each sorted point
     const int32_t* seg_start;
+    int n_points;
 };
 
-struct WaveRange { int p_lo, p_hi, j_lo, j_hi; };
+// every wave owns kVfePts consecutive sorted points -- all waves do the same work however the points are
+// distributed over pillars (a wave per range of WHOLE pillars made the wave with the 284-point pillar run
+// 4.5x longer than the rest, profiles/r01q_step_timeline.txt)
+struct WaveRange { int j_lo, j_hi; };
 
-__device__ __forceinline__ WaveRange wave_range(const int32_t* __restrict__ ranges, const int32_t* __restrict__ seg_start,
-                                                int wave_id, int n_waves) {
+__device__ __forceinline__ WaveRange wave_range(const VfeGeo& G, int wave_id) {
     WaveRange r;
-    r.p_lo = wave_id < n_waves ? ranges[wave_id] : 0;
-    r.p_hi = wave_id < n_waves ? ranges[wave_id + 1] : 0;
-    r.j_lo = seg_start[r.p_lo];
-    r.j_hi = seg_start[r.p_hi];
+    const int64_t lo = (int64_t)wave_id * kVfePts;
+    r.j_lo = lo < G.n_points ? (int)lo : G.n_points;
+    r.j_hi = r.j_lo + kVfePts < G.n_points ? r.j_lo + kVfePts : G.n_points;
     return r;
 }
 
@@ -67,7 +72,7 @@ __device__ __forceinline__ int pillar_of(const VfeGeo& G, int j) { return G.pid[
 // the lane's 4 of the 16 (11 used) decorated features of its point, T-layout: feature index 4g + r.
 // One coalesced 16-byte load: the gathers (order -> point -> pillar mean / centre) were hoisted into
 // vfe_prepare_kernel, because as per-tile dependent loads they cost ~5 us per tile in every sweep.
-__device__ __forceinline__ void build_features(const VfeGeo& G, int j, int pid, bool valid, int g, float (&f)[4]) {
+__device__ __forceinline__ void build_features(const VfeGeo& G, int j, bool valid, int g, float (&f)[4]) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (valid) v = *reinterpret_cast<const float4*>(G.feat + (int64_t)j * 16 + 4 * g);
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
@@ -179,13 +184,40 @@ __device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1
     }
 }
 
+// BatchNorm vectors are read per tile by every lane: keep them in LDS (one VGPR address + immediate offsets
+// instead of a 64-bit global pointer per vector per tile, which is what spilled vfe_bwd_stats1_kernel)
+__device__ __forceinline__ void stage_vec(const float* __restrict__ src, float* dst, int n) {
+    for (int c = threadIdx.x; c < n; c += kVfeBlk) dst[c] = src[c];
+}
+#define VFE_STAGE_BN0_FWD(W, Wl)                                   \
+    __shared__ __attribute__((aligned(16))) float bn0f_s[2][64];   \
+    stage_vec((W).scale0, bn0f_s[0], 64);                          \
+    stage_vec((W).shift0, bn0f_s[1], 64);                          \
+    VfeW Wl = (W);                                                 \
+    Wl.scale0 = bn0f_s[0];                                         \
+    Wl.shift0 = bn0f_s[1];
+#define VFE_STAGE_BN1(bn, bnl)                                     \
+    __shared__ __attribute__((aligned(16))) float bn1_s[4][128];   \
+    stage_vec((bn).scale, bn1_s[0], 128);                          \
+    stage_vec((bn).shift, bn1_s[1], 128);                          \
+    stage_vec((bn).mean, bn1_s[2], 128);                           \
+    stage_vec((bn).invstd, bn1_s[3], 128);                         \
+    const Bn1 bnl = {bn1_s[0], bn1_s[1], bn1_s[2], bn1_s[3]};
+#define VFE_STAGE_BN0(bn, bnl)                                     \
+    __shared__ __attribute__((aligned(16))) float bn0_s[4][64];    \
+    stage_vec((bn).scale, bn0_s[0], 64);                           \
+    stage_vec((bn).shift, bn0_s[1], 64);                           \
+    stage_vec((bn).mean, bn0_s[2], 64);                            \
+    stage_vec((bn).invstd, bn0_s[3], 64);                          \
+    const Bn0 bnl = {bn0_s[0], bn0_s[1], bn0_s[2], bn0_s[3]};
+
 // per-wave tile helpers: T-layout registers -> LDS tile[t][c] (fp32)
-template <int NT>
+template <int NT, int LD>
 __device__ __forceinline__ void tile_store(float* tile, const f32x4 (&v)[NT], int lane) {
     const int t = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int ot = 0; ot < NT; ++ot)
-        *reinterpret_cast<float4*>(tile + t * kTileLd + 16 * ot + 4 * g) = make_float4(v[ot][0], v[ot][1], v[ot][2], v[ot][3]);
+        *reinterpret_cast<float4*>(tile + t * LD + 16 * ot + 4 * g) = make_float4(v[ot][0], v[ot][1], v[ot][2], v[ot][3]);
 }
 // LDS hand-off inside ONE wave (tile written by its lanes, scanned by its lanes): DS operations of a wave
 // execute in order, so it is enough to drain the LDS counter and stop the compiler from moving accesses
@@ -201,35 +233,53 @@ __device__ __forceinline__ void wave_global_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// Segmented reduction of a [16 x 64*CPL] tile over the tile's points, lane = channel (+64 per extra channel):
-// `cur_pid` / `cur` carry the open pillar across tiles; a finished pillar's row is stored to out[pid][c].
+// Segmented reduction of a [16 x 64*CPL] tile over the tile's points, lane = channel (+64 per extra channel).
+// The carry holds the open pillar across tiles; a finished pillar's row goes to out[pid][c]: a plain store
+// when the pillar lies inside the wave's point range, an atomic combine when it straddles the range (its
+// other parts belong to neighbouring waves; `out` is zero-filled).  Max rows are >= 0 (post-ReLU), so the
+// integer atomicMax on the float bits is exact and order independent; sums use float atomicAdd (a pillar
+// cut in more than two parts may round differently from run to run in the last bit).
+template <int CPL>
+struct SegCarry {
+    int pid;
+    bool shared;
+    float cur[CPL];
+    __device__ __forceinline__ void init(bool) { pid = -1; shared = false; }
+};
 template <int CPL, bool IS_MAX>
+__device__ __forceinline__ void seg_row_out(int C, float* __restrict__ out, const SegCarry<CPL>& c, bool shared, int lane) {
+#pragma unroll
+    for (int k = 0; k < CPL; ++k) {
+        float* dst = out + (int64_t)c.pid * C + lane + 64 * k;
+        if (!shared) *dst = c.cur[k];
+        else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k]));
+        else atomicAdd(dst, c.cur[k]);
+    }
+}
+template <int CPL, bool IS_MAX, int LD>
 __device__ __forceinline__ void seg_scan(const float* tile, const int* pids, int npts, int C, float* __restrict__ out,
-                                         int& cur_pid, float (&cur)[CPL], int lane) {
+                                         const int32_t* __restrict__ seg_start, const WaveRange& R,
+                                         SegCarry<CPL>& c, int lane) {
     for (int t = 0; t < npts; ++t) {
         const int p = pids[t];
-        if (p != cur_pid) {
-            if (cur_pid >= 0) {
+        if (p != c.pid) {
+            if (c.pid >= 0) seg_row_out<CPL, IS_MAX>(C, out, c, c.shared, lane);     // ends inside the range
+            c.shared = c.pid < 0 && seg_start[p] < R.j_lo;                           // only the first can start outside
+            c.pid = p;
 #pragma unroll
-                for (int k = 0; k < CPL; ++k) out[(int64_t)cur_pid * C + lane + 64 * k] = cur[k];
-            }
-            cur_pid = p;
-#pragma unroll
-            for (int k = 0; k < CPL; ++k) cur[k] = IS_MAX ? -INFINITY : 0.f;
+            for (int k = 0; k < CPL; ++k) c.cur[k] = IS_MAX ? -INFINITY : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            const float v = tile[t * kTileLd + lane + 64 * k];
-            cur[k] = IS_MAX ? fmaxf(cur[k], v) : cur[k] + v;
+            const float v = tile[t * LD + lane + 64 * k];
+            c.cur[k] = IS_MAX ? fmaxf(c.cur[k], v) : c.cur[k] + v;
         }
     }
 }
-template <int CPL>
-__device__ __forceinline__ void seg_flush(int C, float* __restrict__ out, int cur_pid, const float (&cur)[CPL], int lane) {
-    if (cur_pid >= 0) {
-#pragma unroll
-        for (int k = 0; k < CPL; ++k) out[(int64_t)cur_pid * C + lane + 64 * k] = cur[k];
-    }
+template <int CPL, bool IS_MAX>
+__device__ __forceinline__ void seg_flush(int C, float* __restrict__ out, const int32_t* __restrict__ seg_start,
+                                          const WaveRange& R, const SegCarry<CPL>& c, int lane) {
+    if (c.pid >= 0) seg_row_out<CPL, IS_MAX>(C, out, c, c.shared || seg_start[c.pid + 1] > R.j_hi, lane);
 }
 
 // sum over the 16 points of the tile and accumulate per-lane partials (kept until the end of the kernel)
@@ -257,22 +307,6 @@ __device__ __forceinline__ void flush_channel_sums(const f32x4 (&s1)[NT], const 
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void vfe_plan_kernel(const int32_t* __restrict__ seg_start,
-                                                       const int32_t* __restrict__ num_pillars, int n_points,
-                                                       int pts_per_wave, int n_waves, int32_t* __restrict__ ranges) {
-    const int V = num_pillars[0];
-    for (int w = blockIdx.x * 256 + threadIdx.x; w <= n_waves; w += gridDim.x * 256) {
-        // first pillar whose first point is at or after w * pts_per_wave
-        const int64_t target = (int64_t)w * pts_per_wave;
-        int lo = 0, hi = V;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (seg_start[mid] >= target) hi = mid; else lo = mid + 1;
-        }
-        ranges[w] = (w == n_waves || target >= n_points) ? V : lo;
-    }
-}
-
 __global__ __launch_bounds__(256) void vfe_mean_accum_kernel(const float* __restrict__ pts, int stride, int64_t n,
                                                              const int32_t* __restrict__ inv,
                                                              unsigned long long* __restrict__ sum64) {
@@ -347,23 +381,21 @@ __device__ __forceinline__ Bn1 shifted(const Bn1& b, int z) { return Bn1{b.scale
 __device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale + z, b.shift + z, b.mean + z, b.invstd + z}; }
 
 // sweep 1 of layer 0: per-channel sum / sum of squares of y0 = W0 f over all points
-__global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
-                                                             int n_waves, double* __restrict__ sums0) {
+__global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, double* __restrict__ sums0) {
     __shared__ float W0s[64 * 16];
     __shared__ float red[kVfeWaves * 2 * 64];
     stage_w0(W.w0, W0s);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     f32x4 s1[4], s2[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
-        build_features(G, j, pid, valid, g, f);
+        build_features(G, j, valid, g, f);
         f32x4 y[4];
         layer0_linear(W0s, f, y, lane);
         if (valid) {
@@ -374,45 +406,68 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, c
     flush_channel_sums<4>(s1, s2, sums0, 64, red, lane, wave);
 }
 
-// sweep 2 of layer 0 (h0, segmented max m0) fused with sweep 1 of layer 1 (statistics of y1 = W1 [h0 | m0])
-__global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
-                                                             int n_waves, float* __restrict__ m0,
+// sweep 2 of layer 0: h0 = ReLU(BN(y0)), m0 = segmented max (m0 zero-filled by the caller: rows of pillars
+// that straddle waves are combined with integer atomicMax, exact because h0 >= 0)
+__global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, float* __restrict__ m0) {
+    __shared__ float W0s[64 * 16];
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
+    __shared__ int pids[kVfeWaves][16];
+    stage_w0(W.w0, W0s);
+    VFE_STAGE_BN0_FWD(W, Wl)
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
+    float* tile = tiles[wave];
+    SegCarry<1> carry;
+    carry.init(true);
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G, j) : 0;
+        float f[4];
+        build_features(G, j, valid, g, f);
+        f32x4 y[4], h[4];
+        layer0_linear(W0s, f, y, lane);
+        bn_relu<4>(y, Wl.scale0, Wl.shift0, h, lane);
+        tile_store<4, kTile0Ld>(tile, h, lane);
+        if (g == 0) pids[wave][lane & 15] = pid;
+        wave_sync();
+        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
+        seg_scan<1, true, kTile0Ld>(tile, pids[wave], npts, 64, m0, G.seg_start, R, carry, lane);
+        wave_sync();
+    }
+    seg_flush<1, true>(64, m0, G.seg_start, R, carry, lane);
+}
+
+// recompute h0 and g = [h0 | m0[pid]] for the lane's point (shared by every later sweep so that the values
+// are bit-identical to the forward's)
+__device__ __forceinline__ void recompute_g(const VfeGeo& G, const VfeW& W, const float* W0s, const float* __restrict__ m0,
+                                            int j, int pid, bool valid, int lane, f32x4 (&y0)[4], f32x4 (&gin)[8]) {
+    const int g = lane >> 4;
+    float f[4];
+    build_features(G, j, valid, g, f);
+    layer0_linear(W0s, f, y0, lane);
+    bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        float4 v = make_float4(0, 0, 0, 0);
+        if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
+        gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
+    }
+}
+
+// sweep 1 of layer 1: statistics of y1 = W1 [h0 | m0]
+__global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                              double* __restrict__ sums1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
-    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
-    __shared__ int pids[kVfeWaves][16];
     __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
+    VFE_STAGE_BN0_FWD(W, Ws)
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
-    float* tile = tiles[wave];
-    // ---- pass A: h0 -> m0 (whole pillars, this wave only)
-    {
-        int cur_pid = -1;
-        float cur[1] = {0.f};
-        for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-            const int j = j0 + (lane & 15);
-            const bool valid = j < R.j_hi;
-            const int pid = valid ? pillar_of(G, j) : 0;
-            float f[4];
-            build_features(G, j, pid, valid, g, f);
-            f32x4 y[4], h[4];
-            layer0_linear(W0s, f, y, lane);
-            bn_relu<4>(y, W.scale0, W.shift0, h, lane);
-            tile_store<4>(tile, h, lane);
-            if (g == 0) pids[wave][lane & 15] = pid;
-            wave_sync();
-            const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-            seg_scan<1, true>(tile, pids[wave], npts, 64, m0, cur_pid, cur, lane);
-            wave_sync();
-        }
-        seg_flush<1>(64, m0, cur_pid, cur, lane);
-    }
-    wave_global_sync();
-    // ---- pass B: y1 statistics
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     f32x4 s1[8], s2[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
@@ -422,17 +477,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
         const int pid = valid ? pillar_of(G, j) : 0;
         const int oz = opaque_zero();
         const float* W1l = W1s + oz;
-        float f[4];
-        build_features(G, j, pid, valid, g, f);
         f32x4 y0[4], gin[8];
-        layer0_linear(W0s + oz, f, y0, lane);
-        bn_relu<4>(y0, W.scale0 + oz, W.shift0 + oz, reinterpret_cast<f32x4(&)[4]>(gin), lane);
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            float4 v = make_float4(0, 0, 0, 0);
-            if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
-            gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
-        }
+        recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 y2[2];
@@ -446,57 +492,45 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, c
     flush_channel_sums<8>(s1, s2, sums1, 128, red, lane, wave);
 }
 
-// recompute h0 and g = [h0 | m0[pid]] for the lane's point (shared by every later sweep so that the values
-// are bit-identical to the forward's)
-__device__ __forceinline__ void recompute_g(const VfeGeo& G, const VfeW& W, const float* W0s, const float* __restrict__ m0,
-                                            int j, int pid, bool valid, int lane, f32x4 (&y0)[4], f32x4 (&gin)[8]) {
-    const int g = lane >> 4;
-    float f[4];
-    build_features(G, j, pid, valid, g, f);
-    layer0_linear(W0s, f, y0, lane);
-    bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
-#pragma unroll
-    for (int ct = 0; ct < 4; ++ct) {
-        float4 v = make_float4(0, 0, 0, 0);
-        if (valid) v = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + 16 * ct + 4 * g);
-        gin[4 + ct] = f32x4{v.x, v.y, v.z, v.w};
-    }
-}
-
-// sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max
-__global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
-                                                             int n_waves, const float* __restrict__ m0,
+// sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max (zero-filled by the caller)
+__global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                              float* __restrict__ vf) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
     __shared__ int pids[kVfeWaves][16];
+    __shared__ __attribute__((aligned(16))) float bn1f_s[2][128];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
+    VFE_STAGE_BN0_FWD(W, Ws)
+    stage_vec(W.scale1, bn1f_s[0], 128);
+    stage_vec(W.shift1, bn1f_s[1], 128);
+    Ws.scale1 = bn1f_s[0];
+    Ws.shift1 = bn1f_s[1];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
-    int cur_pid = -1;
-    float cur[2] = {0.f, 0.f};
+    SegCarry<2> carry;
+    carry.init(true);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
         const int oz = opaque_zero();
-        const VfeW Wl = shifted(W, oz);
+        const VfeW Wl = shifted(Ws, oz);
         f32x4 y0[4], gin[8], y1[8], h1[8];
         recompute_g(G, Wl, W0s + oz, m0, j, pid, valid, lane, y0, gin);
         layer1_linear(W1s + oz, gin, y1, lane);
         bn_relu<8>(y1, Wl.scale1, Wl.shift1, h1, lane);
-        tile_store<8>(tile, h1, lane);
+        tile_store<8, kTileLd>(tile, h1, lane);
         if (g == 0) pids[wave][lane & 15] = pid;
         wave_sync();
         const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-        seg_scan<2, true>(tile, pids[wave], npts, 128, vf, cur_pid, cur, lane);
+        seg_scan<2, true, kTileLd>(tile, pids[wave], npts, 128, vf, G.seg_start, R, carry, lane);
         wave_sync();
     }
-    seg_flush<2>(128, vf, cur_pid, cur, lane);
+    seg_flush<2, true>(128, vf, G.seg_start, R, carry, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -525,8 +559,7 @@ __device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const 
     }
 }
 
-__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
-                                                                 int n_waves, const float* __restrict__ m0,
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                                  const float* __restrict__ vf, const float* __restrict__ dvf,
                                                                  Bn1 bn, double* __restrict__ bsums1) {
     __shared__ float W0s[64 * 16];
@@ -534,62 +567,69 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
     __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
+    VFE_STAGE_BN0_FWD(W, Ws)
+    VFE_STAGE_BN1(bn, bns)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
+    // two passes over the points, 4 output tiles each: 16 instead of 32 accumulator vectors live across the
+    // loop (the single-pass version spilled); layer 0 is recomputed twice, layer 1's MFMA count is unchanged
     f32x4 s1[8], s2[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
-    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-        const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
-        const int oz = opaque_zero();
-        const Bn1 bnl = shifted(bn, oz);
-        f32x4 y0[4], gin[8];
-        recompute_g(G, shifted(W, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
 #pragma unroll
-        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
-            f32x4 y4[2];
-            layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
+    for (int half = 0; half < 2; ++half) {
+        for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+            const int j = j0 + (lane & 15);
+            const bool valid = j < R.j_hi;
+            const int pid = valid ? pillar_of(G, j) : 0;
+            const int oz = opaque_zero();
+            const Bn1 bnl = shifted(bns, oz);
+            f32x4 y0[4], gin[8];
+            recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                f32x4 dh, yh;
-                routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
-                s1[ot0 + u] += dh;
-                s2[ot0 + u] += dh * yh;
+            for (int q = 0; q < 4; q += 2) {
+                const int ot0 = 4 * half + q;
+                f32x4 y4[2];
+                layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    f32x4 dh, yh;
+                    routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
+                    s1[ot0 + u] += dh;
+                    s2[ot0 + u] += dh * yh;
+                }
             }
         }
     }
     flush_channel_sums<8>(s1, s2, bsums1, 128, red, lane, wave);
 }
 
-// layer-1 backward sweep + layer-0 routing/statistics sweep.
+// layer-1 backward sweep:
 //   dy1 = invstd1 * (dyh - S1/n - yhat * S2/n)  -> bf16 copy + g bf16 copy (operands of dW1 = dy1^T g)
-//   dg = dy1 W1 ; dh0_direct = dg[:, :64] (stored fp32) ; dm0 = segmented sum of dg[:, 64:]
-//   second pass: dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ; dyh0 = dh0 * gamma0 ; sums for BN0
+//   dg = dy1 W1 ; dh0_direct = dg[:, :64] (stored fp32) ; dm0 = segmented sum of dg[:, 64:] (zero-filled by
+//   the caller; pillars that straddle waves are combined with float atomics)
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
-    VfeGeo G, VfeW W, const int32_t* __restrict__ ranges, int n_waves, const float* __restrict__ m0,
-    const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn, const double* __restrict__ bsums1, float n_eff,
-    Bn0 bn0, bf16_t* __restrict__ dy1_b, bf16_t* __restrict__ g_b, float* __restrict__ dy1_f, float* __restrict__ dh0,
-    float* __restrict__ dm0, double* __restrict__ bsums0) {
+    VfeGeo G, VfeW W, const float* __restrict__ m0, const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn,
+    const double* __restrict__ bsums1, float n_eff, bf16_t* __restrict__ dy1_b, bf16_t* __restrict__ g_b,
+    float* __restrict__ dy1_f, float* __restrict__ dh0, float* __restrict__ dm0) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
-    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
     __shared__ int pids[kVfeWaves][16];
-    __shared__ float red[kVfeWaves * 2 * 64];
     __shared__ float bn1s[2][128];                                         // S1/n, S2/n
     stage_w0(W.w0, W0s);
+    VFE_STAGE_BN0_FWD(W, Ws)
+    VFE_STAGE_BN1(bn, bns)
     for (int c = threadIdx.x; c < 128; c += kVfeBlk) {
         bn1s[0][c] = (float)(bsums1[c] / (double)n_eff);
         bn1s[1][c] = (float)(bsums1[128 + c] / (double)n_eff);
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
-    // ---- pass A needs W1 (recompute y1) AND W1^T (dg = dy1 W1).  Two fp32 copies do not fit in LDS next to
-    // the tiles, so it is split: A1 computes dy1 with W1 and parks it in HBM (fp32); A2 re-reads it and
-    // multiplies by W1^T.
+    // Both W1 (recompute y1) and W1^T (dg = dy1 W1) are needed.  Two fp32 copies do not fit in LDS, so the
+    // sweep is split: A1 computes dy1 with W1 and parks it in HBM (fp32); A2 re-reads it and multiplies by W1^T.
     stage_w1(W.w1, W1s, false);
     __syncthreads();
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
@@ -597,11 +637,11 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
         const int oz = opaque_zero();
-        const Bn1 bnl = shifted(bn, oz);
+        const Bn1 bnl = shifted(bns, oz);
         const float* bs0 = bn1s[0] + oz;
         const float* bs1 = bn1s[1] + oz;
         f32x4 y0[4], gin[8];
-        recompute_g(G, shifted(W, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
         store_rows_bf16<128>(g_b, j, 128, 0, valid, gin, lane);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
@@ -627,43 +667,53 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     __syncthreads();
     stage_w1(W.w1, W1s, true);
     __syncthreads();
-    {
-        int cur_pid = -1;
-        float cur[1] = {0.f};
-        for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-            const int j = j0 + (lane & 15);
-            const bool valid = j < R.j_hi;
-            const int pid = valid ? pillar_of(G, j) : 0;
-            const float* W1l = W1s + opaque_zero();
-            f32x4 dy1[8];
-            load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
-            // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
+    SegCarry<1> carry;
+    carry.init(false);
+    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const int j = j0 + (lane & 15);
+        const bool valid = j < R.j_hi;
+        const int pid = valid ? pillar_of(G, j) : 0;
+        const float* W1l = W1s + opaque_zero();
+        f32x4 dy1[8];
+        load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
+        // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
 #pragma unroll
-            for (int ot0 = 0; ot0 < 8; ot0 += 2) {
-                f32x4 d2[2];
-                layer1_group<2>(W1l, dy1, ot0, d2, lane);
+        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+            f32x4 d2[2];
+            layer1_group<2>(W1l, dy1, ot0, d2, lane);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    const int ct = ot0 + u;
-                    if (ct < 4) {
-                        if (valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + 16 * ct + 4 * g) =
-                                       make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
-                    } else {
-                        *reinterpret_cast<float4*>(tile + (lane & 15) * kTileLd + 16 * (ct - 4) + 4 * g) =
-                            make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
-                    }
+            for (int u = 0; u < 2; ++u) {
+                const int ct = ot0 + u;
+                if (ct < 4) {
+                    if (valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + 16 * ct + 4 * g) =
+                                   make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
+                } else {
+                    *reinterpret_cast<float4*>(tile + (lane & 15) * kTile0Ld + 16 * (ct - 4) + 4 * g) =
+                        make_float4(d2[u][0], d2[u][1], d2[u][2], d2[u][3]);
                 }
             }
-            if (g == 0) pids[wave][lane & 15] = pid;
-            wave_sync();
-            const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-            seg_scan<1, false>(tile, pids[wave], npts, 64, dm0, cur_pid, cur, lane);
-            wave_sync();
         }
-        seg_flush<1>(64, dm0, cur_pid, cur, lane);
+        if (g == 0) pids[wave][lane & 15] = pid;
+        wave_sync();
+        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
+        seg_scan<1, false, kTile0Ld>(tile, pids[wave], npts, 64, dm0, G.seg_start, R, carry, lane);
+        wave_sync();
     }
-    wave_global_sync();
-    // ---- pass B: total dh0, BN0 backward statistics
+    seg_flush<1, false>(64, dm0, G.seg_start, R, carry, lane);
+}
+
+// layer-0 routing sweep (needs the complete dm0): dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ;
+// sums of dh0 and dh0 * yhat0 for the BN0 backward
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
+                                                                 Bn0 bn0, const float* __restrict__ dm0,
+                                                                 float* __restrict__ dh0, double* __restrict__ bsums0) {
+    __shared__ float W0s[64 * 16];
+    __shared__ float red[kVfeWaves * 2 * 64];
+    stage_w0(W.w0, W0s);
+    VFE_STAGE_BN0(bn0, bn0l)
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     f32x4 s1[4], s2[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
@@ -672,9 +722,9 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
         const int oz = opaque_zero();
-        const Bn0 b0 = shifted(bn0, oz);
+        const Bn0 b0 = shifted(bn0l, oz);
         float f[4];
-        build_features(G, j, pid, valid, g, f);
+        build_features(G, j, valid, g, f);
         f32x4 y0[4];
         layer0_linear(W0s + oz, f, y0, lane);
 #pragma unroll
@@ -711,15 +761,15 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
 }
 
 // layer-0 backward: dy0 = invstd0 * (dyh0 - T1/n - yhat0 * T2/n) ; dW0 += dy0^T f   (64 x 11)
-__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW W, const int32_t* __restrict__ ranges,
-                                                                 int n_waves, const float* __restrict__ dh0, Bn0 bn0,
+__global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW W, const float* __restrict__ dh0, Bn0 bn0,
                                                                  const double* __restrict__ bsums0, float n_eff,
                                                                  float* __restrict__ dw0) {
     __shared__ float W0s[64 * 16];
-    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];      // [t][0..63] dy0, [t][64..79] f
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];     // [t][0..63] dy0, [t][64..79] f
     __shared__ float acc_s[64 * 16];
     __shared__ float bn0s[2][64];
     stage_w0(W.w0, W0s);
+    VFE_STAGE_BN0(bn0, bn0l)
     for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) acc_s[e] = 0.f;
     for (int c = threadIdx.x; c < 64; c += kVfeBlk) {
         bn0s[0][c] = (float)(bsums0[c] / (double)n_eff);
@@ -727,7 +777,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
-    const WaveRange R = wave_range(ranges, G.seg_start, blockIdx.x * kVfeWaves + wave, n_waves);
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
     f32x4 dw[4];                                   // C layout: row = out channel 16*ot' ... see below
 #pragma unroll
@@ -735,17 +785,16 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
         float f[4];
-        build_features(G, j, pid, valid, g, f);
+        build_features(G, j, valid, g, f);
         f32x4 y0[4], dy0[4];
         layer0_linear(W0s, f, y0, lane);
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
             const int c0 = 16 * ot + 4 * g;
-            const float4 s = *reinterpret_cast<const float4*>(bn0.scale + c0);
-            const float4 mu = *reinterpret_cast<const float4*>(bn0.mean + c0);
-            const float4 is = *reinterpret_cast<const float4*>(bn0.invstd + c0);
+            const float4 s = *reinterpret_cast<const float4*>(bn0l.scale + c0);
+            const float4 mu = *reinterpret_cast<const float4*>(bn0l.mean + c0);
+            const float4 is = *reinterpret_cast<const float4*>(bn0l.invstd + c0);
             float4 dd = make_float4(0, 0, 0, 0);
             if (valid) dd = *reinterpret_cast<const float4*>(dh0 + (int64_t)j * 64 + c0);
             const float sc[4] = {s.x, s.y, s.z, s.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w}, iv[4] = {is.x, is.y, is.z, is.w},
@@ -757,16 +806,16 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
             }
         }
         // dW0[o][k] += sum_t dy0[t][o] f[t][k]: token contraction -> tile through LDS, MFMA with k = t
-        tile_store<4>(tile, dy0, lane);
-        *reinterpret_cast<float4*>(tile + (lane & 15) * kTileLd + 64 + 4 * g) = make_float4(f[0], f[1], f[2], f[3]);
+        tile_store<4, kTile0Ld>(tile, dy0, lane);
+        *reinterpret_cast<float4*>(tile + (lane & 15) * kTile0Ld + 64 + 4 * g) = make_float4(f[0], f[1], f[2], f[3]);
         wave_sync();
         const int o = lane & 15;
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                const float a = tile[(4 * s + g) * kTileLd + 16 * ot + o];       // A[row = o][k = t = 4s + g]
-                const float b = tile[(4 * s + g) * kTileLd + 64 + o];            // B[k = t][col = feature o]
+                const float a = tile[(4 * s + g) * kTile0Ld + 16 * ot + o];      // A[row = o][k = t = 4s + g]
+                const float b = tile[(4 * s + g) * kTile0Ld + 64 + o];           // B[k = t][col = feature o]
                 dw[ot] = mfma_f32(a, b, dw[ot]);
             }
         wave_sync();
@@ -789,13 +838,13 @@ using namespace geomae;
 
 static int vfe_common(const GeomaeVfeArgs* a, VfeGeo* G, VfeW* W, const char* who) {
     GEOMAE_REQUIRE(a, "%s: null args", who);
-    GEOMAE_REQUIRE(a->feat_sorted && a->pid_sorted && a->seg_start && a->ranges && a->w0 && a->w1,
-                   "%s: null pointer in args", who);
-    GEOMAE_REQUIRE(a->num_waves >= 1, "%s: bad sizes", who);
-    G->feat = a->feat_sorted; G->pid = a->pid_sorted; G->seg_start = a->seg_start;
+    GEOMAE_REQUIRE(a->feat_sorted && a->pid_sorted && a->seg_start && a->w0 && a->w1, "%s: null pointer in args", who);
+    GEOMAE_REQUIRE(a->num_points >= 1 && a->num_points < (1ll << 31) - kVfePts && a->max_pillars >= 1, "%s: bad sizes", who);
+    G->feat = a->feat_sorted; G->pid = a->pid_sorted; G->seg_start = a->seg_start; G->n_points = (int)a->num_points;
     W->w0 = a->w0; W->w1 = a->w1; W->scale0 = a->scale0; W->shift0 = a->shift0; W->scale1 = a->scale1; W->shift1 = a->shift1;
     return GEOMAE_OK;
 }
+static dim3 vfe_grid(const GeomaeVfeArgs* a) { return dim3(cdiv(cdiv(a->num_points, kVfePts), kVfeWaves)); }
 
 extern "C" int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
                                   const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
@@ -809,14 +858,6 @@ extern "C" int geomae_vfe_prepare(const float* points, int32_t num_features, int
                        num_points, order, inv, pillar_mean, (const int4*)voxel_coors, voxel_size[0], voxel_size[1],
                        voxel_size[2], center_offset[0], center_offset[1], center_offset[2], feat_sorted, pid_sorted);
     return check_launch("vfe_prepare_kernel");
-}
-
-extern "C" int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,
-                               int32_t points_per_wave, int32_t num_waves, int32_t* ranges, hipStream_t stream) {
-    GEOMAE_REQUIRE(seg_start && num_pillars && ranges && points_per_wave >= 16 && num_waves >= 1, "vfe_plan: bad argument");
-    hipLaunchKernelGGL(vfe_plan_kernel, dim3(cdiv(num_waves + 1, 256)), dim3(256), 0, stream, seg_start, num_pillars,
-                       num_points, points_per_wave, num_waves, ranges);
-    return check_launch("vfe_plan_kernel");
 }
 
 extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features, int64_t num_points,
@@ -850,8 +891,7 @@ extern "C" int geomae_vfe_stats0(const GeomaeVfeArgs* a, double* sums0, hipStrea
     if (rc) return rc;
     GEOMAE_REQUIRE(sums0, "vfe_stats0: null output");
     GEOMAE_HIP(hipMemsetAsync(sums0, 0, 128 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_stats0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, sums0);
+    hipLaunchKernelGGL(vfe_stats0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, sums0);
     return check_launch("vfe_stats0_kernel");
 }
 
@@ -861,9 +901,11 @@ extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && sums1 && a->scale0 && a->shift0, "vfe_layer0: null argument");
     GEOMAE_HIP(hipMemsetAsync(sums1, 0, 256 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_layer0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, m0, sums1);
-    return check_launch("vfe_layer0_kernel");
+    GEOMAE_HIP(hipMemsetAsync(m0, 0, (size_t)a->max_pillars * 64 * sizeof(float), stream));
+    hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0);
+    if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
+    hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
+    return check_launch("vfe_stats1_kernel");
 }
 
 extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float* voxel_feats, hipStream_t stream) {
@@ -871,8 +913,8 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     int rc = vfe_common(a, &G, &W, "vfe_layer1");
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
-    hipLaunchKernelGGL(vfe_layer1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, m0, voxel_feats);
+    GEOMAE_HIP(hipMemsetAsync(voxel_feats, 0, (size_t)a->max_pillars * 128 * sizeof(float), stream));
+    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats);
     return check_launch("vfe_layer1_kernel");
 }
 
@@ -895,8 +937,8 @@ extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnS
     if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1, "vfe_backward_stats: null argument");
     GEOMAE_HIP(hipMemsetAsync(bsums1, 0, 256 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1);
+    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats,
+                       d_voxel_feats, bn, bsums1);
     return check_launch("vfe_bwd_stats1_kernel");
 }
 
@@ -914,10 +956,13 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dy1_f32 && dh0 && dm0 &&
                    bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
     GEOMAE_HIP(hipMemsetAsync(bsums0, 0, 128 * sizeof(double), stream));
-    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, m0, voxel_feats, d_voxel_feats, bn, bsums1_global, n_eff, bn0, (bf16_t*)dy1_bf16,
-                       (bf16_t*)g_bf16, dy1_f32, dh0, dm0, bsums0);
-    return check_launch("vfe_bwd_layer1_kernel");
+    GEOMAE_HIP(hipMemsetAsync(dm0, 0, (size_t)a->max_pillars * 64 * sizeof(float), stream));
+    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
+                       bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0);
+    if ((rc = check_launch("vfe_bwd_layer1_kernel"))) return rc;
+    hipLaunchKernelGGL(vfe_bwd_route0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0, dh0,
+                       bsums0);
+    return check_launch("vfe_bwd_route0_kernel");
 }
 
 extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBnState* bnst, const float* dh0,
@@ -931,8 +976,8 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
     GEOMAE_REQUIRE(dh0 && bsums0_global && dy1_bf16 && g_bf16 && dw0 && dw1 && n_eff > 0,
                    "vfe_backward_layer0: null argument");
-    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, dim3(cdiv(a->num_waves, kVfeWaves)), dim3(kVfeBlk), 0, stream, G, W, a->ranges,
-                       a->num_waves, dh0, bn0, bsums0_global, n_eff, dw0);
+    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, dh0, bn0, bsums0_global, n_eff,
+                       dw0);
     rc = check_launch("vfe_bwd_layer0_kernel");
     if (rc) return rc;
     DwTasks T;

@@ -427,8 +427,7 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 
 # ------------------------------------------------------------------------------------ fused VFE
 class VfePlan:
-    """Per-batch plan of the fused VFE sweeps: pillar mean, wave -> pillar ranges, the argument struct."""
-    POINTS_PER_WAVE = 64
+    """Per-batch state of the fused VFE sweeps: pillar mean, sorted point features, the argument struct."""
 
     def __init__(self, points, seg, w0, w1, voxel_size, center_offset):
         from ._lib import GeomaeVfeArgs
@@ -436,10 +435,6 @@ class VfePlan:
         dev = points.device
         self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
         self.mean = segment_mean_xyz(points, seg)
-        self.num_waves = max(1, (self.N + self.POINTS_PER_WAVE - 1) // self.POINTS_PER_WAVE)
-        self.ranges = torch.empty(self.num_waves + 1, dtype=torch.int32, device=dev)
-        check(lib.geomae_vfe_plan(_ptr(seg.seg_start), _ptr(seg.num_pillars), self.N, self.POINTS_PER_WAVE,
-                                  self.num_waves, _ptr(self.ranges), _stream()), "geomae_vfe_plan")
         self.bn = torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)    # [layer][scale, shift, mean, invstd]
         self.feat = torch.empty((max(self.N, 1), 16), dtype=torch.float32, device=dev)
         self.pid = torch.empty(max(self.N, 1), dtype=torch.int32, device=dev)
@@ -448,7 +443,7 @@ class VfePlan:
                                      _ptr(self.feat), _ptr(self.pid), _stream()), "geomae_vfe_prepare")
         a = GeomaeVfeArgs()
         a.feat_sorted, a.pid_sorted, a.seg_start = self.feat.data_ptr(), self.pid.data_ptr(), seg.seg_start.data_ptr()
-        a.ranges, a.num_waves = self.ranges.data_ptr(), self.num_waves
+        a.num_points, a.max_pillars = self.N, max(self.V, 1)
         a.w0, a.w1 = w0.data_ptr(), w1.data_ptr()
         a.scale0, a.shift0 = self.bn[0, 0].data_ptr(), self.bn[0, 1].data_ptr()
         a.scale1, a.shift1 = self.bn[1, 0].data_ptr(), self.bn[1, 1].data_ptr()

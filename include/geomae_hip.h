@@ -239,13 +239,13 @@ int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const v
  * their autograd, for in_channels 5 (+3 cluster +3 centre), feat_channels [64, 128], mode 'max', in exact
  * fp32.  BatchNorm is training-mode over all points: each layer is a statistics sweep, a host-visible
  * [2C] fp64 sum vector (where naiveSyncBN1d's cross-rank average happens, ops/norm.py:64-70), and an apply
- * sweep.  A wave owns whole pillars (geomae_vfe_plan: ranges [num_waves + 1], <= points_per_wave points each,
- * more only for a pillar larger than that). */
+ * sweep.  Every wave owns 64 consecutive points of the pillar-sorted order; pillars cut by a wave boundary
+ * are combined with atomics (max: exact; sums: float).  The [V,*] outputs are zero-filled by the calls. */
 typedef struct GeomaeVfeArgs {
     const float* feat_sorted;                        /* [N,16] from geomae_vfe_prepare                   */
     const int32_t* pid_sorted;                       /* [N]                                              */
     const int32_t* seg_start;                        /* from geomae_pillar_segment                       */
-    const int32_t* ranges; int32_t num_waves;        /* from geomae_vfe_plan                             */
+    int64_t num_points; int32_t max_pillars;         /* N, and the row count of the [V,*] outputs        */
     const float *w0, *w1;                            /* vfe_layers.0.linear.weight [64,11], .1 [128,128] */
     const float *scale0, *shift0, *scale1, *shift1;  /* folded BatchNorm (geomae_bn_finalize); may be NULL
                                                         for the sweeps that do not need them            */
@@ -256,8 +256,6 @@ int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_po
                        const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
                        const float* voxel_size, const float* center_offset, float* feat_sorted,
                        int32_t* pid_sorted, geomaeStream_t stream);
-int geomae_vfe_plan(const int32_t* seg_start, const int32_t* num_pillars, int32_t num_points,
-                    int32_t points_per_wave, int32_t num_waves, int32_t* ranges, geomaeStream_t stream);
 /* sums [2C] fp64 (sum, sum of squares) and count -> (mean, mean of squares) in moments_out [2C] and/or, when
  * scale != NULL, the folded affine scale/shift, invstd and the running-stat update.  Pass moments_in [2C]
  * instead of sums to finalize from externally averaged moments (naiveSyncBN1d). */
