@@ -86,7 +86,10 @@ def main():
     n_pts = float(np.mean([sum(p.shape[0] for p in batch) for batch in pool]))
 
     def step(i):
-        return trainer.train_step(pool[i % len(pool)])
+        # like a data loader that has batch i+1 ready: its voxelization / pillar sort is enqueued during step i
+        # (Trainer.train_step next_points), so every timed step contains exactly one such stage -- the one of
+        # the following batch -- and no step waits on its pillar-count readback
+        return trainer.train_step(pool[i % len(pool)], next_points=pool[(i + 1) % len(pool)])
 
     for i in range(args.warmup):
         step(i)

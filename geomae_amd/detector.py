@@ -110,7 +110,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         for s in sizes:
             offs.append(offs[-1] + s)
         pts = torch.cat([p.float() for p in points], dim=0).contiguous() if len(points) > 1 else points[0].float().contiguous()
-        boffs = torch.tensor(offs, dtype=torch.int32, device=pts.device)
+        # pinned + non_blocking: a pageable host->device copy blocks the CPU until every kernel enqueued before
+        # it has run (it was a hidden full sync per step)
+        boffs = torch.tensor(offs, dtype=torch.int32).pin_memory().to(pts.device, non_blocking=True)
         top, med, low = ops.voxelize_batch3(pts, boffs, len(points), self.voxel_size, self.sub_voxel_size_med,
                                             self.sub_voxel_size_low, self.point_cloud_range)
         return pts, top, med, low
@@ -124,12 +126,28 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         self._iter += 1
         return ops.random_mask(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
 
+    @torch.no_grad()
+    def prefetch(self, points):
+        """Stage 1 of `prepare` for a FUTURE batch: voxelize x3 + pillar segments are enqueued now and the
+        pillar counts travel to pinned host memory asynchronously.  Call it for batch k+1 before enqueuing
+        step k (Trainer.train_step(next_points=...)): when step k+1 starts the counts are already on the host,
+        so the iteration's one device->host readback no longer drains the queue (the GPU idled ~0.3 ms per
+        step behind it, profiles/r01q_step_timeline.txt)."""
+        voxels, coors, sub_med, sub_low = self.voxelize_all(points)
+        seg = ops.pillar_segment(coors, len(points), self.grid_size)
+        seg.start_readback()
+        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg))
+
     def prepare(self, points, ids_keep=None, ids_mask=None):
         """voxelize x3 -> pillar segments -> VFE -> mask -> geometric targets (ssl.py:172-231)."""
         batch_size = len(points)
-        voxels, coors, sub_med, sub_low = self.voxelize_all(points)
-        seg = ops.pillar_segment(coors, batch_size, self.grid_size)
-        V = seg.V                                                     # the iteration's one host sync
+        pre, self._prefetched = getattr(self, "_prefetched", None), None
+        if pre is not None and pre[0] is points:
+            voxels, coors, sub_med, sub_low, seg = pre[1]
+        else:
+            voxels, coors, sub_med, sub_low = self.voxelize_all(points)
+            seg = ops.pillar_segment(coors, batch_size, self.grid_size)
+        V = seg.V                                                     # the iteration's one host readback
         voxel_features, feature_coors = self.voxel_encoder(voxels, coors, seg=seg)
         if ids_keep is None:
             ids_keep, ids_mask, token_row, counts = self.get_vanilla_mask_index(seg)

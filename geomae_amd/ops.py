@@ -126,12 +126,24 @@ def voxelize_batch3(points, batch_offsets, batch_size, vs_top, vs_med, vs_low, c
 class PillarSegments:
     """Result of the one counting sort per batch that replaces the reference's six unique(dim=0)."""
     __slots__ = ("cell_table", "voxel_coors", "inv", "order", "seg_start", "sample_start", "num_pillars",
-                 "cap", "grid", "batch_size", "num_points", "_host")
+                 "cap", "grid", "batch_size", "num_points", "_host", "_pinned", "_event")
+
+    def start_readback(self):
+        """Queue the iteration's one device->host readback (pillar offsets per sample) without waiting: an
+        async copy into pinned memory + an event.  A caller that prepares batch k+1 while step k is still
+        being enqueued (detector.prefetch) finds the counts on the host when it needs them and never stalls."""
+        if self._host is None and self._event is None:
+            self._pinned = torch.empty(self.sample_start.shape, dtype=torch.int32, pin_memory=True)
+            self._pinned.copy_(self.sample_start, non_blocking=True)
+            self._event = torch.cuda.Event()
+            self._event.record()
 
     def sync_counts(self):
-        """The one device->host readback of the iteration: pillar offsets per sample."""
+        """Pillar offsets per sample on the host (waits for the readback if it has not landed yet)."""
         if self._host is None:
-            self._host = self.sample_start.cpu().tolist()
+            self.start_readback()
+            self._event.synchronize()
+            self._host = self._pinned.tolist()
         return self._host
 
     @property
@@ -156,6 +168,7 @@ def pillar_segment(coors, batch_size, grid_zyx, cap=None):
     s.sample_start = torch.empty(batch_size + 1, dtype=torch.int32, device=dev)
     s.num_pillars = torch.empty(1, dtype=torch.int32, device=dev)
     s.cap, s.grid, s.batch_size, s.num_points, s._host = cap, (gz, gy, gx), batch_size, n, None
+    s._pinned = s._event = None
     wsb = lib.geomae_pillar_segment_workspace_bytes(n, batch_size, gz, gy, gx)
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
     check(lib.geomae_pillar_segment(_ptr(coors), n, batch_size, gz, gy, gx, _ptr(s.cell_table), _ptr(s.voxel_coors),

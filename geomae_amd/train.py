@@ -46,16 +46,19 @@ class FlatParams:
 
     def check_views(self):
         """Autograd must have accumulated in place; re-point any .grad that was replaced."""
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            view = self.grad[off:off + n]
-            if p.grad is None:
+        if getattr(self, "_ptrs", None) is None:
+            base, item, off, self._ptrs = self.grad.data_ptr(), self.grad.element_size(), 0, []
+            for p in self.params:
+                self._ptrs.append((base + off * item, off, p.numel()))
+                off += p.numel()
+        for p, (ptr, off, n) in zip(self.params, self._ptrs):
+            g = p.grad
+            if g is None:
+                p.grad = self.grad[off:off + n].view_as(p.data)
+            elif g.data_ptr() != ptr:
+                view = self.grad[off:off + n]
+                view.copy_(g.reshape(-1))
                 p.grad = view.view_as(p.data)
-            elif p.grad.data_ptr() != view.data_ptr():
-                view.copy_(p.grad.reshape(-1))
-                p.grad = view.view_as(p.data)
-            off += n
 
 
 def allreduce_gradients(flat, group=None):
@@ -118,9 +121,23 @@ class Trainer:
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
 
-    def train_step(self, points, **kw):
+    def train_step(self, points, next_points=None, **kw):
+        """next_points: the batch of the FOLLOWING step (the same list object must be passed as `points`
+        then); its voxelization / pillar sort is enqueued ahead of this step so that its count readback is
+        off the critical path (detector.prefetch)."""
         self.flat.zero_grad()
-        losses = self.model.forward_train(points, None, **kw)
+        pre = getattr(self.model, "_prefetched", None)
+        if pre is not None and pre[0] is points:
+            pre[1][4].sync_counts()             # already landed: claim it before the next readback is queued
+        keep = pre if (pre is not None and pre[0] is points) else None
+        if next_points is not None and hasattr(self.model, "prefetch"):
+            self.model.prefetch(next_points)
+            nxt = self.model._prefetched
+            self.model._prefetched = keep
+            losses = self.model.forward_train(points, None, **kw)
+            self.model._prefetched = nxt
+        else:
+            losses = self.model.forward_train(points, None, **kw)
         total = sum(losses.values())
         total.backward()
         self.flat.check_views()

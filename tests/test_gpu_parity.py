@@ -391,6 +391,23 @@ def test_forward_train_random_mask_runs_and_is_finite(dev):
     assert torch.isfinite(total) and all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_trainer_prefetch_matches_plain_steps(dev):
+    """Trainer.train_step(next_points=...) enqueues the next batch's voxelize / pillar sort ahead of the step:
+    same losses as preparing every batch inside its own step."""
+    import copy
+    from geomae_amd.train import Trainer
+    model, _ = _build(dev, 2, 1, "bf16")
+    batches = [[torch.as_tensor(synth.lidar_frame(70 + 2 * k + i, beams=16, n_az=500), device=dev) for i in range(2)]
+               for k in range(3)]
+    ta, tb = Trainer(copy.deepcopy(model)), Trainer(copy.deepcopy(model))
+    for k in range(3):
+        la, _ = ta.train_step(batches[k], next_points=batches[(k + 1) % 3])
+        lb, _ = tb.train_step(batches[k])
+        for key in la:
+            assert torch.allclose(la[key], lb[key], rtol=2e-3, atol=1e-5), (k, key, float(la[key]), float(lb[key]))
+    assert ta.model._prefetched is not None and ta.model._prefetched[0] is batches[0]
+
+
 def test_fused_layer_matches_composed_layer(dev):
     """One BasicShiftBlock: fused kernels (bf16 MFMA) vs the composed fp32 layer, forward and backward."""
     import copy
