@@ -54,17 +54,68 @@ inline int stream_grid(int64_t work_items, int block) {
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// ---- cross-lane reductions without the LDS crossbar.  __shfl_xor compiles to ds_bpermute_b32 (~100 cycles of
+// latency each and a dependent chain per reduction: phase timing showed 27 k cycles per LayerNorm backward in
+// sst_ffn_bwd_kernel spent in them).  Inside a row of 16 lanes DPP modifiers do the exchange in the VALU; across
+// rows gfx950's v_permlane16_swap / v_permlane32_swap do.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppHalfMirror = 0x141, kDppMirror = 0x140;
+
+// sum / max over the 16 lanes of a row (lanes l & ~15 .. | 15); result in every lane of the row
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppMirror>(v);
+    return v;
+}
+__device__ __forceinline__ int row16_sum(int v) {
+    v += dpp_mov<kDppXor1>(v);
+    v += dpp_mov<kDppXor2>(v);
+    v += dpp_mov<kDppHalfMirror>(v);
+    v += dpp_mov<kDppMirror>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<kDppXor1>(v));
+    v = fmaxf(v, dpp_mov<kDppXor2>(v));
+    v = fmaxf(v, dpp_mov<kDppHalfMirror>(v));
+    v = fmaxf(v, dpp_mov<kDppMirror>(v));
+    return v;
+}
+// combine lane l with lanes l^16, l^32, l^48 (the same column of the four rows); result in every lane
+__device__ __forceinline__ float rows4_sum(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ int rows4_sum(int v) {
+    const auto a = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+    v = (int)a[0] + (int)a[1];
+    const auto b = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)b[0] + (int)b[1];
+}
+__device__ __forceinline__ float rows4_max(float v) {
+    const auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    const auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
+__device__ __forceinline__ float wave_sum(float v) { return rows4_sum(row16_sum(v)); }
+__device__ __forceinline__ int wave_sum(int v) { return rows4_sum(row16_sum(v)); }
 template <typename T>
-__device__ __forceinline__ T wave_sum(T v) {
+__device__ __forceinline__ T wave_sum(T v) {            // 64-bit types: the generic LDS-crossbar shuffle
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
-
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
+__device__ __forceinline__ float wave_max(float v) { return rows4_max(row16_max(v)); }
 
 }  // namespace geomae

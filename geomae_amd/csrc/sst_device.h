@@ -22,7 +22,15 @@ __device__ __forceinline__ unsigned int f2bf_bits(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return u >> 16;
 }
-__device__ __forceinline__ unsigned int pack2(float a, float b) { return f2bf_bits(a) | (f2bf_bits(b) << 16); }
+// v_cvt_pk_bf16_f32 (gfx950): round-to-nearest-even like f2bf_bits, one instruction per pair
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ unsigned int pack2(float a, float b) {
+    const f32x2_t v = {a, b};
+    union { bf16x2_t h; unsigned int u; } c;
+    c.h = __builtin_convertvector(v, bf16x2_t);
+    return c.u;
+}
 __device__ __forceinline__ uint2 pack4(const f32x4 v) { return make_uint2(pack2(v[0], v[1]), pack2(v[2], v[3])); }
 __device__ __forceinline__ float bf_lo(unsigned int w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(unsigned int w) { return __uint_as_float(w & 0xffff0000u); }
@@ -45,9 +53,24 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 // lane) per matrix per 64 tokens, then each wave reads its A fragments with ds_read_b128.  Without this
 // every wave pulled the whole matrix through its own vector-memory pipe with 1-2 loads in flight (the
 // kernels ran at ~260 cycles per MFMA, profiles/r01b).  All waves of the block must call this together.
+// phase timing instrumentation (scratch/phase_timing.py builds a second library with -DGEOMAE_PHASE_TIMING;
+// a no-op in the product build)
+#ifdef GEOMAE_PHASE_TIMING
+#define GEOMAE_STAMP_SLOTS 32
+#define GEOMAE_STAMP_BLOCKS 512
+static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
+#define GEOMAE_STAMP(i)                                                                                   \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS && (i) >= 0)                             \
+            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (i)] = clock64();                             \
+    } while (0)
+#else
+#define GEOMAE_STAMP(i) do {} while (0)
+#endif
+
 template <int K, int N>
 __device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
-                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane) {
+                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
     constexpr int LD = K + kPad;
     constexpr int CH = K / 8;                  // 16-byte chunks per row
     constexpr int PASSES = N * CH / kLayerBlk;
@@ -59,13 +82,16 @@ __device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __
         const int c = p * kLayerBlk + threadIdx.x;
         stage[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
     }
+    GEOMAE_STAMP(sb);
     __syncthreads();                           // previous matrix fully consumed by every wave
+    GEOMAE_STAMP(sb + 1);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int c = p * kLayerBlk + threadIdx.x;
         *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = stage[p];
     }
     __syncthreads();
+    GEOMAE_STAMP(sb + 2);
     const int o = lane & 15, g = lane >> 4;
     // groups of 4 output tiles advance together over K: consecutive MFMAs hit independent accumulators, so the
     // dependent-accumulator latency of a chain (kk inner loop: 38 % issue stalls in profiles/r01 PMC) is hidden
@@ -137,11 +163,7 @@ __device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int64_
 }
 
 // sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)
-__device__ __forceinline__ float row_sum(float v) {
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
+__device__ __forceinline__ float row_sum(float v) { return rows4_sum(v); }
 
 // LayerNorm over 128 channels in T-layout; returns xhat in place, rstd out
 __device__ __forceinline__ void layer_norm_t(f32x4 (&u)[8], float eps, float* rstd_out) {
@@ -226,13 +248,7 @@ __device__ __forceinline__ float gelu_grad(float x) {
 }
 
 // sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
-__device__ __forceinline__ float tok_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
-    return v;
-}
+__device__ __forceinline__ float tok_sum(float v) { return row16_sum(v); }
 
 
 

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
     const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
+    GEOMAE_STAMP(0);
     const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
     f32x4 dv[8];
     load_rows_f32<128>(dz, tok, valid, dv, lane);
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
     }
     store_rows_bf16<128>(dv_b, tok, 128, 0, valid, dv, lane);
+    GEOMAE_STAMP(1);
     // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
     uint2 dhpb[16];
     {
@@ -206,7 +208,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         f32x4 dh[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_t<128, 256>(W.w2T, smem, dvb, dh, lane);
+        gemm_t<128, 256>(W.w2T, smem, dvb, dh, lane, 2);
+        GEOMAE_STAMP(5);
         uint2 hpb[16];
         load_rows_bf16<256>(hp_in, tok, valid, hpb, lane);
         f32x4 h[16];
@@ -225,7 +228,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         store_rows_bf16<256>(h_b, tok, 256, 0, valid, h, lane);
         store_rows_bf16<256>(dhp_b, tok, 256, 0, valid, dh, lane);
     }
-    gemm_t<256, 128>(W.w1T, smem, dhpb, dv, lane);                    // dv now holds dy
+    GEOMAE_STAMP(6);
+    gemm_t<256, 128>(W.w1T, smem, dhpb, dv, lane, 7);                 // dv now holds dy
+    GEOMAE_STAMP(10);
     // ---- LN1 backward
     {
         f32x4 xh1[8];
@@ -250,6 +255,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
     }
     store_rows_f32<128>(dx_res, tok, valid, dv, lane);
     store_rows_bf16<128>(du_b, tok, 128, 0, valid, dv, lane);
+    GEOMAE_STAMP(11);
     {
         uint2 dub[8];
 #pragma unroll
@@ -257,9 +263,11 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         f32x4 da[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_t<128, 128>(W.woT, smem, dub, da, lane);
+        gemm_t<128, 128>(W.woT, smem, dub, da, lane, 12);
+        GEOMAE_STAMP(15);
         store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
     }
+    GEOMAE_STAMP(16);
     // ---- flush LayerNorm parameter gradients (invalid rows contributed zeros: dz was loaded as 0)
     __syncthreads();
     for (int e = threadIdx.x; e < 4 * 128; e += kLayerBlk) {
@@ -268,6 +276,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         float* dst = k == 0 ? dg2 : (k == 1 ? dbe2 : (k == 2 ? dg1 : dbe1));
         atomicAdd(dst + c, s);
     }
+    GEOMAE_STAMP(17);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -416,8 +425,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float v = bsum[e];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
+            v = rows4_sum(v);
             if (lane < 16) bred[wave][8 * cch + e] = v;
         }
         __syncthreads();
@@ -449,6 +457,18 @@ static int check_weights(const GeomaeSstLayerWeights* w, const char* who) {
 }  // namespace geomae
 
 using namespace geomae;
+
+#ifdef GEOMAE_PHASE_TIMING
+extern "C" int geomae_debug_read_stamps(unsigned long long* host, int clear) {
+    hipDeviceSynchronize();
+    if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(geomae_stamps), sizeof(unsigned long long) * GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS);
+    if (clear) {
+        static unsigned long long zeros[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
+        hipMemcpyToSymbol(HIP_SYMBOL(geomae_stamps), zeros, sizeof(zeros));
+    }
+    return 0;
+}
+#endif
 
 extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc,
                                    int64_t max_elems, void* packed_bf16, float* aux_f32, hipStream_t stream) {

@@ -166,10 +166,10 @@ constexpr int kDh = 16;
 constexpr int kMaxT = 144;                 // 12 x 12 window
 constexpr int kMaxTiles = kMaxT / 16;      // 9
 
-__device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned int u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+__device__ __forceinline__ unsigned short f2bf(float f) {      // v_cvt_pk_bf16_f32: round to nearest even
+    union { __bf16 h; unsigned short u; } c;
+    c.h = (__bf16)f;
+    return c.u;
 }
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float(((unsigned int)h) << 16); }
 
@@ -327,8 +327,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                     }
                 }
             }
-            m = fmaxf(m, __shfl_xor(m, 16, 64));
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            m = rows4_max(m);
             float sum = 0.0f;
 #pragma unroll
             for (int jt = 0; jt < kMaxTiles; ++jt) {
@@ -341,8 +340,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                     }
                 }
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
+            sum = rows4_sum(sum);
             // O tile = P V : A = P (row i = c, k = 4g + r), B = V (k = j, col = d) read from V^T
             f32x4 o = {0, 0, 0, 0};
 #pragma unroll
@@ -414,7 +412,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                 const int t = k * kAttnBlk + threadIdx.x;
                 const int row = t >> 1;
                 float d = dot8_bf16(rdo[k], ro[k]);
-                d += __shfl_xor(d, 1, 64);
+                d += dpp_mov<kDppXor1>(d);
                 if ((t & 1) == 0 && row < Tp) {
                     Ds[row] = d;                                                    // zero for padded rows
                     Ls[row] = row < T ? lse[(int64_t)toks[row] * n_heads + h] : INFINITY;   // P = exp(s - inf) = 0
