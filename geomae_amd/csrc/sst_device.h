@@ -61,34 +61,46 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
 #define GEOMAE_STAMP(i)                                                                                   \
     do {                                                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS && (i) >= 0)                             \
-            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (i)] = clock64();                             \
+        if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x && (i) >= 0)               \
+            geomae_stamps[(blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS + (i)] = clock64();     \
     } while (0)
 #else
 #define GEOMAE_STAMP(i) do {} while (0)
 #endif
 
+// The copy is split in two so that a kernel can issue the global loads of the NEXT matrix (stage_issue) before
+// the elementwise phase that precedes its GEMM: phase timing (scratch/phase_timing.py) showed each GEMM waiting
+// ~2-3 k cycles for its weights and each elementwise phase waiting as long for its activation rows, with one
+// wave per SIMD and nothing else to run.
 template <int K, int N>
-__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
-                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
-    constexpr int LD = K + kPad;
+struct WStage { u32x4 r[N * (K / 8) / kLayerBlk]; };
+
+template <int K, int N>
+__device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ Wp, WStage<K, N>& st) {
     constexpr int CH = K / 8;                  // 16-byte chunks per row
     constexpr int PASSES = N * CH / kLayerBlk;
     static_assert(N * CH % kLayerBlk == 0, "matrix must tile over the block");
-    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
-    u32x4 stage[PASSES];
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int c = p * kLayerBlk + threadIdx.x;
-        stage[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
+        st.r[p] = *reinterpret_cast<const u32x4*>(Wp + (size_t)(c / CH) * K + 8 * (c % CH));
     }
+}
+
+template <int K, int N>
+__device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __restrict__ smem,
+                                            const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
+    constexpr int LD = K + kPad;
+    constexpr int CH = K / 8;
+    constexpr int PASSES = N * CH / kLayerBlk;
+    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
     GEOMAE_STAMP(sb);
     __syncthreads();                           // previous matrix fully consumed by every wave
     GEOMAE_STAMP(sb + 1);
 #pragma unroll
     for (int p = 0; p < PASSES; ++p) {
         const int c = p * kLayerBlk + threadIdx.x;
-        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = stage[p];
+        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = st.r[p];
     }
     __syncthreads();
     GEOMAE_STAMP(sb + 2);
@@ -108,6 +120,14 @@ __device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __
             }
         }
     }
+}
+
+template <int K, int N>
+__device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
+                                       const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
+    WStage<K, N> st;
+    stage_issue<K, N>(Wp, st);
+    gemm_staged<K, N>(st, smem, xb, acc, lane, sb);
 }
 
 template <int N>
@@ -263,5 +283,9 @@ struct DwTask {
 constexpr int kMaxDwTasks = 12;
 struct DwTasks { DwTask t[kMaxDwTasks]; };
 int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t stream);
+// the next geomae_sst_weight_grad call of this host thread only records its tasks; the following
+// geomae_sst_ffn_backward launches them inside its own kernel (sst_ffn_bwd_dw_kernel)
+void defer_next_weight_grad();
+int flush_pending_weight_grad(hipStream_t stream);      // launches a recorded-but-unlaunched contraction, if any
 
 }  // namespace geomae

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
     const int64_t tc = valid ? tok : n - 1;
     uint2 xb[8], xpb[8];
     const int p = tok_pos[tc];
+    WStage<128, 256> s_qk;
+    WStage<128, 128> s_v;
+    stage_issue<128, 256>(W.wqkv, s_qk);
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) {
         const float4 xv = *reinterpret_cast<const float4*>(x + tc * 128 + 16 * ct + 4 * g);
@@ -85,13 +88,14 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
     {
         f32x4 acc[16];
         load_bias<256>(W.bqkv, acc, lane);
-        gemm_t<128, 256>(W.wqkv, smem, xpb, acc, lane);
+        gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
+        stage_issue<128, 128>(W.wqkv + 256 * 128, s_v);               // in flight under the q/k stores
         store_rows_bf16<256>(qkv, tok, 384, 0, valid, acc, lane);
     }
     {
         f32x4 acc[8];
         load_bias<128>(W.bqkv + 256, acc, lane);
-        gemm_t<128, 128>(W.wqkv + 256 * 128, smem, xb, acc, lane);
+        gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
         store_rows_bf16<128>(qkv, tok, 384, 256, valid, acc, lane);
     }
 }
@@ -115,13 +119,17 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     const bool valid = tok < n;
     f32x4 u[8], y[8];
     float r1, r2;
+    WStage<128, 256> s_w1;
     {
+        WStage<128, 128> s_wo;
+        stage_issue<128, 128>(W.wo, s_wo);
         uint2 ob[8];
         load_rows_bf16<128>(attn, tok, valid, ob, lane);
-        load_bias<128>(W.bo, u, lane);
-        gemm_t<128, 128>(W.wo, smem, ob, u, lane);
         f32x4 xr[8];
-        load_rows_f32<128>(x, tok, valid, xr, lane);
+        load_rows_f32<128>(x, tok, valid, xr, lane);                  // needed after the GEMM: in flight under it
+        load_bias<128>(W.bo, u, lane);
+        gemm_staged<128, 128>(s_wo, smem, ob, u, lane);
+        stage_issue<128, 256>(W.w1, s_w1);                            // lands under the LayerNorm arithmetic
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
@@ -129,13 +137,15 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     if (xh1_out) store_rows_f32<128>(xh1_out, tok, valid, u, lane);
     affine_t(u, W.g1, W.be1, y, lane);
     uint2 hb[16];
+    WStage<256, 128> s_w2;
     {
         uint2 yb[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
         f32x4 hp[16];
         load_bias<256>(W.b1, hp, lane);
-        gemm_t<128, 256>(W.w1, smem, yb, hp, lane);
+        gemm_staged<128, 256>(s_w1, smem, yb, hp, lane);
+        stage_issue<256, 128>(W.w2, s_w2);                            // lands under the GELU arithmetic
         if (hp_out) store_rows_bf16<256>(hp_out, tok, 256, 0, valid, hp, lane);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -144,7 +154,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         }
     }
     load_bias<128>(W.b2, u, lane);
-    gemm_t<256, 128>(W.w2, smem, hb, u, lane);
+    gemm_staged<256, 128>(s_w2, smem, hb, u, lane);
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
     layer_norm_t(u, eps, &r2);
@@ -163,27 +173,42 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
 //   bf16 row-major operands of the weight-gradient GEMMs: du, dv, dhp [n,256], y, h [n,256]
 //   and the LayerNorm parameter gradients (atomics, one flush per workgroup).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
-    const float* __restrict__ xh1_in, const float* __restrict__ xh2_in, const bf16_t* __restrict__ hp_in,
-    const float* __restrict__ rstd_in, const float* __restrict__ dz, LayerW W, int n,
-    float* __restrict__ dx_res, bf16_t* __restrict__ dattn, bf16_t* __restrict__ du_b,
-    bf16_t* __restrict__ dv_b, bf16_t* __restrict__ dhp_b, bf16_t* __restrict__ y_b, bf16_t* __restrict__ h_b,
-    float* __restrict__ dg1, float* __restrict__ dbe1, float* __restrict__ dg2, float* __restrict__ dbe2) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
-    __shared__ float red[4][4][128];     // [wave][tensor][channel]
+struct FfnBwdArgs {
+    const float *xh1_in, *xh2_in;
+    const bf16_t* hp_in;
+    const float *rstd_in, *dz;
+    LayerW W;
+    int n;
+    float* dx_res;
+    bf16_t *dattn, *du_b, *dv_b, *dhp_b, *y_b, *h_b;
+    float *dg1, *dbe1, *dg2, *dbe2;
+};
+
+__device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf16_t* __restrict__ smem,
+                                             float (*red)[4][128] /* [wave][tensor][channel] */) {
+    const float* __restrict__ xh1_in = A.xh1_in; const float* __restrict__ xh2_in = A.xh2_in;
+    const bf16_t* __restrict__ hp_in = A.hp_in; const float* __restrict__ rstd_in = A.rstd_in;
+    const float* __restrict__ dz = A.dz; const LayerW& W = A.W; const int n = A.n;
+    float* __restrict__ dx_res = A.dx_res; bf16_t* __restrict__ dattn = A.dattn; bf16_t* __restrict__ du_b = A.du_b;
+    bf16_t* __restrict__ dv_b = A.dv_b; bf16_t* __restrict__ dhp_b = A.dhp_b; bf16_t* __restrict__ y_b = A.y_b;
+    bf16_t* __restrict__ h_b = A.h_b;
+    float* __restrict__ dg1 = A.dg1; float* __restrict__ dbe1 = A.dbe1; float* __restrict__ dg2 = A.dg2;
+    float* __restrict__ dbe2 = A.dbe2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
-    const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
+    const int tile = block * (kLayerBlk / 64) + wave;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
     GEOMAE_STAMP(0);
     const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
     f32x4 dv[8];
     load_rows_f32<128>(dz, tok, valid, dv, lane);
+    WStage<128, 256> s_w2T;
     // ---- LN2 backward
     {
         f32x4 xh2[8];
         load_rows_f32<128>(xh2_in, tok, valid, xh2, lane);
+        stage_issue<128, 256>(W.w2T, s_w2T);                          // lands under the LayerNorm arithmetic
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
@@ -201,40 +226,46 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
     GEOMAE_STAMP(1);
     // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
     uint2 dhpb[16];
+    WStage<256, 128> s_w1T;
     {
+        uint2 hpb[16];
+        load_rows_bf16<256>(hp_in, tok, valid, hpb, lane);            // needed after the GEMM: in flight under it
         uint2 dvb[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
         f32x4 dh[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_t<128, 256>(W.w2T, smem, dvb, dh, lane, 2);
+        gemm_staged<128, 256>(s_w2T, smem, dvb, dh, lane, 2);
         GEOMAE_STAMP(5);
-        uint2 hpb[16];
-        load_rows_bf16<256>(hp_in, tok, valid, hpb, lane);
-        f32x4 h[16];
+        stage_issue<256, 128>(W.w1T, s_w1T);                          // lands under the GELU arithmetic
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             const f32x4 hp = unpack4(hpb[ct]);
+            f32x4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float c, p;
                 gelu_parts(hp[r], &c, &p);
-                h[ct][r] = hp[r] * c;
+                h[r] = hp[r] * c;
                 dh[ct][r] *= c + hp[r] * p;
             }
             dhpb[ct] = pack4(dh[ct]);
+            if (valid) {
+                *reinterpret_cast<uint2*>(h_b + tok * 256 + 16 * ct + 4 * g) = pack4(h);
+                *reinterpret_cast<uint2*>(dhp_b + tok * 256 + 16 * ct + 4 * g) = dhpb[ct];
+            }
         }
-        store_rows_bf16<256>(h_b, tok, 256, 0, valid, h, lane);
-        store_rows_bf16<256>(dhp_b, tok, 256, 0, valid, dh, lane);
     }
     GEOMAE_STAMP(6);
-    gemm_t<256, 128>(W.w1T, smem, dhpb, dv, lane, 7);                 // dv now holds dy
+    f32x4 xh1[8];
+    load_rows_f32<128>(xh1_in, tok, valid, xh1, lane);                // in flight under the GEMM
+    gemm_staged<256, 128>(s_w1T, smem, dhpb, dv, lane, 7);            // dv now holds dy
     GEOMAE_STAMP(10);
+    WStage<128, 128> s_woT;
+    stage_issue<128, 128>(W.woT, s_woT);                              // lands under the LayerNorm arithmetic
     // ---- LN1 backward
     {
-        f32x4 xh1[8];
-        load_rows_f32<128>(xh1_in, tok, valid, xh1, lane);
         {
             f32x4 y[8];
             affine_t(xh1, W.g1, W.be1, y, lane);
@@ -263,7 +294,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         f32x4 da[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_t<128, 128>(W.woT, smem, dub, da, lane, 12);
+        gemm_staged<128, 128>(s_woT, smem, dub, da, lane, 12);
         GEOMAE_STAMP(15);
         store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
     }
@@ -277,6 +308,12 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(
         atomicAdd(dst + c, s);
     }
     GEOMAE_STAMP(17);
+}
+
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ float red[4][4][128];
+    ffn_bwd_body(A, blockIdx.x, smem, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -297,21 +334,23 @@ __global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __
     const bool valid = tok < n;
     const int64_t tc = valid ? tok : n - 1;
     f32x4 acc[8];
+    WStage<256, 128> s_qk;
+    WStage<128, 128> s_v;
+    stage_issue<256, 128>(W.wqkT, s_qk);
     load_rows_f32<128>(dx_res, tok, valid, acc, lane);
+    uint2 dv_rows[8];
     {
         uint2 d[16];
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct)
             d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-        gemm_t<256, 128>(W.wqkT, smem, d, acc, lane);
-    }
-    {
-        uint2 d[8];
 #pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-        gemm_t<128, 128>(W.wvT, smem, d, acc, lane);
+        for (int ct = 0; ct < 8; ++ct)                                // operand of the second GEMM: in flight under the first
+            dv_rows[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+        stage_issue<128, 128>(W.wvT, s_v);
+        gemm_staged<256, 128>(s_qk, smem, d, acc, lane);
     }
+    gemm_staged<128, 128>(s_v, smem, dv_rows, acc, lane);
     store_rows_f32<128>(dx, tok, valid, acc, lane);
     if (valid) {
         const int p = tok_pos[tc];
@@ -345,14 +384,11 @@ __device__ __forceinline__ uint2 tr_read(const bf16_t* p) {
     return c.u;
 }
 
-__global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
-    __shared__ float bred[4][128];
-    const DwTask T = tasks.t[blockIdx.y];
+__device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int bx, bf16_t* __restrict__ As,
+                                        bf16_t* __restrict__ Bs, float (*bred)[128]) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = lane & 15, g = lane >> 4;
-    const int t_begin = blockIdx.x * chunk;
+    const int t_begin = bx * chunk;
     const int t_end = t_begin + chunk < n ? t_begin + chunk : n;
     if (t_begin >= n) return;
     f32x4 acc[2][8];
@@ -434,6 +470,50 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
                       bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
     }
 }
+
+__global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk) {
+    __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
+    __shared__ float bred[4][128];
+    dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred);
+}
+
+// Horizontal fusion for the backward of a layer stack: the data-gradient kernel of layer l and the weight-
+// gradient contraction of layer l+1 (whose operands the previous three kernels left in the other scratch
+// set) are independent, and at encoder size neither fills the chip (105 and 112 workgroups on 256 CUs;
+// running the dw kernel on a second stream gained only 0.03 ms/step because of the cross-queue event hops).
+// One launch carries both: workgroups [0, n_ffn) run ffn_bwd_body, the rest run dw_body, sharing the LDS
+// allocation of the larger body.
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs A, int n_ffn, DwTasks tasks, int dw_n,
+                                                                     int dw_chunk, int dw_gx) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ float red[4][4][128];
+    static_assert(2 * kDwTok * kDwLd <= kWeightLds, "dw slabs must fit in the weight buffer");
+    if ((int)blockIdx.x < n_ffn) {
+        ffn_bwd_body(A, blockIdx.x, smem, red);
+    } else {
+        const int b = blockIdx.x - n_ffn;
+        dw_body(tasks.t[b / dw_gx], dw_n, dw_chunk, b % dw_gx, smem, smem + kDwTok * kDwLd,
+                reinterpret_cast<float (*)[128]>(&red[0][0][0]));
+    }
+}
+
+// enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
+static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out) {
+    int G = cdiv(num_tokens, 512);
+    const int cap = num_tasks >= 8 ? 32 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
+    if (G > cap) G = cap;
+    int chunk = cdiv(num_tokens, G);
+    chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
+    *gx = cdiv(num_tokens, chunk);
+    *chunk_out = chunk;
+}
+
+// hand-over between geomae_sst_weight_grad (deferred) and the next geomae_sst_ffn_backward on the same host
+// thread; only sst_stack_backward uses it (defer_next_weight_grad), the plain C-ABI calls launch immediately
+struct PendingDw { DwTasks tasks; int num_tasks, num_tokens; bool active; };
+static thread_local PendingDw g_pending_dw = {{}, 0, 0, false};
+static thread_local bool t_defer_weight_grad = false;
 
 static LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
@@ -521,12 +601,22 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     GEOMAE_REQUIRE(xhat1 && xhat2 && hp_bf16 && rstd && dz && dx_res && dattn_bf16 && du_bf16 && dv_bf16 &&
                    dhp_bf16 && y_bf16 && h_bf16, "sst_ffn_backward: null argument");
     GEOMAE_REQUIRE(grads && grads->ln1_w && grads->ln1_b && grads->ln2_w && grads->ln2_b, "sst_ffn_backward: null grads");
-    const int tiles = cdiv(num_tokens, 16);
-    hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, xhat1, xhat2,
-                       (const bf16_t*)hp_bf16, rstd, dz, to_layer(w), num_tokens, dx_res, (bf16_t*)dattn_bf16,
-                       (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16, (bf16_t*)h_bf16,
-                       grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b);
-    return check_launch("sst_ffn_bwd_kernel");
+    const FfnBwdArgs A = {xhat1, xhat2, (const bf16_t*)hp_bf16, rstd, dz, to_layer(w), num_tokens, dx_res,
+                          (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
+                          (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b};
+    const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
+    if (!g_pending_dw.active) {
+        hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);
+        return check_launch("sst_ffn_bwd_kernel");
+    }
+    // geomae::fuse_next_ffn_backward_with(): this call also carries a weight-gradient contraction
+    const PendingDw P = g_pending_dw;
+    g_pending_dw.active = false;
+    int gx, chunk;
+    dw_grid(P.num_tasks, P.num_tokens, &gx, &chunk);
+    hipLaunchKernelGGL(sst_ffn_bwd_dw_kernel, dim3(n_ffn + gx * P.num_tasks), dim3(kLayerBlk), 0, stream, A, n_ffn, P.tasks,
+                       P.num_tokens, chunk, gx);
+    return check_launch("sst_ffn_bwd_dw_kernel");
 }
 
 extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
@@ -567,17 +657,28 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1,   128};   // dW1 rows 128..255
     T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2,   128};  // dW2 cols 0..127
     T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
+    if (t_defer_weight_grad) {          // sst_stack_backward: ride on the next layer's ffn-backward launch
+        t_defer_weight_grad = false;
+        g_pending_dw.tasks = T;
+        g_pending_dw.num_tasks = 8;
+        g_pending_dw.num_tokens = num_tokens;
+        g_pending_dw.active = true;
+        return GEOMAE_OK;
+    }
     return launch_dw(T, 8, num_tokens, stream);
 }
 
+void geomae::defer_next_weight_grad() { t_defer_weight_grad = true; }
+int geomae::flush_pending_weight_grad(hipStream_t stream) {
+    t_defer_weight_grad = false;
+    if (!g_pending_dw.active) return GEOMAE_OK;
+    g_pending_dw.active = false;
+    return launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
+}
+
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
-    // enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
-    int G = cdiv(num_tokens, 512);
-    const int cap = num_tasks >= 8 ? 32 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
-    if (G > cap) G = cap;
-    int chunk = cdiv(num_tokens, G);
-    chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
-    G = cdiv(num_tokens, chunk);
+    int G, chunk;
+    dw_grid(num_tasks, num_tokens, &G, &chunk);
     hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks), dim3(256), 0, stream, T, num_tokens, chunk);
     return check_launch("dw_kernel");
 }

@@ -17,6 +17,12 @@
 #include <vector>
 
 namespace geomae {
+// sst_layer.hip: lets the weight-gradient contraction of a layer ride inside the next ffn-backward launch
+void defer_next_weight_grad();
+int flush_pending_weight_grad(hipStream_t stream);
+}
+
+namespace geomae {
 
 static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 
@@ -186,6 +192,9 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
     // The weight-gradient kernel of layer l only feeds .grad, so it runs on `side_stream` (if given) under the
     // data-path kernels of layer l-1; its operand slabs are double-buffered and fenced with events.
     const bool overlap = side_stream != nullptr && side_stream != stream;
+    // default: the weight-gradient contraction of layer l rides inside the ffn-backward launch of layer l-1
+    // (sst_ffn_bwd_dw_kernel); its operand slabs are double-buffered either way
+    const bool fuse = !overlap;
     hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
     bool done_pending[2] = {false, false};
     if (overlap)
@@ -200,7 +209,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
         const int set = l & 1;
-        char* ws = w + sc.set0 + (overlap ? set * sc.set_bytes : 0);
+        char* ws = w + sc.set0 + set * sc.set_bytes;
         float* dnext = (l == 0) ? dx_out : (float*)(w + ((l & 1) ? sc.dxa : sc.dxb));
         if (overlap && done_pending[set]) {            // slab set still being read by the dw of layer l+2
             GEOMAE_HIP(hipStreamWaitEvent(stream, done[set], 0));
@@ -234,7 +243,11 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
             GEOMAE_HIP(hipStreamWaitEvent(side_stream, ready[set], 0));
             ds = side_stream;
         }
-        {
+        if (fuse && l > 0) {
+            defer_next_weight_grad();
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, ws + sc.xp, ws + sc.xb, ws + sc.du, sv + so.attn,
+                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
+        } else {
             Timed t(profiler, GEOMAE_KERNEL_DW, ds);
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, ws + sc.xp, ws + sc.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
@@ -245,6 +258,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         }
         dcur = dnext;
     }
+    if (flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK) rc = GEOMAE_ERR_HIP;   // error paths only
     if (overlap) {
         for (int k = 0; k < 2; ++k) {
             if (done_pending[k]) hipStreamWaitEvent(stream, done[k], 0);      // join: the caller sees one stream

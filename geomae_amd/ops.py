@@ -613,7 +613,7 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
                                         ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream),
                                         ctypes.c_void_p(_side_stream((dz.device.index, side_key)).cuda_stream)
-                                        if OVERLAP_WEIGHT_GRADS else None),
+                                        if (OVERLAP_WEIGHT_GRADS is True or OVERLAP_WEIGHT_GRADS == side_key) else None),
           "geomae_sst_stack_backward")
     # `scratch` must outlive the kernels: with a side stream the caller keeps it until the streams are joined
     return (dx, scratch) if stream is not None else dx
