@@ -91,14 +91,46 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
     LOSS_KEYS = ("loss_curv_around", "loss_centroid_low", "loss_centroid_med", "loss_centroid_top", "loss_cls_low",
                  "loss_cls_med")
 
+    OVERLAP_GEOMETRY = True     # mask / targets / window CSR on a side stream, concurrent with the VFE forward
+
     def forward_train_fused(self, points, ids_keep=None, ids_mask=None):
         """Same result as extract_feat + backbone heads + forward_loss, without materialising the eight
-        prediction tensors: the heads, the six losses and their gradients are one kernel."""
-        (voxel_features, feature_coors, ik, im, tgt), batch_size = self.prepare(points, ids_keep, ids_mask), len(points)
+        prediction tensors: the heads, the six losses and their gradients are one kernel.
+
+        Everything that depends only on the pillar coordinates -- the random mask, the geometric targets and
+        the four window layouts (a dozen launches of one to a few hundred workgroups, ~0.3 ms of a mostly idle
+        GPU) -- is enqueued on a side stream while the main stream runs the VFE forward."""
+        batch_size = len(points)
+        voxels, coors, sub_med, sub_low, seg = self._stage1(points)
+        V = seg.V                                                     # the iteration's one host readback
+        main = torch.cuda.current_stream()
+        overlap = self.OVERLAP_GEOMETRY
+        if overlap:
+            if getattr(self, "_geo_stream", None) is None:
+                self._geo_stream = torch.cuda.Stream()
+            side = self._geo_stream
+            side.wait_stream(main)
+        else:
+            side = main
+        with torch.cuda.stream(side), torch.no_grad():
+            if ids_keep is None:
+                ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
+            else:
+                ik, im = ids_keep.int(), ids_mask.int()
+                token_row, counts = ops.token_rows_from_ids(ik, im, V)
+            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts,
+                                       n_rows=int(im.numel()))
+            ik, im = ik.long(), im.long()
+            feature_coors = seg.voxel_coors[:V]
+            coors_keep, coors_mask = feature_coors[ik], feature_coors[im]
+            layouts = self.backbone.build_layouts(coors_keep, coors_mask, batch_size)
+        voxel_features, _ = self.voxel_encoder(voxels, coors, seg=seg)
+        if overlap:
+            main.wait_stream(side)
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
-        losses = self.backbone.forward_losses(voxel_features[ik], feature_coors[ik], feature_coors[im], batch_size,
-                                              tgt, w)
+        losses = self.backbone.forward_losses(voxel_features[ik], coors_keep, coors_mask, batch_size, tgt, w,
+                                              layouts=layouts)
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     # ------------------------------------------------------------------ preprocessing
@@ -138,15 +170,18 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         seg.start_readback()
         self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg))
 
-    def prepare(self, points, ids_keep=None, ids_mask=None):
-        """voxelize x3 -> pillar segments -> VFE -> mask -> geometric targets (ssl.py:172-231)."""
-        batch_size = len(points)
+    def _stage1(self, points):
+        """voxelize x3 + pillar segments: taken from `prefetch` when it ran for this batch."""
         pre, self._prefetched = getattr(self, "_prefetched", None), None
         if pre is not None and pre[0] is points:
-            voxels, coors, sub_med, sub_low, seg = pre[1]
-        else:
-            voxels, coors, sub_med, sub_low = self.voxelize_all(points)
-            seg = ops.pillar_segment(coors, batch_size, self.grid_size)
+            return pre[1]
+        voxels, coors, sub_med, sub_low = self.voxelize_all(points)
+        seg = ops.pillar_segment(coors, len(points), self.grid_size)
+        return voxels, coors, sub_med, sub_low, seg
+
+    def prepare(self, points, ids_keep=None, ids_mask=None):
+        """voxelize x3 -> pillar segments -> VFE -> mask -> geometric targets (ssl.py:172-231)."""
+        voxels, coors, sub_med, sub_low, seg = self._stage1(points)
         V = seg.V                                                     # the iteration's one host readback
         voxel_features, feature_coors = self.voxel_encoder(voxels, coors, seg=seg)
         if ids_keep is None:

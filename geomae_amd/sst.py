@@ -409,21 +409,29 @@ class MultiMAESSTSPChoose(nn.Module):
     def forward_encoder(self, x, layouts, pos):
         return self._run_stack(self.encoder_blocks, "enc", x, pos, layouts)
 
-    def forward_losses(self, voxel_feat, coors, coors_mask, batch_size, tgt, loss_weights):
+    def build_layouts(self, coors, coors_mask, batch_size):
+        """Window layouts of the encoder tokens (kept pillars) and of the decoder tokens (kept + masked): they depend
+        on coordinates only, so the detector builds them on a side stream under the VFE forward."""
+        enc, _ = self.get_voxel_info(coors, batch_size)
+        dec, _ = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
+        return enc, dec
+
+    def forward_losses(self, voxel_feat, coors, coors_mask, batch_size, tgt, loss_weights, layouts=None):
         """Fused training path: encoder, both decoder stacks, then heads + losses (+ their backward) in one
         kernel -- the eight prediction tensors of forward() are never materialised.  Returns the [6] losses."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
         self._packed.refresh()
-        layouts, pos = self.get_voxel_info(coors, batch_size)
-        x = self.forward_encoder(voxel_feat.float(), layouts, pos)
-        cen, den = self.decode(x, coors, coors_mask, batch_size)
+        enc_layouts, dec_layouts = layouts if layouts is not None else self.build_layouts(coors, coors_mask, batch_size)
+        x = self.forward_encoder(voxel_feat.float(), enc_layouts, None)
+        cen, den = self.decode(x, coors, coors_mask, batch_size, layouts=dec_layouts)
         return _HeadsLoss.apply(cen, den, self._packed, coors.shape[0], coors_mask.shape[0], tgt, loss_weights)
 
-    def decode(self, visible_voxel_feat, coors, coors_mask, batch_size):
+    def decode(self, visible_voxel_feat, coors, coors_mask, batch_size, layouts=None):
         mask_tokens = self.mask_token.repeat(coors_mask.shape[0], 1)
         tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)
-        coors_all = torch.cat([coors, coors_mask], dim=0)
-        layouts, pos = self.get_voxel_info(coors_all, batch_size)
+        pos = None
+        if layouts is None:
+            layouts, pos = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
         if self.fused and self.concurrent_decoders:
             if self._streams is None:
                 self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
