@@ -562,6 +562,17 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
     return check_launch("window_build");
 }
 
+// Workgroups to launch: one per (bundle, head).  The bundle count lives on the device; its bound from the
+// greedy packing (two consecutive bundles always hold more than `cap` tokens, win_bundle_kernel) is
+// 2 n / cap + 1, far below max_bundles = min(n, window slots) -- the old grid of 4096 was mostly workgroups
+// that only read num_bundles and left.
+static int attn_grid(int num_tokens, int num_heads, int max_bundles, int cap) {
+    int64_t nb = 2 * (int64_t)num_tokens / (cap > 0 ? cap : 1) + 2;
+    if (nb > max_bundles) nb = max_bundles;
+    const int64_t items = nb * num_heads;
+    return (int)(items < 256 * 16 ? items : 256 * 16);
+}
+
 extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
                                                int32_t head_dim, const int32_t* win_start,
                                                const int32_t* win_tokens, const int32_t* tok_win,
@@ -573,8 +584,7 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
                    "window_attention_forward: null argument");
     GEOMAE_REQUIRE(head_dim == kDh, "window_attention_forward: head_dim must be %d", kDh);
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_forward: windows hold at most %d tokens", kMaxT);
-    const int64_t items = (int64_t)max_bundles * num_heads;
-    const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
+    const int grid = attn_grid(num_tokens, num_heads, max_bundles, max_window_tokens);
     hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
                        1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse);
@@ -593,8 +603,7 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
                    num_bundles && dqkv_bf16, "window_attention_backward: null argument");
     GEOMAE_REQUIRE(head_dim == kDh, "window_attention_backward: head_dim must be %d", kDh);
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_backward: windows hold at most %d tokens", kMaxT);
-    const int64_t items = (int64_t)max_bundles * num_heads;
-    const int grid = (int)(items < 256 * 16 ? items : 256 * 16);
+    const int grid = attn_grid(num_tokens, num_heads, max_bundles, max_window_tokens);
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
                        win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),

@@ -131,6 +131,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
         losses = self.backbone.forward_losses(voxel_features[ik], coors_keep, coors_mask, batch_size, tgt, w,
                                               layouts=layouts)
+        self._loss_vector = losses                   # Trainer sums this once instead of adding six scalars
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     # ------------------------------------------------------------------ preprocessing

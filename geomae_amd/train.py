@@ -44,6 +44,13 @@ class FlatParams:
     def zero_grad(self):
         self.grad.zero_()
 
+    def check_storage(self):
+        """load_state_dict copies in place, so every parameter must still be a view of the flat buffer."""
+        base, item, off = self.flat.data_ptr(), self.flat.element_size(), 0
+        for n, p in zip(self.names, self.params):
+            assert p.data_ptr() == base + off * item, f"parameter {n} left the flat buffer"
+            off += p.numel()
+
     def check_views(self):
         """Autograd must have accumulated in place; re-point any .grad that was replaced."""
         if getattr(self, "_ptrs", None) is None:
@@ -80,13 +87,19 @@ def clip_grad_norm(flat, max_norm, norm_type=2):
 
 class FlatAdamW:
     """AdamW over the flat buffers; weight decay only on the decayed segment.  Update rule of
-    torch.optim.AdamW: p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)."""
+    torch.optim.AdamW: p *= 1 - lr*wd ; m,v EMA ; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps).
+
+    On a GPU the whole step (gradient norm, clip, update, zero_grad) is two HIP kernels
+    (geomae_grad_sumsq + geomae_adamw_step, csrc/optim.hip); `step()` alone keeps the composed torch form
+    (CPU / gloo tests, and the parity check of the kernel)."""
 
     def __init__(self, flat, lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05):
         self.flat, self.lr, self.betas, self.eps, self.weight_decay = flat, lr, betas, eps, weight_decay
+        self.base_lr = lr
         self.exp_avg = torch.zeros_like(flat.flat)
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
+        self._sumsq = self._gnorm = None
 
     @torch.no_grad()
     def step(self):
@@ -103,14 +116,86 @@ class FlatAdamW:
         denom = (self.exp_avg_sq.sqrt() / (bc2 ** 0.5)).add_(self.eps)
         f.flat.addcdiv_(self.exp_avg, denom, value=-self.lr / bc1)
 
+    @torch.no_grad()
+    def fused_clip_step(self, max_norm=0.0, grad_scale=1.0, zero_grad=True):
+        """clip_grad_norm_(max_norm) + AdamW (+ zero_grad) in two launches; returns the pre-clip gradient norm
+        (0-d tensor).  grad_scale folds the data-parallel 1/world averaging into the same pass."""
+        import ctypes
+        from . import _lib
+        from .ops import _ptr, _stream
+        lib, f = _lib.load(), self.flat
+        if self._sumsq is None:
+            self._sumsq = torch.zeros(1, dtype=torch.float64, device=f.flat.device)
+            self._gnorm = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
+        self.step_count += 1
+        n = f.flat.numel()
+        _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
+        _lib.check(lib.geomae_adamw_step(_ptr(f.flat), _ptr(f.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), n,
+                                         f.n_no_decay, float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                         float(self.eps), float(self.weight_decay), self.step_count, float(max_norm or 0.0),
+                                         _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)), _ptr(self._gnorm),
+                                         _stream()), "geomae_adamw_step")
+        return self._gnorm[0]
+
+    # ---- torch.optim.AdamW-shaped state (what mmcv's checkpoint hook stores under 'optimizer'): mmcv's
+    # DefaultOptimizerConstructor with a paramwise_cfg makes ONE param group per parameter
     def state_dict(self):
-        return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr)
+        f, off, state, groups = self.flat, 0, {}, []
+        for i, p in enumerate(f.params):
+            n = p.numel()
+            wd = 0.0 if off < f.n_no_decay else self.weight_decay
+            state[i] = dict(step=torch.tensor(float(self.step_count)),
+                            exp_avg=self.exp_avg[off:off + n].view_as(p).clone(),
+                            exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p).clone())
+            groups.append(dict(params=[i], lr=self.lr, initial_lr=self.base_lr, betas=tuple(self.betas), eps=self.eps,
+                               weight_decay=wd, amsgrad=False))
+            off += n
+        return dict(state=state, param_groups=groups)
+
+    def load_state_dict(self, sd):
+        f, off = self.flat, 0
+        for i, p in enumerate(f.params):
+            n = p.numel()
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count = int(float(st["step"]))
+            off += n
+        if sd.get("param_groups"):
+            self.lr = sd["param_groups"][0]["lr"]
+            self.base_lr = sd["param_groups"][0].get("initial_lr", self.base_lr)
+
+
+class CyclicLr:
+    """mmcv CyclicLrUpdaterHook (un-vendored dependency, mmcv 1.x `runner/hooks/lr_updater.py`; parity unpinned:
+    restated from its published behaviour) as selected by configs/_base_/schedules/cosine_2x.py:10-15:
+    policy='cyclic', target_ratio=(100, 1e-3), cyclic_times=1, step_ratio_up=0.1, cosine annealing, per iteration.
+    Phase 1 [0, up): base_lr -> base_lr * ratio_up ; phase 2 [up, max): base_lr * ratio_up -> base_lr * ratio_down."""
+
+    def __init__(self, base_lr, max_iters, target_ratio=(100, 1e-3), cyclic_times=1, step_ratio_up=0.1):
+        import math
+        self._cos, self._pi = math.cos, math.pi
+        self.base_lr = base_lr
+        per = max_iters // cyclic_times
+        up = int(step_ratio_up * per)
+        self.per = max(per, 1)
+        self.phases = [(0, up, 1.0, target_ratio[0]), (up, per, target_ratio[0], target_ratio[1])]
+
+    def lr_at(self, it):
+        it %= self.per
+        for start, end, r0, r1 in self.phases:
+            if start <= it < end:
+                factor = (it - start) / (end - start)
+                a, b = self.base_lr * r0, self.base_lr * r1
+                return b + 0.5 * (a - b) * (self._cos(self._pi * factor) + 1)
+        return self.base_lr * self.phases[-1][3]
 
 
 class Trainer:
     """One process per GPU.  train_step = forward_train + backward + gradient exchange + clip + AdamW."""
 
-    def __init__(self, model, optimizer_cfg=None, grad_clip=None):
+    def __init__(self, model, optimizer_cfg=None, grad_clip=None, lr_schedule=None):
         from .configs import GRAD_CLIP, OPTIMIZER
         ocfg = dict(optimizer_cfg or OPTIMIZER)
         assert ocfg.pop("type") == "AdamW"
@@ -120,12 +205,19 @@ class Trainer:
         self.flat = FlatParams(model, no_decay_keys=keys or ("\0",))
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
+        self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
+        self.iter = 0
+        self.fused_optimizer = self.flat.flat.is_cuda
 
     def train_step(self, points, next_points=None, **kw):
         """next_points: the batch of the FOLLOWING step (the same list object must be passed as `points`
         then); its voxelization / pillar sort is enqueued ahead of this step so that its count readback is
         off the critical path (detector.prefetch)."""
-        self.flat.zero_grad()
+        if not getattr(self, "_grads_clean", False):
+            self.flat.zero_grad()
+        self._grads_clean = False
+        if self.lr_schedule is not None:
+            self.opt.lr = self.lr_schedule.lr_at(self.iter)
         pre = getattr(self.model, "_prefetched", None)
         if pre is not None and pre[0] is points:
             pre[1][4].sync_counts()             # already landed: claim it before the next readback is queued
@@ -138,10 +230,37 @@ class Trainer:
             self.model._prefetched = nxt
         else:
             losses = self.model.forward_train(points, None, **kw)
-        total = sum(losses.values())
+        vec = getattr(self.model, "_loss_vector", None)     # the fused path's [6] loss tensor: one sum, not five adds
+        total = vec.sum() if vec is not None else sum(losses.values())
+        self.model._loss_vector = None
         total.backward()
         self.flat.check_views()
-        allreduce_gradients(self.flat)
-        gnorm = clip_grad_norm(self.flat, **self.grad_clip)
-        self.opt.step()
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.fused_optimizer:
+            if world > 1:
+                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)        # the 1/world rides in the update pass
+            gnorm = self.opt.fused_clip_step(self.grad_clip.get("max_norm", 0.0), 1.0 / world, zero_grad=True)
+            self._grads_clean = True
+        else:
+            allreduce_gradients(self.flat)
+            gnorm = clip_grad_norm(self.flat, **self.grad_clip)
+            self.opt.step()
+        self.iter += 1
         return losses, gnorm
+
+    # ---- checkpoint in the layout mmcv's CheckpointHook writes ({'meta', 'state_dict', 'optimizer'}), so that
+    # epoch_N.pth interchanges with the reference's fine-tune config (load_from, configs/pre_sst/...:280)
+    def save_checkpoint(self, path, meta=None):
+        m = dict(iter=self.iter, epoch=0)
+        m.update(meta or {})
+        sd = {k: v.detach().cpu() for k, v in self.model.state_dict().items()}
+        torch.save(dict(meta=m, state_dict=sd, optimizer=self.opt.state_dict()), path)
+
+    def load_checkpoint(self, path, strict=True):
+        ck = torch.load(path, map_location="cpu", weights_only=False)
+        self.model.load_state_dict(ck["state_dict"], strict=strict)        # parameters are views of the flat buffer
+        self.flat.check_storage()
+        if ck.get("optimizer"):
+            self.opt.load_state_dict(ck["optimizer"])
+        self.iter = int(ck.get("meta", {}).get("iter", 0))
+        return ck.get("meta", {})

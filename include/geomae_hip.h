@@ -309,6 +309,20 @@ int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeS
                               float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream,
                               geomaeStream_t side_stream /* or NULL: weight-gradient kernels overlap on it */);
 
+/* ------------------------------------------------------------------ N4 optimizer step
+ * replaces mmcv OptimizerHook.clip_grads (torch.nn.utils.clip_grad_norm_, max_norm 10, L2) + torch.optim.AdamW
+ * as configured by configs/_base_/schedules/cosine_2x.py:1-17, on flat fp32 buffers (16-byte aligned) whose first
+ * `num_no_decay` elements are the parameters exempt from weight decay (names containing 'norm').
+ * geomae_grad_sumsq: *sumsq = sum g^2 (fp64).  geomae_adamw_step: g *= grad_scale * min(1, max_norm / (norm + 1e-6))
+ * with norm = grad_scale * sqrt(*grad_sumsq) (max_norm <= 0: no clipping, grad_sumsq may be NULL), then the
+ * AdamW update of torch's single-tensor path op by op in fp32; `step` counts from 1; zero_grad != 0 clears the
+ * gradient buffer in the same pass; grad_norm_out (or NULL) receives the pre-clip norm. */
+int geomae_grad_sumsq(const float* grad, int64_t num_elems, double* sumsq, geomaeStream_t stream);
+int geomae_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t num_elems,
+                      int64_t num_no_decay, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      int64_t step, float max_norm, const double* grad_sumsq, float grad_scale, int32_t zero_grad,
+                      float* grad_norm_out, geomaeStream_t stream);
+
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
 enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_FWD = 3, GEOMAE_KERNEL_FFN_BWD = 4,

@@ -408,6 +408,45 @@ def test_trainer_prefetch_matches_plain_steps(dev):
     assert ta.model._prefetched is not None and ta.model._prefetched[0] is batches[0]
 
 
+@pytest.mark.parametrize("max_norm", [10.0, 0.05])
+def test_fused_clip_adamw_matches_torch(dev, max_norm):
+    """geomae_grad_sumsq + geomae_adamw_step vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (the optimizer
+    configs/_base_/schedules/cosine_2x.py selects), 5 steps, with the 'norm' no-decay split; max_norm 0.05 forces clipping."""
+    import torch.nn as nn
+    from geomae_amd.train import FlatAdamW, FlatParams
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(37, 53)
+            self.norm1 = nn.LayerNorm(53)
+            self.b = nn.Linear(53, 11, bias=False)
+    torch.manual_seed(3)
+    m1 = M().to(dev)
+    import copy
+    m2 = copy.deepcopy(m1)
+    flat = FlatParams(m1, no_decay_keys=("norm",))
+    opt = FlatAdamW(flat, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    named = dict(m2.named_parameters())
+    ref = torch.optim.AdamW([dict(params=[p], weight_decay=0.0 if "norm" in n else 0.05) for n, p in named.items()],
+                            lr=3e-3, betas=(0.9, 0.999), eps=1e-8, foreach=False)
+    g = torch.Generator().manual_seed(9)
+    for step in range(5):
+        grads = {n: torch.randn(p.shape, generator=g).to(dev) * (0.1 + step) for n, p in named.items()}
+        for n, p in m1.named_parameters():
+            p.grad.copy_(grads[n])
+        for n, p in named.items():
+            p.grad = grads[n].clone()
+        ref_norm = torch.nn.utils.clip_grad_norm_(list(named.values()), max_norm)
+        ref.step()
+        gnorm = opt.fused_clip_step(max_norm, 1.0, zero_grad=True)
+        assert abs(float(gnorm) - float(ref_norm)) <= 2e-6 * float(ref_norm)
+        assert float(flat.grad.abs().max()) == 0.0
+        for n, p in m1.named_parameters():
+            # same op order in fp32; the only difference is the clip coefficient's last bit (fp64 vs fp32 norm)
+            assert torch.allclose(p, named[n], rtol=2e-6, atol=1e-8), (step, n, float((p - named[n]).abs().max()))
+
+
 def test_fused_layer_matches_composed_layer(dev):
     """One BasicShiftBlock: fused kernels (bf16 MFMA) vs the composed fp32 layer, forward and backward."""
     import copy

@@ -103,3 +103,60 @@ def test_syncbn_single_process_is_plain_bn():
     x = torch.randn(32, 4)
     assert torch.allclose(bn(x), ref(x))
     assert torch.allclose(bn.running_var, ref.running_var)
+
+
+def test_cyclic_lr_matches_mmcv_formula():
+    """CyclicLrUpdaterHook restated (cosine_2x.py:10-15): target_ratio (100, 1e-3), cyclic_times 1, step_ratio_up 0.1."""
+    import math
+    from geomae_amd.train import CyclicLr
+    base, T = 1e-5, 1000
+    sch = CyclicLr(base, T)
+    up = int(0.1 * T)
+    assert sch.lr_at(0) == pytest.approx(base)
+    assert sch.lr_at(up) == pytest.approx(base * 100)                       # top of the cycle
+    assert sch.lr_at(up // 2) == pytest.approx(base * (100 + 0.5 * (1 - 100) * (math.cos(math.pi * 0.5) + 1)))
+    assert base * 1e-3 <= sch.lr_at(T - 1) <= base * 2e-3                    # last iteration, one step before the bottom
+    lrs = [sch.lr_at(i) for i in range(T)]
+    assert all(a <= b for a, b in zip(lrs[:up], lrs[1:up + 1])) and all(a >= b for a, b in zip(lrs[up:-1], lrs[up + 1:]))
+
+
+def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
+    """{'meta','state_dict','optimizer'} with torch.optim.AdamW-shaped optimizer state (one group per parameter)."""
+    import torch.nn as nn
+    from geomae_amd.train import FlatAdamW, FlatParams, Trainer
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 3)
+            self.norm = nn.LayerNorm(3)
+
+        def forward_train(self, points, metas, **kw):
+            return dict(loss=self.norm(self.lin(points)).pow(2).mean())
+
+    torch.manual_seed(0)
+    tr = Trainer(Tiny())
+    x = torch.randn(5, 4)
+    for _ in range(3):
+        tr.train_step(x)
+    path = str(tmp_path / "epoch_1.pth")
+    tr.save_checkpoint(path, meta=dict(epoch=1))
+    ck = torch.load(path, weights_only=False)
+    assert set(ck) == {"meta", "state_dict", "optimizer"} and ck["meta"]["epoch"] == 1 and ck["meta"]["iter"] == 3
+    groups = ck["optimizer"]["param_groups"]
+    assert len(groups) == 4 and [g["weight_decay"] for g in groups] == [0.0, 0.0, 0.05, 0.05]      # norm.* first, undecayed
+    ref = torch.optim.AdamW([dict(params=[nn.Parameter(torch.zeros_like(p))]) for p in tr.flat.params])   # loads into torch's own
+    ref.load_state_dict(dict(state=ck["optimizer"]["state"],
+                             param_groups=[dict(g, maximize=False, foreach=None, capturable=False, differentiable=False,
+                                                fused=None, decoupled_weight_decay=True) for g in groups]))
+    torch.manual_seed(1)
+    tr2 = Trainer(Tiny())
+    tr2.load_checkpoint(path)
+    assert tr2.iter == 3 and tr2.opt.step_count == 3
+    for a, b in zip(tr.flat.params, tr2.flat.params):
+        assert torch.equal(a, b)
+    l1, _ = tr.train_step(x)
+    l2, _ = tr2.train_step(x)
+    assert torch.equal(l1["loss"], l2["loss"])
+    for a, b in zip(tr.flat.params, tr2.flat.params):
+        assert torch.equal(a, b)
