@@ -27,12 +27,24 @@ __device__ __forceinline__ int64_t key_of(const int4 c, int gz, int gy, int gx) 
     return (((int64_t)c.x * gz + c.y) * gy + c.z) * gx + c.w;
 }
 
-__global__ __launch_bounds__(kBlk) void hist_kernel(const int4* __restrict__ coors, int64_t n, int gz, int gy,
-                                                    int gx, int32_t* __restrict__ table,
+// row i of coors [n, ndim]: (b, z, y, x) for ndim 4, (z, y, x) with b = 0 for ndim 3.  A row with a negative or
+// out-of-grid coordinate is invalid (vanilla dynamic voxelization marks out-of-range points with -1,
+// voxelization_cuda.cu:35-57 upstream; scatter_points_cuda.cu:199 drops them): key -1.
+__device__ __forceinline__ int64_t row_key(const int32_t* __restrict__ coors, int64_t i, int ndim, int nb, int gz, int gy,
+                                           int gx) {
+    int4 c;
+    if (ndim == 4) c = reinterpret_cast<const int4*>(coors)[i];
+    else c = make_int4(0, coors[i * 3 + 0], coors[i * 3 + 1], coors[i * 3 + 2]);
+    const bool ok = c.x >= 0 && c.x < nb && c.y >= 0 && c.y < gz && c.z >= 0 && c.z < gy && c.w >= 0 && c.w < gx;
+    return ok ? key_of(c, gz, gy, gx) : -1;
+}
+
+__global__ __launch_bounds__(kBlk) void hist_kernel(const int32_t* __restrict__ coors, int64_t n, int ndim, int nb, int gz,
+                                                    int gy, int gx, int32_t* __restrict__ table,
                                                     int32_t* __restrict__ rank_in_cell) {
     for (int64_t i = blockIdx.x * (int64_t)kBlk + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlk) {
-        const int64_t k = key_of(coors[i], gz, gy, gx);
-        rank_in_cell[i] = atomicAdd(&table[k], 1);
+        const int64_t k = row_key(coors, i, ndim, nb, gz, gy, gx);
+        rank_in_cell[i] = k >= 0 ? atomicAdd(&table[k], 1) : -1;
     }
 }
 
@@ -99,7 +111,10 @@ __global__ __launch_bounds__(kBlk) void scan_tiles_kernel(int2* __restrict__ til
         run_o += tot_o;
         run_c += tot_c;
     }
-    if (threadIdx.x == 0) num_pillars[0] = run_o;
+    if (threadIdx.x == 0) {
+        num_pillars[0] = run_o;
+        tile_sums[n_tiles] = make_int2(run_o, run_c);      // totals: pillars, valid points
+    }
 }
 
 // pass 3: per-cell pillar id / segment start; emit pillar coordinates; table <- pillar id | -1
@@ -149,19 +164,21 @@ __global__ __launch_bounds__(kBlk) void scan_emit_kernel(int32_t* __restrict__ t
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         const int V = num_pillars[0];
         sample_start[n_batch] = V;
-        seg_start[V] = (int32_t)n_points;
+        seg_start[V] = tile_sums[gridDim.x].y;             // number of valid points (= n_points when none is dropped)
     }
 }
 
-__global__ __launch_bounds__(kBlk) void place_kernel(const int4* __restrict__ coors, int64_t n, int gz, int gy,
-                                                     int gx, const int32_t* __restrict__ table,
+__global__ __launch_bounds__(kBlk) void place_kernel(const int32_t* __restrict__ coors, int64_t n, int ndim, int nb,
+                                                     int gz, int gy, int gx, const int32_t* __restrict__ table,
                                                      const int32_t* __restrict__ rank_in_cell,
                                                      const int32_t* __restrict__ seg_start,
                                                      int32_t* __restrict__ inv, int32_t* __restrict__ order) {
     for (int64_t i = blockIdx.x * (int64_t)kBlk + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlk) {
-        const int p = table[key_of(coors[i], gz, gy, gx)];
+        const int r = rank_in_cell[i];
+        if (r < 0) { inv[i] = -1; continue; }
+        const int p = table[row_key(coors, i, ndim, nb, gz, gy, gx)];
         inv[i] = p;
-        order[seg_start[p] + rank_in_cell[i]] = (int32_t)i;
+        order[seg_start[p] + r] = (int32_t)i;
     }
 }
 
@@ -211,9 +228,9 @@ extern "C" int64_t geomae_pillar_segment_workspace_bytes(int64_t num_points, int
                                                          int32_t gy, int32_t gx) {
     const int64_t cells = (int64_t)batch_size * gz * gy * gx;
     const int64_t tiles = (cells + kTile - 1) / kTile;
-    // rank_in_cell [n] int32 + tile sums [tiles] int2, 256-byte aligned pieces
+    // rank_in_cell [n] int32 + tile sums [tiles + 1] int2, 256-byte aligned pieces
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    return al(num_points * 4) + al(tiles * 8);
+    return al(num_points * 4) + al((tiles + 1) * 8);
 }
 
 extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, int32_t batch_size, int32_t gz,
@@ -221,6 +238,16 @@ extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, i
                                      int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
                                      int32_t* num_pillars, void* workspace, int64_t workspace_bytes,
                                      hipStream_t stream) {
+    return geomae_pillar_segment_nd(coors, 4, num_points, batch_size, gz, gy, gx, cell_table, voxel_coors, inv, order,
+                                    seg_start, sample_start, num_pillars, workspace, workspace_bytes, stream);
+}
+
+extern "C" int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int64_t num_points, int32_t batch_size,
+                                        int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors,
+                                        int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
+                                        int32_t* num_pillars, void* workspace, int64_t workspace_bytes,
+                                        hipStream_t stream) {
+    GEOMAE_REQUIRE(ndim == 4 || (ndim == 3 && batch_size == 1), "pillar_segment: coors are [N,4] (b,z,y,x) or [N,3] (z,y,x)");
     GEOMAE_REQUIRE(num_points >= 0 && batch_size >= 1 && gz >= 1 && gy >= 1 && gx >= 1, "pillar_segment: bad sizes");
     GEOMAE_REQUIRE(cell_table && voxel_coors && seg_start && sample_start && num_pillars,
                    "pillar_segment: null output");
@@ -238,17 +265,16 @@ extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, i
     GEOMAE_HIP(hipMemsetAsync(cell_table, 0, cells * sizeof(int32_t), stream));
     if (num_points > 0) {
         GEOMAE_REQUIRE(coors && inv && order, "pillar_segment: null argument");
-        hipLaunchKernelGGL(hist_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream,
-                           (const int4*)coors, num_points, gz, gy, gx, cell_table, rank_in_cell);
+        hipLaunchKernelGGL(hist_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream, coors, num_points,
+                           ndim, batch_size, gz, gy, gx, cell_table, rank_in_cell);
     }
     hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlk), 0, stream, cell_table, cells, tile_sums);
     hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kBlk), 0, stream, tile_sums, tiles, num_pillars);
     hipLaunchKernelGGL(scan_emit_kernel, dim3(tiles), dim3(kBlk), 0, stream, cell_table, cells, tile_sums, gz, gy,
                        gx, batch_size, voxel_coors, seg_start, sample_start, num_points, num_pillars);
     if (num_points > 0) {
-        hipLaunchKernelGGL(place_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream,
-                           (const int4*)coors, num_points, gz, gy, gx, cell_table, rank_in_cell, seg_start, inv,
-                           order);
+        hipLaunchKernelGGL(place_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream, coors, num_points,
+                           ndim, batch_size, gz, gy, gx, cell_table, rank_in_cell, seg_start, inv, order);
     }
     return check_launch("pillar_segment");
 }

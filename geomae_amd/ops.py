@@ -250,6 +250,114 @@ def scatter_v2(feat, coors, mode, return_inv=True, min_points=0, unq_inv=None, n
     return new_feat, out_coors, seg.inv.long()
 
 
+# ------------------------------------------------------------------------------------ N3 DynamicScatter
+_REDUCE = dict(sum=0, mean=1, max=2)
+
+
+def dynamic_point_to_voxel_forward(feats, coors, reduce_type="max", grid_zyx=None, batch_size=None):
+    """Drop-in for voxel_layer.dynamic_point_to_voxel_forward (voxelization.h:112-134): -> [reduced_feats [M,C],
+    out_coors [M,ndim] (lexicographic), coors_map [N] int32 (-1 = dropped row), reduce_count [M] int32].
+    The dense-grid counting sort needs the coordinate bounds: pass grid_zyx (DynamicScatter does), or they are
+    read from coors.max() (one more host sync; the reference's unique_dim syncs for the output size anyway)."""
+    _check_input(feats, "feats", torch.float32)
+    _check_input(coors, "coors", torch.int32)
+    n, C = feats.shape
+    ndim = coors.shape[1]
+    if n == 0:      # scatter_points_cuda.cu:193-197
+        e = torch.empty(0, dtype=torch.int32, device=feats.device)
+        return [feats.clone().detach(), coors.clone().detach(), e, e.clone()]
+    if ndim not in (3, 4):
+        raise RuntimeError("coors must be [N,3] (z,y,x) or [N,4] (b,z,y,x)")
+    if grid_zyx is None or (ndim == 4 and batch_size is None):
+        mx = [max(int(v), 0) + 1 for v in coors.max(0).values.tolist()]
+        if grid_zyx is None:
+            grid_zyx = mx[-3:]
+        if ndim == 4 and batch_size is None:
+            batch_size = mx[0]
+    nb = int(batch_size) if ndim == 4 else 1
+    gz, gy, gx = [int(g) for g in grid_zyx]
+    cap = min(n, nb * gz * gy * gx)
+    dev, lib = feats.device, _lib.load()
+    reduced = torch.empty((cap, C), dtype=torch.float32, device=dev)
+    out_coors = torch.empty((cap, ndim), dtype=torch.int32, device=dev)
+    cmap = torch.empty(n, dtype=torch.int32, device=dev)
+    count = torch.empty(cap, dtype=torch.int32, device=dev)
+    num = torch.empty(1, dtype=torch.int32, device=dev)
+    wsb = lib.geomae_dynamic_point_to_voxel_workspace_bytes(n, cap, nb, gz, gy, gx)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.geomae_dynamic_point_to_voxel_forward(_ptr(feats), _ptr(coors), n, C, ndim, nb, gz, gy, gx,
+                                                    _REDUCE[reduce_type], cap, _ptr(reduced), _ptr(out_coors), _ptr(cmap),
+                                                    _ptr(count), _ptr(num), _ptr(ws), wsb, _stream()),
+          "geomae_dynamic_point_to_voxel_forward")
+    M = int(num.item())
+    return [reduced[:M], out_coors[:M], cmap, count[:M]]
+
+
+def dynamic_point_to_voxel_backward(grad_feats, grad_reduced_feats, feats, reduced_feats, coors_map, reduce_count,
+                                    reduce_type="max"):
+    """Drop-in for voxel_layer.dynamic_point_to_voxel_backward (voxelization.h:136-154): fills grad_feats [N,C]."""
+    n, C = feats.shape
+    M = reduced_feats.shape[0]
+    ws = torch.empty(max(M * C, 1), dtype=torch.int32, device=feats.device) if reduce_type == "max" else None
+    check(_lib.load().geomae_dynamic_point_to_voxel_backward(
+        _ptr(grad_feats), _ptr(grad_reduced_feats.contiguous()), _ptr(feats), _ptr(reduced_feats), _ptr(coors_map),
+        _ptr(reduce_count), n, M, C, _REDUCE[reduce_type], _ptr(ws), _stream()), "geomae_dynamic_point_to_voxel_backward")
+
+
+class _DynamicScatterFn(torch.autograd.Function):
+    """mmdet3d/ops/voxel/scatter_points.py:9-47 (_dynamic_scatter)."""
+
+    @staticmethod
+    def forward(ctx, feats, coors, reduce_type, grid_zyx, batch_size):
+        voxel_feats, voxel_coors, p2v, cnt = dynamic_point_to_voxel_forward(feats, coors, reduce_type, grid_zyx, batch_size)
+        ctx.reduce_type = reduce_type
+        ctx.save_for_backward(feats, voxel_feats, p2v, cnt)
+        ctx.mark_non_differentiable(voxel_coors)
+        return voxel_feats, voxel_coors
+
+    @staticmethod
+    def backward(ctx, grad_voxel_feats, grad_voxel_coors=None):
+        feats, voxel_feats, p2v, cnt = ctx.saved_tensors
+        grad_feats = torch.zeros_like(feats)
+        if feats.shape[0] > 0:
+            dynamic_point_to_voxel_backward(grad_feats, grad_voxel_feats.contiguous().float(), feats, voxel_feats, p2v, cnt,
+                                            ctx.reduce_type)
+        return grad_feats, None, None, None, None
+
+
+def dynamic_scatter(feats, coors, reduce_type="max", grid_zyx=None, batch_size=None):
+    return _DynamicScatterFn.apply(feats, coors, reduce_type, grid_zyx, batch_size)
+
+
+class DynamicScatter(nn.Module):
+    """mmdet3d.ops.DynamicScatter (ops/voxel/scatter_points.py:53-99): scatters point features into voxels by mean
+    (average_points=True) or max.  coors [N,3] (z,y,x) or [N,4] (b,z,y,x); the reference loops over the samples of a
+    batch and concatenates -- the same rows in the same order as one lexicographic (b,z,y,x) grouping."""
+
+    def __init__(self, voxel_size, point_cloud_range, average_points: bool):
+        super().__init__()
+        self.voxel_size, self.point_cloud_range, self.average_points = voxel_size, point_cloud_range, average_points
+        # The reference op groups ANY non-negative coordinates (its own test feeds z up to 19 to a module whose
+        # range holds one z cell), so the table extent comes from coors.max() (one readback; unique_dim in the
+        # reference syncs for its output size too).  Set `grid_zyx` to skip it when the caller knows the bounds.
+        self.grid_zyx = None
+
+    def forward_single(self, points, coors):
+        return dynamic_scatter(points.contiguous(), coors.contiguous(), "mean" if self.average_points else "max", self.grid_zyx)
+
+    def forward(self, points, coors, batch_size=None):
+        if coors.size(-1) == 3 or coors.shape[0] == 0:
+            return self.forward_single(points, coors)
+        if batch_size is None:
+            batch_size = int(coors[-1, 0].item()) + 1            # as the reference (scatter_points.py:81)
+        return dynamic_scatter(points.contiguous(), coors.contiguous(), "mean" if self.average_points else "max",
+                               self.grid_zyx, batch_size)
+
+    def __repr__(self):
+        return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range={self.point_cloud_range}, "
+                f"average_points={self.average_points})")
+
+
 # ------------------------------------------------------------------------------------ A6
 def random_mask(seg, keep_fraction, seed):
     """-> ids_keep [n_keep], ids_mask [n_mask] (int64, ascending), token_row [V] int32, counts [2] int32."""

@@ -63,6 +63,14 @@ int geomae_pillar_segment(const int32_t* coors /*[N,4]*/, int64_t num_points, in
                           int32_t* voxel_coors, int32_t* inv, int32_t* order, int32_t* seg_start,
                           int32_t* sample_start, int32_t* num_pillars, void* workspace,
                           int64_t workspace_bytes, geomaeStream_t stream);
+/* same for coors [N, ndim]: ndim 4 = (b,z,y,x), ndim 3 = (z,y,x) with batch_size 1.  Rows with a negative or
+ * out-of-grid coordinate are dropped: inv[i] = -1, they do not appear in `order`, and seg_start[V] = number of
+ * valid points (upstream dynamic voxelization marks out-of-range points with -1; this fork's clamps instead,
+ * voxelization_cuda.cu:35-57, so the pre-training path never has any). */
+int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int64_t num_points, int32_t batch_size,
+                             int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors,
+                             int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
+                             int32_t* num_pillars, void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
 
 /* torch_scatter.scatter(reduce='mean') of the xyz columns (voxel_encoder.py:375): mean [cap, 3].
  * 2^-32 fixed-point int64 atomics per point (order independent); sum_workspace: cap * 3 * 8 bytes. */
@@ -308,6 +316,30 @@ int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeS
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
                               float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream,
                               geomaeStream_t side_stream /* or NULL: weight-gradient kernels overlap on it */);
+
+/* ------------------------------------------------------------------ N3 DynamicScatter native op
+ * replaces the pybind functions dynamic_point_to_voxel_forward / _backward (ops/voxel/src/voxelization.h:112-154,
+ * scatter_points_cuda.cu:183-310; Python wrapper ops/voxel/scatter_points.py:11-49).  coors [N, ndim] int32, ndim 3
+ * (z,y,x; batch_size 1) or 4 (b,z,y,x); rows with a negative (or out-of-grid) coordinate are dropped like the
+ * reference's masked_fill(-1) rows.  Outputs (caller allocated, max_voxels rows; *num_voxels = M on the device):
+ * reduced_feats [M,C], out_coors [M,ndim] in lexicographic order (= at::unique_dim sorted), coors_map [N] (voxel
+ * row or -1), reduce_count [M].  reduce_type: 0 sum, 1 mean, 2 max.  The grid (gz,gy,gx) bounds the coordinates:
+ * DynamicScatter knows it from voxel_size / point_cloud_range.
+ * backward: the reference's signature; grad_feats [N,C] is overwritten.  max routes each voxel/channel gradient to
+ * the lowest-index point that equals the maximum; reduce_from_ws: num_voxels * C int32 (max only). */
+int64_t geomae_dynamic_point_to_voxel_workspace_bytes(int64_t num_points, int32_t max_voxels, int32_t batch_size,
+                                                      int32_t gz, int32_t gy, int32_t gx);
+int geomae_dynamic_point_to_voxel_forward(const float* feats, const int32_t* coors, int64_t num_points,
+                                          int32_t channels, int32_t ndim, int32_t batch_size, int32_t gz, int32_t gy,
+                                          int32_t gx, int32_t reduce_type, int32_t max_voxels, float* reduced_feats,
+                                          int32_t* out_coors, int32_t* coors_map, int32_t* reduce_count,
+                                          int32_t* num_voxels, void* workspace, int64_t workspace_bytes,
+                                          geomaeStream_t stream);
+int geomae_dynamic_point_to_voxel_backward(float* grad_feats, const float* grad_reduced_feats, const float* feats,
+                                           const float* reduced_feats, const int32_t* coors_map,
+                                           const int32_t* reduce_count, int64_t num_points, int32_t num_voxels,
+                                           int32_t channels, int32_t reduce_type, int32_t* reduce_from_ws,
+                                           geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ N4 optimizer step
  * replaces mmcv OptimizerHook.clip_grads (torch.nn.utils.clip_grad_norm_, max_norm 10, L2) + torch.optim.AdamW

@@ -637,3 +637,55 @@ def make_params(seed, encoder_num_blocks=6, decoder_num_blocks=2, perturb=True):
             v = 0.05 * rng.standard_normal(shape) if perturb else np.zeros(shape)
         p[name] = torch.tensor(np.asarray(v, np.float32))
     return p
+
+
+# ---------------------------------------------------------------------------------- N3 DynamicScatter
+def dynamic_point_to_voxel(feats, coors, reduce_type="max"):
+    """CPU restatement of dynamic_point_to_voxel_forward_gpu (ops/voxel/src/scatter_points_cuda.cu:183-241):
+    rows with any negative coordinate are dropped (:199 masked_fill), the rest grouped by at::unique_dim(sorted)
+    (:201-202); features reduced by max / sum / mean (:75-97, :233).  -> reduced [M,C], out_coors [M,ndim],
+    coors_map [N] (-1 = dropped), reduce_count [M].  Same brute force as the reference's own test
+    (tests/test_models/test_voxel_encoder/test_dynamic_scatter.py:56-64)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    coors = np.asarray(coors, dtype=np.int64)
+    n, C = feats.shape
+    valid = (coors >= 0).all(axis=1)
+    cmap = np.full(n, -1, dtype=np.int32)
+    if not valid.any():
+        return (np.zeros((0, C), np.float32), np.zeros((0, coors.shape[1]), np.int32), cmap, np.zeros(0, np.int32))
+    uq, inv, cnt = np.unique(coors[valid], axis=0, return_inverse=True, return_counts=True)
+    cmap[valid] = inv.reshape(-1).astype(np.int32)
+    M = uq.shape[0]
+    red = np.zeros((M, C), dtype=np.float64)
+    if reduce_type == "max":
+        red[:] = -np.inf
+        np.maximum.at(red, cmap[valid], feats[valid].astype(np.float64))
+    else:
+        np.add.at(red, cmap[valid], feats[valid].astype(np.float64))
+        if reduce_type == "mean":
+            red /= cnt[:, None]
+    return red.astype(np.float32), uq.astype(np.int32), cmap, cnt.astype(np.int32)
+
+
+def dynamic_point_to_voxel_grad(grad_reduced, feats, reduced, cmap, cnt, reduce_type="max"):
+    """dynamic_point_to_voxel_backward_gpu (scatter_points_cuda.cu:243-310): sum copies, mean divides by the count
+    (:99-133), max sends the gradient of (voxel, channel) to the LOWEST-index point equal to the maximum (:135-179)."""
+    feats = np.asarray(feats, dtype=np.float32)
+    n, C = feats.shape
+    g = np.zeros((n, C), dtype=np.float32)
+    ok = cmap >= 0
+    if reduce_type in ("sum", "mean"):
+        g[ok] = grad_reduced[cmap[ok]]
+        if reduce_type == "mean":
+            g[ok] /= cnt[cmap[ok]][:, None].astype(np.float32)
+        return g
+    M = reduced.shape[0]
+    src = np.full((M, C), n, dtype=np.int64)
+    for i in np.nonzero(ok)[0]:
+        eq = feats[i] == reduced[cmap[i]]
+        src[cmap[i]][eq] = np.minimum(src[cmap[i]][eq], i)
+    for m in range(M):
+        for c in range(C):
+            if src[m, c] < n:
+                g[src[m, c], c] = grad_reduced[m, c]
+    return g

@@ -408,6 +408,78 @@ def test_trainer_prefetch_matches_plain_steps(dev):
     assert ta.model._prefetched is not None and ta.model._prefetched[0] is batches[0]
 
 
+# ---------------------------------------------------------------------------------- N3 DynamicScatter
+@pytest.mark.parametrize("ndim", [3, 4])
+def test_dynamic_scatter_matches_oracle(dev, ndim):
+    """mmdet3d.ops.DynamicScatter drop-in vs the oracle; same cases as the reference's test_dynamic_scatter.py:
+    empty input, every row dropped, 200 k random rows with -1 entries (coordinates, lexicographic order, mean / max
+    values), and the gradients (mean: 1/count; max: lowest-index maximum)."""
+    from geomae_amd import ops
+    vs, rng_ = [0.32, 0.32, 6], [-74.88, -74.88, -2, 74.88, 74.88, 4]
+    dsmean, dsmax = ops.DynamicScatter(vs, rng_, True), ops.DynamicScatter(vs, rng_, False)
+    # empty input
+    ef = torch.empty((0, 3), dtype=torch.float32, device=dev, requires_grad=True)
+    ec = torch.empty((0, ndim), dtype=torch.int32, device=dev)
+    for ds in (dsmean, dsmax):
+        o, c = ds(ef, ec)
+        o.sum().backward()
+        assert o.shape == ef.shape and c.shape == ec.shape
+    # every row dropped
+    g = torch.Generator().manual_seed(0)
+    f = (torch.rand((20000, 3), generator=g) * 100 - 50).to(dev).requires_grad_()
+    c = torch.randint(-1, 0, (20000, ndim), generator=g, dtype=torch.int32).to(dev)
+    for ds in (dsmean, dsmax):
+        o, oc = ds(f, c, batch_size=1) if ndim == 4 else ds(f, c)
+        assert o.shape == (0, 3) and oc.shape == (0, ndim)
+        o.sum().backward()
+        assert (f.grad == 0).all()
+    # random rows
+    n = 200000
+    feats = (torch.rand((n, 3), generator=g) * 100 - 50)
+    coors = torch.randint(-1, 20, (n, ndim), generator=g, dtype=torch.int32)
+    if ndim == 4:
+        coors[:, 0] = torch.randint(-1, 3, (n,), generator=g, dtype=torch.int32)
+    for mode, ds in (("mean", dsmean), ("max", dsmax)):
+        red, uq, cmap, cnt = O.dynamic_point_to_voxel(feats.numpy(), coors.numpy(), mode)
+        x = feats.to(dev).requires_grad_()
+        out, oc = ds(x, coors.to(dev), batch_size=3) if ndim == 4 else ds(x, coors.to(dev))
+        assert np.array_equal(oc.cpu().numpy(), uq)                       # bit-exact coordinates and order
+        assert np.allclose(out.detach().cpu().numpy(), red, rtol=1e-5, atol=1e-4 if mode == "mean" else 0.0)
+        w = torch.randn(out.shape, generator=g)
+        (out * w.to(dev)).sum().backward()
+        gref = O.dynamic_point_to_voxel_grad(w.numpy(), feats.numpy(), out.detach().cpu().numpy(), cmap, cnt, mode) \
+            if mode == "mean" else None
+        if mode == "mean":
+            assert np.allclose(x.grad.cpu().numpy(), gref, rtol=1e-6, atol=1e-7)
+    # max gradient incl. ties, small enough for the oracle's python loop
+    f2 = torch.randint(0, 4, (400, 4), generator=g).float()
+    c2 = torch.randint(-1, 3, (400, ndim), generator=g, dtype=torch.int32)
+    x = f2.to(dev).requires_grad_()
+    out, oc = dsmax(x, c2.to(dev), batch_size=3) if ndim == 4 else dsmax(x, c2.to(dev))
+    red, uq, cmap, cnt = O.dynamic_point_to_voxel(f2.numpy(), c2.numpy(), "max")
+    assert np.array_equal(out.detach().cpu().numpy(), red) and np.array_equal(oc.cpu().numpy(), uq)
+    w = torch.randn(out.shape, generator=g)
+    (out * w.to(dev)).sum().backward()
+    assert np.array_equal(x.grad.cpu().numpy(), O.dynamic_point_to_voxel_grad(w.numpy(), f2.numpy(), red, cmap, cnt, "max"))
+
+
+def test_pillar_segment_drops_invalid_rows(dev):
+    """geomae_pillar_segment_nd: rows with a negative / out-of-grid coordinate get inv = -1 and are not in `order`."""
+    from geomae_amd import ops
+    g = torch.Generator().manual_seed(5)
+    coors = torch.stack([torch.randint(0, 2, (5000,), generator=g), torch.zeros(5000, dtype=torch.int64),
+                         torch.randint(-1, 41, (5000,), generator=g), torch.randint(-1, 41, (5000,), generator=g)], 1).int()
+    seg = ops.pillar_segment(coors.to(dev), 2, (1, 40, 40))
+    ok = ((coors[:, 2:] >= 0) & (coors[:, 2:] < 40)).all(1).numpy()
+    inv = seg.inv.cpu().numpy()
+    assert (inv[~ok] == -1).all() and (inv[ok] >= 0).all()
+    uq = np.unique(coors.numpy()[ok], axis=0)
+    assert seg.V == len(uq) and np.array_equal(seg.voxel_coors[:seg.V].cpu().numpy(), uq)
+    n_ok = int(ok.sum())
+    assert int(seg.seg_start[seg.V]) == n_ok
+    assert sorted(seg.order[:n_ok].cpu().tolist()) == np.nonzero(ok)[0].tolist()
+
+
 @pytest.mark.parametrize("max_norm", [10.0, 0.05])
 def test_fused_clip_adamw_matches_torch(dev, max_norm):
     """geomae_grad_sumsq + geomae_adamw_step vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (the optimizer
