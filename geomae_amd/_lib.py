@@ -78,6 +78,8 @@ SIGNATURES = {
     "geomae_dynamic_point_to_voxel_forward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                              c_int32, c_int32, c_int32, P, P, P, P, P, P, c_int64, P]),
     "geomae_dynamic_point_to_voxel_backward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int32, c_int32, c_int32, P, P]),
+    "geomae_hard_voxelize_workspace_bytes": (c_int64, [c_int64, F3, F3]),
+    "geomae_hard_voxelize": (ctypes.c_int, [P, c_int64, c_int32, F3, F3, c_int32, c_int32, P, P, P, P, P, c_int64, P]),
     "geomae_grad_sumsq": (ctypes.c_int, [P, c_int64, P, P]),
     "geomae_adamw_step": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          c_int64, c_float, P, c_float, c_int32, P, P]),

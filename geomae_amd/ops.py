@@ -77,10 +77,35 @@ def dynamic_voxelize(points, coors, voxel_size, coors_range, NDim=3):
                                               f3(coors_range), _ptr(coors), _stream()), "geomae_dynamic_voxelize")
 
 
+def hard_voxelize(points, voxels, coors, num_points_per_voxel, voxel_size, coors_range, max_points, max_voxels, NDim=3):
+    """Drop-in for voxel_layer.hard_voxelize (voxelization.h:58-76): fills the pre-allocated voxels
+    [max_voxels, max_points, C], coors [max_voxels, 3] int32 (z,y,x), num_points_per_voxel [max_voxels] int32 and
+    returns the number of voxels (one device->host readback, as the reference's return value implies)."""
+    if NDim != 3:
+        raise RuntimeError("only NDim == 3 is supported")
+    _check_input(points, "points", torch.float32)
+    _check_input(voxels, "voxels", torch.float32)
+    _check_input(coors, "coors", torch.int32)
+    _check_input(num_points_per_voxel, "num_points_per_voxel", torch.int32)
+    n, C = points.shape
+    if voxels.shape != (max_voxels, max_points, C) or coors.shape != (max_voxels, 3) or \
+            num_points_per_voxel.shape != (max_voxels,):
+        raise RuntimeError("voxels [max_voxels, max_points, C], coors [max_voxels, 3], num_points_per_voxel [max_voxels]")
+    lib = _lib.load()
+    wsb = lib.geomae_hard_voxelize_workspace_bytes(n, f3(voxel_size), f3(coors_range))
+    if wsb < 0:
+        raise RuntimeError("hard_voxelize: empty voxel grid")
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=points.device)
+    num = torch.empty(1, dtype=torch.int32, device=points.device)
+    check(lib.geomae_hard_voxelize(_ptr(points), n, C, f3(voxel_size), f3(coors_range), int(max_points), int(max_voxels),
+                                   _ptr(voxels), _ptr(coors), _ptr(num_points_per_voxel), _ptr(num), _ptr(ws), wsb,
+                                   _stream()), "geomae_hard_voxelize")
+    return int(num.item())
+
+
 class Voxelization(nn.Module):
-    """mmdet3d.ops.Voxelization (voxelize.py:63-121).  Only the dynamic mode (max_num_points == -1 or
-    max_voxels == -1) is on the pre-training path; hard voxelization is constructed by the config
-    (hard_sub_voxel_layer_*) but never called, so calling it raises."""
+    """mmdet3d.ops.Voxelization (voxelize.py:63-121): dynamic mode (max_num_points == -1 or max_voxels == -1) ->
+    coors [N,3]; hard mode -> (voxels [M, max_points, C], coors [M,3], num_points_per_voxel [M])."""
 
     def __init__(self, voxel_size, point_cloud_range, max_num_points, max_voxels=20000):
         super().__init__()
@@ -100,14 +125,20 @@ class Voxelization(nn.Module):
             coors = input.new_zeros(size=(input.size(0), 3), dtype=torch.int)
             dynamic_voxelize(input.contiguous(), coors, self.voxel_size, self.point_cloud_range, 3)
             return coors
-        raise NotImplementedError("hard voxelization is not part of the GeoMAE pre-training path")
+        input = input.contiguous()
+        voxels = input.new_zeros(size=(max_voxels, self.max_num_points, input.size(1)))
+        coors = input.new_zeros(size=(max_voxels, 3), dtype=torch.int)
+        num_points_per_voxel = input.new_zeros(size=(max_voxels,), dtype=torch.int)
+        voxel_num = hard_voxelize(input, voxels, coors, num_points_per_voxel, self.voxel_size, self.point_cloud_range,
+                                  self.max_num_points, max_voxels, 3)
+        return voxels[:voxel_num], coors[:voxel_num], num_points_per_voxel[:voxel_num]
 
     def __repr__(self):
         return (f"{self.__class__.__name__}(voxel_size={self.voxel_size}, point_cloud_range="
                 f"{self.point_cloud_range}, max_num_points={self.max_num_points}, max_voxels={self.max_voxels})")
 
 
-Voxelization_with_flag = Voxelization   # constructed by the config, never called on this path
+Voxelization_with_flag = Voxelization   # constructed by the config (hard_sub_voxel_layer_*), never called on this path
 
 
 def voxelize_batch3(points, batch_offsets, batch_size, vs_top, vs_med, vs_low, coors_range):

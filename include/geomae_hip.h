@@ -341,6 +341,18 @@ int geomae_dynamic_point_to_voxel_backward(float* grad_feats, const float* grad_
                                            int32_t channels, int32_t reduce_type, int32_t* reduce_from_ws,
                                            geomaeStream_t stream);
 
+/* hard voxelization: voxel_layer.hard_voxelize (ops/voxel/src/voxelization.h:58-76; semantics of the CPU path
+ * voxelization_cpu.cpp:42-100, wrapper ops/voxel/voxelize.py:44-58).  grid = round((max - min) / voxel_size);
+ * coordinates clamped into the grid (this fork); voxels numbered in order of first appearance (point index order),
+ * at most max_voxels; each keeps its first max_points points.  Outputs (caller allocated, zero-filled by the call):
+ * voxels [max_voxels, max_points, num_features], coors [max_voxels, 3] (z,y,x), num_points_per_voxel [max_voxels],
+ * *voxel_num on the device (the pybind function returns it; the caller reads it back to slice). */
+int64_t geomae_hard_voxelize_workspace_bytes(int64_t num_points, const float* voxel_size, const float* coors_range);
+int geomae_hard_voxelize(const float* points, int64_t num_points, int32_t num_features, const float* voxel_size,
+                         const float* coors_range, int32_t max_points, int32_t max_voxels, float* voxels,
+                         int32_t* coors, int32_t* num_points_per_voxel, int32_t* voxel_num, void* workspace,
+                         int64_t workspace_bytes, geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ N4 optimizer step
  * replaces mmcv OptimizerHook.clip_grads (torch.nn.utils.clip_grad_norm_, max_norm 10, L2) + torch.optim.AdamW
  * as configured by configs/_base_/schedules/cosine_2x.py:1-17, on flat fp32 buffers (16-byte aligned) whose first

@@ -689,3 +689,35 @@ def dynamic_point_to_voxel_grad(grad_reduced, feats, reduced, cmap, cnt, reduce_
             if src[m, c] < n:
                 g[src[m, c], c] = grad_reduced[m, c]
     return g
+
+
+# ---------------------------------------------------------------------------------- N3 hard voxelization
+def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
+    """CPU restatement of hard_voxelize_cpu / hard_voxelize_kernel (ops/voxel/src/voxelization_cpu.cpp:42-132):
+    grid = round((max - min) / vs) in fp32 (:113-116); coordinates by the dynamic kernel with THAT grid (clamped,
+    :19-36); points walked in index order, a voxel is created on first sight of its cell while fewer than max_voxels
+    exist (:66-79), each voxel keeps its first max_points points (:82-88).
+    -> voxels [M, max_points, C] f32 zero padded, coors [M,3] int32 (z,y,x), num_points_per_voxel [M] int32."""
+    pts = np.asarray(points, dtype=np.float32)
+    vs = np.asarray(voxel_size, dtype=np.float32)
+    rng = np.asarray(coors_range, dtype=np.float32)
+    grid = np.round((rng[3:] - rng[:3]) / vs).astype(np.int64)
+    c = np.floor((pts[:, :3] - rng[:3]) / vs).astype(np.int64)
+    c = np.clip(c, 0, grid - 1)[:, ::-1]                       # (z, y, x)
+    lut, coors, counts = {}, [], []
+    voxels = np.zeros((max_voxels, max_points, pts.shape[1]), dtype=np.float32)
+    for i in range(pts.shape[0]):
+        key = (int(c[i, 0]), int(c[i, 1]), int(c[i, 2]))
+        v = lut.get(key, -1)
+        if v == -1:
+            if len(coors) >= max_voxels:
+                continue
+            v = len(coors)
+            lut[key] = v
+            coors.append(key)
+            counts.append(0)
+        if counts[v] < max_points:
+            voxels[v, counts[v]] = pts[i]
+            counts[v] += 1
+    M = len(coors)
+    return voxels[:M], np.asarray(coors, dtype=np.int32).reshape(M, 3), np.asarray(counts, dtype=np.int32)

@@ -176,7 +176,38 @@ def pipeline(enc_blocks, dec_blocks, tag, frames):
     print(tag, "V", feature_coors.shape[0], "N", voxels.shape[0], "losses", {k: round(float(v), 5) for k, v in loss.items()})
 
 
+def g_hard_voxelize():
+    """voxel_layer.hard_voxelize of the reference (CPU path, voxelization_cpu.cpp:42-132) on seeded clouds:
+    a LiDAR frame with the PointPillars-style config, a dense cloud that hits max_points and max_voxels, and a
+    cloud with out-of-range points (clamped into the border cells by this fork)."""
+    out = {}
+    cases = dict(
+        lidar=(synth.lidar_frame(5, beams=16, n_az=600), (0.25, 0.25, 8.0), RANGE, 20, 30000),
+        dense=(synth.uniform_cloud(6, 20000, [-4, -4, -1, 4, 4, 1]), (0.5, 0.5, 0.5), [-4.0, -4.0, -1.0, 4.0, 4.0, 1.0], 8, 600),
+        clamp=(synth.uniform_cloud(7, 6000, [-12, -12, -3, 12, 12, 3]), (1.0, 1.0, 2.0), [-8.0, -8.0, -2.0, 8.0, 8.0, 2.0], 5, 200))
+    for name, (pts, vs, rng, mp, mv) in cases.items():
+        p = torch.as_tensor(pts)
+        voxels = p.new_zeros((mv, mp, p.shape[1]))
+        coors = p.new_zeros((mv, 3), dtype=torch.int32)
+        num = p.new_zeros((mv,), dtype=torch.int32)
+        n = ref.voxel_layer.hard_voxelize(p, voxels, coors, num, list(map(float, vs)), list(map(float, rng)), mp, mv, 3)
+        out[f"{name}_cfg"] = np.array([*vs, *rng, mp, mv], dtype=np.float64)
+        out[f"{name}_points"] = pts if name != "lidar" else np.zeros(0, np.float32)     # lidar: regenerated by seed
+        out[f"{name}_voxel_num"] = np.int64(n)
+        out[f"{name}_coors"] = coors[:n].numpy().astype(np.int16)
+        out[f"{name}_num"] = num[:n].numpy().astype(np.int16)
+        # the kept point rows are identified by their xyz sum per voxel (full voxels would be large)
+        out[f"{name}_voxel_sum"] = voxels[:n].numpy().astype(np.float64).sum(axis=(1, 2))
+        out[f"{name}_first_voxels"] = voxels[:16].numpy()
+        print("hard", name, "voxels", n, "max pts", int(num.max()))
+    np.savez_compressed(os.path.join(OUT, "g_hard_voxelize.npz"), **out)
+
+
 if __name__ == "__main__":
+    if "--hard-only" in sys.argv:
+        g_hard_voxelize()
+        sys.exit(0)
     g1_voxelize()
+    g_hard_voxelize()
     pipeline(1, 1, "tiny", small_scene())
     pipeline(6, 2, "full", small_scene())

@@ -463,6 +463,29 @@ def test_dynamic_scatter_matches_oracle(dev, ndim):
     assert np.array_equal(x.grad.cpu().numpy(), O.dynamic_point_to_voxel_grad(w.numpy(), f2.numpy(), red, cmap, cnt, "max"))
 
 
+@pytest.mark.parametrize("name", ["lidar", "dense", "clamp"])
+def test_hard_voxelize_bit_exact_vs_reference_fixture(dev, golden_dir, name):
+    """mmdet3d.ops.Voxelization in hard mode vs the reference's compiled CPU hard_voxelize (fixture) and the oracle:
+    voxel order, coordinates, point counts and every kept point row, bit-exact; max_points / max_voxels caps hit."""
+    from geomae_amd import ops
+    g = np.load(os.path.join(golden_dir, "g_hard_voxelize.npz"))
+    cfg = g[f"{name}_cfg"]
+    vs, rng, mp, mv = [float(v) for v in cfg[:3]], [float(v) for v in cfg[3:9]], int(cfg[9]), int(cfg[10])
+    pts = synth.lidar_frame(5, beams=16, n_az=600) if name == "lidar" else g[f"{name}_points"]
+    layer = ops.Voxelization(vs, rng, mp, max_voxels=mv)
+    voxels, coors, num = layer(torch.as_tensor(pts, device=dev))
+    assert voxels.shape[0] == int(g[f"{name}_voxel_num"])
+    assert np.array_equal(coors.cpu().numpy(), g[f"{name}_coors"].astype(np.int32))
+    assert np.array_equal(num.cpu().numpy(), g[f"{name}_num"].astype(np.int32))
+    ov, oc, on = O.hard_voxelize(pts, vs, rng, mp, mv)
+    assert np.array_equal(voxels.cpu().numpy(), ov)
+    k = min(16, ov.shape[0])
+    assert np.array_equal(voxels[:k].cpu().numpy(), g[f"{name}_first_voxels"][:k])
+    # empty input
+    v0, c0, n0 = layer(torch.empty((0, pts.shape[1]), dtype=torch.float32, device=dev))
+    assert v0.shape == (0, mp, pts.shape[1]) and c0.shape == (0, 3) and n0.shape == (0,)
+
+
 def test_pillar_segment_drops_invalid_rows(dev):
     """geomae_pillar_segment_nd: rows with a negative / out-of-grid coordinate get inv = -1 and are not in `order`."""
     from geomae_amd import ops
