@@ -43,6 +43,17 @@ class GeomaeVfeArgs(ctypes.Structure):
                 ("scale1", c_void_p), ("shift1", c_void_p)]
 
 
+class GeomaeSweepInfo(ctypes.Structure):
+    _fields_ = [("rot", c_double * 9), ("trans", c_double * 3), ("dt", c_float), ("frame", c_int32),
+                ("remove_close", c_int32), ("has_transform", c_int32)]
+
+
+class GeomaeFrameAug(ctypes.Structure):
+    _fields_ = [("rot_cos", c_float), ("rot_sin", c_float), ("scale", c_float), ("trans", c_float * 3),
+                ("flip_horizontal", c_int32), ("flip_vertical", c_int32), ("shuffle_seed_lo", ctypes.c_uint32),
+                ("shuffle_seed_hi", ctypes.c_uint32)]
+
+
 class GeomaeBnState(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("scale0", "shift0", "mean0", "invstd0", "scale1", "shift1", "mean1", "invstd1")]
 
@@ -80,6 +91,9 @@ SIGNATURES = {
     "geomae_dynamic_point_to_voxel_backward": (ctypes.c_int, [P, P, P, P, P, P, c_int64, c_int32, c_int32, c_int32, P, P]),
     "geomae_hard_voxelize_workspace_bytes": (c_int64, [c_int64, F3, F3]),
     "geomae_hard_voxelize": (ctypes.c_int, [P, c_int64, c_int32, F3, F3, c_int32, c_int32, P, P, P, P, P, c_int64, P]),
+    "geomae_points_pipeline_workspace_bytes": (c_int64, [c_int64, c_int32]),
+    "geomae_points_pipeline": (ctypes.c_int, [P, c_int64, c_int32, P, P, c_int32, P, P, c_int32, F3, c_float, P, P, P,
+                                              c_int64, P]),
     "geomae_grad_sumsq": (ctypes.c_int, [P, c_int64, P, P]),
     "geomae_adamw_step": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          c_int64, c_float, P, c_float, c_int32, P, P]),

@@ -153,6 +153,16 @@ __global__ __launch_bounds__(256) void hv_fill_kernel(const float* __restrict__ 
     }
 }
 
+// in-place exclusive scan of n int32 (tile_ws: n / 1024 + 2 ints); shared with points_pipeline.hip
+int exclusive_scan_i32(int32_t* values, int64_t n, int32_t* tile_ws, hipStream_t stream) {
+    if (n <= 0) return GEOMAE_OK;
+    const int n_tiles = cdiv(n, 1024);
+    hipLaunchKernelGGL(hv_scan_reduce_kernel, dim3(n_tiles), dim3(256), 0, stream, values, n, tile_ws);
+    hipLaunchKernelGGL(hv_scan_tiles_kernel, dim3(1), dim3(256), 0, stream, tile_ws, n_tiles);
+    hipLaunchKernelGGL(hv_scan_emit_kernel, dim3(n_tiles), dim3(256), 0, stream, values, n, tile_ws);
+    return check_launch("exclusive_scan_i32");
+}
+
 struct HvWs { int64_t coors4, table, cell_coors, inv, order0, order1, seg, sample, nv, flag, tiles, seg_ws, total; };
 static HvWs hv_ws(int64_t n, int gz, int gy, int gx) {
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
@@ -229,10 +239,7 @@ extern "C" int geomae_hard_voxelize(const float* points, int64_t num_points, int
     const int cap = (int)(num_points < cells ? num_points : cells);
     hipLaunchKernelGGL(hv_seg_sort_kernel, dim3(cap < 8192 ? cap : 8192), dim3(64), 0, stream, seg, nv, order0, order1);
     hipLaunchKernelGGL(hv_flag_kernel, dim3(stream_grid(num_points, 256)), dim3(256), 0, stream, inv, seg, order1, num_points, flag);
-    const int n_tiles = cdiv(num_points, 1024);
-    hipLaunchKernelGGL(hv_scan_reduce_kernel, dim3(n_tiles), dim3(256), 0, stream, flag, num_points, tiles);
-    hipLaunchKernelGGL(hv_scan_tiles_kernel, dim3(1), dim3(256), 0, stream, tiles, n_tiles);
-    hipLaunchKernelGGL(hv_scan_emit_kernel, dim3(n_tiles), dim3(256), 0, stream, flag, num_points, tiles);
+    if ((rc = exclusive_scan_i32(flag, num_points, tiles, stream))) return rc;
     hipLaunchKernelGGL(hv_fill_kernel, dim3(cap / 4 + 1 < 4096 ? cap / 4 + 1 : 4096), dim3(256), 0, stream, points, num_features,
                        seg, nv, order1, flag, cell_coors, max_points, max_voxels, voxels, coors, num_points_per_voxel, voxel_num);
     return check_launch("hard_voxelize");

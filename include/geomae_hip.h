@@ -353,6 +353,36 @@ int geomae_hard_voxelize(const float* points, int64_t num_points, int32_t num_fe
                          int32_t* coors, int32_t* num_points_per_voxel, int32_t* voxel_num, void* workspace,
                          int64_t workspace_bytes, geomaeStream_t stream);
 
+/* ------------------------------------------------------------------ N2 input pipeline
+ * replaces, per batch, the CPU transforms of the train pipeline (configs/mae_sst/...6x_1e-5.py:167-197):
+ * LoadPointsFromMultiSweeps' per-sweep work (datasets/pipelines/loading.py:184-233: remove_close, sensor->lidar
+ * transform, time lag, concatenation), GlobalRotScaleTrans, RandomFlip3D, PointsRangeFilter, PointShuffle
+ * (datasets/pipelines/transforms_3d.py:734-757, 125-160, 849-884, 770-797).  The random draws are made by the
+ * caller (GeomaeFrameAug); file reading stays on the host.
+ * raw_points [N, F] = the sweeps of all frames concatenated (key frame first, then its sweeps), device;
+ * sweep_offsets [S+1], frame_offsets [B+1] (raw point index where each sweep / frame starts), sweeps [S],
+ * frames [B]: device arrays.  out_points [<= N, F] = frames concatenated, out_offsets [B+1] on the device. */
+typedef struct GeomaeSweepInfo {
+    double rot[9];            /* sensor2lidar_rotation, row major (applied as xyz @ rot^T)  */
+    double trans[3];          /* sensor2lidar_translation                                    */
+    float dt;                 /* value of column 4: 0 for the key frame, ts - sweep_ts       */
+    int32_t frame;            /* which frame of the batch this sweep belongs to              */
+    int32_t remove_close;     /* drop |x| < r and |y| < r (sensor frame)                     */
+    int32_t has_transform;    /* 0 for the key frame                                         */
+} GeomaeSweepInfo;
+typedef struct GeomaeFrameAug {
+    float rot_cos, rot_sin, scale;        /* GlobalRotScaleTrans (fp32 sin/cos of the drawn angle) */
+    float trans[3];
+    int32_t flip_horizontal, flip_vertical;
+    uint32_t shuffle_seed_lo, shuffle_seed_hi;   /* both 0: keep the concatenation order */
+} GeomaeFrameAug;
+int64_t geomae_points_pipeline_workspace_bytes(int64_t num_points, int32_t num_features);
+int geomae_points_pipeline(const float* raw_points, int64_t num_points, int32_t num_features,
+                           const int32_t* sweep_offsets, const GeomaeSweepInfo* sweeps, int32_t num_sweeps,
+                           const int32_t* frame_offsets, const GeomaeFrameAug* frames, int32_t num_frames,
+                           const float* point_cloud_range /*host [6]*/, float close_radius, float* out_points,
+                           int32_t* out_offsets, void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ N4 optimizer step
  * replaces mmcv OptimizerHook.clip_grads (torch.nn.utils.clip_grad_norm_, max_norm 10, L2) + torch.optim.AdamW
  * as configured by configs/_base_/schedules/cosine_2x.py:1-17, on flat fp32 buffers (16-byte aligned) whose first

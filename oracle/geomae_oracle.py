@@ -721,3 +721,49 @@ def hard_voxelize(points, voxel_size, coors_range, max_points, max_voxels):
             counts[v] += 1
     M = len(coors)
     return voxels[:M], np.asarray(coors, dtype=np.int32).reshape(M, 3), np.asarray(counts, dtype=np.int32)
+
+
+# ---------------------------------------------------------------------------------- N2 input pipeline
+def train_pipeline_cpu(frame, draw, point_cloud_range, sweeps_num=9, remove_close=True, pad_empty_sweeps=True,
+                       close_radius=1.0):
+    """CPU restatement of the per-sample train pipeline with the random decisions given (`draw`: sweep_choices,
+    rotation, scale, translation, flip_horizontal, flip_vertical): LoadPointsFromMultiSweeps.__call__
+    (datasets/pipelines/loading.py:184-233; numpy, fp64 products stored into the fp32 array), GlobalRotScaleTrans
+    (transforms_3d.py:734-757 via core/points/base_points.py:139-179,186-205,263-269; torch fp32), RandomFlip3D
+    (lidar_points.py:28-33), PointsRangeFilter (base_points.py:207-229).  PointShuffle is a permutation: the caller
+    compares as a multiset.  -> [N,5] fp32 in concatenation order."""
+    key = np.array(frame["points"], dtype=np.float32, copy=True)
+    key[:, 4] = 0
+
+    def not_close(p):
+        return p[~((np.abs(p[:, 0]) < close_radius) & (np.abs(p[:, 1]) < close_radius))]
+    parts = [key]
+    sweeps = frame.get("sweeps", [])
+    if pad_empty_sweeps and len(sweeps) == 0:
+        for _ in range(sweeps_num):
+            parts.append(not_close(key) if remove_close else key)
+    else:
+        ts = frame["timestamp"]
+        for idx in draw.sweep_choices:
+            sw = sweeps[idx]
+            p = np.copy(np.asarray(sw["points"], dtype=np.float32)).reshape(-1, key.shape[1])
+            if remove_close:
+                p = not_close(p)
+            p[:, :3] = p[:, :3] @ np.asarray(sw["sensor2lidar_rotation"], dtype=np.float64).T
+            p[:, :3] += np.asarray(sw["sensor2lidar_translation"], dtype=np.float64)
+            p[:, 4] = ts - sw["timestamp"] / 1e6
+            parts.append(p)
+    t = torch.from_numpy(np.concatenate(parts, axis=0))
+    rot = t.new_tensor(draw.rotation)
+    s, c = torch.sin(rot), torch.cos(rot)
+    rot_mat_T = rot.new_tensor([[c, -s, 0], [s, c, 0], [0, 0, 1]]).T
+    t[:, :3] = t[:, :3] @ rot_mat_T
+    t[:, :3] *= draw.scale
+    t[:, :3] += t.new_tensor(draw.translation)
+    if draw.flip_horizontal:
+        t[:, 1] = -t[:, 1]
+    if draw.flip_vertical:
+        t[:, 0] = -t[:, 0]
+    r = np.asarray(point_cloud_range, dtype=np.float32)
+    m = (t[:, 0] > r[0]) & (t[:, 1] > r[1]) & (t[:, 2] > r[2]) & (t[:, 0] < r[3]) & (t[:, 1] < r[4]) & (t[:, 2] < r[5])
+    return t[m].numpy()

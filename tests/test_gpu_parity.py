@@ -463,6 +463,37 @@ def test_dynamic_scatter_matches_oracle(dev, ndim):
     assert np.array_equal(x.grad.cpu().numpy(), O.dynamic_point_to_voxel_grad(w.numpy(), f2.numpy(), red, cmap, cnt, "max"))
 
 
+# ---------------------------------------------------------------------------------- N2 input pipeline
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_gpu_input_pipeline_matches_oracle(dev, shuffle):
+    """geomae_points_pipeline (sweep transform, remove_close, time lag, rot/scale/flip, range filter, shuffle) vs the
+    CPU restatement of the reference transforms with the same random decisions.  Without shuffle the rows come out in
+    concatenation order (compared row by row); with shuffle the output must be a permutation of them that is not the
+    identity.  xyz within 2e-5 m (fp32 products, the reference's own BLAS order is not specified)."""
+    from test_pipeline_cpu import make_frames
+    from geomae_amd.pipeline import GpuTrainPipeline
+    frames = make_frames(11, n_frames=3, n_sweeps=(4, 0, 1), n_pts=6000)
+    pipe = GpuTrainPipeline(RANGE, sweeps_num=3, shuffle=shuffle)
+    rs = np.random.RandomState(5)
+    draws = [pipe.draw(fr, rs) for fr in frames]
+    outs = pipe(frames, dev, draws=draws)
+    assert len(outs) == 3
+    for fr, d, got in zip(frames, draws, outs):
+        ref = O.train_pipeline_cpu(fr, d, RANGE, sweeps_num=3)
+        got = got.cpu().numpy()
+        assert got.shape == ref.shape, (got.shape, ref.shape)
+        if shuffle:
+            assert not np.array_equal(got[:, 3], ref[:, 3])                  # really permuted
+            # intensity / lag are copied bit-exactly; coarse xyz breaks the rare intensity ties between different points
+            key = lambda a: np.lexsort((np.round(a[:, 1], 1), np.round(a[:, 0], 1), a[:, 4], a[:, 3]))
+            got, ref = got[key(got)], ref[key(ref)]
+        assert np.array_equal(got[:, 3:], ref[:, 3:])
+        assert np.abs(got[:, :3] - ref[:, :3]).max() < 2e-5
+    # same seed -> same permutation; different seed -> different
+    again = pipe(frames, dev, draws=draws)
+    assert all(torch.equal(a, b) for a, b in zip(outs, again))
+
+
 @pytest.mark.parametrize("name", ["lidar", "dense", "clamp"])
 def test_hard_voxelize_bit_exact_vs_reference_fixture(dev, golden_dir, name):
     """mmdet3d.ops.Voxelization in hard mode vs the reference's compiled CPU hard_voxelize (fixture) and the oracle:
