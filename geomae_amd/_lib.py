@@ -94,6 +94,11 @@ SIGNATURES = {
     "geomae_points_pipeline_workspace_bytes": (c_int64, [c_int64, c_int32]),
     "geomae_points_pipeline": (ctypes.c_int, [P, c_int64, c_int32, P, P, c_int32, P, P, c_int32, F3, c_float, P, P, P,
                                               c_int64, P]),
+    "geomae_window_drop_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
+    "geomae_window_drop": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, c_int32,
+                                          POINTER(c_int32), POINTER(c_int32), POINTER(c_int32), P, P, P, c_int64, P]),
+    "geomae_recover_bev_forward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P]),
+    "geomae_recover_bev_backward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P]),
     "geomae_grad_sumsq": (ctypes.c_int, [P, c_int64, P, P]),
     "geomae_adamw_step": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          c_int64, c_float, P, c_float, c_int32, P, P]),

@@ -494,6 +494,52 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
     }
 }
 
+// ---- SSTInputLayer voxel drop (fine-tune path): keep a voxel iff its arrival rank inside its
+// window is below the max_tokens of the window's drop level (level = the range (lower, upper] its token count
+// falls in; mmdet3d/models/middle_encoders/sst_input_layer.py:213-238 drop_single_shift).  The reference ranks by a
+// sort after a random shuffle of the voxels, i.e. which voxels survive in an over-full window is random; here
+// the rank is the atomic arrival order.
+struct DropLevels { int n; int max_tokens[8]; int lower[8]; int upper[8]; };
+__global__ __launch_bounds__(kWBlk) void win_drop_kernel(int n, const int32_t* __restrict__ table,
+                                                         const int32_t* __restrict__ rank,
+                                                         const int32_t* __restrict__ tok_win_id, DropLevels L,
+                                                         uint8_t* __restrict__ keep, int32_t* __restrict__ level) {
+    for (int i = blockIdx.x * kWBlk + threadIdx.x; i < n; i += gridDim.x * kWBlk) {
+        const int cnt = table[tok_win_id[i]];
+        int l = L.n - 1;                      // a count above the last range is treated as the last level
+        for (int k = 0; k < L.n; ++k)
+            if (cnt > L.lower[k] && cnt <= L.upper[k]) { l = k; break; }
+        keep[i] = rank[i] < L.max_tokens[l];
+        if (level) level[i] = l;
+    }
+}
+
+// ---- recover_bev (sst_second_pretrained_v1.py:243-280): scatter token rows into a dense BEV canvas.  The canvas
+// is stored channels-last ([B, ny, nx, C] in memory, i.e. an NCHW tensor in torch's channels_last format): a
+// token is one coalesced C*4-byte row, and MIOpen's convolutions take the layout as is.
+__global__ __launch_bounds__(256) void bev_scatter_kernel(const float* __restrict__ feat, const int4* __restrict__ coors,
+                                                          int64_t n, int C, int ny, int nx, float* __restrict__ canvas) {
+    const int64_t total = n * (C / 4);
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / (C / 4);
+        const int c4 = (int)(t - i * (C / 4));
+        const int4 c = coors[i];
+        reinterpret_cast<float4*>(canvas + (((int64_t)c.x * ny + c.z) * nx + c.w) * C)[c4] =
+            reinterpret_cast<const float4*>(feat + i * C)[c4];
+    }
+}
+__global__ __launch_bounds__(256) void bev_gather_kernel(const float* __restrict__ canvas, const int4* __restrict__ coors,
+                                                         int64_t n, int C, int ny, int nx, float* __restrict__ out) {
+    const int64_t total = n * (C / 4);
+    for (int64_t t = blockIdx.x * (int64_t)256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int64_t i = t / (C / 4);
+        const int c4 = (int)(t - i * (C / 4));
+        const int4 c = coors[i];
+        reinterpret_cast<float4*>(out + i * C)[c4] =
+            reinterpret_cast<const float4*>(canvas + (((int64_t)c.x * ny + c.z) * nx + c.w) * C)[c4];
+    }
+}
+
 }  // namespace geomae
 
 using namespace geomae;
@@ -609,4 +655,67 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
                        win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),
                        (unsigned short*)dqkv_bf16);
     return check_launch("win_attn_bwd_kernel");
+}
+
+extern "C" int64_t geomae_window_drop_workspace_bytes(int32_t num_tokens, int32_t batch_size, const GeomaeWindowConfig* cfg) {
+    WinGeom g;
+    int sps;
+    if (win_geom(cfg, 0, &g, &sps)) return -1;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    return al((int64_t)batch_size * sps * 4) + 3 * al((int64_t)num_tokens * 4);
+}
+
+extern "C" int geomae_window_drop(const int32_t* coors, int32_t num_tokens, int32_t batch_size, const GeomaeWindowConfig* cfg,
+                                  int32_t shift_index, int32_t num_levels, const int32_t* max_tokens,
+                                  const int32_t* range_lower, const int32_t* range_upper, uint8_t* keep,
+                                  int32_t* drop_level, void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    WinGeom g;
+    int sps;
+    int rc = win_geom(cfg, shift_index, &g, &sps);
+    if (rc) return rc;
+    GEOMAE_REQUIRE(coors && keep && max_tokens && range_lower && range_upper && num_levels >= 1 && num_levels <= 8,
+                   "window_drop: bad argument (1..8 drop levels)");
+    const int64_t need = geomae_window_drop_workspace_bytes(num_tokens, batch_size, cfg);
+    if (workspace_bytes < need || !workspace) {
+        set_error("window_drop: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    const int slots = batch_size * sps;
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    char* ws = (char*)workspace;
+    int32_t* table = (int32_t*)ws;  ws += al((int64_t)slots * 4);
+    int32_t* rank = (int32_t*)ws;   ws += al((int64_t)num_tokens * 4);
+    int32_t* wid = (int32_t*)ws;    ws += al((int64_t)num_tokens * 4);
+    int32_t* pos = (int32_t*)ws;
+    GEOMAE_HIP(hipMemsetAsync(table, 0, (size_t)slots * 4, stream));
+    hipLaunchKernelGGL(win_hist_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream, (const int4*)coors,
+                       num_tokens, g, table, rank, wid, pos);
+    DropLevels L;
+    L.n = num_levels;
+    for (int k = 0; k < num_levels; ++k) { L.max_tokens[k] = max_tokens[k]; L.lower[k] = range_lower[k]; L.upper[k] = range_upper[k]; }
+    hipLaunchKernelGGL(win_drop_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream, num_tokens, table, rank,
+                       wid, L, keep, drop_level);
+    return check_launch("win_drop_kernel");
+}
+
+extern "C" int geomae_recover_bev_forward(const float* feat, const int32_t* coors, int64_t num_tokens, int32_t channels,
+                                          int32_t batch_size, int32_t ny, int32_t nx, float* canvas, hipStream_t stream) {
+    GEOMAE_REQUIRE(canvas && channels >= 4 && channels % 4 == 0 && batch_size >= 1 && ny >= 1 && nx >= 1,
+                   "recover_bev_forward: bad argument (channels must be a multiple of 4)");
+    GEOMAE_HIP(hipMemsetAsync(canvas, 0, (size_t)batch_size * ny * nx * channels * sizeof(float), stream));
+    if (num_tokens <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(feat && coors, "recover_bev_forward: null argument");
+    hipLaunchKernelGGL(bev_scatter_kernel, dim3(stream_grid(num_tokens * (channels / 4), 256)), dim3(256), 0, stream, feat,
+                       (const int4*)coors, num_tokens, channels, ny, nx, canvas);
+    return check_launch("bev_scatter_kernel");
+}
+
+extern "C" int geomae_recover_bev_backward(const float* grad_canvas, const int32_t* coors, int64_t num_tokens, int32_t channels,
+                                           int32_t batch_size, int32_t ny, int32_t nx, float* grad_feat, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(grad_canvas && coors && grad_feat && channels >= 4 && channels % 4 == 0, "recover_bev_backward: bad argument");
+    hipLaunchKernelGGL(bev_gather_kernel, dim3(stream_grid(num_tokens * (channels / 4), 256)), dim3(256), 0, stream, grad_canvas,
+                       (const int4*)coors, num_tokens, channels, ny, nx, grad_feat);
+    return check_launch("bev_gather_kernel");
 }

@@ -53,4 +53,29 @@ class NaiveSyncBatchNorm1d(nn.BatchNorm1d):
         return input * scale.reshape(1, -1) + bias.reshape(1, -1)
 
 
+@NORM_LAYERS.register_module("naiveSyncBN2d")
+class NaiveSyncBatchNorm2d(nn.BatchNorm2d):
+    """mmdet3d/ops/norm.py:89-140: the 4-D variant used by the fine-tune backbone's conv stack and SECONDFPN."""
+
+    def forward(self, input):
+        assert input.dtype == torch.float32, f"input should be in float32 type, got {input.dtype}"
+        if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1 or not self.training:
+            return super().forward(input)
+        assert input.shape[0] > 0, "SyncBN does not support empty inputs"
+        C = input.shape[1]
+        mean = torch.mean(input, dim=[0, 2, 3])
+        meansqr = torch.mean(input * input, dim=[0, 2, 3])
+        vec = AllReduce.apply(torch.cat([mean, meansqr], dim=0)) * (1.0 / dist.get_world_size())
+        mean, meansqr = torch.split(vec, C)
+        var = meansqr - mean * mean
+        with torch.no_grad():
+            self.running_mean += self.momentum * (mean.detach() - self.running_mean)
+            self.running_var += self.momentum * (var.detach() - self.running_var)
+        invstd = torch.rsqrt(var + self.eps)
+        scale = self.weight * invstd
+        bias = self.bias - mean * scale
+        return input * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
 NORM_LAYERS.register_module("BN1d", module=nn.BatchNorm1d)
+NORM_LAYERS.register_module(["BN", "BN2d"], module=nn.BatchNorm2d)

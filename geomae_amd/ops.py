@@ -548,6 +548,54 @@ def window_attention(qkv_bf16, layout, num_heads):
     return _WindowAttention.apply(qkv_bf16, layout, num_heads)
 
 
+# ------------------------------------------------------------------------------------ N1 fine-tune pieces
+def window_drop(coors, batch_size, wcfg, shift_index, drop_info):
+    """SSTInputLayer.drop_single_shift (sst_input_layer.py:213-238): -> keep [n] bool, drop_level [n] int32.
+    drop_info: {level: dict(max_tokens=.., drop_range=(lower, upper))}."""
+    coors = coors.contiguous()
+    _check_input(coors, "coors", torch.int32)
+    n, dev, lib = coors.shape[0], coors.device, _lib.load()
+    keep = torch.empty(max(n, 1), dtype=torch.uint8, device=dev)
+    level = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+    lv = sorted(drop_info)
+    arr = lambda vals: (ctypes.c_int32 * len(vals))(*[int(min(v, 2 ** 31 - 1)) for v in vals])
+    wsb = lib.geomae_window_drop_workspace_bytes(n, batch_size, ctypes.byref(wcfg))
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.geomae_window_drop(_ptr(coors), n, batch_size, ctypes.byref(wcfg), shift_index, len(lv),
+                                 arr([drop_info[k]["max_tokens"] for k in lv]), arr([drop_info[k]["drop_range"][0] for k in lv]),
+                                 arr([drop_info[k]["drop_range"][1] for k in lv]), _ptr(keep), _ptr(level), _ptr(ws), wsb,
+                                 _stream()), "geomae_window_drop")
+    return keep[:n].bool(), level[:n]
+
+
+class _RecoverBev(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, coors, batch_size, ny, nx):
+        feat = feat.contiguous().float()
+        n, C = feat.shape
+        canvas = torch.empty((batch_size, ny, nx, C), dtype=torch.float32, device=feat.device)
+        check(_lib.load().geomae_recover_bev_forward(_ptr(feat), _ptr(coors), n, C, batch_size, ny, nx, _ptr(canvas),
+                                                     _stream()), "geomae_recover_bev_forward")
+        ctx.coors, ctx.shape = coors, (n, C, batch_size, ny, nx)
+        return canvas.permute(0, 3, 1, 2)                     # [B, C, ny, nx] view in channels_last memory format
+
+    @staticmethod
+    def backward(ctx, g):
+        n, C, B, ny, nx = ctx.shape
+        g = g.permute(0, 2, 3, 1).contiguous().float()        # no copy when the conv backward is channels_last too
+        out = torch.empty((n, C), dtype=torch.float32, device=g.device)
+        check(_lib.load().geomae_recover_bev_backward(_ptr(g), _ptr(ctx.coors), n, C, B, ny, nx, _ptr(out), _stream()),
+              "geomae_recover_bev_backward")
+        return out, None, None, None, None
+
+
+def recover_bev(feat, coors, batch_size, ny, nx):
+    """SSTSecondPretrainedv1.recover_bev (sst_second_pretrained_v1.py:243-280): [n,C] tokens -> dense [B,C,ny,nx]."""
+    coors = coors.contiguous()
+    _check_input(coors, "coors", torch.int32)
+    return _RecoverBev.apply(feat, coors, batch_size, ny, nx)
+
+
 # ------------------------------------------------------------------------------------ fused SST layer
 def pack_weights(desc, num_desc, max_elems, packed, aux=None):
     check(_lib.load().geomae_pack_weights(ctypes.c_void_p(0), _ptr(desc), num_desc, max_elems, _ptr(packed),

@@ -63,6 +63,9 @@ MODELS = Registry("models")
 DETECTORS = MODELS
 BACKBONES = MODELS
 VOXEL_ENCODERS = MODELS
+MIDDLE_ENCODERS = MODELS
+NECKS = MODELS
+HEADS = MODELS
 LOSSES = Registry("losses")
 NORM_LAYERS = Registry("norm layer")
 DATASETS = Registry("dataset")

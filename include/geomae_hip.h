@@ -353,6 +353,25 @@ int geomae_hard_voxelize(const float* points, int64_t num_points, int32_t num_fe
                          int32_t* coors, int32_t* num_points_per_voxel, int32_t* voxel_num, void* workspace,
                          int64_t workspace_bytes, geomaeStream_t stream);
 
+/* ------------------------------------------------------------------ N1 fine-tune path pieces
+ * geomae_window_drop: SSTInputLayer's region batching drop (models/middle_encoders/sst_input_layer.py:213-238
+ * drop_single_shift): keep[i] = (rank of voxel i inside its window) < max_tokens[level], level = first k with
+ * range_lower[k] < window count <= range_upper[k] (a count above every range uses the last level).  The rank is
+ * the atomic arrival order (the reference shuffles the voxels first, so WHICH voxels of an over-full window
+ * survive is random there too).  drop_level [n] (or NULL) receives the level.
+ * geomae_recover_bev_*: SSTSecondPretrainedv1.recover_bev (models/backbones/sst_second_pretrained_v1.py:243-280):
+ * canvas [B, ny, nx, C] fp32 (an NCHW tensor in channels_last memory format), zero-filled, row (b, y, x) <- feat[i];
+ * backward gathers grad_feat[i] <- grad_canvas row. */
+int64_t geomae_window_drop_workspace_bytes(int32_t num_tokens, int32_t batch_size, const GeomaeWindowConfig* cfg);
+int geomae_window_drop(const int32_t* coors, int32_t num_tokens, int32_t batch_size, const GeomaeWindowConfig* cfg,
+                       int32_t shift_index, int32_t num_levels, const int32_t* max_tokens /*host*/,
+                       const int32_t* range_lower /*host*/, const int32_t* range_upper /*host*/, uint8_t* keep,
+                       int32_t* drop_level, void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
+int geomae_recover_bev_forward(const float* feat, const int32_t* coors, int64_t num_tokens, int32_t channels,
+                               int32_t batch_size, int32_t ny, int32_t nx, float* canvas, geomaeStream_t stream);
+int geomae_recover_bev_backward(const float* grad_canvas, const int32_t* coors, int64_t num_tokens, int32_t channels,
+                                int32_t batch_size, int32_t ny, int32_t nx, float* grad_feat, geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ N2 input pipeline
  * replaces, per batch, the CPU transforms of the train pipeline (configs/mae_sst/...6x_1e-5.py:167-197):
  * LoadPointsFromMultiSweeps' per-sweep work (datasets/pipelines/loading.py:184-233: remove_close, sensor->lidar

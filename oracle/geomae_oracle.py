@@ -767,3 +767,27 @@ def train_pipeline_cpu(frame, draw, point_cloud_range, sweeps_num=9, remove_clos
     r = np.asarray(point_cloud_range, dtype=np.float32)
     m = (t[:, 0] > r[0]) & (t[:, 1] > r[1]) & (t[:, 2] > r[2]) & (t[:, 0] < r[3]) & (t[:, 1] < r[4]) & (t[:, 2] < r[5])
     return t[m].numpy()
+
+
+# ---------------------------------------------------------------------------------- N1 fine-tune fixtures
+def seeded_state(seed, shapes):
+    """Deterministic values for a state_dict given {name: shape}: the golden generator (reference modules) and the
+    tests (this package's modules) call it with the same names, so both load identical weights."""
+    import zlib
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(shapes[name])
+        rs = np.random.RandomState((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if name.endswith("num_batches_tracked"):
+            v = np.zeros(shape, dtype=np.int64)
+        elif name.endswith("running_var"):
+            v = (1.0 + 0.1 * np.abs(rs.standard_normal(shape))).astype(np.float32)
+        elif len(shape) <= 1 and ("norm" in name or name.split(".")[-2].isdigit()) and name.endswith("weight"):
+            v = (1.0 + 0.1 * rs.standard_normal(shape)).astype(np.float32)
+        elif len(shape) <= 1:
+            v = (0.02 * rs.standard_normal(shape)).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = (rs.standard_normal(shape) / np.sqrt(fan_in)).astype(np.float32)
+        out[name] = torch.from_numpy(v)
+    return out

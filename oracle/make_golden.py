@@ -203,11 +203,60 @@ def g_hard_voxelize():
     np.savez_compressed(os.path.join(OUT, "g_hard_voxelize.npz"), **out)
 
 
+FT_DROP = {0: dict(max_tokens=30, drop_range=(0, 30)), 1: dict(max_tokens=60, drop_range=(30, 60)),
+           2: dict(max_tokens=144, drop_range=(60, 100000))}
+FT_CFG = dict(d_model=[128, 128], nhead=[8, 8], num_blocks=1, dim_feedforward=[256, 256], output_shape=[400, 400], conv_in_channels=128,
+              conv_out_channels=[32, 48], layer_nums=[1, 2], layer_strides=[2, 2], debug=False, drop_info=(FT_DROP, FT_DROP),
+              pos_temperature=10000, normalize_pos=False, window_shape=(12, 12))
+
+
+def g_finetune():
+    """SSTInputLayer + SSTSecondPretrainedv1 of the reference (sst_input_layer.py, sst_second_pretrained_v1.py) on a
+    small scene, fp32, training mode, no shuffle; the bucket sizes are chosen so that nothing is dropped (what is dropped
+    in an over-full window is random in the reference).  Outputs are summarised (the maps are 200x200 and 100x100)."""
+    frames = [synth.lidar_frame(31, beams=16, n_az=500), synth.lidar_frame(32, beams=16, n_az=400)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = O.unique_rows(coors)[0]
+    n = vc.shape[0]
+    feat = torch.randn(n, 128, generator=torch.Generator().manual_seed(3))
+    mid = ref.mid.SSTInputLayer(drop_info=(FT_DROP, FT_DROP), shifts_list=[(0, 0), (6, 6)], window_shape=(12, 12),
+                                point_cloud_range=RANGE, voxel_size=LEVELS["top"], shuffle_voxels=False, debug=False)
+    bb = ref.ft.SSTSecondPretrainedv1(**FT_CFG)
+    state = O.seeded_state(5, {k: v.shape for k, v in bb.state_dict().items()})
+    bb.load_state_dict(state)
+    mid.train()
+    bb.train()
+    x = feat.clone().requires_grad_(True)
+    out_tuple = mid(x, torch.as_tensor(vc).long(), 2)
+    assert out_tuple[0].shape[0] == n                                  # nothing dropped
+    outs = bb(out_tuple)
+    w = [torch.randn(o.shape, generator=torch.Generator().manual_seed(11 + i)) for i, o in enumerate(outs)]
+    loss = sum((o * wi).sum() for o, wi in zip(outs, w)) * 1e-2
+    loss.backward()
+    res = dict(coors=vc.astype(np.int16), n=np.int64(n), loss=np.float64(loss.item()), dx=x.grad.numpy())
+    for i, o in enumerate(outs):
+        o = o.detach()
+        res[f"out{i}_shape"] = np.array(o.shape)
+        res[f"out{i}_sum"] = np.float64(o.double().sum())
+        res[f"out{i}_abs"] = np.float64(o.double().abs().sum())
+        res[f"out{i}_chan"] = o.double().sum(dim=(0, 2, 3)).numpy()
+        res[f"out{i}_patch"] = o[:, :, 96:104, 96:104].numpy()
+    gn = {k: float(p.grad.double().norm()) for k, p in bb.named_parameters()}
+    res["grad_names"] = np.array(sorted(gn))
+    res["grad_norms"] = np.array([gn[k] for k in sorted(gn)])
+    np.savez_compressed(os.path.join(OUT, "g_finetune.npz"), **res)
+    print("finetune n", n, "loss", float(loss), {f"out{i}": tuple(o.shape) for i, o in enumerate(outs)})
+
+
 if __name__ == "__main__":
+    if "--finetune-only" in sys.argv:
+        g_finetune()
+        sys.exit(0)
     if "--hard-only" in sys.argv:
         g_hard_voxelize()
         sys.exit(0)
     g1_voxelize()
     g_hard_voxelize()
+    g_finetune()
     pipeline(1, 1, "tiny", small_scene())
     pipeline(6, 2, "full", small_scene())

@@ -145,11 +145,19 @@ def load_reference():
     def _build_norm_layer(cfg, num_features):
         # mmcv.cnn.build_norm_layer restated for the one norm type on the path:
         # 'naiveSyncBN1d' == nn.BatchNorm1d when world_size == 1 (ops/norm.py:58-59)
+        if cfg["type"] in ("naiveSyncBN2d", "BN", "BN2d"):      # == nn.BatchNorm2d when world_size == 1 (ops/norm.py:121-122)
+            return "bn", nn.BatchNorm2d(num_features, eps=cfg.get("eps", 1e-5), momentum=cfg.get("momentum", 0.1))
         assert cfg["type"] in ("naiveSyncBN1d", "BN1d")
         return "bn", nn.BatchNorm1d(num_features, eps=cfg.get("eps", 1e-5),
                                     momentum=cfg.get("momentum", 0.1))
 
-    _mod("mmcv.cnn", build_conv_layer=None, build_norm_layer=_build_norm_layer,
+    def _build_conv_layer(cfg, *args, **kwargs):
+        # mmcv.cnn.build_conv_layer restated for cfg type 'Conv2d': the remaining cfg keys are constructor kwargs
+        c = dict(cfg or dict(type="Conv2d"))
+        assert c.pop("type") == "Conv2d"
+        return nn.Conv2d(*args, **kwargs, **c)
+
+    _mod("mmcv.cnn", build_conv_layer=_build_conv_layer, build_norm_layer=_build_norm_layer,
          NORM_LAYERS=_Registry())
     _mod("mmcv.runner", auto_fp16=_identity_decorator, force_fp32=_identity_decorator)
     _mod("mmdet")
@@ -174,7 +182,7 @@ def load_reference():
     models.__path__ = []
     _mod("mmdet3d.models.sst").__path__ = []
     _mod("mmdet3d.models.builder", build_loss=_build_loss, build_voxel_encoder=lambda cfg: None,
-         VOXEL_ENCODERS=_Registry(), build_fusion_layer=None)
+         VOXEL_ENCODERS=_Registry(), MIDDLE_ENCODERS=_Registry(), build_fusion_layer=None)
     models.builder = sys.modules["mmdet3d.models.builder"]
     _mod("mmdet3d.models.detectors").__path__ = []
     _mod("mmdet3d.models.detectors.voxelnet", VoxelNet=object)
@@ -197,6 +205,14 @@ def load_reference():
     vfe = _load("mmdet3d.models.voxel_encoders.voxel_encoder",
                 "mmdet3d/models/voxel_encoders/voxel_encoder.py",
                 package="mmdet3d.models.voxel_encoders")
+    # fine-tune path (N1): SSTInputLayer + SSTSecondPretrainedv1
+    _mod("mmdet3d.models.middle_encoders").__path__ = []
+    mid = _load("mmdet3d.models.middle_encoders.sst_input_layer", "mmdet3d/models/middle_encoders/sst_input_layer.py",
+                package="mmdet3d.models.middle_encoders")
+    _mod("mmdet3d.models.backbones").__path__ = []
+    ft = _load("mmdet3d.models.backbones.sst_second_pretrained_v1", "mmdet3d/models/backbones/sst_second_pretrained_v1.py",
+               package="mmdet3d.models.backbones")
+    _LOADED.update(mid=mid, ft=ft)
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import build_ref
     build_ref.build()

@@ -62,3 +62,26 @@ def test_pos_table_matches_oracle():
     import geomae_oracle as O
     from geomae_amd.sst import pos_embed_table
     assert torch.equal(pos_embed_table((12, 12), 128), O.pos_embed_table((12, 12), 128))
+
+
+FT_CFG = "/root/reference/configs/pre_sst/m_sst_nus_second_pointpillar_fpn355_222_curv_07_ssl_data_wo_dbsampler_6x_1e-5.py"
+
+
+@pytest.mark.skipif(not os.path.exists(FT_CFG), reason="reference not mounted (GPU box)")
+def test_finetune_config_builds_and_takes_pretrained_encoder():
+    """N1: the fine-tune config resolves (detector, middle encoder, backbone, neck; the Anchor3DHead of its base config is
+    mmdet3d machinery outside this package and is skipped), and the pre-trained backbone.encoder_blocks.* keys load into it."""
+    cfg = Config.fromfile(FT_CFG)
+    m = dict(cfg.model)
+    assert m["type"] == "DynamicVoxelNet" and m["middle_encoder"]["type"] == "SSTInputLayer"
+    assert m["backbone"]["type"] == "SSTSecondPretrainedv1" and m["neck"]["type"] == "SECONDFPN"
+    m["bbox_head"] = None
+    model = geomae_amd.build_model(m)
+    assert len(model.backbone.encoder_blocks) == 6 and len(model.backbone.conv_blocks) == 3
+    pre = geomae_amd.build_model(mae_sst_model())
+    src = {k: v for k, v in pre.state_dict().items() if k.startswith("backbone.encoder_blocks.")}
+    missing = model.load_state_dict(src, strict=False)
+    assert not missing.unexpected_keys
+    assert not [k for k in missing.missing_keys if k.startswith("backbone.encoder_blocks.")]
+    a = pre.state_dict()["backbone.encoder_blocks.3.encoder_list.1.linear1.weight"]
+    assert torch.equal(model.state_dict()["backbone.encoder_blocks.3.encoder_list.1.linear1.weight"], a)
