@@ -53,7 +53,7 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 // lane) per matrix per 64 tokens, then each wave reads its A fragments with ds_read_b128.  Without this
 // every wave pulled the whole matrix through its own vector-memory pipe with 1-2 loads in flight (the
 // kernels ran at ~260 cycles per MFMA, profiles/r01b).  All waves of the block must call this together.
-// phase timing instrumentation (scratch/phase_timing.py builds a second library with -DGEOMAE_PHASE_TIMING;
+// phase timing instrumentation (tools/phase_timing.py builds a second library with -DGEOMAE_PHASE_TIMING;
 // a no-op in the product build)
 #ifdef GEOMAE_PHASE_TIMING
 #define GEOMAE_STAMP_SLOTS 32
@@ -69,7 +69,7 @@ static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_
 #endif
 
 // The copy is split in two so that a kernel can issue the global loads of the NEXT matrix (stage_issue) before
-// the elementwise phase that precedes its GEMM: phase timing (scratch/phase_timing.py) showed each GEMM waiting
+// the elementwise phase that precedes its GEMM: phase timing (tools/phase_timing.py) showed each GEMM waiting
 // ~2-3 k cycles for its weights and each elementwise phase waiting as long for its activation rows, with one
 // wave per SIMD and nothing else to run.
 template <int K, int N>

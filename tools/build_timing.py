@@ -1,9 +1,9 @@
-"""Build scratch/libgeomae_timing.so = the product sources with -DGEOMAE_PHASE_TIMING (clock64 stamps)."""
+"""Build tools/libgeomae_timing.so = the product sources with -DGEOMAE_PHASE_TIMING (clock64 stamps)."""
 import glob, os, subprocess, sys
 from concurrent.futures import ThreadPoolExecutor
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "geomae_amd", "csrc")
-OBJ = os.path.join(ROOT, "scratch", "build_timing")
+OBJ = os.path.join(ROOT, "tools", "build_timing")
 os.makedirs(OBJ, exist_ok=True)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-Wno-unused-result",
          "-DGEOMAE_PHASE_TIMING"]
@@ -14,6 +14,6 @@ for src in sorted(glob.glob(os.path.join(SRC, "*.hip"))):
     jobs.append(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", src, "-o", o])
 with ThreadPoolExecutor(8) as ex:
     list(ex.map(subprocess.check_call, jobs))
-out = os.path.join(ROOT, "scratch", "libgeomae_timing.so")
+out = os.path.join(ROOT, "tools", "libgeomae_timing.so")
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 print(out)

@@ -1,7 +1,7 @@
 import ctypes, sys, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from geomae_amd import _lib
-lib = _lib.load(path='/root/repo/scratch/libgeomae_timing.so')
+lib = _lib.load(path='/root/repo/tools/libgeomae_timing.so')
 from geomae_amd import ops
 import geomae_amd
 from geomae_amd.configs import mae_sst_model

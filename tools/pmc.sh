@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_pmc.sh <tag> "<counters>" <bench args...>  -- rocprofv3 PMC pass (kernel-trace only), aggregated per kernel
+# usage: tools/pmc.sh <tag> "<counters>" <bench args...>  -- rocprofv3 PMC pass (kernel-trace only), aggregated per kernel
 tag=$1; shift; ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag

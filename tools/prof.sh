@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_prof.sh <tag> <bench args...>   -- rocprofv3 kernel-trace stats of bench.py, summaries only
+# usage: tools/prof.sh <tag> <bench args...>   -- rocprofv3 kernel-trace stats of bench.py, summaries only
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_$tag

@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: tools_trace.sh <tag> <bench args...>   -- rocprofv3 per-dispatch kernel trace of bench.py (csv)
+# usage: tools/trace.sh <tag> <bench args...>   -- rocprofv3 per-dispatch kernel trace of bench.py (csv)
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/trace_$tag
