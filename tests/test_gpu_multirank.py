@@ -1,0 +1,111 @@
+"""World-size-2 run of the fused path on ONE GPU (two processes on cuda:0, gloo collectives): the code the driver
+launches at N = 2, 4, 8 with RCCL, checked for numerics here -- naiveSyncBN1d inside the fused VFE kernels
+(mmdet3d/ops/norm.py:54-86: equal weight per rank), the gradient all-reduce with the 1/world averaging folded into the
+fused AdamW pass, identical parameters on every rank after the step."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(rank):
+    from geomae_amd import synth
+    return [torch.as_tensor(synth.lidar_frame(300 + 10 * rank + i, beams=16, n_az=300 + 40 * rank), device="cuda:0")
+            for i in range(2)]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import copy
+        import geomae_amd
+        from geomae_amd.configs import mae_sst_model
+        from geomae_amd.train import Trainer
+        torch.cuda.set_device(0)
+        torch.manual_seed(7)                                   # same initial weights on both ranks
+        cfg = mae_sst_model(encoder_num_blocks=1, decoder_num_blocks=1)
+        cfg["backbone"]["compute_dtype"] = "bf16"
+        fused = geomae_amd.build_model(cfg).cuda().train()
+        composed = copy.deepcopy(fused)
+        composed.voxel_encoder.use_fused = False               # torch ops + the NaiveSyncBatchNorm1d module
+        pts = _frames(rank)
+
+        # ---- 1. fused VFE with cross-rank BatchNorm statistics vs the composed module path (fp32 both)
+        outs = []
+        for m in (fused, composed):
+            voxels, coors, _, _ = m.voxelize_all(pts)
+            from geomae_amd import ops
+            seg = ops.pillar_segment(coors, len(pts), m.grid_size)
+            vf, _ = m.voxel_encoder(voxels, coors, seg=seg)
+            w = torch.randn(vf.shape, generator=torch.Generator().manual_seed(rank)).cuda()
+            (vf * w).sum().backward()
+            outs.append((vf.detach().clone(), {k: p.grad.clone() for k, p in m.voxel_encoder.named_parameters()},
+                         {k: b.clone() for k, b in m.voxel_encoder.named_buffers() if "running" in k}))
+            for p in m.parameters():
+                p.grad = None
+        (vf_f, g_f, rb_f), (vf_c, g_c, rb_c) = outs
+        assert torch.allclose(vf_f, vf_c, rtol=1e-4, atol=2e-4), float((vf_f - vf_c).abs().max())
+        for k in g_f:
+            rel = float((g_f[k] - g_c[k]).norm() / g_c[k].norm().clamp(min=1e-12))
+            assert rel < 1e-2, (k, rel)          # dW1 is contracted from bf16 copies of dy1 and g (dw_kernel)
+        for k in rb_f:
+            assert torch.allclose(rb_f[k], rb_c[k], rtol=1e-5, atol=1e-6), k
+
+        # ---- 2. two full training steps: every rank ends with the same parameters, and they are what the composed
+        #         optimizer path (all-reduce + mul 1/world + clip + AdamW) produces from the same gradients
+        tr = Trainer(fused)
+        for _ in range(2):
+            losses, gnorm = tr.train_step(pts)
+        assert all(torch.isfinite(v) for v in losses.values()) and torch.isfinite(gnorm)
+        mine = tr.flat.flat.clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.equal(gathered[0], gathered[1])
+        gn = torch.stack([gnorm.detach().float().reshape(())]).cuda()
+        both = [torch.zeros_like(gn) for _ in range(world)]
+        dist.all_gather(both, gn)
+        assert torch.equal(both[0], both[1])                   # the clip coefficient is computed from the reduced gradient
+
+        # the composed optimizer path (all-reduce, * 1/world, clip, AdamW in torch ops) from the SAME local gradients
+        # (a second backward would differ in the last bits -- float atomics -- and Adam's first steps are sign-like)
+        from geomae_amd.train import FlatAdamW, FlatParams, allreduce_gradients, clip_grad_norm
+        def toy():
+            torch.manual_seed(11)
+            return torch.nn.Sequential(torch.nn.Linear(96, 200), torch.nn.LayerNorm(200), torch.nn.Linear(200, 33)).cuda()
+        fa, fb = FlatParams(toy(), no_decay_keys=("1.",)), FlatParams(toy(), no_decay_keys=("1.",))
+        oa, ob = FlatAdamW(fa, lr=1e-3), FlatAdamW(fb, lr=1e-3)
+        for step in range(3):
+            g = torch.randn(fa.grad.shape, generator=torch.Generator().manual_seed(50 + 10 * step + rank)).cuda() * (1 + step)
+            fa.grad.copy_(g)
+            fb.grad.copy_(g)
+            dist.all_reduce(fa.grad, op=dist.ReduceOp.SUM)
+            na = oa.fused_clip_step(10.0, 1.0 / world, zero_grad=True)
+            allreduce_gradients(fb)
+            nb = clip_grad_norm(fb, 10.0)
+            ob.step()
+            assert abs(float(na) - float(nb)) <= 2e-6 * float(nb)
+            assert torch.allclose(fa.flat, fb.flat, rtol=2e-6, atol=1e-8), float((fa.flat - fb.flat).abs().max())
+        torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_2_fused_path_on_one_gpu(tmp_path):
+    assert torch.cuda.is_available()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert all(os.path.exists(tmp_path / f"ok{r}.pt") for r in range(2))
