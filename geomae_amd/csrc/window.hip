@@ -178,6 +178,16 @@ __device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+// phase timing (tools/phase_timing_attn.py; a no-op in the product build)
+#ifdef GEOMAE_PHASE_TIMING
+static __device__ unsigned long long attn_stamps[512 * 16];
+#define ATTN_STAMP(i)                                                                                   \
+    do {                                                                                                \
+        if (threadIdx.x == 0 && blockIdx.x < 512) attn_stamps[blockIdx.x * 16 + (i)] = clock64();       \
+    } while (0)
+#else
+#define ATTN_STAMP(i) do {} while (0)
+#endif
 constexpr int kAttnBlk = 256;                           // 4 waves share one (bundle, head): query/key tiles round-robin
 constexpr int kStageIters = (kMaxT * 2 + kAttnBlk - 1) / kAttnBlk;   // 16-byte pieces per thread per [T,16] head slice (2)
 
@@ -239,6 +249,17 @@ __device__ __forceinline__ float dot8_bf16(const u32x4 a, const u32x4 b) {
 
 __device__ __forceinline__ bf16x4 lds4(const unsigned short* p) { return *reinterpret_cast<const bf16x4*>(p); }
 
+// B operand (k = 4 consecutive tokens row0 .. row0+3, n = channel c = lane & 15) of a token contraction, read
+// straight from a ROW-MAJOR [T][16] head slice with ds_read_b64_tr_b16: lane m of a 16-lane group points at row
+// row0 + (m >> 2), channel chunk 4 * (m & 3); it receives channel m of the four rows (lane mapping measured in
+// tools/microbench_ds_read_tr.hip).  Replaces the transposed LDS copies (Q^T, K^T, dO^T, V^T) that cost
+// 8 two-byte LDS stores per 16-byte piece.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__device__ __forceinline__ bf16x4 lds4_tr(const unsigned short* rm, int row0, int c) {
+    const unsigned short* p = rm + (row0 + (c >> 2)) * kDh + 4 * (c & 3);
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)p);
+}
+
 struct BundleCtx {
     int s0, T, nt, Tp;
 };
@@ -282,9 +303,9 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                                                           float* __restrict__ lse) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) unsigned short Vt[kDh * kMaxT];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Os[kMaxT * kDh];
-    __shared__ int toks[kMaxT], wid[kMaxT];
+    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
@@ -301,7 +322,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
             stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
             stage_store(rq, Tp, Qs, nullptr);
             stage_store(rk, Tp, Ks, nullptr);
-            stage_store(rv, Tp, nullptr, Vt);
+            stage_store(rv, Tp, Vs, nullptr);
         }
         __syncthreads();
         for (int it = wave; it < nt; it += kAttnBlk / 64) {
@@ -319,10 +340,11 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                     const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
                     f32x4 z = {0, 0, 0, 0};
                     st[jt] = mfma16(ka, qb, z);
+                    const int4 W4 = *reinterpret_cast<const int4*>(wid + jt * 16 + 4 * g);
+                    const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int j = jt * 16 + 4 * g + r;
-                        st[jt][r] = (wid[j] == wq) ? st[jt][r] * scale : -INFINITY;
+                        st[jt][r] = (Wr[r] == wq) ? st[jt][r] * scale : -INFINITY;
                         m = fmaxf(m, st[jt][r]);
                     }
                 }
@@ -349,7 +371,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                     bf16x4 pa;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pa[r] = (short)f2bf(st[jt][r]);
-                    const bf16x4 vb = lds4(Vt + c * Tp + jt * 16 + 4 * g);
+                    const bf16x4 vb = lds4_tr(Vs, jt * 16 + 4 * g, c);
                     o = mfma16(pa, vb, o);
                 }
             }
@@ -382,19 +404,21 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                                                           const int32_t* __restrict__ num_bundles, float scale,
                                                           unsigned short* __restrict__ dqkv) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
-        dOs[kMaxT * kDh], Qt[kDh * kMaxT], Kt[kDh * kMaxT], dOt[kDh * kMaxT];
+        dOs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short G1[kMaxT * kDh], G2[kMaxT * kDh];   // dQ, then dK / dV
-    __shared__ float Ls[kMaxT], Ds[kMaxT];
-    __shared__ int toks[kMaxT], wid[kMaxT];
+    __shared__ __attribute__((aligned(16))) float Ls[kMaxT], Ds[kMaxT];
+    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
     for (int bh = blockIdx.x; bh < NB * n_heads; bh += gridDim.x) {
+        ATTN_STAMP(0);
         const int b = bh / n_heads, h = bh - b * n_heads;
         const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
+        ATTN_STAMP(1);
         {
             u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters], rdo[kStageIters], ro[kStageIters];
             stage_load(qkv, 3 * C, h * kDh, toks, T, rq);
@@ -402,10 +426,10 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
             stage_load(dout, C, h * kDh, toks, T, rdo);
             stage_load(out, C, h * kDh, toks, T, ro);
-            stage_store(rq, Tp, Qs, Qt);
-            stage_store(rk, Tp, Ks, Kt);
+            stage_store(rq, Tp, Qs, nullptr);
+            stage_store(rk, Tp, Ks, nullptr);
             stage_store(rv, Tp, Vs, nullptr);
-            stage_store(rdo, Tp, dOs, dOt);
+            stage_store(rdo, Tp, dOs, nullptr);
             // delta_i = sum_d dO[i,d] * O[i,d] (two 8-wide halves per row, adjacent lanes) ; L_i
 #pragma unroll
             for (int k = 0; k < kStageIters; ++k) {
@@ -420,6 +444,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             }
         }
         __syncthreads();
+        ATTN_STAMP(2);
         // ---- pass 1: dQ.  S^T orientation: lane holds query i = it*16 + c, keys j = jt*16 + 4g + r
         for (int it = wave; it < nt; it += kAttnBlk / 64) {
             int jlo, jhi;
@@ -436,22 +461,25 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                 const f32x4 s = mfma16(ka, qb, z);       // [j][i]
                 const f32x4 dp = mfma16(va, dob, z);     // dP^T[j][i] = sum_d V[j,d] dO[i,d]
                 bf16x4 dsa;
+                const int4 W4 = *reinterpret_cast<const int4*>(wid + jt * 16 + 4 * g);
+                const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int j = jt * 16 + 4 * g + r;
-                    const float p = (wid[j] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
+                    const float p = (Wr[r] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
                     dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
                 }
                 // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
-                const bf16x4 kb = lds4(Kt + c * Tp + jt * 16 + 4 * g);
+                const bf16x4 kb = lds4_tr(Ks, jt * 16 + 4 * g, c);
                 dq = mfma16(dsa, kb, dq);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) G1[(it * 16 + 4 * g + r) * kDh + c] = f2bf(dq[r]);
         }
         __syncthreads();
+        ATTN_STAMP(3);
         unstage_store(G1, dqkv, 3 * C, h * kDh, toks, T);
         __syncthreads();
+        ATTN_STAMP(4);
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
         for (int jt = wave; jt < nt; jt += kAttnBlk / 64) {
             int ilo, ihi;
@@ -467,18 +495,22 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                 const f32x4 s = mfma16(qa, kb, z);       // [i][j]
                 const f32x4 dp = mfma16(doa, vb, z);     // dP[i][j]
                 bf16x4 pa, dsa;
+                const int i0 = it * 16 + 4 * g;                       // 4 consecutive queries: one 16-byte LDS read each
+                const float4 L4 = *reinterpret_cast<const float4*>(Ls + i0), D4 = *reinterpret_cast<const float4*>(Ds + i0);
+                const int4 W4 = *reinterpret_cast<const int4*>(wid + i0);
+                const float Lr[4] = {L4.x, L4.y, L4.z, L4.w}, Dr[4] = {D4.x, D4.y, D4.z, D4.w};
+                const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int i = it * 16 + 4 * g + r;
-                    const float p = (wid[i] == wk) ? __expf(s[r] * scale - Ls[i]) : 0.0f;
+                    const float p = (Wr[r] == wk) ? __expf(s[r] * scale - Lr[r]) : 0.0f;
                     pa[r] = (short)f2bf(p);
-                    dsa[r] = (short)f2bf(p * (dp[r] - Ds[i]) * scale);
+                    dsa[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
                 }
                 // dV[j][d] += sum_i P[i][j] dO[i][d] : A = P^T (row j = c, k = i), B = dO[k=i][col=d] from dO^T
-                const bf16x4 dob = lds4(dOt + c * Tp + it * 16 + 4 * g);
+                const bf16x4 dob = lds4_tr(dOs, it * 16 + 4 * g, c);
                 dv = mfma16(pa, dob, dv);
                 // dK[j][d] += sum_i dS[i][j] Q[i][d]
-                const bf16x4 qb = lds4(Qt + c * Tp + it * 16 + 4 * g);
+                const bf16x4 qb = lds4_tr(Qs, it * 16 + 4 * g, c);
                 dk = mfma16(dsa, qb, dk);
             }
 #pragma unroll
@@ -488,9 +520,11 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             }
         }
         __syncthreads();
+        ATTN_STAMP(5);
         unstage_store(G1, dqkv, 3 * C, C + h * kDh, toks, T);
         unstage_store(G2, dqkv, 3 * C, 2 * C + h * kDh, toks, T);
         __syncthreads();
+        ATTN_STAMP(6);
     }
 }
 
@@ -543,6 +577,16 @@ __global__ __launch_bounds__(256) void bev_gather_kernel(const float* __restrict
 }  // namespace geomae
 
 using namespace geomae;
+
+#ifdef GEOMAE_PHASE_TIMING
+extern "C" int geomae_debug_read_attn_stamps(unsigned long long* host) {
+    hipDeviceSynchronize();
+    static unsigned long long zeros[512 * 16];
+    hipMemcpyFromSymbol(host, HIP_SYMBOL(attn_stamps), sizeof(zeros));
+    hipMemcpyToSymbol(HIP_SYMBOL(attn_stamps), zeros, sizeof(zeros));
+    return 0;
+}
+#endif
 
 static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, int* slots_per_sample) {
     GEOMAE_REQUIRE(cfg, "window: null config");
