@@ -155,17 +155,20 @@ def main():
                     sq += [float((nw * nw).sum())] * (layers // 2)
                     n_tok += [int(toks.shape[0])] * (layers // 2)
         n_sum, sq_sum = float(np.sum(n_tok)), float(np.sum(sq))          # over the 20 layers of one step
-        # The weight-gradient contraction of every layer but the last of a stack (12-layer encoder, two 4-layer
-        # decoders) rides inside the NEXT layer's ffn-backward launch (sst_ffn_bwd_dw_kernel): 17 of the 20
-        # ffn-backward launches carry one, 3 stand-alone dw_kernel launches remain per step.
+        # Fusion structure of a stack of L layers (12-layer encoder, two 4-layer decoders; csrc/sst_stack.hip):
+        #   forward : F1(0) | attn | F3(l)+F1(l+1) ... | F3(L-1)             -> 17 of 20 ffn-forward launches carry an F1
+        #   backward: B3(L-1) | battn | B1(l+1)+B3(l) [+ dW(l+1)] ... | B1(0) | dW(0)
+        #                                                                     -> 17 of 20 ffn-backward launches carry B1 + dW
+        # 3 stand-alone F1 / B1 / dW launches remain per step (one per stack).
         n_e, n_d = float(n_tok[0]), float(n_tok[-1])
-        dw_fused, dw_alone = 2 * 131072 * (11 * n_e + 6 * n_d), 2 * 131072 * (n_e + 2 * n_d)
-        flops_step = {"sst_ffn_bwd_kernel": 2 * 81920 * n_sum + dw_fused, "sst_ffn_fwd_kernel": 2 * 81920 * n_sum,
-                      "sst_qkv_fwd_kernel": 2 * 49152 * n_sum, "sst_qkv_bwd_kernel": 2 * 49152 * n_sum,
-                      "dw_kernel": dw_alone, "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum,
+        carried, alone = 11 * n_e + 6 * n_d, n_e + 2 * n_d
+        flops_step = {"sst_ffn_bwd_kernel": 2 * 81920 * n_sum + 2 * (49152 + 131072) * carried,
+                      "sst_ffn_fwd_kernel": 2 * 81920 * n_sum + 2 * 49152 * carried,
+                      "sst_qkv_fwd_kernel": 2 * 49152 * alone, "sst_qkv_bwd_kernel": 2 * 49152 * alone,
+                      "dw_kernel": 2 * 131072 * alone, "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum,
                       "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum}
         launches_step = {k: 20.0 for k in flops_step}
-        launches_step["dw_kernel"] = 3.0
+        launches_step.update({"dw_kernel": 3.0, "sst_qkv_fwd_kernel": 3.0, "sst_qkv_bwd_kernel": 3.0})
         report_name = {"sst_ffn_bwd_kernel": "sst_ffn_bwd_dw_kernel"}
         peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         traffic = {}

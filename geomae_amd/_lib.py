@@ -126,11 +126,13 @@ SIGNATURES = {
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
     "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_heads_weight_grad": (ctypes.c_int, [c_int32, P, P, P, POINTER(GeomaeHeadGrads), P]),
-    "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
+    "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
     "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),
+    "geomae_sst_ffn_qkv_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P,
+                                                  POINTER(GeomaeSstLayerWeights), P, P, P, P, P, P]),
     "geomae_sst_ffn_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P,
-                                               P, P, P, POINTER(GeomaeSstLayerGrads), P]),
-    "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
+                                               P, P, P, POINTER(GeomaeSstLayerGrads), P, P, POINTER(GeomaeSstLayerWeights), P]),
+    "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
     "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
     "geomae_sst_stack_saved_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "geomae_sst_stack_scratch_bytes": (c_int64, [c_int32]),

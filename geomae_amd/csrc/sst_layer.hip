@@ -65,7 +65,8 @@ struct LayerW {
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* __restrict__ x,
                                                                 const int32_t* __restrict__ tok_pos,
                                                                 const float* __restrict__ pos_table, LayerW W,
-                                                                int n, bf16_t* __restrict__ qkv) {
+                                                                int n, bf16_t* __restrict__ qkv,
+                                                                bf16_t* __restrict__ x_b, bf16_t* __restrict__ xp_b) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
@@ -84,6 +85,10 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
         const float4 pv = *reinterpret_cast<const float4*>(pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
         xb[ct] = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
         xpb[ct] = make_uint2(pack2(xv.x + pv.x, xv.y + pv.y), pack2(xv.z + pv.z, xv.w + pv.w));
+        if (x_b && valid) {          // the bf16 operands of this layer's weight-gradient contraction (dW_qk, dW_v)
+            *reinterpret_cast<uint2*>(x_b + tok * 128 + 16 * ct + 4 * g) = xb[ct];
+            *reinterpret_cast<uint2*>(xp_b + tok * 128 + 16 * ct + 4 * g) = xpb[ct];
+        }
     }
     {
         f32x4 acc[16];
@@ -105,13 +110,26 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
 // needs instead of recomputing three GEMMs there: the two normalised residuals (fp32), the FFN
 // pre-activation (bf16) and the two 1/sigma per token.
 // ------------------------------------------------------------------------------------------------
+// Vertical fusion: when `N.wqkv` is set the kernel continues with F1 of the NEXT layer on the z it still holds in
+// registers (q/k/v projection with the next layer's positional term) -- a 10 us kernel at encoder size whose
+// duration is launch ramp + first-load latency + store drain rather than work (a weight-stationary rewrite of F1
+// that cut its LDS traffic 6x did not get under that floor), so merging it removes one such floor per layer.
+struct NextQkv {
+    const bf16_t* wqkv;           // packed [384][128] of the next layer, or nullptr
+    const float* bqkv;
+    const int32_t* tok_pos;       // the next layer's window layout (the shift alternates)
+    const float* pos_table;
+    bf16_t* qkv;                  // [n, 384] of the next layer
+    bf16_t *x_b, *xp_b;           // bf16 copies of z and z + pos (weight-gradient operands of the next layer), or null
+};
+
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* __restrict__ x,
                                                                 const bf16_t* __restrict__ attn, LayerW W, int n,
                                                                 float eps, float* __restrict__ z,
                                                                 float* __restrict__ xh1_out,
                                                                 float* __restrict__ xh2_out,
                                                                 bf16_t* __restrict__ hp_out,
-                                                                float* __restrict__ rstd_out) {
+                                                                float* __restrict__ rstd_out, NextQkv N) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
@@ -155,6 +173,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     }
     load_bias<128>(W.b2, u, lane);
     gemm_staged<256, 128>(s_w2, smem, hb, u, lane);
+    const bool has_next = N.wqkv != nullptr;
+    WStage<128, 256> s_qk;
+    if (has_next) stage_issue<128, 256>(N.wqkv, s_qk);                // lands under the LayerNorm arithmetic
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
     layer_norm_t(u, eps, &r2);
@@ -165,6 +186,37 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     }
     affine_t(u, W.g2, W.be2, y, lane);
     store_rows_f32<128>(z, tok, valid, y, lane);
+    if (!has_next) return;
+    // ---- F1 of the next layer on z = y (registers)
+    const int g = lane >> 4;
+    const int64_t tc = valid ? tok : n - 1;
+    const int p = N.tok_pos[tc];
+    uint2 xb[8], xpb[8];
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        const float4 pv = *reinterpret_cast<const float4*>(N.pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
+        xb[ct] = pack4(y[ct]);
+        const f32x4 xp = {y[ct][0] + pv.x, y[ct][1] + pv.y, y[ct][2] + pv.z, y[ct][3] + pv.w};
+        xpb[ct] = pack4(xp);
+        if (N.x_b && valid) {
+            *reinterpret_cast<uint2*>(N.x_b + tok * 128 + 16 * ct + 4 * g) = xb[ct];
+            *reinterpret_cast<uint2*>(N.xp_b + tok * 128 + 16 * ct + 4 * g) = xpb[ct];
+        }
+    }
+    WStage<128, 128> s_v;
+    {
+        f32x4 acc[16];
+        load_bias<256>(N.bqkv, acc, lane);
+        gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
+        stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
+        store_rows_bf16<256>(N.qkv, tok, 384, 0, valid, acc, lane);
+    }
+    {
+        f32x4 acc[8];
+        load_bias<128>(N.bqkv + 256, acc, lane);
+        gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
+        store_rows_bf16<128>(N.qkv, tok, 384, 256, valid, acc, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -182,7 +234,35 @@ struct FfnBwdArgs {
     float* dx_res;
     bf16_t *dattn, *du_b, *dv_b, *dhp_b, *y_b, *h_b;
     float *dg1, *dbe1, *dg2, *dbe2;
+    // optional head: B1 of the layer ABOVE (l+1) -- its dx is this layer's dz and stays in registers
+    const bf16_t* up_dqkv;            // [n,384] or nullptr (then dz is read from memory)
+    const float* up_dx_res;           // [n,128]
+    const bf16_t *up_wqkT, *up_wvT;   // packed transposed in-projection of layer l+1
 };
+
+// B1 arithmetic: acc = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv
+__device__ __forceinline__ void qkv_bwd_rows(const bf16_t* __restrict__ dqkv, const float* __restrict__ dx_res,
+                                             const bf16_t* __restrict__ wqkT, const bf16_t* __restrict__ wvT, int64_t tok,
+                                             bool valid, bf16_t* __restrict__ smem, f32x4 (&acc)[8], int lane) {
+    const int g = lane >> 4;
+    WStage<256, 128> s_qk;
+    WStage<128, 128> s_v;
+    stage_issue<256, 128>(wqkT, s_qk);
+    load_rows_f32<128>(dx_res, tok, valid, acc, lane);
+    uint2 dv_rows[8];
+    {
+        uint2 d[16];
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct)
+            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)                                // operand of the second GEMM: in flight under the first
+            dv_rows[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+        stage_issue<128, 128>(wvT, s_v);
+        gemm_staged<256, 128>(s_qk, smem, d, acc, lane);
+    }
+    gemm_staged<128, 128>(s_v, smem, dv_rows, acc, lane);
+}
 
 __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf16_t* __restrict__ smem,
                                              float (*red)[4][128] /* [wave][tensor][channel] */) {
@@ -202,7 +282,8 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     GEOMAE_STAMP(0);
     const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
     f32x4 dv[8];
-    load_rows_f32<128>(dz, tok, valid, dv, lane);
+    if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, tok, valid, smem, dv, lane);
+    else load_rows_f32<128>(dz, tok, valid, dv, lane);
     WStage<128, 256> s_w2T;
     // ---- LN2 backward
     {
@@ -317,52 +398,21 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// B1: dx = dx_res + dqk Wqk + dv Wv   (+ bf16 copies of x + pos and x for the weight-gradient GEMMs)
+// B1: dx = dx_res + dqk Wqk + dv Wv.  Stand-alone only for the first layer of a stack; for every other layer it is
+// the head of the ffn-backward kernel of the layer below (FfnBwdArgs.up_*).  The bf16 copies of x and x + pos that
+// the weight-gradient contraction needs are written by the forward (F1), not here.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kLayerBlk) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
-                                                                const float* __restrict__ dx_res,
-                                                                const float* __restrict__ x,
-                                                                const int32_t* __restrict__ tok_pos,
-                                                                const float* __restrict__ pos_table, LayerW W, int n,
-                                                                float* __restrict__ dx, bf16_t* __restrict__ xp_b,
-                                                                bf16_t* __restrict__ x_b) {
+__global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
+                                                                const float* __restrict__ dx_res, LayerW W, int n,
+                                                                float* __restrict__ dx) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    const int g = lane >> 4;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
-    const int64_t tc = valid ? tok : n - 1;
     f32x4 acc[8];
-    WStage<256, 128> s_qk;
-    WStage<128, 128> s_v;
-    stage_issue<256, 128>(W.wqkT, s_qk);
-    load_rows_f32<128>(dx_res, tok, valid, acc, lane);
-    uint2 dv_rows[8];
-    {
-        uint2 d[16];
-#pragma unroll
-        for (int ct = 0; ct < 16; ++ct)
-            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)                                // operand of the second GEMM: in flight under the first
-            dv_rows[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-        stage_issue<128, 128>(W.wvT, s_v);
-        gemm_staged<256, 128>(s_qk, smem, d, acc, lane);
-    }
-    gemm_staged<128, 128>(s_v, smem, dv_rows, acc, lane);
+    qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, tok, valid, smem, acc, lane);
     store_rows_f32<128>(dx, tok, valid, acc, lane);
-    if (valid) {
-        const int p = tok_pos[tc];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const float4 xv = *reinterpret_cast<const float4*>(x + tc * 128 + 16 * ct + 4 * g);
-            const float4 pv = *reinterpret_cast<const float4*>(pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
-            *reinterpret_cast<uint2*>(x_b + tok * 128 + 16 * ct + 4 * g) = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
-            *reinterpret_cast<uint2*>(xp_b + tok * 128 + 16 * ct + 4 * g) =
-                make_uint2(pack2(xv.x + pv.x, xv.y + pv.y), pack2(xv.z + pv.z, xv.w + pv.w));
-        }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -563,47 +613,73 @@ extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc
 
 extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, void* qkv_bf16,
-                                      hipStream_t stream) {
+                                      void* x_bf16, void* xp_bf16, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_qkv_forward");
     if (rc) return rc;
     GEOMAE_REQUIRE(x && tok_pos && pos_table && qkv_bf16, "sst_qkv_forward: null argument");
+    GEOMAE_REQUIRE((x_bf16 == nullptr) == (xp_bf16 == nullptr), "sst_qkv_forward: pass both operand copies or none");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_qkv_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x, tok_pos,
-                       pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16);
+                       pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16, (bf16_t*)x_bf16, (bf16_t*)xp_bf16);
     return check_launch("sst_qkv_fwd_kernel");
 }
 
-extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
-                                      int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
-                                      float* rstd, hipStream_t stream) {
+extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
+                                          int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
+                                          float* rstd, const GeomaeSstLayerWeights* next_w, const int32_t* next_tok_pos,
+                                          const float* pos_table, void* next_qkv_bf16, void* next_x_bf16,
+                                          void* next_xp_bf16, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_forward");
     if (rc) return rc;
     GEOMAE_REQUIRE(x && attn_bf16 && z, "sst_ffn_forward: null argument");
     const bool save = xhat1 || xhat2 || hp_bf16 || rstd;
     GEOMAE_REQUIRE(!save || (xhat1 && xhat2 && hp_bf16 && rstd), "sst_ffn_forward: pass all four save buffers or none");
+    NextQkv N = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (next_w) {
+        if ((rc = check_weights(next_w, "sst_ffn_qkv_forward"))) return rc;
+        GEOMAE_REQUIRE(next_tok_pos && pos_table && next_qkv_bf16, "sst_ffn_qkv_forward: null argument for the next layer");
+        GEOMAE_REQUIRE((next_x_bf16 == nullptr) == (next_xp_bf16 == nullptr), "sst_ffn_qkv_forward: pass both operand copies or none");
+        N = NextQkv{(const bf16_t*)next_w->wqkv_p, next_w->bqkv, next_tok_pos, pos_table, (bf16_t*)next_qkv_bf16,
+                    (bf16_t*)next_x_bf16, (bf16_t*)next_xp_bf16};
+    }
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
                        (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
-                       (bf16_t*)hp_bf16, rstd);
+                       (bf16_t*)hp_bf16, rstd, N);
     return check_launch("sst_ffn_fwd_kernel");
+}
+
+extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
+                                      int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
+                                      float* rstd, hipStream_t stream) {
+    return geomae_sst_ffn_qkv_forward(x, attn_bf16, w, num_tokens, z, xhat1, xhat2, hp_bf16, rstd, nullptr, nullptr, nullptr,
+                                      nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, const void* hp_bf16,
                                        const float* rstd, const float* dz, const GeomaeSstLayerWeights* w,
                                        int32_t num_tokens, float* dx_res, void* dattn_bf16, void* du_bf16,
                                        void* dv_bf16, void* dhp_bf16, void* y_bf16, void* h_bf16,
-                                       const GeomaeSstLayerGrads* grads, hipStream_t stream) {
+                                       const GeomaeSstLayerGrads* grads, const void* up_dqkv_bf16, const float* up_dx_res,
+                                       const GeomaeSstLayerWeights* up_w, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_backward");
     if (rc) return rc;
-    GEOMAE_REQUIRE(xhat1 && xhat2 && hp_bf16 && rstd && dz && dx_res && dattn_bf16 && du_bf16 && dv_bf16 &&
-                   dhp_bf16 && y_bf16 && h_bf16, "sst_ffn_backward: null argument");
+    GEOMAE_REQUIRE(xhat1 && xhat2 && hp_bf16 && rstd && dx_res && dattn_bf16 && du_bf16 && dv_bf16 && dhp_bf16 && y_bf16 &&
+                   h_bf16, "sst_ffn_backward: null argument");
+    GEOMAE_REQUIRE((dz != nullptr) != (up_dqkv_bf16 != nullptr), "sst_ffn_backward: pass dz OR the upper layer's dqkv");
+    if (up_dqkv_bf16) {
+        GEOMAE_REQUIRE(up_dx_res && up_w, "sst_ffn_backward: the fused B1 head needs up_dx_res and up_w");
+        if ((rc = check_weights(up_w, "sst_ffn_backward(up)"))) return rc;
+    }
     GEOMAE_REQUIRE(grads && grads->ln1_w && grads->ln1_b && grads->ln2_w && grads->ln2_b, "sst_ffn_backward: null grads");
     const FfnBwdArgs A = {xhat1, xhat2, (const bf16_t*)hp_bf16, rstd, dz, to_layer(w), num_tokens, dx_res,
                           (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
-                          (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b};
+                          (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b,
+                          (const bf16_t*)up_dqkv_bf16, up_dx_res, up_w ? (const bf16_t*)up_w->wqkT_p : nullptr,
+                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr};
     const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
     if (!g_pending_dw.active) {
         hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);
@@ -619,19 +695,15 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     return check_launch("sst_ffn_bwd_dw_kernel");
 }
 
-extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
-                                       const int32_t* tok_pos, const float* pos_table,
-                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, float* dx, void* xp_bf16,
-                                       void* x_bf16, hipStream_t stream) {
+extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const GeomaeSstLayerWeights* w,
+                                       int32_t num_tokens, float* dx, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_qkv_backward");
     if (rc) return rc;
-    GEOMAE_REQUIRE(dqkv_bf16 && dx_res && x && tok_pos && pos_table && dx && xp_bf16 && x_bf16,
-                   "sst_qkv_backward: null argument");
+    GEOMAE_REQUIRE(dqkv_bf16 && dx_res && dx, "sst_qkv_backward: null argument");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,
-                       (const bf16_t*)dqkv_bf16, dx_res, x, tok_pos, pos_table, to_layer(w), num_tokens, dx,
-                       (bf16_t*)xp_bf16, (bf16_t*)x_bf16);
+                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx);
     return check_launch("sst_qkv_bwd_kernel");
 }
 

@@ -9,9 +9,15 @@
 //
 // saved   (kept from forward to backward), per layer, 256-byte aligned pieces:
 //           x_in f32 [n,128] | qkv bf16 [n,384] | attn bf16 [n,128] | lse f32 [n,H] |
-//           xhat1 f32 [n,128] | xhat2 f32 [n,128] | hp bf16 [n,256] | rstd f32 [n,2]
-// scratch (backward only, reused by every layer): dx_res f32 [n,128] | dx ping-pong f32 2x[n,128] |
-//           bf16 slabs dattn, du, dv, y, xp, xb [n,128] each, dhp, h [n,256] each, dqkv [n,384]
+//           xhat1 f32 [n,128] | xhat2 f32 [n,128] | hp bf16 [n,256] | rstd f32 [n,2] | xb, xp bf16 [n,128] each
+// scratch (backward only, reused by every layer): dx_res f32 [n,128] | dattn bf16 [n,128] |
+//           two sets of bf16 slabs du, dv, y [n,128] each, dhp, h [n,256] each, dqkv [n,384]
+//
+// Kernel chain (vertical fusion: every ~10-50 us kernel of a small stack pays a fixed launch-ramp / first-load /
+// store-drain floor, so the two projection kernels ride on their neighbours):
+//   forward :  F1(0) | attn(0) | F3(0)+F1(1) | attn(1) | F3(1)+F1(2) | ... | F3(L-1)
+//   backward:  B3(L-1) | battn(L-1) | B1(L-1)+B3(L-2) [+ dW(L-1)] | battn(L-2) | ... | B1(1)+B3(0) [+ dW(1)] | battn(0) |
+//              B1(0) | dW(0)
 #include "common.h"
 #include "../../include/geomae_hip.h"
 #include <vector>
@@ -27,7 +33,7 @@ namespace geomae {
 static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 
 struct SavedOffsets {
-    int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, stride;
+    int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
 };
 static SavedOffsets saved_offsets(int64_t n, int heads) {
     SavedOffsets o;
@@ -40,30 +46,28 @@ static SavedOffsets saved_offsets(int64_t n, int heads) {
     o.xh2 = p;  p += al256(n * 128 * 4);
     o.hp = p;   p += al256(n * 256 * 2);
     o.rstd = p; p += al256(n * 2 * 4);
+    o.xb = p;   p += al256(n * 128 * 2);
+    o.xp = p;   p += al256(n * 128 * 2);
     o.stride = p;
     return o;
 }
 
 struct ScratchOffsets {
-    int64_t dx_res, dxa, dxb, dattn;
+    int64_t dx_res, dattn;
     int64_t set0;                               // first of two identical slab sets read by the weight-gradient kernel
-    int64_t du, dv, y, xp, xb, dhp, h, dqkv;    // offsets inside a set
+    int64_t du, dv, y, dhp, h, dqkv;            // offsets inside a set
     int64_t set_bytes, total;
 };
 static ScratchOffsets scratch_offsets(int64_t n) {
     ScratchOffsets o;
     int64_t p = 0;
     o.dx_res = p; p += al256(n * 128 * 4);
-    o.dxa = p;    p += al256(n * 128 * 4);
-    o.dxb = p;    p += al256(n * 128 * 4);
     o.dattn = p;  p += al256(n * 128 * 2);
     o.set0 = p;
     int64_t q = 0;
     o.du = q;     q += al256(n * 128 * 2);
     o.dv = q;     q += al256(n * 128 * 2);
     o.y = q;      q += al256(n * 128 * 2);
-    o.xp = q;     q += al256(n * 128 * 2);
-    o.xb = q;     q += al256(n * 128 * 2);
     o.dhp = q;    q += al256(n * 256 * 2);
     o.h = q;      q += al256(n * 256 * 2);
     o.dqkv = q;   q += al256(n * 384 * 2);
@@ -147,14 +151,17 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     }
     char* base = (char*)saved;
     GEOMAE_HIP(hipMemcpyAsync(base + so.x, x_in, (size_t)num_tokens * 128 * 4, hipMemcpyDeviceToDevice, stream));
+    // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
     for (int l = 0; l < num_layers; ++l) {
         char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
         const float* x = (const float*)(sv + so.x);
         float* z = (l + 1 < num_layers) ? (float*)(sv + so.stride + so.x) : z_out;
-        {
+        if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_FWD, stream);
-            if ((rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, stream))) return rc;
+            if ((rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, sv + so.xb,
+                                             sv + so.xp, stream)))
+                return rc;
         }
         {
             Timed t(profiler, GEOMAE_KERNEL_ATTN_FWD, stream);
@@ -165,8 +172,13 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         }
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
-            if ((rc = geomae_sst_ffn_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
-                                             (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd), stream)))
+            const bool next = l + 1 < num_layers;
+            if ((rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
+                                                 (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd),
+                                                 next ? &layers[l + 1] : nullptr, next ? layouts[(l + 1) & 1].tok_pos : nullptr,
+                                                 pos_table, next ? sv + so.stride + so.qkv : nullptr,
+                                                 next ? sv + so.stride + so.xb : nullptr, next ? sv + so.stride + so.xp : nullptr,
+                                                 stream)))
                 return rc;
         }
     }
@@ -204,23 +216,25 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         }
     const char* base = (const char*)saved;
     char* w = (char*)scratch;
-    const float* dcur = dz;
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
         const int set = l & 1;
         char* ws = w + sc.set0 + set * sc.set_bytes;
-        float* dnext = (l == 0) ? dx_out : (float*)(w + ((l & 1) ? sc.dxa : sc.dxb));
+        const bool top = l + 1 == num_layers;
+        const char* ws_up = w + sc.set0 + ((l + 1) & 1) * sc.set_bytes;       // slabs of the layer above
         if (overlap && done_pending[set]) {            // slab set still being read by the dw of layer l+2
             GEOMAE_HIP(hipStreamWaitEvent(stream, done[set], 0));
             done_pending[set] = false;
         }
         {
+            // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
             rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
-                                         (const float*)(sv + so.rstd), dcur, &layers[l], num_tokens,
+                                         (const float*)(sv + so.rstd), top ? dz : nullptr, &layers[l], num_tokens,
                                          (float*)(w + sc.dx_res), w + sc.dattn, ws + sc.du, ws + sc.dv, ws + sc.dhp,
-                                         ws + sc.y, ws + sc.h, &grads[l], stream);
+                                         ws + sc.y, ws + sc.h, &grads[l], top ? nullptr : ws_up + sc.dqkv,
+                                         top ? nullptr : (const float*)(w + sc.dx_res), top ? nullptr : &layers[l + 1], stream);
         }
         if (rc) break;
         {
@@ -231,12 +245,11 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
                                                   max_window_tokens, ws + sc.dqkv, stream);
         }
         if (rc) break;
-        {
+        if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_BWD, stream);
-            rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), (const float*)(sv + so.x), L.tok_pos,
-                                         pos_table, &layers[l], num_tokens, dnext, ws + sc.xp, ws + sc.xb, stream);
+            rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), &layers[0], num_tokens, dx_out, stream);
+            if (rc) break;
         }
-        if (rc) break;
         hipStream_t ds = stream;
         if (overlap) {
             GEOMAE_HIP(hipEventRecord(ready[set], stream));
@@ -245,18 +258,17 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         }
         if (fuse && l > 0) {
             defer_next_weight_grad();
-            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, ws + sc.xp, ws + sc.xb, ws + sc.du, sv + so.attn,
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
         } else {
             Timed t(profiler, GEOMAE_KERNEL_DW, ds);
-            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, ws + sc.xp, ws + sc.xb, ws + sc.du, sv + so.attn,
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
         }
         if (overlap && rc == GEOMAE_OK) {
             GEOMAE_HIP(hipEventRecord(done[set], side_stream));
             done_pending[set] = true;
         }
-        dcur = dnext;
     }
     if (flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK) rc = GEOMAE_ERR_HIP;   // error paths only
     if (overlap) {

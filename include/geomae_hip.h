@@ -190,28 +190,39 @@ typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into 
 int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
                         void* packed_bf16, float* aux_f32 /* target of transpose==2 rows: plain fp32 gather */,
                         geomaeStream_t stream);
-/* qkv [n,384] bf16 = [(x + pos_table[tok_pos]) Wqk^T + b | x Wv^T + b];  x [n,128] fp32 */
+/* qkv [n,384] bf16 = [(x + pos_table[tok_pos]) Wqk^T + b | x Wv^T + b];  x [n,128] fp32.  For training also pass
+ * x_bf16, xp_bf16 [n,128]: bf16(x) and bf16(x + pos), the operands of this layer's dW_v / dW_qk contraction
+ * (geomae_sst_weight_grad); both NULL for inference. */
 int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                            const GeomaeSstLayerWeights* w /*host*/, int32_t num_tokens, void* qkv_bf16,
-                           geomaeStream_t stream);
+                           void* x_bf16, void* xp_bf16, geomaeStream_t stream);
 /* z = LN2(y + W2 gelu(W1 y + b1) + b2), y = LN1(x + attn Wo^T + bo);  attn [n,128] bf16, z [n,128] fp32.
  * For training pass the four save buffers (else all NULL): xhat1, xhat2 [n,128] f32 (normalised residuals),
  * hp [n,256] bf16 (FFN pre-activation), rstd [n,2] f32. */
 int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
                            int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16,
                            float* rstd, geomaeStream_t stream);
+/* the same, followed -- when next_w != NULL -- by geomae_sst_qkv_forward of the NEXT layer on the z still held in
+ * registers (next_tok_pos: window layout of that layer; next_qkv_bf16 [n,384]): one launch instead of two */
+int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16, const GeomaeSstLayerWeights* w,
+                               int32_t num_tokens, float* z, float* xhat1, float* xhat2, void* hp_bf16, float* rstd,
+                               const GeomaeSstLayerWeights* next_w, const int32_t* next_tok_pos, const float* pos_table,
+                               void* next_qkv_bf16, void* next_x_bf16, void* next_xp_bf16, geomaeStream_t stream);
 /* backward of geomae_sst_ffn_forward from its saved tensors: dx_res [n,128] f32, dattn [n,128] bf16, and the
  * bf16 operands of the weight-gradient GEMMs du,dv,y [n,128], dhp,h [n,256]; LayerNorm parameter
- * gradients are accumulated into grads->ln*. */
+ * gradients are accumulated into grads->ln*.  The incoming gradient is either dz [n,128] (then up_* are NULL) or
+ * -- vertical fusion -- computed in the same launch as geomae_sst_qkv_backward of the layer ABOVE:
+ * dz = up_dx_res + up_dqkv[:, :256] Wqk(up_w) + up_dqkv[:, 256:] Wv(up_w), never written to memory (dz NULL).
+ * up_dx_res may alias dx_res (every wave reads its rows before it writes them). */
 int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, const void* hp_bf16, const float* rstd,
                             const float* dz, const GeomaeSstLayerWeights* w, int32_t num_tokens,
                             float* dx_res, void* dattn_bf16, void* du_bf16, void* dv_bf16, void* dhp_bf16,
                             void* y_bf16, void* h_bf16, const GeomaeSstLayerGrads* grads,
+                            const void* up_dqkv_bf16, const float* up_dx_res, const GeomaeSstLayerWeights* up_w,
                             geomaeStream_t stream);
-/* dx = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv;  also xp = bf16(x + pos), xb = bf16(x) */
-int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const float* x,
-                            const int32_t* tok_pos, const float* pos_table, const GeomaeSstLayerWeights* w,
-                            int32_t num_tokens, float* dx, void* xp_bf16, void* x_bf16, geomaeStream_t stream);
+/* dx = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv (stand-alone: the first layer of a stack) */
+int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_res, const GeomaeSstLayerWeights* w,
+                            int32_t num_tokens, float* dx, geomaeStream_t stream);
 /* all weight + bias gradients of the layer (token contractions), accumulated into grads */
 int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16, const void* xp_bf16, const void* x_bf16,
                            const void* du_bf16, const void* attn_bf16, const void* dhp_bf16, const void* y_bf16,
