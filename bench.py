@@ -60,11 +60,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    # GEOMAE_BENCH_SHARE_GPU=1 (test hook): every rank on cuda:0 with gloo collectives, to exercise the N > 1 code
+    # path on a one-GPU box; the driver's multi-GPU runs use one GPU per rank and RCCL ("nccl")
+    share = os.environ.get("GEOMAE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
 
     import geomae_amd
@@ -133,7 +141,7 @@ def main():
             for i in range(3):
                 step(i)
             durations[k] = profile_off()
-    loss_val = float(sum(losses.values()))
+    loss_val = float(sum(v.detach() for v in losses.values()))
     assert np.isfinite(loss_val), "non-finite loss"
 
     if rank == 0:

@@ -189,8 +189,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
                                          const GeomaeSstLayerGrads* grads, int32_t num_layers,
                                          const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                                          int32_t max_window_tokens, const void* saved, void* scratch,
-                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream,
-                                         hipStream_t side_stream) {
+                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -201,19 +200,10 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         set_error("sst_stack_backward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)sc.total);
         return GEOMAE_ERR_WORKSPACE;
     }
-    // The weight-gradient kernel of layer l only feeds .grad, so it runs on `side_stream` (if given) under the
-    // data-path kernels of layer l-1; its operand slabs are double-buffered and fenced with events.
-    const bool overlap = side_stream != nullptr && side_stream != stream;
-    // default: the weight-gradient contraction of layer l rides inside the ffn-backward launch of layer l-1
-    // (sst_ffn_bwd_dw_kernel); its operand slabs are double-buffered either way
-    const bool fuse = !overlap;
-    hipEvent_t ready[2] = {nullptr, nullptr}, done[2] = {nullptr, nullptr};
-    bool done_pending[2] = {false, false};
-    if (overlap)
-        for (int k = 0; k < 2; ++k) {
-            GEOMAE_HIP(hipEventCreateWithFlags(&ready[k], hipEventDisableTiming));
-            GEOMAE_HIP(hipEventCreateWithFlags(&done[k], hipEventDisableTiming));
-        }
+    // The weight-gradient contraction of layer l only feeds .grad: it rides inside the ffn-backward launch of layer
+    // l-1 (sst_ffn_bwd_dw_kernel), reading the slab set the three kernels of layer l left behind while layer l-1
+    // writes the other set.  (Running it on a second stream instead was tried and rejected: the cross-queue event
+    // hops cost more than the overlap gained)
     const char* base = (const char*)saved;
     char* w = (char*)scratch;
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
@@ -223,10 +213,6 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         char* ws = w + sc.set0 + set * sc.set_bytes;
         const bool top = l + 1 == num_layers;
         const char* ws_up = w + sc.set0 + ((l + 1) & 1) * sc.set_bytes;       // slabs of the layer above
-        if (overlap && done_pending[set]) {            // slab set still being read by the dw of layer l+2
-            GEOMAE_HIP(hipStreamWaitEvent(stream, done[set], 0));
-            done_pending[set] = false;
-        }
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
@@ -250,33 +236,16 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
             rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), &layers[0], num_tokens, dx_out, stream);
             if (rc) break;
         }
-        hipStream_t ds = stream;
-        if (overlap) {
-            GEOMAE_HIP(hipEventRecord(ready[set], stream));
-            GEOMAE_HIP(hipStreamWaitEvent(side_stream, ready[set], 0));
-            ds = side_stream;
-        }
-        if (fuse && l > 0) {
-            defer_next_weight_grad();
+        if (l > 0) {
+            defer_next_weight_grad();               // recorded now, launched inside B3(l-1)
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
-                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
+                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         } else {
-            Timed t(profiler, GEOMAE_KERNEL_DW, ds);
+            Timed t(profiler, GEOMAE_KERNEL_DW, stream);
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
-                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], ds);
-        }
-        if (overlap && rc == GEOMAE_OK) {
-            GEOMAE_HIP(hipEventRecord(done[set], side_stream));
-            done_pending[set] = true;
+                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
     if (flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK) rc = GEOMAE_ERR_HIP;   // error paths only
-    if (overlap) {
-        for (int k = 0; k < 2; ++k) {
-            if (done_pending[k]) hipStreamWaitEvent(stream, done[k], 0);      // join: the caller sees one stream
-            hipEventDestroy(ready[k]);
-            hipEventDestroy(done[k]);
-        }
-    }
     return rc;
 }

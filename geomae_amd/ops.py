@@ -775,21 +775,7 @@ def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None):
     return z, saved
 
 
-_SIDE_STREAMS = {}
-
-
-def _side_stream(key):
-    """One persistent side stream per (device, role) for the overlapped weight-gradient kernels."""
-    if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream()
-    return _SIDE_STREAMS[key]
-
-
-OVERLAP_WEIGHT_GRADS = False   # measured on MI355X (round 1): the cross-stream event hops cost more (5.79 ms/step) than
-                               # hiding the 27 us weight-gradient kernels saves (5.41 ms/step serial); kept for bigger inputs
-
-
-def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, side_key="main"):
+def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None):
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
@@ -798,9 +784,7 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
     dx = torch.empty_like(dz)
     check(lib.geomae_sst_stack_backward(_ptr(dz), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream),
-                                        ctypes.c_void_p(_side_stream((dz.device.index, side_key)).cuda_stream)
-                                        if (OVERLAP_WEIGHT_GRADS is True or OVERLAP_WEIGHT_GRADS == side_key) else None),
+                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
           "geomae_sst_stack_backward")
-    # `scratch` must outlive the kernels: with a side stream the caller keeps it until the streams are joined
+    # `scratch` must outlive the kernels: a caller that runs the stack on a stream of its own keeps it until the join
     return (dx, scratch) if stream is not None else dx

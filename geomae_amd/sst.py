@@ -221,9 +221,9 @@ class _FusedDecoderPair(torch.autograd.Function):
         for s in ctx.streams:
             s.wait_stream(cur)
         dxa, keep_a = ops.sst_stack_backward(dza, ctx.n, ctx.weights[0], ga, ctx.layouts, ctx.pos_table, ctx.nhead, sa,
-                                             stream=ctx.streams[0], side_key="dec_a")
+                                             stream=ctx.streams[0])
         dxb, keep_b = ops.sst_stack_backward(dzb, ctx.n, ctx.weights[1], gb, ctx.layouts, ctx.pos_table, ctx.nhead, sb,
-                                             stream=ctx.streams[1], side_key="dec_b")
+                                             stream=ctx.streams[1])
         for s in ctx.streams:
             cur.wait_stream(s)
         dx = dxa + dxb

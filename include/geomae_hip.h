@@ -325,8 +325,7 @@ int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeS
                               const GeomaeSstLayerGrads* grads, int32_t num_layers,
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
-                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream,
-                              geomaeStream_t side_stream /* or NULL: weight-gradient kernels overlap on it */);
+                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ N3 DynamicScatter native op
  * replaces the pybind functions dynamic_point_to_voxel_forward / _backward (ops/voxel/src/voxelization.h:112-154,
