@@ -39,7 +39,15 @@ class _timed:
         return False
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """Handle of torch's current HIP stream.  torch.cuda.current_stream() builds a Stream object through several
+    Python layers (12 us per call, 24 calls per step); the raw accessor is a single C call."""
+    if _raw_stream is not None and _raw_device is not None:
+        return ctypes.c_void_p(_raw_stream(_raw_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

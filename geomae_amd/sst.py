@@ -426,6 +426,51 @@ class MultiMAESSTSPChoose(nn.Module):
         cen, den = self.decode(x, coors, coors_mask, batch_size, layouts=dec_layouts)
         return _HeadsLoss.apply(cen, den, self._packed, coors.shape[0], coors_mask.shape[0], tgt, loss_weights)
 
+    # ---- explicit (autograd-free) schedule: the forward keeps what the backward needs, the backward is called by
+    # hand in reverse order.  Same kernels and the same parameter-gradient accumulation as the autograd Functions
+    # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
+    @torch.no_grad()
+    def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts):
+        """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad."""
+        assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
+        P, nh, pt = self._packed, self.nhead[0], self.pos_table
+        P.refresh()
+        enc_layouts, dec_layouts = layouts
+        n_keep = voxel_feat.shape[0]
+        n_enc, n_dec = 2 * len(self.encoder_blocks), 2 * len(self.decoder_centroid_blocks)
+        w_enc = P.weight_array(self._stack_base["enc"], n_enc)
+        w_cen, w_den = P.weight_array(self._stack_base["cen"], n_dec), P.weight_array(self._stack_base["den"], n_dec)
+        z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
+        tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        cur, (sa_, sb_) = torch.cuda.current_stream(), self._streams
+        sa_.wait_stream(cur)
+        sb_.wait_stream(cur)
+        cen, s_cen = ops.sst_stack_forward(tokens, w_cen, dec_layouts, pt, nh, stream=sa_)
+        den, s_den = ops.sst_stack_forward(tokens, w_den, dec_layouts, pt, nh, stream=sb_)
+        cur.wait_stream(sa_)
+        cur.wait_stream(sb_)
+        losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights)
+        # ---------------- backward
+        ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
+        g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
+        n = tokens.shape[0]
+        sa_.wait_stream(cur)
+        sb_.wait_stream(cur)
+        dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, stream=sa_)
+        dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
+        cur.wait_stream(sa_)
+        cur.wait_stream(sb_)
+        d_tok = dxa.add_(dxb)
+        del keep_a, keep_b
+        if self.mask_token.grad is None:
+            self.mask_token.grad = torch.zeros_like(self.mask_token)
+        self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+        g_enc = P.grad_array(self._stack_base["enc"], n_enc)
+        d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+        return losses, d_vf
+
     def decode(self, visible_voxel_feat, coors, coors_mask, batch_size, layouts=None):
         mask_tokens = self.mask_token.repeat(coors_mask.shape[0], 1)
         tokens = torch.cat([visible_voxel_feat, mask_tokens], dim=0)

@@ -208,6 +208,7 @@ class Trainer:
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
         self.iter = 0
         self.fused_optimizer = self.flat.flat.is_cuda
+        self.explicit_schedule = self.flat.flat.is_cuda
 
     def train_step(self, points, next_points=None, **kw):
         """next_points: the batch of the FOLLOWING step (the same list object must be passed as `points`
@@ -222,19 +223,25 @@ class Trainer:
         if pre is not None and pre[0] is points:
             pre[1][4].sync_counts()             # already landed: claim it before the next readback is queued
         keep = pre if (pre is not None and pre[0] is points) else None
+        # explicit schedule (no autograd) when the model offers one and nothing non-standard was asked for
+        explicit = (self.explicit_schedule and not kw and hasattr(self.model, "train_step_explicit")
+                    and getattr(getattr(self.model, "backbone", None), "fused", False)
+                    and getattr(self.model.voxel_encoder, "use_fused", True))
+        run = self.model.train_step_explicit if explicit else (lambda p: self.model.forward_train(p, None, **kw))
         if next_points is not None and hasattr(self.model, "prefetch"):
             self.model.prefetch(next_points)
             nxt = self.model._prefetched
             self.model._prefetched = keep
-            losses = self.model.forward_train(points, None, **kw)
+            losses = run(points)
             self.model._prefetched = nxt
         else:
-            losses = self.model.forward_train(points, None, **kw)
-        vec = getattr(self.model, "_loss_vector", None)     # the fused path's [6] loss tensor: one sum, not five adds
-        total = vec.sum() if vec is not None else sum(losses.values())
-        self.model._loss_vector = None
-        total.backward()
-        self.flat.check_views()
+            losses = run(points)
+        if not explicit:
+            vec = getattr(self.model, "_loss_vector", None)     # the fused path's [6] loss tensor: one sum, not five adds
+            total = vec.sum() if vec is not None else sum(losses.values())
+            self.model._loss_vector = None
+            total.backward()
+            self.flat.check_views()
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if self.fused_optimizer:
             if world > 1:

@@ -53,6 +53,13 @@ class _FusedVFE(torch.autograd.Function):
         return (None,) * 9
 
 
+def _vfe_world(enc):
+    from torch import distributed as dist
+    world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+    sync = world > 1 and isinstance(enc.vfe_layers[0].norm, __import__("geomae_amd").norm.NaiveSyncBatchNorm1d)
+    return world if sync else 1
+
+
 @VOXEL_ENCODERS.register_module()
 class DynamicScatterVFE(nn.Module):
     def __init__(self, in_channels=4, feat_channels=[], with_distance=False, with_cluster_center=False,
@@ -102,6 +109,23 @@ class DynamicScatterVFE(nn.Module):
                 and not self.return_point_feats and features.shape[1] == 5 and self._with_cluster_center
                 and self._with_voxel_center and not self._with_distance and self.rel_dist_scaler == 1.0
                 and [l.linear.out_features for l in self.vfe_layers] == [64, 128])
+
+    # ---- explicit (autograd-free) schedule of the fused path: detector.train_step_explicit
+    @torch.no_grad()
+    def forward_explicit(self, features, seg):
+        l0, l1 = self.vfe_layers
+        world = _vfe_world(self)
+        plan = ops.VfePlan(features, seg, l0.linear.weight, l1.linear.weight, (self.vx, self.vy, self.vz),
+                           (self.x_offset, self.y_offset, self.z_offset))
+        vf, m0 = ops.vfe_forward(plan, l0.norm, l1.norm, world)
+        return vf, (plan, m0, vf, world)
+
+    @torch.no_grad()
+    def backward_explicit(self, state, dvf):
+        plan, m0, vf, world = state
+        l0, l1 = self.vfe_layers
+        ops.vfe_backward(plan, m0, vf, dvf, dict(w0=l0.linear.weight, g0=l0.norm.weight, b0=l0.norm.bias,
+                                                 w1=l1.linear.weight, g1=l1.norm.weight, b1=l1.norm.bias), world)
 
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, seg=None):
         """features [N, C_in] fp32, coors [N, 4] int32 (b, z, y, x)."""

@@ -391,6 +391,30 @@ def test_forward_train_random_mask_runs_and_is_finite(dev):
     assert torch.isfinite(total) and all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+def test_explicit_schedule_matches_autograd_path(dev):
+    """detector.train_step_explicit (no autograd tape / engine) vs forward_train + backward through the autograd
+    Functions: the same kernels in the same order.  Two runs of EITHER path differ by ~1e-4 on the losses (the order
+    of the points inside a pillar is the atomic arrival order of the counting sort, the BatchNorm partial sums follow
+    it, and bf16 rounding downstream amplifies the last-bit differences; tools/determinism_check.py), so the
+    comparison uses that noise floor, not bit equality."""
+    import copy
+    model, _ = _build(dev, 2, 1, "bf16")
+    pts = [torch.as_tensor(synth.lidar_frame(80 + i, beams=16, n_az=500), device=dev) for i in range(3)]
+    a, b = copy.deepcopy(model), copy.deepcopy(model)
+    la = a.train_step_explicit(pts)
+    lb = b.forward_train(pts, None)
+    sum(lb.values()).backward()
+    for k in la:
+        assert torch.allclose(la[k], lb[k].detach(), rtol=2e-3, atol=1e-5), (k, float(la[k]), float(lb[k]))
+    ga, gb = dict(a.named_parameters()), dict(b.named_parameters())
+    for k in ga:
+        assert ga[k].grad is not None and gb[k].grad is not None, k
+        d = float((ga[k].grad - gb[k].grad).norm() / gb[k].grad.norm().clamp(min=1e-12))
+        assert d < 3e-2, (k, d)
+    for (k, x), (_, y) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.allclose(x.float(), y.float(), rtol=1e-4, atol=1e-6), k      # BatchNorm running statistics
+
+
 def test_trainer_prefetch_matches_plain_steps(dev):
     """Trainer.train_step(next_points=...) enqueues the next batch's voxelize / pillar sort ahead of the step:
     same losses as preparing every batch inside its own step."""
