@@ -200,7 +200,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[1]: nuScenes-like {args.sweeps}-sweep GeoMAE-SST pretrain (mae_sst model "
+            "config": {"workload": f"configs[{1 if args.sweeps == 1 else 2}]: nuScenes-like {args.sweeps}-sweep GeoMAE-SST pretrain (mae_sst model "
                                    f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}"},
             "loss": round(loss_val, 4),

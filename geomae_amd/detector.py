@@ -135,7 +135,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     @torch.no_grad()
-    def train_step_explicit(self, points):
+    def train_step_explicit(self, points, on_early_grads=None):
         """forward_train_fused + backward as an explicit schedule: no autograd tape or engine.  Accumulates every
         parameter gradient into .grad and returns the loss dict (detached).  Used by Trainer for the fused path
         (the step was host-bound at ~3.3 ms of Python / autograd per 3.5 ms of GPU work)."""
@@ -158,7 +158,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         main.wait_stream(side)
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
-        losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], int(im.numel()), batch_size, tgt, w, layouts)
+        losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], int(im.numel()), batch_size, tgt, w, layouts,
+                                                                 on_early_grads)
         d_vf = torch.zeros_like(vf)
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
         self.voxel_encoder.backward_explicit(vfe_state, d_vf)

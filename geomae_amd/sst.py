@@ -430,8 +430,10 @@ class MultiMAESSTSPChoose(nn.Module):
     # hand in reverse order.  Same kernels and the same parameter-gradient accumulation as the autograd Functions
     # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
     @torch.no_grad()
-    def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts):
-        """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad."""
+    def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None):
+        """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad.
+        on_early_grads(): called once the gradients of the heads, both decoders and the mask token are enqueued
+        (everything except the encoder), so that the caller can start exchanging them."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
         P, nh, pt = self._packed, self.nhead[0], self.pos_table
         P.refresh()
@@ -467,6 +469,8 @@ class MultiMAESSTSPChoose(nn.Module):
         if self.mask_token.grad is None:
             self.mask_token.grad = torch.zeros_like(self.mask_token)
         self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+        if on_early_grads is not None:
+            on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
         d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
         return losses, d_vf

@@ -13,57 +13,74 @@ exchange is a single in-place all_reduce of the gradient buffer with no flatten/
 clipping is one norm over one buffer, and the optimizer is one fused update over two segments
 (decayed / undecayed).  Host logic is device agnostic (tested with gloo on CPU, world_size 2).
 """
+import ctypes
+
 import torch
 from torch import distributed as dist
 
 
 class FlatParams:
     """Re-homes every parameter of `model` (and its .grad) into two contiguous fp32 buffers.
-    Order: undecayed ('norm' in the name, or listed in no_decay_keys) first, then decayed."""
 
-    def __init__(self, model, no_decay_keys=("norm",)):
+    Order: up to two SEGMENTS, each laid out [undecayed ('norm' in the name, or listed in no_decay_keys) | decayed] and
+    padded to a multiple of 4 elements.  Segment 0 holds the parameters whose gradients are complete EARLY in the
+    backward pass (decoders, heads), segment 1 those matched by `late_keys` (encoder, voxel encoder): the trainer
+    all-reduces segment 0 while the encoder backward is still running.  Without late_keys there is one segment."""
+
+    def __init__(self, model, no_decay_keys=("norm",), late_keys=()):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
-        nd = [(n, p) for n, p in named if any(k in n for k in no_decay_keys)]
-        dc = [(n, p) for n, p in named if not any(k in n for k in no_decay_keys)]
-        self.names = [n for n, _ in nd + dc]
-        self.params = [p for _, p in nd + dc]
-        self.n_no_decay = sum(p.numel() for _, p in nd)
-        total = sum(p.numel() for p in self.params)
-        dev = self.params[0].device
-        self.flat = torch.empty(total, dtype=torch.float32, device=dev)
-        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        is_nd = lambda n: any(k in n for k in no_decay_keys)
+        is_late = lambda n: any(n.startswith(k) for k in late_keys)
+        groups = [[(n, p) for n, p in named if not is_late(n)], [(n, p) for n, p in named if is_late(n)]]
+        groups = [g for g in groups if g]
+        self.names, self.params, self.offsets, self.segments = [], [], [], []
         off = 0
-        for p in self.params:
+        for g in groups:
+            nd = [(n, p) for n, p in g if is_nd(n)]
+            dc = [(n, p) for n, p in g if not is_nd(n)]
+            start = off
+            for n, p in nd + dc:
+                self.names.append(n)
+                self.params.append(p)
+                self.offsets.append(off)
+                off += p.numel()
+            n_nd = sum(p.numel() for _, p in nd)
+            off = (off + 3) // 4 * 4                                # keep every segment 16-byte aligned
+            self.segments.append((start, off, n_nd))
+        total = off
+        self.n_no_decay = self.segments[0][2] if len(self.segments) == 1 else None
+        dev = self.params[0].device
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
             n = p.numel()
-            self.flat[off:off + n].copy_(p.data.reshape(-1))
-            p.data = self.flat[off:off + n].view_as(p.data)
-            p.grad = self.grad[off:off + n].view_as(p.data)
-            off += n
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view_as(p.data)
+            p.grad = self.grad[o:o + n].view_as(p.data)
         self.total = total
 
     def zero_grad(self):
         self.grad.zero_()
 
+    def decay_ranges(self):
+        """[(start, end)] of the elements that take weight decay."""
+        return [(s + nd, e) for s, e, nd in self.segments]
+
     def check_storage(self):
         """load_state_dict copies in place, so every parameter must still be a view of the flat buffer."""
-        base, item, off = self.flat.data_ptr(), self.flat.element_size(), 0
-        for n, p in zip(self.names, self.params):
-            assert p.data_ptr() == base + off * item, f"parameter {n} left the flat buffer"
-            off += p.numel()
+        base, item = self.flat.data_ptr(), self.flat.element_size()
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            assert p.data_ptr() == base + o * item, f"parameter {n} left the flat buffer"
 
     def check_views(self):
         """Autograd must have accumulated in place; re-point any .grad that was replaced."""
-        if getattr(self, "_ptrs", None) is None:
-            base, item, off, self._ptrs = self.grad.data_ptr(), self.grad.element_size(), 0, []
-            for p in self.params:
-                self._ptrs.append((base + off * item, off, p.numel()))
-                off += p.numel()
-        for p, (ptr, off, n) in zip(self.params, self._ptrs):
-            g = p.grad
+        base, item = self.grad.data_ptr(), self.grad.element_size()
+        for p, o in zip(self.params, self.offsets):
+            g, n = p.grad, p.numel()
             if g is None:
-                p.grad = self.grad[off:off + n].view_as(p.data)
-            elif g.data_ptr() != ptr:
-                view = self.grad[off:off + n]
+                p.grad = self.grad[o:o + n].view_as(p.data)
+            elif g.data_ptr() != base + o * item:
+                view = self.grad[o:o + n]
                 view.copy_(g.reshape(-1))
                 p.grad = view.view_as(p.data)
 
@@ -108,7 +125,8 @@ class FlatAdamW:
         b1, b2 = self.betas
         g = f.grad
         if self.weight_decay != 0:
-            f.flat[f.n_no_decay:].mul_(1 - self.lr * self.weight_decay)
+            for a, b in f.decay_ranges():
+                f.flat[a:b].mul_(1 - self.lr * self.weight_decay)
         self.exp_avg.lerp_(g, 1 - b1)
         self.exp_avg_sq.mul_(b2).addcmul_(g, g, value=1 - b2)
         bc1 = 1 - b1 ** self.step_count
@@ -130,38 +148,40 @@ class FlatAdamW:
         self.step_count += 1
         n = f.flat.numel()
         _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
-        _lib.check(lib.geomae_adamw_step(_ptr(f.flat), _ptr(f.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), n,
-                                         f.n_no_decay, float(self.lr), float(self.betas[0]), float(self.betas[1]),
-                                         float(self.eps), float(self.weight_decay), self.step_count, float(max_norm or 0.0),
-                                         _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)), _ptr(self._gnorm),
-                                         _stream()), "geomae_adamw_step")
+        P = lambda t, o: ctypes.c_void_p(t.data_ptr() + 4 * o)
+        for start, end, n_nd in f.segments:                       # one launch per segment (its own no-decay prefix)
+            _lib.check(lib.geomae_adamw_step(P(f.flat, start), P(f.grad, start), P(self.exp_avg, start),
+                                             P(self.exp_avg_sq, start), end - start, n_nd, float(self.lr),
+                                             float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                             float(self.weight_decay), self.step_count, float(max_norm or 0.0),
+                                             _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)), _ptr(self._gnorm),
+                                             _stream()), "geomae_adamw_step")
         return self._gnorm[0]
 
     # ---- torch.optim.AdamW-shaped state (what mmcv's checkpoint hook stores under 'optimizer'): mmcv's
     # DefaultOptimizerConstructor with a paramwise_cfg makes ONE param group per parameter
     def state_dict(self):
-        f, off, state, groups = self.flat, 0, {}, []
-        for i, p in enumerate(f.params):
+        f, state, groups = self.flat, {}, []
+        decayed = f.decay_ranges()
+        for i, (p, off) in enumerate(zip(f.params, f.offsets)):
             n = p.numel()
-            wd = 0.0 if off < f.n_no_decay else self.weight_decay
+            wd = self.weight_decay if any(a <= off < b for a, b in decayed) else 0.0
             state[i] = dict(step=torch.tensor(float(self.step_count)),
                             exp_avg=self.exp_avg[off:off + n].view_as(p).clone(),
                             exp_avg_sq=self.exp_avg_sq[off:off + n].view_as(p).clone())
             groups.append(dict(params=[i], lr=self.lr, initial_lr=self.base_lr, betas=tuple(self.betas), eps=self.eps,
                                weight_decay=wd, amsgrad=False))
-            off += n
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        f, off = self.flat, 0
-        for i, p in enumerate(f.params):
+        f = self.flat
+        for i, (p, off) in enumerate(zip(f.params, f.offsets)):
             n = p.numel()
             st = sd["state"].get(i)
             if st is not None:
                 self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
-            off += n
         if sd.get("param_groups"):
             self.lr = sd["param_groups"][0]["lr"]
             self.base_lr = sd["param_groups"][0].get("initial_lr", self.base_lr)
@@ -202,7 +222,10 @@ class Trainer:
         pw = ocfg.pop("paramwise_cfg", None) or {}
         keys = tuple(k for k, v in pw.get("custom_keys", {}).items() if v.get("decay_mult", 1.0) == 0.0)
         self.model = model
-        self.flat = FlatParams(model, no_decay_keys=keys or ("\0",))
+        # gradients of the decoders / heads are complete before the encoder backward starts: they form the early
+        # segment, whose all-reduce overlaps the rest of the backward (explicit schedule, world > 1)
+        late = ("backbone.encoder_blocks.", "voxel_encoder.") if hasattr(model, "train_step_explicit") else ()
+        self.flat = FlatParams(model, no_decay_keys=keys or ("\0",), late_keys=late)
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
@@ -227,7 +250,17 @@ class Trainer:
         explicit = (self.explicit_schedule and not kw and hasattr(self.model, "train_step_explicit")
                     and getattr(getattr(self.model, "backbone", None), "fused", False)
                     and getattr(self.model.voxel_encoder, "use_fused", True))
-        run = self.model.train_step_explicit if explicit else (lambda p: self.model.forward_train(p, None, **kw))
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        works = []
+
+        def early_ready():
+            # called by the model when every gradient of segment 0 has been enqueued: start its all-reduce now, under
+            # the encoder / voxel-encoder backward (RCCL runs it on its own stream after the kernels enqueued so far)
+            if world > 1 and len(self.flat.segments) > 1:
+                a, b, _ = self.flat.segments[0]
+                works.append((0, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early_ready)) if explicit else \
+            (lambda p: self.model.forward_train(p, None, **kw))
         if next_points is not None and hasattr(self.model, "prefetch"):
             self.model.prefetch(next_points)
             nxt = self.model._prefetched
@@ -242,10 +275,14 @@ class Trainer:
             self.model._loss_vector = None
             total.backward()
             self.flat.check_views()
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         if self.fused_optimizer:
-            if world > 1:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)        # the 1/world rides in the update pass
+            if world > 1:                                                    # the 1/world rides in the update pass
+                done = {i for i, _ in works}
+                for i, (a, b, _) in enumerate(self.flat.segments):
+                    if i not in done:
+                        works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+                for _, w in works:
+                    w.wait()
             gnorm = self.opt.fused_clip_step(self.grad_clip.get("max_norm", 0.0), 1.0 / world, zero_grad=True)
             self._grads_clean = True
         else:
