@@ -44,7 +44,8 @@ __device__ __forceinline__ int kperm_inv(int k) { return (k & ~31) + 8 * ((k >> 
 __device__ __forceinline__ void bce(float x, float y, float* l, float* d) {
     const float e = __expf(-fabsf(x));
     *l = fmaxf(x, 0.f) - x * y + __logf(1.f + e);
-    const float sig = x >= 0.f ? 1.f / (1.f + e) : e / (1.f + e);
+    const float r = __builtin_amdgcn_rcpf(1.f + e);   // v_rcp_f32 (1 ulp); the IEEE divide is a 12-instruction sequence
+    const float sig = x >= 0.f ? r : e * r;
     *d = sig - y;
 }
 

@@ -249,7 +249,10 @@ __device__ __forceinline__ void layer_norm_bwd_t(f32x4 (&dy)[8], const f32x4 (&x
 // exp + one rcp instead of libm erff (~60 instructions); exp(-x^2/2) is shared with the pdf term.
 __device__ __forceinline__ void gelu_parts(float x, float* cdf, float* pdf) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    // v_rcp_f32 (1 ulp).  __frcp_rn is the correctly rounded reciprocal: under -fno-fast-math it expands to the
+    // div_scale / div_fmas / div_fixup sequence (~12 instructions per element, 768 per kernel), far more precision
+    // than the 1.5e-7 polynomial around it needs.
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
     const float e = __expf(-z * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float erf_abs = 1.0f - poly * e;
