@@ -134,6 +134,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         self._loss_vector = losses                   # Trainer sums this once instead of adding six scalars
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
+    TARGETS_LATE = True
+
     @torch.no_grad()
     def train_step_explicit(self, points, on_early_grads=None):
         """forward_train_fused + backward as an explicit schedule: no autograd tape or engine.  Accumulates every
@@ -148,18 +150,27 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         side = self._geo_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
+            # side-stream order = order of need: packed weights and window layouts (encoder forward), then the
+            # targets (first read by the heads+loss kernel, a whole forward later: they finish under the encoder,
+            # whose launches fill 105 of 256 CUs)
+            self.backbone._packed.refresh()
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
-            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
-            ik, im = ik.long(), im.long()
+            ik_l, im_l = ik.long(), im.long()
             feature_coors = seg.voxel_coors[:V]
-            coors_keep, coors_mask = feature_coors[ik], feature_coors[im]
+            coors_keep, coors_mask = feature_coors[ik_l], feature_coors[im_l]
             layouts = self.backbone.build_layouts(coors_keep, coors_mask, batch_size)
+            layouts_ready = side.record_event()
+            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
+            tgt_ready = side.record_event()
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg)
-        main.wait_stream(side)
+        main.wait_event(layouts_ready)
+        if not self.TARGETS_LATE:
+            main.wait_event(tgt_ready)
+        ik = ik_l
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
         losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], int(im.numel()), batch_size, tgt, w, layouts,
-                                                                 on_early_grads)
+                                                                 on_early_grads, packed_fresh=True, tgt_ready=tgt_ready)
         d_vf = torch.zeros_like(vf)
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
         self.voxel_encoder.backward_explicit(vfe_state, d_vf)
@@ -197,15 +208,26 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         step k (Trainer.train_step(next_points=...)): when step k+1 starts the counts are already on the host,
         so the iteration's one device->host readback no longer drains the queue (the GPU idled ~0.3 ms per
         step behind it, profiles/r01q_step_timeline.txt)."""
-        voxels, coors, sub_med, sub_low = self.voxelize_all(points)
-        seg = ops.pillar_segment(coors, len(points), self.grid_size)
-        seg.start_readback()
-        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg))
+        main = torch.cuda.current_stream()
+        if getattr(self, "_prefetch_stream", None) is None:
+            self._prefetch_stream = torch.cuda.Stream()
+        ps = self._prefetch_stream
+        # its own stream: nothing in the current step depends on it.  Ordered after the work already enqueued on the
+        # main stream (the previous step), which also makes the allocator's reuse of this stream's freed blocks safe:
+        # their last readers (the previous step's kernels) are enqueued on `main` before this point.
+        ps.wait_stream(main)
+        with torch.cuda.stream(ps):
+            voxels, coors, sub_med, sub_low = self.voxelize_all(points)
+            seg = ops.pillar_segment(coors, len(points), self.grid_size)
+            seg.start_readback()
+            done = ps.record_event()
+        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done)
 
     def _stage1(self, points):
         """voxelize x3 + pillar segments: taken from `prefetch` when it ran for this batch."""
         pre, self._prefetched = getattr(self, "_prefetched", None), None
         if pre is not None and pre[0] is points:
+            torch.cuda.current_stream().wait_event(pre[2])
             return pre[1]
         voxels, coors, sub_med, sub_low = self.voxelize_all(points)
         seg = ops.pillar_segment(coors, len(points), self.grid_size)

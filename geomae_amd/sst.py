@@ -430,13 +430,17 @@ class MultiMAESSTSPChoose(nn.Module):
     # hand in reverse order.  Same kernels and the same parameter-gradient accumulation as the autograd Functions
     # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
     @torch.no_grad()
-    def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None):
+    def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None,
+                                  packed_fresh=False, tgt_ready=None):
         """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad.
         on_early_grads(): called once the gradients of the heads, both decoders and the mask token are enqueued
-        (everything except the encoder), so that the caller can start exchanging them."""
+        (everything except the encoder), so that the caller can start exchanging them.
+        packed_fresh: the caller already re-packed the bf16 weights for this step (on another stream, ordered before
+        this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream)."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
         P, nh, pt = self._packed, self.nhead[0], self.pos_table
-        P.refresh()
+        if not packed_fresh:
+            P.refresh()
         enc_layouts, dec_layouts = layouts
         n_keep = voxel_feat.shape[0]
         n_enc, n_dec = 2 * len(self.encoder_blocks), 2 * len(self.decoder_centroid_blocks)
@@ -453,6 +457,8 @@ class MultiMAESSTSPChoose(nn.Module):
         den, s_den = ops.sst_stack_forward(tokens, w_den, dec_layouts, pt, nh, stream=sb_)
         cur.wait_stream(sa_)
         cur.wait_stream(sb_)
+        if tgt_ready is not None:
+            cur.wait_event(tgt_ready)
         losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights)
         # ---------------- backward
         ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
