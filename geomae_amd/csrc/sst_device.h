@@ -273,6 +273,42 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // sum over the 16 tokens of the wave (lanes with equal g); result valid in every lane
 __device__ __forceinline__ float tok_sum(float v) { return row16_sum(v); }
 
+// LayerNorm parameter gradients of one wave's token tile: red[k0][c] = sum_t dy[c][t] * xhat[c][t],
+// red[k0 + 1][c] = sum_t dy[c][t].  In T-layout the token index is the lane (l & 15), so a register-level
+// reduction costs 4 DPP steps for each of the 2 x 32 values of a lane plus a leader-lane branch per value
+// (~700 instructions per LayerNorm, a fifth of sst_ffn_bwd_kernel).  Instead the wave writes both tensors
+// token-major into a private LDS scratch (16 x ds_write_b128), and every lane sums a 4-channel column
+// of one tensor over the 16 token rows (16 x ds_read_b128 + 15 float4 adds): ~90 instructions, no branches.
+// Row stride 132 floats: the 16 lanes of a token-group start 4 banks apart (conflict-free b128 writes), the
+// reads of a row are contiguous.  `scratch` is the (idle) weight buffer: the caller has a workgroup barrier
+// between the last GEMM that read it and this call; the next gemm_staged barriers before overwriting it.
+constexpr int kRedLd = 132;
+constexpr int kRedWaveFloats = 2 * 16 * kRedLd;              // per wave: two tensors x 16 tokens
+static_assert(4 * kRedWaveFloats * 4 <= kWeightLds * 2, "token-reduction scratch must fit the weight buffer");
+__device__ __forceinline__ void ln_param_grads_t(const f32x4 (&dy)[8], const f32x4 (&xhat)[8], float* __restrict__ scratch,
+                                                 float (*red_wave)[128] /* [tensor][channel] of this wave */, int k0,
+                                                 int lane) {
+    const int t = lane & 15, g = lane >> 4;
+    float* row = scratch + t * kRedLd + 4 * g;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct) {
+        *reinterpret_cast<f32x4*>(row + 16 * ct) = dy[ct] * xhat[ct];
+        *reinterpret_cast<f32x4*>(row + 16 * kRedLd + 16 * ct) = dy[ct];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int k = lane >> 5, c4 = lane & 31;
+    const float* col = scratch + k * 16 * kRedLd + 4 * c4;
+    f32x4 s0 = *reinterpret_cast<const f32x4*>(col), s1 = *reinterpret_cast<const f32x4*>(col + kRedLd);
+#pragma unroll
+    for (int tt = 2; tt < 16; tt += 2) {
+        s0 += *reinterpret_cast<const f32x4*>(col + tt * kRedLd);
+        s1 += *reinterpret_cast<const f32x4*>(col + (tt + 1) * kRedLd);
+    }
+    *reinterpret_cast<f32x4*>(&red_wave[k0 + k][4 * c4]) = s0 + s1;
+}
+
 
 
 // weight-gradient (token contraction) tasks, see dw_kernel in sst_layer.hip

@@ -279,6 +279,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     const int tile = block * (kLayerBlk / 64) + wave;
     const int64_t tok = (int64_t)tile * 16 + (lane & 15);
     const bool valid = tok < n;
+    float* red_scratch = reinterpret_cast<float*>(smem) + wave * kRedWaveFloats;   // see ln_param_grads_t
     GEOMAE_STAMP(0);
     const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
     f32x4 dv[8];
@@ -290,17 +291,8 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         f32x4 xh2[8];
         load_rows_f32<128>(xh2_in, tok, valid, xh2, lane);
         stage_issue<128, 256>(W.w2T, s_w2T);                          // lands under the LayerNorm arithmetic
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = tok_sum(dv[ct][r] * xh2[ct][r]);      // d gamma2
-                const float b = tok_sum(dv[ct][r]);                   // d beta2
-                if ((lane & 15) == 0) {
-                    red[wave][0][16 * ct + 4 * g + r] = a;
-                    red[wave][1][16 * ct + 4 * g + r] = b;
-                }
-            }
+        if (A.up_dqkv) __syncthreads();                               // B1's last matrix consumed by every wave
+        ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane);   // d gamma2, d beta2
         layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
     }
     store_rows_bf16<128>(dv_b, tok, 128, 0, valid, dv, lane);
@@ -352,17 +344,8 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
             affine_t(xh1, W.g1, W.be1, y, lane);
             store_rows_bf16<128>(y_b, tok, 128, 0, valid, y, lane);
         }
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float a = tok_sum(dv[ct][r] * xh1[ct][r]);      // d gamma1
-                const float b = tok_sum(dv[ct][r]);                   // d beta1
-                if ((lane & 15) == 0) {
-                    red[wave][2][16 * ct + 4 * g + r] = a;
-                    red[wave][3][16 * ct + 4 * g + r] = b;
-                }
-            }
+        __syncthreads();                                              // w1T consumed by every wave
+        ln_param_grads_t(dv, xh1, red_scratch, red[wave], 2, lane);   // d gamma1, d beta1
         layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
     }
     store_rows_f32<128>(dx_res, tok, valid, dv, lane);

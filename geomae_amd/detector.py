@@ -106,9 +106,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         main = torch.cuda.current_stream()
         overlap = self.OVERLAP_GEOMETRY
         if overlap:
-            if getattr(self, "_geo_stream", None) is None:
-                self._geo_stream = torch.cuda.Stream()
-            side = self._geo_stream
+            side = ops.side_streams()["geo"]
             side.wait_stream(main)
         else:
             side = main
@@ -145,9 +143,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         voxels, coors, sub_med, sub_low, seg = self._stage1(points)
         V = seg.V
         main = torch.cuda.current_stream()
-        if getattr(self, "_geo_stream", None) is None:
-            self._geo_stream = torch.cuda.Stream()
-        side = self._geo_stream
+        side = ops.side_streams()["geo"]
         side.wait_stream(main)
         with torch.cuda.stream(side):
             # side-stream order = order of need: packed weights and window layouts (encoder forward), then the
@@ -209,9 +205,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         so the iteration's one device->host readback no longer drains the queue (the GPU idled ~0.3 ms per
         step behind it, profiles/r01q_step_timeline.txt)."""
         main = torch.cuda.current_stream()
-        if getattr(self, "_prefetch_stream", None) is None:
-            self._prefetch_stream = torch.cuda.Stream()
-        ps = self._prefetch_stream
+        ps = getattr(self, "_prefetch_stream", None) or ops.side_streams()["prefetch"]
         # its own stream: nothing in the current step depends on it.  Ordered after the work already enqueued on the
         # main stream (the previous step), which also makes the allocator's reuse of this stream's freed blocks safe:
         # their last readers (the previous step's kernels) are enqueued on `main` before this point.

@@ -449,7 +449,8 @@ class MultiMAESSTSPChoose(nn.Module):
         z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
         tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
         if self._streams is None:
-            self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+            st = ops.side_streams()
+            self._streams = (st["dec_a"], st["dec_b"])
         cur, (sa_, sb_) = torch.cuda.current_stream(), self._streams
         sa_.wait_stream(cur)
         sb_.wait_stream(cur)
@@ -489,7 +490,8 @@ class MultiMAESSTSPChoose(nn.Module):
             layouts, pos = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
         if self.fused and self.concurrent_decoders:
             if self._streams is None:
-                self._streams = (torch.cuda.Stream(), torch.cuda.Stream())
+                st = ops.side_streams()
+                self._streams = (st["dec_a"], st["dec_b"])
             cen, den = _FusedDecoderPair.apply(tokens, self._packed, self._stack_base["cen"], self._stack_base["den"],
                                                2 * len(self.decoder_centroid_blocks), layouts, self.pos_table,
                                                self.nhead[0], self._streams)

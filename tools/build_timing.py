@@ -5,13 +5,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "geomae_amd", "csrc")
 OBJ = os.path.join(ROOT, "tools", "build_timing")
 os.makedirs(OBJ, exist_ok=True)
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=off", "-Wno-unused-result",
-         "-DGEOMAE_PHASE_TIMING"]
+sys.path.insert(0, ROOT)
+from geomae_amd.csrc.build import flags_for  # the product's per-file flags
 objs, jobs = [], []
 for src in sorted(glob.glob(os.path.join(SRC, "*.hip"))):
     o = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     objs.append(o)
-    jobs.append(["/opt/rocm/bin/hipcc"] + FLAGS + ["-c", src, "-o", o])
+    jobs.append(["/opt/rocm/bin/hipcc"] + flags_for(src) + ["-DGEOMAE_PHASE_TIMING", "-c", src, "-o", o])
 with ThreadPoolExecutor(8) as ex:
     list(ex.map(subprocess.check_call, jobs))
 out = os.path.join(ROOT, "tools", "libgeomae_timing.so")

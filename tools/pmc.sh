@@ -11,7 +11,7 @@ files = glob.glob('/tmp/pmc_$tag/**/*counter_collection.csv', recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in files:
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:60]
+        k = r['Kernel_Name'][:48] + ' g' + r.get('Grid_Size', '?')
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
 with open('/root/repo/gpurun_out/pmc_$tag/summary.csv', 'w') as out:
