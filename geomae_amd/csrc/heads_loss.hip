@@ -92,10 +92,10 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
     uint2 xb[8];
     {
         f32x4 x[8];
-        load_rows_f32<128>(A.cen, tok, valid, x, lane);
+        load_rows_f32<128>(A.cen, A.n_keep + A.M, (int)tok, x, lane);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) xb[ct] = pack4(x[ct]);
-        store_rows_bf16<128>(A.cm_b, row, 128, 0, valid, x, lane);
+        store_rows_bf16<128>(A.cm_b, A.M, (int)row, 128, 0, x, lane);
     }
     f32x4 dx[8];
 #pragma unroll
@@ -112,13 +112,13 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
                     if (rr < A.M) A.d_cen[(A.n_keep + rr) * 128 + 16 * ct + (lane & 15)] = dx[ct][r];
                 }
             f32x4 x[8];
-            load_rows_f32<128>(A.den, tok, valid, x, lane);
+            load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
 #pragma unroll
             for (int ct = 0; ct < 8; ++ct) {
                 xb[ct] = pack4(x[ct]);
                 dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            store_rows_bf16<128>(A.dm_b, row, 128, 0, valid, x, lane);
+            store_rows_bf16<128>(A.dm_b, A.M, (int)row, 128, 0, x, lane);
         }
         const int row0 = chunk < 6 ? 128 * chunk : 768;         // first output row of this chunk
         f32x4 z[8];

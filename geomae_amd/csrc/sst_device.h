@@ -140,46 +140,76 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&a
     }
 }
 
-template <int C>
-__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int64_t tok, bool valid,
-                                              f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (valid) t = *reinterpret_cast<const float4*>(src + tok * C + 16 * ct + 4 * g);
-        v[ct][0] = t.x; v[ct][1] = t.y; v[ct][2] = t.z; v[ct][3] = t.w;
-    }
+// ------------------------------------------------------------------------------------------------
+// Token rows through raw buffer descriptors.  A [n, C] activation is addressed as a buffer of n * row_bytes bytes:
+// rows at or past n (the tail of the last 16-token tile, up to 63 rows) read as ZERO and their stores are dropped
+// by the hardware's range check.  That removes the per-access `if (valid)` (an s_and_saveexec / branch / s_or
+// triple around every load and store, ~270 of them in sst_ffn_bwd_kernel, which also fenced the scheduler) and
+// the 64-bit address arithmetic: one 32-bit byte offset per tensor, the tile / column steps ride in the 12-bit
+// immediate.  Host side guarantees n * 768 < 2^31 (geomae_sst_* entry points).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, int n, int row_bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n * row_bytes, 0x00020000);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* base) {   // no bound known / needed
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+}
+__device__ __forceinline__ uint2 buf_load_b64(__amdgpu_buffer_rsrc_t r, int off) {
+    const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+    return make_uint2(v[0], v[1]);
+}
+__device__ __forceinline__ void buf_store_b64(__amdgpu_buffer_rsrc_t r, int off, uint2 v) {
+    __builtin_amdgcn_raw_buffer_store_b64(u32x2{v.x, v.y}, r, off, 0, 0);
+}
+__device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// lane (t = l & 15, g = l >> 4) holds channels 16 ct + 4 g + {0..3} of token `tok` (T-layout accumulator order)
 template <int C>
-__device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int64_t tok, bool valid,
+__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int n, int tok, f32x4 (&v)[C / 16], int lane) {
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(src, n, C * 4);
+    const int off = tok * (C * 4) + 16 * (lane >> 4);
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) v[ct] = buf_load_f32x4(r, off + 64 * ct);
+}
+
+// C channels starting at column col0 of a [n, ld] bf16 matrix
+template <int C>
+__device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int n, int tok, int ld, int col0,
                                                uint2 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(src, n, ld * 2);
+    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) {
-        v[ct] = valid ? *reinterpret_cast<const uint2*>(src + tok * C + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-    }
+    for (int ct = 0; ct < C / 16; ++ct) v[ct] = buf_load_b64(r, off + 32 * ct);
 }
 
 template <int C>
-__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int64_t tok, bool valid,
-                                               const f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-    if (!valid) return;
+__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int n, int tok, const f32x4 (&v)[C / 16], int lane) {
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, C * 4);
+    const int off = tok * (C * 4) + 16 * (lane >> 4);
 #pragma unroll
     for (int ct = 0; ct < C / 16; ++ct)
-        *reinterpret_cast<float4*>(dst + tok * C + 16 * ct + 4 * g) = make_float4(v[ct][0], v[ct][1], v[ct][2], v[ct][3]);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ct]), r, off + 64 * ct, 0, 0);
 }
 
 template <int C>
-__device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int64_t tok, int ld, int col0, bool valid,
+__device__ __forceinline__ void store_rows_packed(bf16_t* __restrict__ dst, int n, int tok, int ld, int col0,
+                                                  const uint2 (&v)[C / 16], int lane) {
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, ld * 2);
+    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct) buf_store_b64(r, off + 32 * ct, v[ct]);
+}
+
+template <int C>
+__device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int n, int tok, int ld, int col0,
                                                 const f32x4 (&v)[C / 16], int lane) {
-    const int g = lane >> 4;
-    if (!valid) return;
+    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, ld * 2);
+    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct)
-        *reinterpret_cast<uint2*>(dst + tok * ld + col0 + 16 * ct + 4 * g) = pack4(v[ct]);
+    for (int ct = 0; ct < C / 16; ++ct) buf_store_b64(r, off + 32 * ct, pack4(v[ct]));
 }
 
 // sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)

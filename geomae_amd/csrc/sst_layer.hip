@@ -71,37 +71,39 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
     const int t = lane & 15, g = lane >> 4;
-    const int64_t tok = (int64_t)tile * 16 + t;
-    const bool valid = tok < n;
-    const int64_t tc = valid ? tok : n - 1;
+    const int tok = tile * 16 + t;
     uint2 xb[8], xpb[8];
-    const int p = tok_pos[tc];
+    const int p = __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(tok_pos, n, 4), tok * 4, 0, 0);   // 0 past the end
     WStage<128, 256> s_qk;
     WStage<128, 128> s_v;
     stage_issue<128, 256>(W.wqkv, s_qk);
+    {
+        f32x4 xv[8];
+        load_rows_f32<128>(x, n, tok, xv, lane);
+        const __amdgpu_buffer_rsrc_t pr = table_rsrc(pos_table);
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const float4 xv = *reinterpret_cast<const float4*>(x + tc * 128 + 16 * ct + 4 * g);
-        const float4 pv = *reinterpret_cast<const float4*>(pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
-        xb[ct] = make_uint2(pack2(xv.x, xv.y), pack2(xv.z, xv.w));
-        xpb[ct] = make_uint2(pack2(xv.x + pv.x, xv.y + pv.y), pack2(xv.z + pv.z, xv.w + pv.w));
-        if (x_b && valid) {          // the bf16 operands of this layer's weight-gradient contraction (dW_qk, dW_v)
-            *reinterpret_cast<uint2*>(x_b + tok * 128 + 16 * ct + 4 * g) = xb[ct];
-            *reinterpret_cast<uint2*>(xp_b + tok * 128 + 16 * ct + 4 * g) = xpb[ct];
+        for (int ct = 0; ct < 8; ++ct) {
+            const f32x4 pv = buf_load_f32x4(pr, p * 512 + 64 * ct + 16 * g);
+            xb[ct] = pack4(xv[ct]);
+            xpb[ct] = pack4(xv[ct] + pv);
         }
+    }
+    if (x_b) {                       // the bf16 operands of this layer's weight-gradient contraction (dW_qk, dW_v)
+        store_rows_packed<128>(x_b, n, tok, 128, 0, xb, lane);
+        store_rows_packed<128>(xp_b, n, tok, 128, 0, xpb, lane);
     }
     {
         f32x4 acc[16];
         load_bias<256>(W.bqkv, acc, lane);
         gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
         stage_issue<128, 128>(W.wqkv + 256 * 128, s_v);               // in flight under the q/k stores
-        store_rows_bf16<256>(qkv, tok, 384, 0, valid, acc, lane);
+        store_rows_bf16<256>(qkv, n, tok, 384, 0, acc, lane);
     }
     {
         f32x4 acc[8];
         load_bias<128>(W.bqkv + 256, acc, lane);
         gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
-        store_rows_bf16<128>(qkv, tok, 384, 256, valid, acc, lane);
+        store_rows_bf16<128>(qkv, n, tok, 384, 256, acc, lane);
     }
 }
 
@@ -133,8 +135,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
-    const bool valid = tok < n;
+    const int tok = tile * 16 + (lane & 15);
     f32x4 u[8], y[8];
     float r1, r2;
     WStage<128, 256> s_w1;
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         WStage<128, 128> s_wo;
         stage_issue<128, 128>(W.wo, s_wo);
         uint2 ob[8];
-        load_rows_bf16<128>(attn, tok, valid, ob, lane);
+        load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane);
         f32x4 xr[8];
-        load_rows_f32<128>(x, tok, valid, xr, lane);                  // needed after the GEMM: in flight under it
+        load_rows_f32<128>(x, n, tok, xr, lane);                      // needed after the GEMM: in flight under it
         load_bias<128>(W.bo, u, lane);
         gemm_staged<128, 128>(s_wo, smem, ob, u, lane);
         stage_issue<128, 256>(W.w1, s_w1);                            // lands under the LayerNorm arithmetic
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
     layer_norm_t(u, eps, &r1);
-    if (xh1_out) store_rows_f32<128>(xh1_out, tok, valid, u, lane);
+    if (xh1_out) store_rows_f32<128>(xh1_out, n, tok, u, lane);
     affine_t(u, W.g1, W.be1, y, lane);
     uint2 hb[16];
     WStage<256, 128> s_w2;
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         load_bias<256>(W.b1, hp, lane);
         gemm_staged<128, 256>(s_w1, smem, yb, hp, lane);
         stage_issue<256, 128>(W.w2, s_w2);                            // lands under the GELU arithmetic
-        if (hp_out) store_rows_bf16<256>(hp_out, tok, 256, 0, valid, hp, lane);
+        if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
@@ -179,29 +180,29 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
     layer_norm_t(u, eps, &r2);
-    if (xh2_out) store_rows_f32<128>(xh2_out, tok, valid, u, lane);
-    if (rstd_out && valid && (lane >> 4) == 0) {
-        rstd_out[tok * 2 + 0] = r1;
-        rstd_out[tok * 2 + 1] = r2;
-    }
+    if (xh2_out) store_rows_f32<128>(xh2_out, n, tok, u, lane);
+    if (rstd_out && (lane >> 4) == 0)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
+                                              tok * 8, 0, 0);
     affine_t(u, W.g2, W.be2, y, lane);
-    store_rows_f32<128>(z, tok, valid, y, lane);
+    store_rows_f32<128>(z, n, tok, y, lane);
     if (!has_next) return;
     // ---- F1 of the next layer on z = y (registers)
     const int g = lane >> 4;
-    const int64_t tc = valid ? tok : n - 1;
-    const int p = N.tok_pos[tc];
+    const int p = __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(N.tok_pos, n, 4), tok * 4, 0, 0);
     uint2 xb[8], xpb[8];
+    {
+        const __amdgpu_buffer_rsrc_t pr = table_rsrc(N.pos_table);
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        const float4 pv = *reinterpret_cast<const float4*>(N.pos_table + (int64_t)p * 128 + 16 * ct + 4 * g);
-        xb[ct] = pack4(y[ct]);
-        const f32x4 xp = {y[ct][0] + pv.x, y[ct][1] + pv.y, y[ct][2] + pv.z, y[ct][3] + pv.w};
-        xpb[ct] = pack4(xp);
-        if (N.x_b && valid) {
-            *reinterpret_cast<uint2*>(N.x_b + tok * 128 + 16 * ct + 4 * g) = xb[ct];
-            *reinterpret_cast<uint2*>(N.xp_b + tok * 128 + 16 * ct + 4 * g) = xpb[ct];
+        for (int ct = 0; ct < 8; ++ct) {
+            const f32x4 pv = buf_load_f32x4(pr, p * 512 + 64 * ct + 16 * g);
+            xb[ct] = pack4(y[ct]);
+            xpb[ct] = pack4(y[ct] + pv);
         }
+    }
+    if (N.x_b) {
+        store_rows_packed<128>(N.x_b, n, tok, 128, 0, xb, lane);
+        store_rows_packed<128>(N.xp_b, n, tok, 128, 0, xpb, lane);
     }
     WStage<128, 128> s_v;
     {
@@ -209,13 +210,13 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         load_bias<256>(N.bqkv, acc, lane);
         gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
         stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
-        store_rows_bf16<256>(N.qkv, tok, 384, 0, valid, acc, lane);
+        store_rows_bf16<256>(N.qkv, n, tok, 384, 0, acc, lane);
     }
     {
         f32x4 acc[8];
         load_bias<128>(N.bqkv + 256, acc, lane);
         gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
-        store_rows_bf16<128>(N.qkv, tok, 384, 256, valid, acc, lane);
+        store_rows_bf16<128>(N.qkv, n, tok, 384, 256, acc, lane);
     }
 }
 
@@ -242,22 +243,17 @@ struct FfnBwdArgs {
 
 // B1 arithmetic: acc = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv
 __device__ __forceinline__ void qkv_bwd_rows(const bf16_t* __restrict__ dqkv, const float* __restrict__ dx_res,
-                                             const bf16_t* __restrict__ wqkT, const bf16_t* __restrict__ wvT, int64_t tok,
-                                             bool valid, bf16_t* __restrict__ smem, f32x4 (&acc)[8], int lane) {
-    const int g = lane >> 4;
+                                             const bf16_t* __restrict__ wqkT, const bf16_t* __restrict__ wvT, int n,
+                                             int tok, bf16_t* __restrict__ smem, f32x4 (&acc)[8], int lane) {
     WStage<256, 128> s_qk;
     WStage<128, 128> s_v;
     stage_issue<256, 128>(wqkT, s_qk);
-    load_rows_f32<128>(dx_res, tok, valid, acc, lane);
+    load_rows_f32<128>(dx_res, n, tok, acc, lane);
     uint2 dv_rows[8];
     {
         uint2 d[16];
-#pragma unroll
-        for (int ct = 0; ct < 16; ++ct)
-            d[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct)                                // operand of the second GEMM: in flight under the first
-            dv_rows[ct] = valid ? *reinterpret_cast<const uint2*>(dqkv + tok * 384 + 256 + 16 * ct + 4 * g) : make_uint2(0u, 0u);
+        load_rows_bf16<256>(dqkv, n, tok, 384, 0, d, lane);
+        load_rows_bf16<128>(dqkv, n, tok, 384, 256, dv_rows, lane);   // operand of the second GEMM: in flight under the first
         stage_issue<128, 128>(wvT, s_v);
         gemm_staged<256, 128>(s_qk, smem, d, acc, lane);
     }
@@ -277,32 +273,32 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int tile = block * (kLayerBlk / 64) + wave;
-    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
-    const bool valid = tok < n;
+    const int tok = tile * 16 + (lane & 15);
     float* red_scratch = reinterpret_cast<float*>(smem) + wave * kRedWaveFloats;   // see ln_param_grads_t
     GEOMAE_STAMP(0);
-    const float r1 = valid ? rstd_in[tok * 2 + 0] : 0.f, r2 = valid ? rstd_in[tok * 2 + 1] : 0.f;
+    const uint2 rs = buf_load_b64(rows_rsrc(rstd_in, n, 8), tok * 8);
+    const float r1 = __uint_as_float(rs.x), r2 = __uint_as_float(rs.y);
     f32x4 dv[8];
-    if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, tok, valid, smem, dv, lane);
-    else load_rows_f32<128>(dz, tok, valid, dv, lane);
+    if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, n, tok, smem, dv, lane);
+    else load_rows_f32<128>(dz, n, tok, dv, lane);
     WStage<128, 256> s_w2T;
     // ---- LN2 backward
     {
         f32x4 xh2[8];
-        load_rows_f32<128>(xh2_in, tok, valid, xh2, lane);
+        load_rows_f32<128>(xh2_in, n, tok, xh2, lane);
         stage_issue<128, 256>(W.w2T, s_w2T);                          // lands under the LayerNorm arithmetic
         if (A.up_dqkv) __syncthreads();                               // B1's last matrix consumed by every wave
         ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane);   // d gamma2, d beta2
         layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
     }
-    store_rows_bf16<128>(dv_b, tok, 128, 0, valid, dv, lane);
+    store_rows_bf16<128>(dv_b, n, tok, 128, 0, dv, lane);
     GEOMAE_STAMP(1);
     // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
     uint2 dhpb[16];
     WStage<256, 128> s_w1T;
     {
         uint2 hpb[16];
-        load_rows_bf16<256>(hp_in, tok, valid, hpb, lane);            // needed after the GEMM: in flight under it
+        load_rows_bf16<256>(hp_in, n, tok, 256, 0, hpb, lane);           // needed after the GEMM: in flight under it
         uint2 dvb[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
@@ -312,6 +308,8 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         gemm_staged<128, 256>(s_w2T, smem, dvb, dh, lane, 2);
         GEOMAE_STAMP(5);
         stage_issue<256, 128>(W.w1T, s_w1T);                          // lands under the GELU arithmetic
+        const __amdgpu_buffer_rsrc_t h_r = rows_rsrc(h_b, n, 512), dhp_r = rows_rsrc(dhp_b, n, 512);
+        const int hoff = tok * 512 + 8 * g;
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             const f32x4 hp = unpack4(hpb[ct]);
@@ -324,15 +322,13 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
                 dh[ct][r] *= c + hp[r] * p;
             }
             dhpb[ct] = pack4(dh[ct]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(h_b + tok * 256 + 16 * ct + 4 * g) = pack4(h);
-                *reinterpret_cast<uint2*>(dhp_b + tok * 256 + 16 * ct + 4 * g) = dhpb[ct];
-            }
+            buf_store_b64(h_r, hoff + 32 * ct, pack4(h));
+            buf_store_b64(dhp_r, hoff + 32 * ct, dhpb[ct]);
         }
     }
     GEOMAE_STAMP(6);
     f32x4 xh1[8];
-    load_rows_f32<128>(xh1_in, tok, valid, xh1, lane);                // in flight under the GEMM
+    load_rows_f32<128>(xh1_in, n, tok, xh1, lane);                    // in flight under the GEMM
     gemm_staged<256, 128>(s_w1T, smem, dhpb, dv, lane, 7);            // dv now holds dy
     GEOMAE_STAMP(10);
     WStage<128, 128> s_woT;
@@ -342,14 +338,14 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         {
             f32x4 y[8];
             affine_t(xh1, W.g1, W.be1, y, lane);
-            store_rows_bf16<128>(y_b, tok, 128, 0, valid, y, lane);
+            store_rows_bf16<128>(y_b, n, tok, 128, 0, y, lane);
         }
         __syncthreads();                                              // w1T consumed by every wave
         ln_param_grads_t(dv, xh1, red_scratch, red[wave], 2, lane);   // d gamma1, d beta1
         layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
     }
-    store_rows_f32<128>(dx_res, tok, valid, dv, lane);
-    store_rows_bf16<128>(du_b, tok, 128, 0, valid, dv, lane);
+    store_rows_f32<128>(dx_res, n, tok, dv, lane);
+    store_rows_bf16<128>(du_b, n, tok, 128, 0, dv, lane);
     GEOMAE_STAMP(11);
     {
         uint2 dub[8];
@@ -360,7 +356,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm_staged<128, 128>(s_woT, smem, dub, da, lane, 12);
         GEOMAE_STAMP(15);
-        store_rows_bf16<128>(dattn, tok, 128, 0, valid, da, lane);
+        store_rows_bf16<128>(dattn, n, tok, 128, 0, da, lane);
     }
     GEOMAE_STAMP(16);
     // ---- flush LayerNorm parameter gradients (invalid rows contributed zeros: dz was loaded as 0)
@@ -391,11 +387,10 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t*
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
-    const int64_t tok = (int64_t)tile * 16 + (lane & 15);
-    const bool valid = tok < n;
+    const int tok = tile * 16 + (lane & 15);
     f32x4 acc[8];
-    qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, tok, valid, smem, acc, lane);
-    store_rows_f32<128>(dx, tok, valid, acc, lane);
+    qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, n, tok, smem, acc, lane);
+    store_rows_f32<128>(dx, n, tok, acc, lane);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -594,12 +589,18 @@ extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc
     return check_launch("pack_weights_kernel");
 }
 
+// the layer kernels address token rows with 32-bit byte offsets (raw buffer descriptors, sst_device.h): the widest
+// row is 768 bytes (bf16 qkv) and a launch touches up to 63 rows past the end
+constexpr int kMaxLayerTokens = 2700000;
+#define GEOMAE_CHECK_TOKENS(n, who) GEOMAE_REQUIRE((n) <= kMaxLayerTokens, who ": more than 2.7 M tokens per call")
+
 extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, void* qkv_bf16,
                                       void* x_bf16, void* xp_bf16, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_qkv_forward");
     if (rc) return rc;
+    GEOMAE_CHECK_TOKENS(num_tokens, "sst_qkv_forward");
     GEOMAE_REQUIRE(x && tok_pos && pos_table && qkv_bf16, "sst_qkv_forward: null argument");
     GEOMAE_REQUIRE((x_bf16 == nullptr) == (xp_bf16 == nullptr), "sst_qkv_forward: pass both operand copies or none");
     const int tiles = cdiv(num_tokens, 16);
@@ -616,6 +617,7 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_forward");
     if (rc) return rc;
+    GEOMAE_CHECK_TOKENS(num_tokens, "sst_ffn_forward");
     GEOMAE_REQUIRE(x && attn_bf16 && z, "sst_ffn_forward: null argument");
     const bool save = xhat1 || xhat2 || hp_bf16 || rstd;
     GEOMAE_REQUIRE(!save || (xhat1 && xhat2 && hp_bf16 && rstd), "sst_ffn_forward: pass all four save buffers or none");
@@ -650,6 +652,7 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_ffn_backward");
     if (rc) return rc;
+    GEOMAE_CHECK_TOKENS(num_tokens, "sst_ffn_backward");
     GEOMAE_REQUIRE(xhat1 && xhat2 && hp_bf16 && rstd && dx_res && dattn_bf16 && du_bf16 && dv_bf16 && dhp_bf16 && y_bf16 &&
                    h_bf16, "sst_ffn_backward: null argument");
     GEOMAE_REQUIRE((dz != nullptr) != (up_dqkv_bf16 != nullptr), "sst_ffn_backward: pass dz OR the upper layer's dqkv");
@@ -683,6 +686,7 @@ extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_re
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_qkv_backward");
     if (rc) return rc;
+    GEOMAE_CHECK_TOKENS(num_tokens, "sst_qkv_backward");
     GEOMAE_REQUIRE(dqkv_bf16 && dx_res && dx, "sst_qkv_backward: null argument");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,

@@ -642,7 +642,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const float* bs1 = bn1s[1] + oz;
         f32x4 y0[4], gin[8];
         recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
-        store_rows_bf16<128>(g_b, j, 128, 0, valid, gin, lane);
+        store_rows_bf16<128>(g_b, R.j_hi, j, 128, 0, gin, lane);      // rows >= j_hi belong to the next wave: dropped
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
           f32x4 y4[2];
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const int pid = valid ? pillar_of(G, j) : 0;
         const float* W1l = W1s + opaque_zero();
         f32x4 dy1[8];
-        load_rows_f32<128>(dy1_f, j, valid, dy1, lane);
+        load_rows_f32<128>(dy1_f, R.j_hi, j, dy1, lane);
         // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
