@@ -293,6 +293,20 @@ __device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int
 }
 
 // qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
+// Work item -> (bundle, head), XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (item % 8), each with its
+// own L2.  A head reads 32-byte slices of the 768-byte qkv rows of its bundle's tokens, so the 8 heads of a bundle
+// share every cache line: with item = bundle * heads + head they landed on 8 different XCDs and each line was
+// fetched by up to 4 of them (measured: 47 MB per forward launch for 13 MB of operands, profiles/r01_pmc_traffic.json).
+// Here all heads of bundle b run on XCD b % 8, in consecutive slots of that XCD.
+constexpr int kXcds = 8;
+__device__ __forceinline__ int attn_items(int NB, int n_heads) { return (NB + kXcds - 1) / kXcds * kXcds * n_heads; }
+__device__ __forceinline__ bool attn_item(int item, int NB, int n_heads, int* b, int* h) {
+    const int xcd = item % kXcds, slot = item / kXcds;
+    *b = slot / n_heads * kXcds + xcd;
+    *h = slot % n_heads;
+    return *b < NB;
+}
+
 __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
                                                           const int32_t* __restrict__ win_start,
                                                           const int32_t* __restrict__ win_tokens,
@@ -310,8 +324,9 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
-    for (int bh = blockIdx.x; bh < NB * n_heads; bh += gridDim.x) {
-        const int b = bh / n_heads, h = bh - b * n_heads;
+    for (int item = blockIdx.x; item < attn_items(NB, n_heads); item += gridDim.x) {
+        int b, h;
+        if (!attn_item(item, NB, n_heads, &b, &h)) continue;
         const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
@@ -412,9 +427,10 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
-    for (int bh = blockIdx.x; bh < NB * n_heads; bh += gridDim.x) {
+    for (int item = blockIdx.x; item < attn_items(NB, n_heads); item += gridDim.x) {
         ATTN_STAMP(0);
-        const int b = bh / n_heads, h = bh - b * n_heads;
+        int b, h;
+        if (!attn_item(item, NB, n_heads, &b, &h)) continue;
         const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
@@ -659,7 +675,7 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
 static int attn_grid(int num_tokens, int num_heads, int max_bundles, int cap) {
     int64_t nb = 2 * (int64_t)num_tokens / (cap > 0 ? cap : 1) + 2;
     if (nb > max_bundles) nb = max_bundles;
-    const int64_t items = nb * num_heads;
+    const int64_t items = (nb + 7) / 8 * 8 * num_heads;               // a multiple of 8: item % 8 (the XCD) is loop-invariant
     return (int)(items < 256 * 16 ? items : 256 * 16);
 }
 
