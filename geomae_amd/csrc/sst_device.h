@@ -58,10 +58,14 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 #ifdef GEOMAE_PHASE_TIMING
 #define GEOMAE_STAMP_SLOTS 32
 #define GEOMAE_STAMP_BLOCKS 512
+#ifndef GEOMAE_STAMP_MAX_GRID
+#define GEOMAE_STAMP_MAX_GRID 1000000     // -DGEOMAE_STAMP_MAX_GRID=300: only encoder-size launches leave stamps
+#endif
 static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
 #define GEOMAE_STAMP(i)                                                                                   \
     do {                                                                                                  \
-        if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x && (i) >= 0)               \
+        if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x && (i) >= 0 &&              \
+            gridDim.x <= GEOMAE_STAMP_MAX_GRID)                                                           \
             geomae_stamps[(blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS + (i)] = clock64();     \
     } while (0)
 #else

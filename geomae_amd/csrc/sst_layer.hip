@@ -281,6 +281,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     f32x4 dv[8];
     if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, n, tok, smem, dv, lane);
     else load_rows_f32<128>(dz, n, tok, dv, lane);
+    GEOMAE_STAMP(20);
     WStage<128, 256> s_w2T;
     // ---- LN2 backward
     {
@@ -317,13 +318,19 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float c, p;
+#ifdef GEOMAE_EXP_TRIVIAL_GELU
+                c = 0.5f; p = 0.1f * hp[r];
+#else
                 gelu_parts(hp[r], &c, &p);
+#endif
                 h[r] = hp[r] * c;
                 dh[ct][r] *= c + hp[r] * p;
             }
             dhpb[ct] = pack4(dh[ct]);
+#ifndef GEOMAE_EXP_NO_GELU_STORES
             buf_store_b64(h_r, hoff + 32 * ct, pack4(h));
             buf_store_b64(dhp_r, hoff + 32 * ct, dhpb[ct]);
+#endif
         }
     }
     GEOMAE_STAMP(6);

@@ -156,6 +156,14 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             coors_keep, coors_mask = feature_coors[ik_l], feature_coors[im_l]
             layouts = self.backbone.build_layouts(coors_keep, coors_mask, batch_size)
             layouts_ready = side.record_event()
+            # buffers the main stream would otherwise allocate-and-fill between kernels of the critical path
+            n_keep, n_mask = int(ik.numel()), int(im.numel())
+            C = self.backbone.mask_token.shape[1]
+            tokens = torch.empty((n_keep + n_mask, C), dtype=torch.float32, device=voxels.device)
+            tokens[n_keep:] = self.backbone.mask_token.detach()
+            bufs = dict(tokens=tokens, d_cen=torch.zeros_like(tokens), d_den=torch.zeros_like(tokens),
+                        d_vf=torch.zeros((V, C), dtype=torch.float32, device=voxels.device), side=side)
+            bufs["ready"] = side.record_event()
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
             tgt_ready = side.record_event()
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg)
@@ -166,8 +174,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
         losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], int(im.numel()), batch_size, tgt, w, layouts,
-                                                                 on_early_grads, packed_fresh=True, tgt_ready=tgt_ready)
-        d_vf = torch.zeros_like(vf)
+                                                                 on_early_grads, packed_fresh=True, tgt_ready=tgt_ready,
+                                                                 bufs=bufs)
+        d_vf = bufs["d_vf"]
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
         self.voxel_encoder.backward_explicit(vfe_state, d_vf)
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}

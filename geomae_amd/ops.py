@@ -634,13 +634,18 @@ def pack_weights(desc, num_desc, max_elems, packed, aux=None):
                                           _ptr(aux), _stream()), "geomae_pack_weights")
 
 
-def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights):
-    """-> losses [6] f32, d_cen, d_den [n,128] f32 (gradient of sum(losses)), saved = (dlogits, cm_b, dm_b)."""
+def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=None):
+    """-> losses [6] f32, d_cen, d_den [n,128] f32 (gradient of sum(losses)), saved = (dlogits, cm_b, dm_b).
+    d_out: optional pair of ZEROED [n,128] f32 buffers for d_cen / d_den (the kernel writes only the masked rows)."""
     dev = cen.device
     n = cen.shape[0]
     losses = torch.empty(6, dtype=torch.float32, device=dev)
-    d_cen = torch.zeros_like(cen)
-    d_den = torch.zeros_like(den)
+    if d_out is None:
+        d_cen, d_den = torch.zeros_like(cen), torch.zeros_like(den)
+    else:
+        d_cen, d_den = d_out
+        if d_cen.shape != cen.shape or d_den.shape != den.shape or not (d_cen.is_contiguous() and d_den.is_contiguous()):
+            raise RuntimeError("heads_loss: d_out must be two contiguous buffers of the decoder outputs' shape")
     dl = torch.empty((n_mask, 896), dtype=torch.bfloat16, device=dev)
     cm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
     dm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
@@ -791,15 +796,22 @@ def _stream_of(stream):
     return _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
 
-def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None):
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None):
     """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8).
-    Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current)."""
+    Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current).
+    out: optional preallocated contiguous [n,128] f32 destination of z (e.g. the head rows of a larger buffer)."""
     lib = _lib.load()
     _check_input(x, "x", torch.float32)
     n, nl = x.shape[0], len(weights)
     sb = lib.geomae_sst_stack_saved_bytes(n, nl, num_heads)
     saved = torch.empty(max(sb, 1), dtype=torch.uint8, device=x.device)
-    z = torch.empty_like(x)
+    if out is None:
+        z = torch.empty_like(x)
+    else:
+        _check_input(out, "out", torch.float32)
+        if out.shape != x.shape:
+            raise RuntimeError("sst_stack_forward: out must have the shape of x")
+        z = out
     check(lib.geomae_sst_stack_forward(_ptr(x), n, weights, nl, _stack_layouts(layouts), _ptr(pos_table), num_heads,
                                        layouts[0].max_tokens, _ptr(saved), sb, _ptr(z),
                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),

@@ -431,12 +431,16 @@ class MultiMAESSTSPChoose(nn.Module):
     # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
     @torch.no_grad()
     def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None,
-                                  packed_fresh=False, tgt_ready=None):
+                                  packed_fresh=False, tgt_ready=None, bufs=None):
         """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad.
         on_early_grads(): called once the gradients of the heads, both decoders and the mask token are enqueued
         (everything except the encoder), so that the caller can start exchanging them.
         packed_fresh: the caller already re-packed the bf16 weights for this step (on another stream, ordered before
-        this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream)."""
+        this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream).
+        bufs: optional dict prepared off the critical path by the caller (detector.train_step_explicit):
+        "tokens" [n_keep + n_mask, 128] with the mask token already in rows n_keep.., zeroed "d_cen" / "d_den" of the
+        same shape, "ready" (event after which they may be used) and "side" (the stream for work nobody waits on
+        until the optimizer: the mask-token gradient reduction)."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
         P, nh, pt = self._packed, self.nhead[0], self.pos_table
         if not packed_fresh:
@@ -446,12 +450,19 @@ class MultiMAESSTSPChoose(nn.Module):
         n_enc, n_dec = 2 * len(self.encoder_blocks), 2 * len(self.decoder_centroid_blocks)
         w_enc = P.weight_array(self._stack_base["enc"], n_enc)
         w_cen, w_den = P.weight_array(self._stack_base["cen"], n_dec), P.weight_array(self._stack_base["den"], n_dec)
-        z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
-        tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
+        cur = torch.cuda.current_stream()
+        if bufs is None:
+            z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
+            tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
+            d_out = None
+        else:                       # the encoder writes straight into the decoder input: no concatenation copy
+            tokens, d_out = bufs["tokens"], (bufs["d_cen"], bufs["d_den"])
+            _, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh, out=tokens[:n_keep])
+            cur.wait_event(bufs["ready"])
         if self._streams is None:
             st = ops.side_streams()
             self._streams = (st["dec_a"], st["dec_b"])
-        cur, (sa_, sb_) = torch.cuda.current_stream(), self._streams
+        sa_, sb_ = self._streams
         sa_.wait_stream(cur)
         sb_.wait_stream(cur)
         cen, s_cen = ops.sst_stack_forward(tokens, w_cen, dec_layouts, pt, nh, stream=sa_)
@@ -460,7 +471,8 @@ class MultiMAESSTSPChoose(nn.Module):
         cur.wait_stream(sb_)
         if tgt_ready is not None:
             cur.wait_event(tgt_ready)
-        losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights)
+        losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights,
+                                                       d_out=d_out)
         # ---------------- backward
         ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
         g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
@@ -475,11 +487,20 @@ class MultiMAESSTSPChoose(nn.Module):
         del keep_a, keep_b
         if self.mask_token.grad is None:
             self.mask_token.grad = torch.zeros_like(self.mask_token)
-        self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+        side = bufs["side"] if (bufs is not None and on_early_grads is None) else None
+        if side is None:
+            self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+        else:                       # nobody reads the mask-token gradient before the optimizer: reduce it off the main stream
+            side.wait_stream(cur)
+            d_tok.record_stream(side)
+            with torch.cuda.stream(side):
+                self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
         if on_early_grads is not None:
             on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
         d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+        if side is not None:
+            cur.wait_stream(side)
         return losses, d_vf
 
     def decode(self, visible_voxel_feat, coors, coors_mask, batch_size, layouts=None):

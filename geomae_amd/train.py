@@ -259,7 +259,8 @@ class Trainer:
             if world > 1 and len(self.flat.segments) > 1:
                 a, b, _ = self.flat.segments[0]
                 works.append((0, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
-        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early_ready)) if explicit else \
+        early = early_ready if (world > 1 and len(self.flat.segments) > 1) else None
+        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early)) if explicit else \
             (lambda p: self.model.forward_train(p, None, **kw))
         if next_points is not None and hasattr(self.model, "prefetch"):
             self.model.prefetch(next_points)

@@ -11,7 +11,7 @@ objs, jobs = [], []
 for src in sorted(glob.glob(os.path.join(SRC, "*.hip"))):
     o = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     objs.append(o)
-    jobs.append(["/opt/rocm/bin/hipcc"] + flags_for(src) + ["-DGEOMAE_PHASE_TIMING", "-c", src, "-o", o])
+    jobs.append(["/opt/rocm/bin/hipcc"] + flags_for(src) + ["-DGEOMAE_PHASE_TIMING"] + os.environ.get("GEOMAE_TIMING_DEFS", "").split() + ["-c", src, "-o", o])
 with ThreadPoolExecutor(8) as ex:
     list(ex.map(subprocess.check_call, jobs))
 out = os.path.join(ROOT, "tools", "libgeomae_timing.so")

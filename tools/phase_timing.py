@@ -41,4 +41,5 @@ for k in order:
     d = rel[:, k] - last
     print(f"{k:2d} {names[k]:40s} mean {d.mean():9.0f}  med {np.median(d):9.0f}  cum {rel[:,k].mean():9.0f}")
     last = rel[:, k]
+print(f"B1 head (stamp 20, from start): mean {rel[:,20].mean():.0f} med {np.median(rel[:,20]):.0f}")
 print("block start spread (cycles):", (s[:,0].max()-s[:,0].min()), " end spread:", s[:,17].max()-s[:,17].min(), "total span", s[:,17].max()-s[:,0].min())
