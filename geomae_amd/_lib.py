@@ -102,15 +102,15 @@ SIGNATURES = {
     "geomae_grad_sumsq": (ctypes.c_int, [P, c_int64, P, P]),
     "geomae_adamw_step": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
                                          c_int64, c_float, P, c_float, c_int32, P, P]),
-    "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P]),
+    "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P, P]),
     "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),
     "geomae_vfe_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
     "geomae_vfe_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
     "geomae_vfe_backward_stats": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, P]),
     "geomae_vfe_backward_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, c_float,
-                                                  P, P, P, P, P, P, P]),
+                                                  P, P, P, P, P, P, P, P, P]),
     "geomae_vfe_backward_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, c_float, c_int64,
-                                                  P, P, P, P, P]),
+                                                  P, P, P, P, P, P, P]),
     "geomae_segment_max_forward": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P]),
     "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
     "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),

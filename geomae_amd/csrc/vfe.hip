@@ -338,7 +338,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           float eps, float momentum, int unbiased_running,
                                                           float* __restrict__ running_mean, float* __restrict__ running_var,
                                                           float* __restrict__ scale, float* __restrict__ shift,
-                                                          float* __restrict__ invstd_out, float* __restrict__ moments_out) {
+                                                          float* __restrict__ invstd_out, float* __restrict__ moments_out,
+                                                          long long* __restrict__ num_batches_tracked) {
+    if (num_batches_tracked && threadIdx.x == 0) num_batches_tracked[0] += 1;
     for (int c = threadIdx.x; c < C; c += 256) {
         float mean, msq;
         if (moments_in) { mean = moments_in[c]; msq = moments_in[C + c]; }
@@ -612,7 +614,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     VfeGeo G, VfeW W, const float* __restrict__ m0, const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn,
     const double* __restrict__ bsums1, float n_eff, bf16_t* __restrict__ dy1_b, bf16_t* __restrict__ g_b,
-    float* __restrict__ dy1_f, float* __restrict__ dh0, float* __restrict__ dm0) {
+    float* __restrict__ dy1_f, float* __restrict__ dh0, float* __restrict__ dm0, float* __restrict__ d_beta1,
+    float* __restrict__ d_gamma1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
@@ -624,6 +627,10 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     for (int c = threadIdx.x; c < 128; c += kVfeBlk) {
         bn1s[0][c] = (float)(bsums1[c] / (double)n_eff);
         bn1s[1][c] = (float)(bsums1[128 + c] / (double)n_eff);
+        if (d_beta1 && blockIdx.x == 0) {          // single process: the sums ARE d beta / d gamma (one writer: no atomics)
+            d_beta1[c] += (float)bsums1[c];
+            d_gamma1[c] += (float)bsums1[128 + c];
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
@@ -763,7 +770,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
 // layer-0 backward: dy0 = invstd0 * (dyh0 - T1/n - yhat0 * T2/n) ; dW0 += dy0^T f   (64 x 11)
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW W, const float* __restrict__ dh0, Bn0 bn0,
                                                                  const double* __restrict__ bsums0, float n_eff,
-                                                                 float* __restrict__ dw0) {
+                                                                 float* __restrict__ dw0, float* __restrict__ d_beta0,
+                                                                 float* __restrict__ d_gamma0) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];     // [t][0..63] dy0, [t][64..79] f
     __shared__ float acc_s[64 * 16];
@@ -774,6 +782,10 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
     for (int c = threadIdx.x; c < 64; c += kVfeBlk) {
         bn0s[0][c] = (float)(bsums0[c] / (double)n_eff);
         bn0s[1][c] = (float)(bsums0[64 + c] / (double)n_eff);
+        if (d_beta0 && blockIdx.x == 0) {
+            d_beta0[c] += (float)bsums0[c];
+            d_gamma0[c] += (float)bsums0[64 + c];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -877,11 +889,13 @@ extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features
 extern "C" int geomae_bn_finalize(const double* sums, double count, const float* moments_in, int32_t channels,
                                   const float* gamma, const float* beta, float eps, float momentum,
                                   int32_t unbiased_running_var, float* running_mean, float* running_var, float* scale,
-                                  float* shift, float* invstd, float* moments_out, hipStream_t stream) {
+                                  float* shift, float* invstd, float* moments_out, int64_t* num_batches_tracked,
+                                  hipStream_t stream) {
     GEOMAE_REQUIRE((sums || moments_in) && channels >= 1 && channels <= 1024, "bn_finalize: bad argument");
     GEOMAE_REQUIRE(!scale || (gamma && beta && shift && invstd), "bn_finalize: scale needs gamma, beta, shift, invstd");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, count, moments_in, channels, gamma, beta,
-                       eps, momentum, unbiased_running_var, running_mean, running_var, scale, shift, invstd, moments_out);
+                       eps, momentum, unbiased_running_var, running_mean, running_var, scale, shift, invstd, moments_out,
+                       (long long*)num_batches_tracked);
     return check_launch("bn_finalize_kernel");
 }
 
@@ -946,7 +960,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
                                           const float* voxel_feats, const float* d_voxel_feats,
                                           const double* bsums1_global, float n_eff, void* dy1_bf16, void* g_bf16,
                                           float* dy1_f32, float* dh0, float* dm0, double* bsums0,
-                                          hipStream_t stream) {
+                                          float* d_beta1, float* d_gamma1, hipStream_t stream) {
     VfeGeo G; VfeW W;
     int rc = vfe_common(a, &G, &W, "vfe_backward_layer1");
     if (rc) return rc;
@@ -958,7 +972,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     GEOMAE_HIP(hipMemsetAsync(bsums0, 0, 128 * sizeof(double), stream));
     GEOMAE_HIP(hipMemsetAsync(dm0, 0, (size_t)a->max_pillars * 64 * sizeof(float), stream));
     hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
-                       bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0);
+                       bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0, d_beta1, d_gamma1);
     if ((rc = check_launch("vfe_bwd_layer1_kernel"))) return rc;
     hipLaunchKernelGGL(vfe_bwd_route0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0, dh0,
                        bsums0);
@@ -968,7 +982,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
 extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBnState* bnst, const float* dh0,
                                           const double* bsums0_global, float n_eff, int64_t num_points,
                                           const void* dy1_bf16, const void* g_bf16, float* dw0, float* dw1,
-                                          hipStream_t stream) {
+                                          float* d_beta0, float* d_gamma0, hipStream_t stream) {
     VfeGeo G; VfeW W;
     int rc = vfe_common(a, &G, &W, "vfe_backward_layer0");
     if (rc) return rc;
@@ -976,8 +990,9 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
     GEOMAE_REQUIRE(dh0 && bsums0_global && dy1_bf16 && g_bf16 && dw0 && dw1 && n_eff > 0,
                    "vfe_backward_layer0: null argument");
+    GEOMAE_REQUIRE((d_beta0 == nullptr) == (d_gamma0 == nullptr), "vfe_backward_layer0: pass both BN gradients or none");
     hipLaunchKernelGGL(vfe_bwd_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, dh0, bn0, bsums0_global, n_eff,
-                       dw0);
+                       dw0, d_beta0, d_gamma0);
     rc = check_launch("vfe_bwd_layer0_kernel");
     if (rc) return rc;
     DwTasks T;

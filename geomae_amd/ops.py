@@ -707,18 +707,17 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
     if world == 1:
         check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N), None, *common, 1, _ptr(norm.running_mean),
                                      _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), _ptr(bn[2]),
-                                     _stream()), "geomae_bn_finalize")
+                                     _ptr(norm.num_batches_tracked), _stream()), "geomae_bn_finalize")
     else:
         mom = torch.empty(2 * C, dtype=torch.float32, device=sums.device)
         check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N), None, C, None, None, 0.0, 0.0, 0, None, None, None, None,
-                                     None, _ptr(mom), _stream()), "geomae_bn_finalize")
+                                     None, _ptr(mom), None, _stream()), "geomae_bn_finalize")
         dist.all_reduce(mom, group=group)
         mom.mul_(1.0 / world)
         check(lib.geomae_bn_finalize(None, float(plan.N), _ptr(mom), *common, 0, _ptr(norm.running_mean),
-                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), None, _stream()),
-              "geomae_bn_finalize")
+                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), None,
+                                     _ptr(norm.num_batches_tracked), _stream()), "geomae_bn_finalize")
         bn[2, :C].copy_(mom[:C])
-    norm.num_batches_tracked += 1
 
 
 def vfe_forward(plan, norm0, norm1, world=1, group=None):
@@ -751,9 +750,12 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
     bs1 = torch.empty(256, dtype=torch.float64, device=dev)
     check(lib.geomae_vfe_backward_stats(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), _stream()),
           "geomae_vfe_backward_stats")
-    params["b1"].grad.add_(bs1[:128])
-    params["g1"].grad.add_(bs1[128:])
-    if world > 1:
+    # d beta / d gamma = the LOCAL sums: one process lets the next kernel add them; with naiveSyncBN1d they are added
+    # here, before the sums are all-reduced for the input gradient
+    fold = world == 1
+    if not fold:
+        params["b1"].grad.add_(bs1[:128])
+        params["g1"].grad.add_(bs1[128:])
         dist.all_reduce(bs1, group=group)
     n_eff = float(world * N)
     dy1_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
@@ -764,13 +766,16 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
     bs0 = torch.empty(128, dtype=torch.float64, device=dev)
     check(lib.geomae_vfe_backward_layer1(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), n_eff,
                                          _ptr(dy1_b), _ptr(g_b), _ptr(dy1_f), _ptr(dh0), _ptr(dm0), _ptr(bs0),
-                                         _stream()), "geomae_vfe_backward_layer1")
-    params["b0"].grad.add_(bs0[:64])
-    params["g0"].grad.add_(bs0[64:])
-    if world > 1:
+                                         _ptr(params["b1"].grad) if fold else None,
+                                         _ptr(params["g1"].grad) if fold else None, _stream()), "geomae_vfe_backward_layer1")
+    if not fold:
+        params["b0"].grad.add_(bs0[:64])
+        params["g0"].grad.add_(bs0[64:])
         dist.all_reduce(bs0, group=group)
     check(lib.geomae_vfe_backward_layer0(a, ctypes.byref(bn), _ptr(dh0), _ptr(bs0), n_eff, N, _ptr(dy1_b), _ptr(g_b),
-                                         _ptr(params["w0"].grad), _ptr(params["w1"].grad), _stream()),
+                                         _ptr(params["w0"].grad), _ptr(params["w1"].grad),
+                                         _ptr(params["b0"].grad) if fold else None,
+                                         _ptr(params["g0"].grad) if fold else None, _stream()),
           "geomae_vfe_backward_layer0")
 
 

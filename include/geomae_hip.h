@@ -281,7 +281,9 @@ int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_po
 int geomae_bn_finalize(const double* sums, double count, const float* moments_in, int32_t channels,
                        const float* gamma, const float* beta, float eps, float momentum,
                        int32_t unbiased_running_var, float* running_mean, float* running_var, float* scale,
-                       float* shift, float* invstd, float* moments_out, geomaeStream_t stream);
+                       float* shift, float* invstd, float* moments_out,
+                       int64_t* num_batches_tracked /* += 1 when not NULL (nn.BatchNorm1d's counter) */,
+                       geomaeStream_t stream);
 int geomae_vfe_stats0(const GeomaeVfeArgs* args /*host*/, double* sums0 /*[128]*/, geomaeStream_t stream);
 int geomae_vfe_layer0(const GeomaeVfeArgs* args, float* m0 /*[V,64]*/, double* sums1 /*[256]*/, geomaeStream_t stream);
 int geomae_vfe_layer1(const GeomaeVfeArgs* args, const float* m0, float* voxel_feats /*[V,128]*/, geomaeStream_t stream);
@@ -299,11 +301,15 @@ int geomae_vfe_backward_layer1(const GeomaeVfeArgs* args, const GeomaeBnState* b
                                const float* voxel_feats, const float* d_voxel_feats, const double* bsums1_global,
                                float n_eff, void* dy1_bf16 /*[N,128]*/, void* g_bf16 /*[N,128]*/,
                                float* dy1_f32 /*[N,128] scratch*/, float* dh0 /*[N,64]*/, float* dm0 /*[V,64]*/,
-                               double* bsums0 /*[128]*/, geomaeStream_t stream);
+                               double* bsums0 /*[128]*/, float* d_beta1 /*[128] += or NULL*/,
+                               float* d_gamma1 /*[128] += or NULL*/, geomaeStream_t stream);
 int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* dh0,
                                const double* bsums0_global, float n_eff, int64_t num_points, const void* dy1_bf16,
                                const void* g_bf16, float* dw0 /*[64,11] +=*/, float* dw1 /*[128,128] +=*/,
+                               float* d_beta0 /*[64] += or NULL*/, float* d_gamma0 /*[64] += or NULL*/,
                                geomaeStream_t stream);
+/* d_beta / d_gamma (both or neither): single-process callers let the kernels add bsums (= d beta, d gamma) to the
+ * BatchNorm parameter gradients; with naiveSyncBN1d the caller adds the LOCAL sums itself before all-reducing them. */
 
 /* ------------------------------------------------------------------ a stack of SST layers in one call
  * replaces the Python block loops of forward_encoder / forward_decoder (bb.py:227-277) and their autograd
