@@ -26,6 +26,12 @@ class GeomaeWindowConfig(ctypes.Structure):
     _fields_ = [("window_shape", c_int32 * 2), ("shift", c_int32 * 2), ("bev_shape", c_int32 * 2)]
 
 
+class GeomaeWindowBuildJob(ctypes.Structure):
+    _fields_ = ([("coors", c_void_p), ("num_tokens", c_int32), ("shift_index", c_int32)]
+                + [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "bun_start",
+                                           "num_bundles")])
+
+
 class GeomaeSstLayerWeights(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("wqkv_p", "wqkT_p", "wvT_p", "wo_p", "woT_p", "w1_p", "w1T_p", "w2_p",
                                          "w2T_p", "bqkv", "bo", "b1", "b2", "ln1_w", "ln1_b", "ln2_w", "ln2_b")]
@@ -119,12 +125,18 @@ SIGNATURES = {
     "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_window_build": (ctypes.c_int, [P, c_int32, c_int32, POINTER(GeomaeWindowConfig), c_int32, P, P, P, P,
                                            P, P, P, P, c_int64, P]),
+    "geomae_window_build_batch_workspace_bytes": (c_int64, [POINTER(c_int32), c_int32, c_int32,
+                                                            POINTER(GeomaeWindowConfig)]),
+    "geomae_window_build_batch": (ctypes.c_int, [POINTER(GeomaeWindowBuildJob), c_int32, c_int32,
+                                                 POINTER(GeomaeWindowConfig), P, c_int64, P]),
     "geomae_window_attention_forward": (ctypes.c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32,
                                                        c_int32, P, P, P]),
     "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, P, P,
                                                         c_int32, c_int32, P, P]),
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
     "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
+    "geomae_set_accumulators_prezeroed": (ctypes.c_int, [c_int32]),
+    "geomae_heads_loss_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_heads_weight_grad": (ctypes.c_int, [c_int32, P, P, P, POINTER(GeomaeHeadGrads), P]),
     "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
     "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),

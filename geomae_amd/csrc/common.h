@@ -32,6 +32,16 @@ inline int check_launch(const char* what) {
         }                                         \
     } while (0)
 
+// Accumulator / atomics-target buffers are zeroed by the entry point that fills them (hipMemsetAsync: a ~5 us fill
+// kernel each, a dozen of them between dependent kernels of a training step) unless the calling thread declared, with
+// geomae_set_accumulators_prezeroed(1), that it hands in buffers that are already zero (one arena fill per step,
+// done off the critical path).  Entry points that honour the mode say so in include/geomae_hip.h.
+bool accumulators_prezeroed();
+#define GEOMAE_ZERO(ptr, bytes, stream)                                                 \
+    do {                                                                                \
+        if (!geomae::accumulators_prezeroed()) GEOMAE_HIP(hipMemsetAsync(ptr, 0, bytes, stream)); \
+    } while (0)
+
 #define GEOMAE_HIP(call)                                                      \
     do {                                                                      \
         hipError_t e_ = (call);                                               \

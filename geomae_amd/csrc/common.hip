@@ -11,7 +11,14 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local bool g_prezeroed = false;
+bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae
+
+extern "C" int geomae_set_accumulators_prezeroed(int32_t enabled) {
+    geomae::g_prezeroed = enabled != 0;
+    return GEOMAE_OK;
+}
 
 extern "C" const char* geomae_last_error(void) { return geomae::g_err; }
 extern "C" int32_t geomae_abi_version(void) { return GEOMAE_ABI_VERSION; }

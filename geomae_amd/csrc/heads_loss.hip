@@ -216,7 +216,8 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 
 using namespace geomae;
 
-extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+// `losses` is ACCUMULATED into (atomics): the caller zeroes it, e.g. off the critical path
+extern "C" int geomae_heads_loss_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
                                  int32_t num_mask, const void* head_w_packed, const float* head_bias,
                                  const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
                                  const uint8_t* mask_med, const float* centroid_top, const float* normal,
@@ -236,10 +237,24 @@ extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_den
     A.w_cls_low = loss_weights[4]; A.w_cls_med = loss_weights[5];
     A.loss = losses; A.d_cen = d_dec_centroid; A.d_den = d_dec_density;
     A.dl = (bf16_t*)dlogits_bf16; A.cm_b = (bf16_t*)cm_bf16; A.dm_b = (bf16_t*)dm_bf16;
-    GEOMAE_HIP(hipMemsetAsync(losses, 0, 6 * sizeof(float), stream));
     const int tiles = cdiv(num_mask, 16);
     hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, A);
     return check_launch("heads_loss_kernel");
+}
+
+extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                 const int32_t* occ_counts, const float* loss_weights, float* losses,
+                                 float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
+                                 void* dm_bf16, hipStream_t stream) {
+    GEOMAE_REQUIRE(losses, "heads_loss: null argument");
+    GEOMAE_HIP(hipMemsetAsync(losses, 0, 6 * sizeof(float), stream));
+    return geomae_heads_loss_accumulate(dec_centroid, dec_density, num_keep, num_mask, head_w_packed, head_bias,
+                                        centroid_low, mask_low, centroid_med, mask_med, centroid_top, normal, occ_counts,
+                                        loss_weights, losses, d_dec_centroid, d_dec_density, dlogits_bf16, cm_bf16,
+                                        dm_bf16, stream);
 }
 
 extern "C" int geomae_heads_weight_grad(int32_t num_mask, const void* dlogits_bf16, const void* cm_bf16,

@@ -100,7 +100,7 @@ using namespace geomae;
 extern "C" int geomae_grad_sumsq(const float* grad, int64_t num_elems, double* sumsq, hipStream_t stream) {
     GEOMAE_REQUIRE(grad && sumsq && num_elems >= 0, "grad_sumsq: bad argument");
     GEOMAE_REQUIRE(((uintptr_t)grad & 15) == 0, "grad_sumsq: buffer must be 16-byte aligned");
-    GEOMAE_HIP(hipMemsetAsync(sumsq, 0, sizeof(double), stream));
+    GEOMAE_ZERO(sumsq, sizeof(double), stream);
     if (num_elems == 0) return GEOMAE_OK;
     hipLaunchKernelGGL(grad_sumsq_kernel, dim3(stream_grid(num_elems / 4 + 1, 256)), dim3(256), 0, stream, grad, num_elems, sumsq);
     return check_launch("grad_sumsq_kernel");

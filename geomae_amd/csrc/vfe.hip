@@ -877,7 +877,7 @@ extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features
                                        int32_t max_pillars, void* sum_workspace, float* mean, hipStream_t stream) {
     if (max_pillars <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(points && inv && seg_start && num_pillars && sum_workspace && mean, "segment_mean_xyz: null argument");
-    GEOMAE_HIP(hipMemsetAsync(sum_workspace, 0, (size_t)max_pillars * 3 * sizeof(unsigned long long), stream));
+    GEOMAE_ZERO(sum_workspace, (size_t)max_pillars * 3 * sizeof(unsigned long long), stream);
     if (num_points > 0)
         hipLaunchKernelGGL(vfe_mean_accum_kernel, dim3(stream_grid(num_points, 256)), dim3(256), 0, stream, points,
                            num_features, num_points, inv, (unsigned long long*)sum_workspace);
@@ -904,7 +904,7 @@ extern "C" int geomae_vfe_stats0(const GeomaeVfeArgs* a, double* sums0, hipStrea
     int rc = vfe_common(a, &G, &W, "vfe_stats0");
     if (rc) return rc;
     GEOMAE_REQUIRE(sums0, "vfe_stats0: null output");
-    GEOMAE_HIP(hipMemsetAsync(sums0, 0, 128 * sizeof(double), stream));
+    GEOMAE_ZERO(sums0, 128 * sizeof(double), stream);
     hipLaunchKernelGGL(vfe_stats0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, sums0);
     return check_launch("vfe_stats0_kernel");
 }
@@ -914,8 +914,8 @@ extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums
     int rc = vfe_common(a, &G, &W, "vfe_layer0");
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && sums1 && a->scale0 && a->shift0, "vfe_layer0: null argument");
-    GEOMAE_HIP(hipMemsetAsync(sums1, 0, 256 * sizeof(double), stream));
-    GEOMAE_HIP(hipMemsetAsync(m0, 0, (size_t)a->max_pillars * 64 * sizeof(float), stream));
+    GEOMAE_ZERO(sums1, 256 * sizeof(double), stream);
+    GEOMAE_ZERO(m0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
     hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0);
     if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
     hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
@@ -927,7 +927,7 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     int rc = vfe_common(a, &G, &W, "vfe_layer1");
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
-    GEOMAE_HIP(hipMemsetAsync(voxel_feats, 0, (size_t)a->max_pillars * 128 * sizeof(float), stream));
+    GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
     hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats);
     return check_launch("vfe_layer1_kernel");
 }
@@ -950,7 +950,7 @@ extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnS
     Bn1 bn;
     if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1, "vfe_backward_stats: null argument");
-    GEOMAE_HIP(hipMemsetAsync(bsums1, 0, 256 * sizeof(double), stream));
+    GEOMAE_ZERO(bsums1, 256 * sizeof(double), stream);
     hipLaunchKernelGGL(vfe_bwd_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats,
                        d_voxel_feats, bn, bsums1);
     return check_launch("vfe_bwd_stats1_kernel");
@@ -969,8 +969,8 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dy1_f32 && dh0 && dm0 &&
                    bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
-    GEOMAE_HIP(hipMemsetAsync(bsums0, 0, 128 * sizeof(double), stream));
-    GEOMAE_HIP(hipMemsetAsync(dm0, 0, (size_t)a->max_pillars * 64 * sizeof(float), stream));
+    GEOMAE_ZERO(bsums0, 128 * sizeof(double), stream);
+    GEOMAE_ZERO(dm0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
     hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
                        bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0, d_beta1, d_gamma1);
     if ((rc = check_launch("vfe_bwd_layer1_kernel"))) return rc;

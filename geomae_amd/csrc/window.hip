@@ -32,10 +32,9 @@ __device__ __forceinline__ void win_of(const int4 c, const WinGeom g, int* win, 
     *pos = (sx % g.wx) * g.wy + (sy % g.wy);
 }
 
-__global__ __launch_bounds__(kWBlk) void win_hist_kernel(const int4* __restrict__ coors, int n, WinGeom g,
-                                                         int32_t* __restrict__ table, int32_t* __restrict__ rank,
-                                                         int32_t* __restrict__ tok_win_id,
-                                                         int32_t* __restrict__ tok_pos) {
+__device__ __forceinline__ void win_hist_body(const int4* __restrict__ coors, int n, WinGeom g,
+                                              int32_t* __restrict__ table, int32_t* __restrict__ rank,
+                                              int32_t* __restrict__ tok_win_id, int32_t* __restrict__ tok_pos) {
     for (int i = blockIdx.x * kWBlk + threadIdx.x; i < n; i += gridDim.x * kWBlk) {
         int w, p;
         win_of(coors[i], g, &w, &p);
@@ -44,11 +43,35 @@ __global__ __launch_bounds__(kWBlk) void win_hist_kernel(const int4* __restrict_
         rank[i] = atomicAdd(&table[w], 1);
     }
 }
+__global__ __launch_bounds__(kWBlk) void win_hist_kernel(const int4* __restrict__ coors, int n, WinGeom g,
+                                                         int32_t* __restrict__ table, int32_t* __restrict__ rank,
+                                                         int32_t* __restrict__ tok_win_id,
+                                                         int32_t* __restrict__ tok_pos) {
+    win_hist_body(coors, n, g, table, rank, tok_win_id, tok_pos);
+}
+
+// One launch of each build stage serves up to kMaxWinJobs layouts (blockIdx.y = job): a training step builds four
+// (encoder / decoder tokens x unshifted / shifted windows), and five tiny dependent kernels per layout, two of them
+// single-workgroup, were 24 launches = ~0.3 ms of a serial chain that gated the encoder (tools/phase_events.py).
+constexpr int kMaxWinJobs = 4;
+struct WinJob {
+    const int4* coors;
+    int n, slots, cap;
+    WinGeom g;
+    int32_t *table, *rank, *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
+};
+struct WinJobs { WinJob j[kMaxWinJobs]; };
+
+__global__ __launch_bounds__(kWBlk) void win_hist_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    win_hist_body(j.coors, j.n, j.g, j.table, j.rank, j.tok_win, j.tok_pos);
+}
 
 // one workgroup: compact the non-empty windows (ascending id) and exclusive-scan their sizes
-__global__ __launch_bounds__(1024) void win_scan_kernel(int32_t* __restrict__ table, int n_slots,
-                                                        int32_t* __restrict__ win_start,
-                                                        int32_t* __restrict__ num_windows, int n_tokens) {
+__global__ __launch_bounds__(1024) void win_scan_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    int32_t* __restrict__ table = j.table; const int n_slots = j.slots; int32_t* __restrict__ win_start = j.win_start;
+    int32_t* __restrict__ num_windows = j.num_windows; const int n_tokens = j.n;
     __shared__ int sm[40];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int run_occ = 0, run_cnt = 0;
@@ -80,11 +103,11 @@ __global__ __launch_bounds__(1024) void win_scan_kernel(int32_t* __restrict__ ta
     if (threadIdx.x == 0) { num_windows[0] = run_occ; win_start[run_occ] = n_tokens; }
 }
 
-__global__ __launch_bounds__(kWBlk) void win_place_kernel(int n, const int32_t* __restrict__ table,
-                                                          const int32_t* __restrict__ rank,
-                                                          const int32_t* __restrict__ win_start,
-                                                          int32_t* __restrict__ tok_win_id,
-                                                          int32_t* __restrict__ win_tokens) {
+__global__ __launch_bounds__(kWBlk) void win_place_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    const int n = j.n; const int32_t* __restrict__ table = j.table; const int32_t* __restrict__ rank = j.rank;
+    const int32_t* __restrict__ win_start = j.win_start; int32_t* __restrict__ tok_win_id = j.tok_win;
+    int32_t* __restrict__ win_tokens = j.win_tokens;
     for (int i = blockIdx.x * kWBlk + threadIdx.x; i < n; i += gridDim.x * kWBlk) {
         const int w = table[tok_win_id[i]];
         tok_win_id[i] = w;     // now the compact (CSR) window index
@@ -93,9 +116,10 @@ __global__ __launch_bounds__(kWBlk) void win_place_kernel(int n, const int32_t* 
 }
 
 // make the in-window token order deterministic (ascending token index): rank sort, one wave / window
-__global__ __launch_bounds__(64) void win_sort_kernel(const int32_t* __restrict__ win_start,
-                                                      const int32_t* __restrict__ num_windows,
-                                                      int32_t* __restrict__ win_tokens) {
+__global__ __launch_bounds__(64) void win_sort_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    const int32_t* __restrict__ win_start = j.win_start; const int32_t* __restrict__ num_windows = j.num_windows;
+    int32_t* __restrict__ win_tokens = j.win_tokens;
     __shared__ int a[1024];
     const int W = num_windows[0];
     for (int w = blockIdx.x; w < W; w += gridDim.x) {
@@ -117,11 +141,11 @@ __global__ __launch_bounds__(64) void win_sort_kernel(const int32_t* __restrict_
 // greedy packing of consecutive windows into bundles of at most `cap` tokens (cap >= the largest window):
 // most windows hold a handful of pillars, and one wavefront per (window, head) drowned in fixed
 // per-wave latency (profiles/r01d: 16k waves per launch).  One thread, sizes pipelined from LDS.
-__global__ __launch_bounds__(1024) void win_bundle_kernel(const int32_t* __restrict__ win_start,
-                                                          const int32_t* __restrict__ num_windows, int cap,
-                                                          int32_t* __restrict__ bun_start,
-                                                          int32_t* __restrict__ num_bundles,
-                                                          int32_t* __restrict__ nxt_ws) {
+__global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    const int32_t* __restrict__ win_start = j.win_start; const int32_t* __restrict__ num_windows = j.num_windows;
+    const int cap = j.cap; int32_t* __restrict__ bun_start = j.bun_start; int32_t* __restrict__ num_bundles = j.num_bundles;
+    int32_t* __restrict__ nxt_ws = j.rank;      // reused: the window counting sort is done with it
     // nxt[w] = end (exclusive) of the greedy bundle that starts at window w: the largest e with
     // win_start[e] - win_start[w] <= cap (binary search, all threads); then one thread follows the chain
     // 0 -> nxt[0] -> ... (one dependent read per BUNDLE instead of per window).
@@ -628,44 +652,78 @@ extern "C" int64_t geomae_window_build_workspace_bytes(int32_t num_tokens, int32
     return al((int64_t)batch_size * sps * 4) + al((int64_t)num_tokens * 4);
 }
 
+extern "C" int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens, int32_t num_jobs,
+                                                             int32_t batch_size, const GeomaeWindowConfig* cfg) {
+    if (!num_tokens || num_jobs < 1 || num_jobs > kMaxWinJobs) return -1;
+    int64_t total = 0;
+    for (int k = 0; k < num_jobs; ++k) {
+        const int64_t b = geomae_window_build_workspace_bytes(num_tokens[k], batch_size, cfg);
+        if (b < 0) return -1;
+        total += b;
+    }
+    return total;
+}
+
+extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32_t num_jobs, int32_t batch_size,
+                                         const GeomaeWindowConfig* cfg, void* workspace, int64_t workspace_bytes,
+                                         hipStream_t stream) {
+    GEOMAE_REQUIRE(jobs && num_jobs >= 1 && num_jobs <= kMaxWinJobs && batch_size >= 1,
+                   "window_build_batch: 1..4 jobs, batch_size >= 1");
+    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
+    WinJobs J;
+    int64_t table_bytes = 0, need = 0;
+    int max_n = 0, max_w = 1;
+    for (int k = 0; k < num_jobs; ++k) {
+        const GeomaeWindowBuildJob& in = jobs[k];
+        WinJob& j = J.j[k];
+        int sps;
+        int rc = win_geom(cfg, in.shift_index, &j.g, &sps);
+        if (rc) return rc;
+        GEOMAE_REQUIRE(in.num_tokens >= 0, "window_build: bad sizes");
+        GEOMAE_REQUIRE(in.win_start && in.num_windows && in.bun_start && in.num_bundles, "window_build: null output");
+        GEOMAE_REQUIRE(in.num_tokens == 0 || (in.coors && in.win_tokens && in.tok_win && in.tok_pos),
+                       "window_build: null argument");
+        j.coors = (const int4*)in.coors; j.n = in.num_tokens; j.slots = batch_size * sps; j.cap = j.g.wx * j.g.wy;
+        j.win_start = in.win_start; j.win_tokens = in.win_tokens; j.tok_win = in.tok_win; j.tok_pos = in.tok_pos;
+        j.num_windows = in.num_windows; j.bun_start = in.bun_start; j.num_bundles = in.num_bundles;
+        table_bytes += al((int64_t)j.slots * 4);
+        need += al((int64_t)j.slots * 4) + al((int64_t)j.n * 4);
+        if (j.n > max_n) max_n = j.n;
+        const int w = j.n < j.slots ? j.n : j.slots;
+        if (w > max_w) max_w = w;
+    }
+    if (workspace_bytes < need || !workspace) {
+        set_error("window_build: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    // workspace = [table_0 | table_1 | ...][rank_0 | rank_1 | ...]: the window tables are zeroed by one memset
+    char* tp = (char*)workspace;
+    char* rp = (char*)workspace + table_bytes;
+    for (int k = 0; k < num_jobs; ++k) {
+        J.j[k].table = (int32_t*)tp; tp += al((int64_t)J.j[k].slots * 4);
+        J.j[k].rank = (int32_t*)rp;  rp += al((int64_t)J.j[k].n * 4);
+    }
+    for (int k = num_jobs; k < kMaxWinJobs; ++k) J.j[k] = J.j[0];
+    GEOMAE_HIP(hipMemsetAsync(workspace, 0, (size_t)table_bytes, stream));
+    const dim3 tok_grid(stream_grid(max_n > 0 ? max_n : 1, kWBlk), num_jobs);
+    if (max_n > 0) hipLaunchKernelGGL(win_hist_jobs_kernel, tok_grid, dim3(kWBlk), 0, stream, J);
+    hipLaunchKernelGGL(win_scan_jobs_kernel, dim3(1, num_jobs), dim3(1024), 0, stream, J);
+    if (max_n > 0) {
+        hipLaunchKernelGGL(win_place_jobs_kernel, tok_grid, dim3(kWBlk), 0, stream, J);
+        hipLaunchKernelGGL(win_sort_jobs_kernel, dim3(max_w < 4096 ? max_w : 4096, num_jobs), dim3(64), 0, stream, J);
+    }
+    hipLaunchKernelGGL(win_bundle_jobs_kernel, dim3(1, num_jobs), dim3(1024), 0, stream, J);
+    return check_launch("window_build");
+}
+
 extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_size,
                                    const GeomaeWindowConfig* cfg, int32_t shift_index, int32_t* win_start,
                                    int32_t* win_tokens, int32_t* tok_win, int32_t* tok_pos,
                                    int32_t* num_windows, int32_t* bun_start, int32_t* num_bundles,
                                    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
-    WinGeom g;
-    int sps;
-    int rc = win_geom(cfg, shift_index, &g, &sps);
-    if (rc) return rc;
-    GEOMAE_REQUIRE(num_tokens >= 0 && batch_size >= 1, "window_build: bad sizes");
-    GEOMAE_REQUIRE(win_start && num_windows && bun_start && num_bundles, "window_build: null output");
-    const int64_t need = geomae_window_build_workspace_bytes(num_tokens, batch_size, cfg);
-    if (workspace_bytes < need || !workspace) {
-        set_error("window_build: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-        return GEOMAE_ERR_WORKSPACE;
-    }
-    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    const int slots = batch_size * sps;
-    int32_t* table = (int32_t*)workspace;
-    int32_t* rank = (int32_t*)((char*)workspace + al((int64_t)slots * 4));
-    GEOMAE_HIP(hipMemsetAsync(table, 0, (size_t)slots * 4, stream));
-    if (num_tokens > 0) {
-        GEOMAE_REQUIRE(coors && win_tokens && tok_win && tok_pos, "window_build: null argument");
-        hipLaunchKernelGGL(win_hist_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream,
-                           (const int4*)coors, num_tokens, g, table, rank, tok_win, tok_pos);
-    }
-    hipLaunchKernelGGL(win_scan_kernel, dim3(1), dim3(1024), 0, stream, table, slots, win_start, num_windows,
-                       num_tokens);
-    if (num_tokens > 0) {
-        hipLaunchKernelGGL(win_place_kernel, dim3(stream_grid(num_tokens, kWBlk)), dim3(kWBlk), 0, stream, num_tokens,
-                           table, rank, win_start, tok_win, win_tokens);
-        const int max_w = num_tokens < slots ? num_tokens : slots;
-        hipLaunchKernelGGL(win_sort_kernel, dim3(max_w < 4096 ? max_w : 4096), dim3(64), 0, stream, win_start,
-                           num_windows, win_tokens);
-    }
-    hipLaunchKernelGGL(win_bundle_kernel, dim3(1), dim3(1024), 0, stream, win_start, num_windows, g.wx * g.wy,
-                       bun_start, num_bundles, rank /* reused: the window counting sort is done with it */);
-    return check_launch("window_build");
+    GeomaeWindowBuildJob job = {coors, num_tokens, shift_index, win_start, win_tokens, tok_win, tok_pos,
+                                num_windows, bun_start, num_bundles};
+    return geomae_window_build_batch(&job, 1, batch_size, cfg, workspace, workspace_bytes, stream);
 }
 
 // Workgroups to launch: one per (bundle, head).  The bundle count lives on the device; its bound from the

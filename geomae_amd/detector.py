@@ -145,10 +145,13 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         main = torch.cuda.current_stream()
         side = ops.side_streams()["geo"]
         side.wait_stream(main)
+        dev = voxels.device
         with torch.cuda.stream(side):
-            # side-stream order = order of need: packed weights and window layouts (encoder forward), then the
-            # targets (first read by the heads+loss kernel, a whole forward later: they finish under the encoder,
-            # whose launches fill 105 of 256 CUs)
+            # side-stream order = order of need: the zero arena of the VFE forward, packed weights and window layouts
+            # (encoder forward), the zero arena of everything later, then the targets (first read by the heads+loss
+            # kernel, a whole forward later: they finish under the encoder, whose launches fill 105 of 256 CUs)
+            zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V)), dev)
+            zeros_fwd_ready = side.record_event()
             self.backbone._packed.refresh()
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
             ik_l, im_l = ik.long(), im.long()
@@ -159,14 +162,21 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             # buffers the main stream would otherwise allocate-and-fill between kernels of the critical path
             n_keep, n_mask = int(ik.numel()), int(im.numel())
             C = self.backbone.mask_token.shape[1]
-            tokens = torch.empty((n_keep + n_mask, C), dtype=torch.float32, device=voxels.device)
+            n = n_keep + n_mask
+            tokens = torch.empty((n, C), dtype=torch.float32, device=dev)
             tokens[n_keep:] = self.backbone.mask_token.detach()
-            bufs = dict(tokens=tokens, d_cen=torch.zeros_like(tokens), d_den=torch.zeros_like(tokens),
-                        d_vf=torch.zeros((V, C), dtype=torch.float32, device=voxels.device), side=side)
+            f32 = torch.float32
+            late = [((n, C), f32), ((n, C), f32), ((V, C), f32), ((6,), f32)] + ops.vfe_backward_zero_specs(V)
+            zeros_late = ops.ZeroArena(ops.ZeroArena.nbytes(*late), dev)
+            bufs = dict(tokens=tokens, d_cen=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
+                        d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
             bufs["ready"] = side.record_event()
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
             tgt_ready = side.record_event()
-        vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg)
+        ops.mark("step_start")
+        main.wait_event(zeros_fwd_ready)
+        vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd)
+        ops.mark("vfe_fwd_done")
         main.wait_event(layouts_ready)
         if not self.TARGETS_LATE:
             main.wait_event(tgt_ready)
@@ -178,7 +188,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
                                                                  bufs=bufs)
         d_vf = bufs["d_vf"]
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
-        self.voxel_encoder.backward_explicit(vfe_state, d_vf)
+        self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late)
+        ops.mark("vfe_bwd_done")
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     # ------------------------------------------------------------------ preprocessing

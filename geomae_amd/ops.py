@@ -39,6 +39,18 @@ class _timed:
         return False
 
 
+# optional phase marks (tools/phase_events.py): list of (name, event) recorded on the current stream at the phase
+# boundaries of the explicit training schedule; None = disabled (one attribute test per mark)
+PHASE_MARKS = None
+
+
+def mark(name):
+    if PHASE_MARKS is not None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        PHASE_MARKS.append((name, e))
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _raw_device = getattr(torch._C, "_cuda_getDevice", None)
 
@@ -162,6 +174,57 @@ def voxelize_batch3(points, batch_offsets, batch_size, vs_top, vs_med, vs_low, c
 
 
 # ------------------------------------------------------------------------------------ A2
+class ZeroArena:
+    """One zero-filled device buffer carved into a training step's accumulator / atomics-target buffers (BatchNorm sums,
+    pillar-mean sums, max-pool outputs, gradient rows that only some kernels write ...).  The library zeroes each such
+    buffer with its own hipMemsetAsync -- a ~5 us fill kernel apiece, a dozen of them between DEPENDENT kernels of a
+    step.  The explicit schedule instead fills one arena on a side stream and calls the entry points under
+    `prezeroed()`, which tells the library (per host thread) to skip its memsets."""
+
+    def __init__(self, nbytes, device):
+        self.buf = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        self.off = 0
+
+    @staticmethod
+    def nbytes(*specs):
+        """specs: (shape, dtype) pairs -> bytes needed (each carve is 256-byte aligned)."""
+        total = 0
+        for shape, dtype in specs:
+            n = torch.empty((), dtype=dtype).element_size()
+            for d in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+                n *= int(d)
+            total += (n + 255) // 256 * 256
+        return total
+
+    def take(self, shape, dtype):
+        shape = tuple(shape) if isinstance(shape, (tuple, list)) else (int(shape),)
+        n = torch.empty((), dtype=dtype).element_size()
+        for d in shape:
+            n *= int(d)
+        start = self.off
+        self.off += (n + 255) // 256 * 256
+        if self.off > self.buf.numel():
+            raise RuntimeError("ZeroArena: carved past the end (size the arena with ZeroArena.nbytes)")
+        return self.buf[start:start + n].view(dtype).view(shape)
+
+
+class prezeroed:
+    """with prezeroed(): ...  -- entry points called inside trust that their accumulator outputs are already zero
+    (geomae_set_accumulators_prezeroed, include/geomae_hip.h lists which ones honour it)."""
+
+    def __enter__(self):
+        check(_lib.load().geomae_set_accumulators_prezeroed(1), "geomae_set_accumulators_prezeroed")
+        return self
+
+    def __exit__(self, *a):
+        check(_lib.load().geomae_set_accumulators_prezeroed(0), "geomae_set_accumulators_prezeroed")
+        return False
+
+
+def _zeros_or_empty(zeros, shape, dtype, device):
+    return zeros.take(shape, dtype) if zeros is not None else torch.empty(shape, dtype=dtype, device=device)
+
+
 _SIDE_STREAMS = {}
 
 
@@ -240,9 +303,10 @@ def pillar_segment(coors, batch_size, grid_zyx, cap=None):
     return s
 
 
-def segment_mean_xyz(points, seg):
+def segment_mean_xyz(points, seg, zeros=None):
+    """zeros: optional ZeroArena for the sum workspace (call under prezeroed())."""
     mean = torch.empty((max(seg.cap, 1), 3), dtype=torch.float32, device=points.device)
-    ws = torch.empty(max(seg.cap, 1) * 3, dtype=torch.int64, device=points.device)
+    ws = _zeros_or_empty(zeros, max(seg.cap, 1) * 3, torch.int64, points.device)
     check(_lib.load().geomae_segment_mean_xyz(_ptr(points), points.shape[1], points.shape[0], _ptr(seg.inv),
                                               _ptr(seg.seg_start), _ptr(seg.num_pillars), seg.cap, _ptr(ws), _ptr(mean),
                                               _stream()), "geomae_segment_mean_xyz")
@@ -512,12 +576,7 @@ class WindowLayout:
                  "bun_start", "num_bundles")
 
 
-def window_build(coors, batch_size, wcfg, shift_index):
-    coors = coors.contiguous()
-    _check_input(coors, "coors", torch.int32)
-    n = coors.shape[0]
-    dev = coors.device
-    lib = _lib.load()
+def _new_window_layout(n, batch_size, wcfg, dev):
     nwx = (wcfg.bev_shape[0] + wcfg.window_shape[0] - 1) // wcfg.window_shape[0] + 1
     nwy = (wcfg.bev_shape[1] + wcfg.window_shape[1] - 1) // wcfg.window_shape[1] + 1
     slots = batch_size * nwx * nwy
@@ -532,6 +591,45 @@ def window_build(coors, batch_size, wcfg, shift_index):
     L.num_windows = torch.empty(1, dtype=torch.int32, device=dev)
     L.bun_start = torch.empty(L.max_windows + 1, dtype=torch.int32, device=dev)
     L.num_bundles = torch.empty(1, dtype=torch.int32, device=dev)
+    return L
+
+
+def window_build_batch(jobs, batch_size, wcfg):
+    """jobs: list of (coors [n,4] int32, shift_index), at most 4 -> list of WindowLayout.  One launch per build stage
+    for all jobs (geomae_window_build_batch): the serial chain is as long as for one layout."""
+    from ._lib import GeomaeWindowBuildJob
+    lib = _lib.load()
+    arr = (GeomaeWindowBuildJob * len(jobs))()
+    ns = (ctypes.c_int32 * len(jobs))()
+    layouts, keep = [], []
+    for k, (coors, shift_index) in enumerate(jobs):
+        coors = coors.contiguous()
+        _check_input(coors, "coors", torch.int32)
+        keep.append(coors)
+        L = _new_window_layout(coors.shape[0], batch_size, wcfg, coors.device)
+        layouts.append(L)
+        j = arr[k]
+        j.coors, j.num_tokens, j.shift_index = coors.data_ptr(), L.n, shift_index
+        j.win_start, j.win_tokens, j.tok_win = L.win_start.data_ptr(), L.win_tokens.data_ptr(), L.tok_win.data_ptr()
+        j.tok_pos, j.num_windows = L.tok_pos.data_ptr(), L.num_windows.data_ptr()
+        j.bun_start, j.num_bundles = L.bun_start.data_ptr(), L.num_bundles.data_ptr()
+        ns[k] = L.n
+    wsb = lib.geomae_window_build_batch_workspace_bytes(ns, len(jobs), batch_size, ctypes.byref(wcfg))
+    if wsb < 0:
+        raise RuntimeError("window_build_batch: bad configuration (1..4 jobs)")
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=keep[0].device)
+    check(lib.geomae_window_build_batch(arr, len(jobs), batch_size, ctypes.byref(wcfg), _ptr(ws), wsb, _stream()),
+          "geomae_window_build_batch")
+    return layouts
+
+
+def window_build(coors, batch_size, wcfg, shift_index):
+    coors = coors.contiguous()
+    _check_input(coors, "coors", torch.int32)
+    n = coors.shape[0]
+    dev = coors.device
+    lib = _lib.load()
+    L = _new_window_layout(n, batch_size, wcfg, dev)
     wsb = lib.geomae_window_build_workspace_bytes(n, batch_size, ctypes.byref(wcfg))
     ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
     check(lib.geomae_window_build(_ptr(coors), n, batch_size, ctypes.byref(wcfg), shift_index, _ptr(L.win_start),
@@ -634,12 +732,15 @@ def pack_weights(desc, num_desc, max_elems, packed, aux=None):
                                           _ptr(aux), _stream()), "geomae_pack_weights")
 
 
-def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=None):
+def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=None, losses=None):
     """-> losses [6] f32, d_cen, d_den [n,128] f32 (gradient of sum(losses)), saved = (dlogits, cm_b, dm_b).
-    d_out: optional pair of ZEROED [n,128] f32 buffers for d_cen / d_den (the kernel writes only the masked rows)."""
+    d_out: optional pair of ZEROED [n,128] f32 buffers for d_cen / d_den (the kernel writes only the masked rows).
+    losses: optional ZEROED [6] f32 buffer (then no memset is enqueued in front of the kernel)."""
     dev = cen.device
     n = cen.shape[0]
-    losses = torch.empty(6, dtype=torch.float32, device=dev)
+    fn = _lib.load().geomae_heads_loss if losses is None else _lib.load().geomae_heads_loss_accumulate
+    if losses is None:
+        losses = torch.empty(6, dtype=torch.float32, device=dev)
     if d_out is None:
         d_cen, d_den = torch.zeros_like(cen), torch.zeros_like(den)
     else:
@@ -649,7 +750,7 @@ def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=
     dl = torch.empty((n_mask, 896), dtype=torch.bfloat16, device=dev)
     cm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
     dm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
-    check(_lib.load().geomae_heads_loss(
+    check(fn(
         _ptr(cen), _ptr(den), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["centroid_low"]),
         _ptr(tgt["mask_low_u8"]), _ptr(tgt["centroid_med"]), _ptr(tgt["mask_med_u8"]), _ptr(tgt["centroid_top"]),
         _ptr(tgt["normal"]), _ptr(tgt["occ_counts"]), f3(weights), _ptr(losses), _ptr(d_cen), _ptr(d_den), _ptr(dl),
@@ -666,12 +767,12 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 class VfePlan:
     """Per-batch state of the fused VFE sweeps: pillar mean, sorted point features, the argument struct."""
 
-    def __init__(self, points, seg, w0, w1, voxel_size, center_offset):
+    def __init__(self, points, seg, w0, w1, voxel_size, center_offset, zeros=None):
         from ._lib import GeomaeVfeArgs
         lib = _lib.load()
         dev = points.device
         self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
-        self.mean = segment_mean_xyz(points, seg)
+        self.mean = segment_mean_xyz(points, seg, zeros)
         self.bn = torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)    # [layer][scale, shift, mean, invstd]
         self.feat = torch.empty((max(self.N, 1), 16), dtype=torch.float32, device=dev)
         self.pid = torch.empty(max(self.N, 1), dtype=torch.int32, device=dev)
@@ -720,24 +821,36 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
         bn[2, :C].copy_(mom[:C])
 
 
-def vfe_forward(plan, norm0, norm1, world=1, group=None):
+def vfe_forward_zero_specs(cap, V):
+    """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order."""
+    V1 = max(int(V), 1)
+    return [((max(int(cap), 1) * 3,), torch.int64), ((128,), torch.float64), ((V1, 64), torch.float32),
+            ((256,), torch.float64), ((V1, 128), torch.float32)]
+
+
+def vfe_backward_zero_specs(V):
+    return [((256,), torch.float64), ((max(int(V), 1), 64), torch.float32), ((128,), torch.float64)]
+
+
+def vfe_forward(plan, norm0, norm1, world=1, group=None, zeros=None):
     lib = _lib.load()
     dev = plan.points.device
     a = ctypes.byref(plan.args)
-    sums0 = torch.empty(128, dtype=torch.float64, device=dev)
+    sums0 = _zeros_or_empty(zeros, (128,), torch.float64, dev)
     check(lib.geomae_vfe_stats0(a, _ptr(sums0), _stream()), "geomae_vfe_stats0")
     _bn_finalize(plan, 0, sums0, norm0, world, group)
-    m0 = torch.empty((max(plan.V, 1), 64), dtype=torch.float32, device=dev)
-    sums1 = torch.empty(256, dtype=torch.float64, device=dev)
+    m0 = _zeros_or_empty(zeros, (max(plan.V, 1), 64), torch.float32, dev)
+    sums1 = _zeros_or_empty(zeros, (256,), torch.float64, dev)
     check(lib.geomae_vfe_layer0(a, _ptr(m0), _ptr(sums1), _stream()), "geomae_vfe_layer0")
     _bn_finalize(plan, 1, sums1, norm1, world, group)
-    vf = torch.empty((max(plan.V, 1), 128), dtype=torch.float32, device=dev)
+    vf = _zeros_or_empty(zeros, (max(plan.V, 1), 128), torch.float32, dev)
     check(lib.geomae_vfe_layer1(a, _ptr(m0), _ptr(vf), _stream()), "geomae_vfe_layer1")
     return vf[:plan.V], m0
 
 
-def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
-    """params: dict w0, w1, g0, b0, g1, b1 -> nn.Parameters whose .grad is accumulated into."""
+def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None):
+    """params: dict w0, w1, g0, b0, g1, b1 -> nn.Parameters whose .grad is accumulated into.
+    zeros: optional ZeroArena sized by vfe_backward_zero_specs (call under prezeroed())."""
     from torch import distributed as dist
     lib = _lib.load()
     dev = dvf.device
@@ -747,7 +860,7 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
         if p.grad is None:
             p.grad = torch.zeros_like(p)
     dvf = dvf.contiguous().float()
-    bs1 = torch.empty(256, dtype=torch.float64, device=dev)
+    bs1 = _zeros_or_empty(zeros, (256,), torch.float64, dev)
     check(lib.geomae_vfe_backward_stats(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), _stream()),
           "geomae_vfe_backward_stats")
     # d beta / d gamma = the LOCAL sums: one process lets the next kernel add them; with naiveSyncBN1d they are added
@@ -762,8 +875,8 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None):
     g_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
     dy1_f = torch.empty((N, 128), dtype=torch.float32, device=dev)
     dh0 = torch.empty((N, 64), dtype=torch.float32, device=dev)
-    dm0 = torch.empty((max(V, 1), 64), dtype=torch.float32, device=dev)
-    bs0 = torch.empty(128, dtype=torch.float64, device=dev)
+    dm0 = _zeros_or_empty(zeros, (max(V, 1), 64), torch.float32, dev)
+    bs0 = _zeros_or_empty(zeros, (128,), torch.float64, dev)
     check(lib.geomae_vfe_backward_layer1(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), n_eff,
                                          _ptr(dy1_b), _ptr(g_b), _ptr(dy1_f), _ptr(dh0), _ptr(dm0), _ptr(bs0),
                                          _ptr(params["b1"].grad) if fold else None,

@@ -412,9 +412,15 @@ class MultiMAESSTSPChoose(nn.Module):
     def build_layouts(self, coors, coors_mask, batch_size):
         """Window layouts of the encoder tokens (kept pillars) and of the decoder tokens (kept + masked): they depend
         on coordinates only, so the detector builds them on a side stream under the VFE forward."""
-        enc, _ = self.get_voxel_info(coors, batch_size)
-        dec, _ = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
-        return enc, dec
+        ns = len(self.shifts_list)
+        if not self.fused or 2 * ns > 4:
+            enc, _ = self.get_voxel_info(coors, batch_size)
+            dec, _ = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
+            return enc, dec
+        c_enc = coors.int().contiguous()
+        c_dec = torch.cat([coors, coors_mask], dim=0).int().contiguous()
+        L = ops.window_build_batch([(c_enc, s) for s in range(ns)] + [(c_dec, s) for s in range(ns)], batch_size, self._wcfg)
+        return L[:ns], L[ns:]
 
     def forward_losses(self, voxel_feat, coors, coors_mask, batch_size, tgt, loss_weights, layouts=None):
         """Fused training path: encoder, both decoder stacks, then heads + losses (+ their backward) in one
@@ -454,11 +460,13 @@ class MultiMAESSTSPChoose(nn.Module):
         if bufs is None:
             z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
             tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
-            d_out = None
+            d_out = losses_buf = None
         else:                       # the encoder writes straight into the decoder input: no concatenation copy
             tokens, d_out = bufs["tokens"], (bufs["d_cen"], bufs["d_den"])
+            losses_buf = bufs.get("losses")
             _, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh, out=tokens[:n_keep])
             cur.wait_event(bufs["ready"])
+        ops.mark("enc_fwd_done")
         if self._streams is None:
             st = ops.side_streams()
             self._streams = (st["dec_a"], st["dec_b"])
@@ -471,18 +479,21 @@ class MultiMAESSTSPChoose(nn.Module):
         cur.wait_stream(sb_)
         if tgt_ready is not None:
             cur.wait_event(tgt_ready)
+        ops.mark("dec_fwd_done")
         losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights,
-                                                       d_out=d_out)
+                                                       d_out=d_out, losses=losses_buf)
         # ---------------- backward
         ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
         g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
         n = tokens.shape[0]
+        ops.mark("heads_done")
         sa_.wait_stream(cur)
         sb_.wait_stream(cur)
         dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, stream=sa_)
         dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
         cur.wait_stream(sa_)
         cur.wait_stream(sb_)
+        ops.mark("dec_bwd_done")
         d_tok = dxa.add_(dxb)
         del keep_a, keep_b
         if self.mask_token.grad is None:
@@ -499,6 +510,7 @@ class MultiMAESSTSPChoose(nn.Module):
             on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
         d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+        ops.mark("enc_bwd_done")
         if side is not None:
             cur.wait_stream(side)
         return losses, d_vf

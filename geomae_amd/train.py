@@ -140,14 +140,24 @@ class FlatAdamW:
         (0-d tensor).  grad_scale folds the data-parallel 1/world averaging into the same pass."""
         import ctypes
         from . import _lib
+        from . import ops
         from .ops import _ptr, _stream
         lib, f = _lib.load(), self.flat
         if self._sumsq is None:
-            self._sumsq = torch.zeros(1, dtype=torch.float64, device=f.flat.device)
+            self._sumsq_ring = torch.zeros(2, dtype=torch.float64, device=f.flat.device)
+            self._sumsq_zeroed = None
             self._gnorm = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
         self.step_count += 1
         n = f.flat.numel()
-        _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
+        # two accumulator slots: this step sums into one (already zero), the other is zeroed on a side stream for the
+        # next step -- no fill kernel between the last backward kernel and the norm reduction
+        slot = self.step_count & 1
+        self._sumsq = self._sumsq_ring[slot:slot + 1]
+        main = torch.cuda.current_stream()
+        if self._sumsq_zeroed is not None:
+            main.wait_event(self._sumsq_zeroed)
+        with ops.prezeroed():
+            _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
         P = lambda t, o: ctypes.c_void_p(t.data_ptr() + 4 * o)
         for start, end, n_nd in f.segments:                       # one launch per segment (its own no-decay prefix)
             _lib.check(lib.geomae_adamw_step(P(f.flat, start), P(f.grad, start), P(self.exp_avg, start),
@@ -156,6 +166,12 @@ class FlatAdamW:
                                              float(self.weight_decay), self.step_count, float(max_norm or 0.0),
                                              _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)), _ptr(self._gnorm),
                                              _stream()), "geomae_adamw_step")
+        side = ops.side_streams(f.flat.device)["geo"]
+        side.wait_stream(main)                                    # after this step's readers of the ring
+        with torch.cuda.stream(side):
+            self._sumsq_ring[1 - slot:2 - slot].zero_()
+            self._sumsq_zeroed = side.record_event()
+        ops.mark("optimizer_done")
         return self._gnorm[0]
 
     # ---- torch.optim.AdamW-shaped state (what mmcv's checkpoint hook stores under 'optimizer'): mmcv's

@@ -112,20 +112,27 @@ class DynamicScatterVFE(nn.Module):
 
     # ---- explicit (autograd-free) schedule of the fused path: detector.train_step_explicit
     @torch.no_grad()
-    def forward_explicit(self, features, seg):
+    def forward_explicit(self, features, seg, zeros=None):
+        """zeros: optional ops.ZeroArena sized by ops.vfe_forward_zero_specs(seg.cap, seg.V): the sweeps' accumulator
+        buffers come out of it and the library skips its own memsets."""
         l0, l1 = self.vfe_layers
         world = _vfe_world(self)
-        plan = ops.VfePlan(features, seg, l0.linear.weight, l1.linear.weight, (self.vx, self.vy, self.vz),
-                           (self.x_offset, self.y_offset, self.z_offset))
-        vf, m0 = ops.vfe_forward(plan, l0.norm, l1.norm, world)
+        import contextlib
+        with (ops.prezeroed() if zeros is not None else contextlib.nullcontext()):
+            plan = ops.VfePlan(features, seg, l0.linear.weight, l1.linear.weight, (self.vx, self.vy, self.vz),
+                               (self.x_offset, self.y_offset, self.z_offset), zeros=zeros)
+            vf, m0 = ops.vfe_forward(plan, l0.norm, l1.norm, world, zeros=zeros)
         return vf, (plan, m0, vf, world)
 
     @torch.no_grad()
-    def backward_explicit(self, state, dvf):
+    def backward_explicit(self, state, dvf, zeros=None):
         plan, m0, vf, world = state
         l0, l1 = self.vfe_layers
-        ops.vfe_backward(plan, m0, vf, dvf, dict(w0=l0.linear.weight, g0=l0.norm.weight, b0=l0.norm.bias,
-                                                 w1=l1.linear.weight, g1=l1.norm.weight, b1=l1.norm.bias), world)
+        import contextlib
+        with (ops.prezeroed() if zeros is not None else contextlib.nullcontext()):
+            ops.vfe_backward(plan, m0, vf, dvf, dict(w0=l0.linear.weight, g0=l0.norm.weight, b0=l0.norm.bias,
+                                                     w1=l1.linear.weight, g1=l1.norm.weight, b1=l1.norm.bias), world,
+                             zeros=zeros)
 
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, seg=None):
         """features [N, C_in] fp32, coors [N, 4] int32 (b, z, y, x)."""

@@ -27,6 +27,12 @@ typedef struct ihipStream_t* geomaeStream_t; /* == hipStream_t */
 #define GEOMAE_ABI_VERSION 1
 
 const char* geomae_last_error(void);
+/* Per host thread.  enabled != 0: the caller promises that the accumulator / atomics-target OUTPUT buffers it passes
+ * from now on are already zero, and the entry points stop enqueueing their own memsets: geomae_segment_mean_xyz
+ * (sum_workspace), geomae_vfe_stats0 (sums0), geomae_vfe_layer0 (m0, sums1), geomae_vfe_layer1 (voxel_feats),
+ * geomae_vfe_backward_stats (bsums1), geomae_vfe_backward_layer1 (bsums0, dm0), geomae_grad_sumsq (sumsq).
+ * A training step zeroes one arena off the critical path instead of a dozen small fills between dependent kernels. */
+int geomae_set_accumulators_prezeroed(int32_t enabled);
 int32_t geomae_abi_version(void);
 
 /* ------------------------------------------------------------------ A1 dynamic voxelization
@@ -149,6 +155,20 @@ int geomae_window_build(const int32_t* coors, int32_t num_tokens, int32_t batch_
                         int32_t* bun_start, int32_t* num_bundles, void* workspace, int64_t workspace_bytes,
                         geomaeStream_t stream);
 
+/* Several layouts in one call (<= 4 jobs: a pre-training step builds encoder / decoder tokens x unshifted / shifted
+ * windows): every build stage is ONE launch over all jobs instead of one per layout, so the serial chain of small
+ * dependent kernels is as long as for a single layout.  Same outputs per job as geomae_window_build. */
+typedef struct GeomaeWindowBuildJob {
+    const int32_t* coors;       /* [num_tokens, 4] (b, z, y, x) */
+    int32_t num_tokens, shift_index;
+    int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
+} GeomaeWindowBuildJob;
+int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens /*host [num_jobs]*/, int32_t num_jobs,
+                                                  int32_t batch_size, const GeomaeWindowConfig* cfg);
+int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs /*host [num_jobs]*/, int32_t num_jobs,
+                              int32_t batch_size, const GeomaeWindowConfig* cfg /*host*/, void* workspace,
+                              int64_t workspace_bytes, geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ A19 windowed attention core
  * replaces flat2window -> nn.MultiheadAttention(key_padding_mask) -> window2flat
  * (sst_basic_block.py:36-59) between the in-projection and the out-projection.
@@ -246,6 +266,14 @@ int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32
                       const float* loss_weights /*host*/, float* losses, float* d_dec_centroid,
                       float* d_dec_density, void* dlogits_bf16, void* cm_bf16, void* dm_bf16,
                       geomaeStream_t stream);
+/* same, but `losses` is accumulated into instead of being zeroed first (the caller zeroes it off the critical path) */
+int geomae_heads_loss_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                 const int32_t* occ_counts, const float* loss_weights /*host*/, float* losses,
+                                 float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
+                                 void* dm_bf16, geomaeStream_t stream);
 typedef struct GeomaeHeadGrads { /* fp32 gradient buffers of the six head Linears, accumulated into */
     float *reg_low_w, *reg_low_b, *cls_low_w, *cls_low_b, *reg_med_w, *reg_med_b, *cls_med_w, *cls_med_b,
           *reg_top_w, *reg_top_b, *nor_top_w, *nor_top_b;

@@ -258,6 +258,31 @@ def test_window_build_matches_partition(dev):
         assert (btok[:-1] + cnt[bs[1:-1]] > 144).all()
 
 
+def test_window_build_batch_equals_single(dev):
+    """Four layouts in one batched call (two token sets x two shifts, ragged sizes incl. an empty one) = the single
+    builds, array for array: the layout is deterministic (tokens ascending inside a window)."""
+    from geomae_amd import ops
+    frames = _frames()
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = O.unique_rows(coors)[0]
+    rng = np.random.default_rng(1)
+    vc = vc[rng.permutation(vc.shape[0])]
+    a = torch.as_tensor(vc, device=dev)
+    b = torch.as_tensor(vc[: vc.shape[0] // 3], device=dev)
+    e = a[:0]
+    wcfg = ops.make_window_config((12, 12), (6, 6), (400, 400))
+    jobs = [(b, 0), (b, 1), (a, 0), (a, 1)]
+    for js in (jobs, [(e, 0), (a, 1)], [(a, 1)]):
+        got = ops.window_build_batch(js, 2, wcfg)
+        for (c, s), L in zip(js, got):
+            R = ops.window_build(c, 2, wcfg, s)
+            W, NB, n = int(R.num_windows.item()), int(R.num_bundles.item()), c.shape[0]
+            assert int(L.num_windows.item()) == W and int(L.num_bundles.item()) == NB
+            assert torch.equal(L.win_start[:W + 1], R.win_start[:W + 1]) and torch.equal(L.bun_start[:NB + 1], R.bun_start[:NB + 1])
+            for k in ("win_tokens", "tok_win", "tok_pos"):
+                assert torch.equal(getattr(L, k)[:n], getattr(R, k)[:n]), k
+
+
 def _ref_window_attention(qkv, win, nhead):
     n, c3 = qkv.shape
     C = c3 // 3
