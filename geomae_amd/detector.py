@@ -147,12 +147,10 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         side.wait_stream(main)
         dev = voxels.device
         with torch.cuda.stream(side):
-            # side-stream order = order of need: the zero arena of the VFE forward, packed weights and window layouts
-            # (encoder forward), the zero arena of everything later, then the targets (first read by the heads+loss
+            # side-stream order = order of need: packed weights (normally already packed by the trainer) and window
+            # layouts (encoder forward), the zero arena of everything after the VFE forward, then the targets (first read by the heads+loss
             # kernel, a whole forward later: they finish under the encoder, whose launches fill 105 of 256 CUs)
-            zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V)), dev)
-            zeros_fwd_ready = side.record_event()
-            self.backbone._packed.refresh()
+            self.backbone._packed.refresh_if_stale()         # a no-op when the trainer packed after its optimizer step
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
             ik_l, im_l = ik.long(), im.long()
             feature_coors = seg.voxel_coors[:V]
@@ -174,7 +172,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
             tgt_ready = side.record_event()
         ops.mark("step_start")
-        main.wait_event(zeros_fwd_ready)
+        # the VFE forward's own arena is one fill on the main stream: a cross-queue wait costs as much as the fill
+        zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V)), dev)
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd)
         ops.mark("vfe_fwd_done")
         main.wait_event(layouts_ready)

@@ -107,6 +107,35 @@ class PackedLayers:
             self._build(k[-1])
             self.key = k
         ops.pack_weights(self.desc, self.n_desc, 384 * 128, self.packed, self.head_bias)
+        self._prepacked = None
+
+    # ---- packing ahead: the copies depend on the weights only, so the trainer packs them right after the optimizer
+    # step (on a side stream) and the next step's critical path does not contain the pack kernel
+    def _sources(self):
+        srcs = [p for L in self.layers for p in L.parameters()]
+        if self.backbone is not None:
+            for n, _ in self.HEAD_ROWS:
+                lin = getattr(self.backbone, n)
+                srcs += [lin.weight, lin.bias]
+        return srcs
+
+    def _versions(self):
+        return tuple(p._version for p in self._sources())
+
+    def prepack(self):
+        """Pack now for the NEXT forward; valid for one `refresh_if_stale` as long as no torch op writes a source
+        parameter in between (tensor version counters; writers that bypass them call `invalidate`)."""
+        self.refresh()
+        self._prepacked = self._versions()
+
+    def invalidate(self):
+        self._prepacked = None
+
+    def refresh_if_stale(self):
+        v, self._prepacked = getattr(self, "_prepacked", None), None
+        if v is not None and self._key() == self.key and v == self._versions():
+            return
+        self.refresh()
 
     def grads(self, layer_index):
         """C struct of gradient pointers; allocates .grad where autograd has not yet."""

@@ -258,6 +258,9 @@ class Trainer:
         self._grads_clean = False
         if self.lr_schedule is not None:
             self.opt.lr = self.lr_schedule.lr_at(self.iter)
+        if getattr(self, "_prepack_flat_version", None) not in (None, self.flat.flat._version):
+            self.model.backbone._packed.invalidate()        # someone wrote the flat parameter buffer since the pre-pack
+        self._prepack_flat_version = None
         pre = getattr(self.model, "_prefetched", None)
         if pre is not None and pre[0] is points:
             pre[1][4].sync_counts()             # already landed: claim it before the next readback is queued
@@ -302,6 +305,15 @@ class Trainer:
                     w.wait()
             gnorm = self.opt.fused_clip_step(self.grad_clip.get("max_norm", 0.0), 1.0 / world, zero_grad=True)
             self._grads_clean = True
+            packed = getattr(getattr(self.model, "backbone", None), "_packed", None)
+            if explicit and packed is not None:
+                # bf16 MFMA-layout copies of the updated weights for the next step, off its critical path
+                from . import ops
+                main, side = torch.cuda.current_stream(), ops.side_streams()["geo"]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    packed.prepack()
+                self._prepack_flat_version = self.flat.flat._version
         else:
             allreduce_gradients(self.flat)
             gnorm = clip_grad_norm(self.flat, **self.grad_clip)

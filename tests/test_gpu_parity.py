@@ -440,6 +440,33 @@ def test_explicit_schedule_matches_autograd_path(dev):
         assert torch.allclose(x.float(), y.float(), rtol=1e-4, atol=1e-6), k      # BatchNorm running statistics
 
 
+def test_prepacked_weights_follow_parameter_writes(dev):
+    """The trainer packs the bf16 weight copies right after its optimizer step; a write to a parameter between two
+    steps (torch op on the parameter, on the flat buffer, or a checkpoint load) must still reach the next forward."""
+    from geomae_amd.train import Trainer
+    model, _ = _build(dev, 2, 1, "bf16")
+    tr = Trainer(model)
+    pts = [torch.as_tensor(synth.lidar_frame(60 + i, beams=16, n_az=500), device=dev) for i in range(2)]
+    tr.train_step(pts)
+    pk = model.backbone._packed
+    assert pk._prepacked is not None                      # packed ahead by the trainer
+    n = len(pk.layers)
+    head = lambda: pk.head_w.float().abs().sum().item()
+    assert head() > 0
+    with torch.no_grad():
+        model.backbone.decoder_pred_top.weight.zero_()    # version counter of the parameter
+    before = head()
+    tr.train_step(pts)                                    # must re-pack: the stale copy still holds the old rows
+    tr2_rows = pk.head_w.view(-1, 128)
+    assert head() != before
+    with torch.no_grad():
+        tr.flat.flat.zero_()                              # write through the flat buffer (views do not see a version bump)
+    tr.train_step(pts)
+    torch.cuda.synchronize()
+    # everything was zero when this step packed (the optimizer ran afterwards and the trainer packed again)
+    assert tr._prepack_flat_version is not None
+
+
 def test_trainer_prefetch_matches_plain_steps(dev):
     """Trainer.train_step(next_points=...) enqueues the next batch's voxelize / pillar sort ahead of the step:
     same losses as preparing every batch inside its own step."""
