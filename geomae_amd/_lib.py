@@ -135,6 +135,7 @@ SIGNATURES = {
                                                         c_int32, c_int32, P, P]),
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
     "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
+    "geomae_gather_token_coors": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, P, P]),
     "geomae_set_accumulators_prezeroed": (ctypes.c_int, [c_int32]),
     "geomae_heads_loss_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_heads_weight_grad": (ctypes.c_int, [c_int32, P, P, P, POINTER(GeomaeHeadGrads), P]),

@@ -143,9 +143,35 @@ __global__ __launch_bounds__(kMaskBlk) void random_mask_kernel(const int32_t* __
     }
 }
 
+// coordinates of the decoder's token list (kept pillars, then masked pillars) + the kept ids widened to int64 (the
+// index dtype torch's gather / index_copy want): one launch instead of two casts, two gathers and a concatenation
+__global__ __launch_bounds__(256) void gather_token_coors_kernel(const int32_t* __restrict__ ids_keep, int n_keep,
+                                                                 const int32_t* __restrict__ ids_mask, int n_mask,
+                                                                 const int4* __restrict__ voxel_coors,
+                                                                 int4* __restrict__ coors_out,
+                                                                 long long* __restrict__ ids_keep_i64) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n_keep + n_mask; i += gridDim.x * 256) {
+        const int id = i < n_keep ? ids_keep[i] : ids_mask[i - n_keep];
+        coors_out[i] = voxel_coors[id];
+        if (ids_keep_i64 && i < n_keep) ids_keep_i64[i] = id;
+    }
+}
+
 }  // namespace geomae
 
 using namespace geomae;
+
+extern "C" int geomae_gather_token_coors(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask,
+                                         int32_t num_mask, const int32_t* voxel_coors, int32_t* coors_out,
+                                         int64_t* ids_keep_i64, hipStream_t stream) {
+    GEOMAE_REQUIRE(num_keep >= 0 && num_mask >= 0, "gather_token_coors: bad sizes");
+    if (num_keep + num_mask == 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE((ids_keep || num_keep == 0) && (ids_mask || num_mask == 0) && voxel_coors && coors_out,
+                   "gather_token_coors: null argument");
+    hipLaunchKernelGGL(gather_token_coors_kernel, dim3(stream_grid(num_keep + num_mask, 256)), dim3(256), 0, stream, ids_keep,
+                       num_keep, ids_mask, num_mask, (const int4*)voxel_coors, (int4*)coors_out, (long long*)ids_keep_i64);
+    return check_launch("gather_token_coors_kernel");
+}
 
 extern "C" int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double keep_fraction,
                                   uint64_t seed, int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row,

@@ -150,12 +150,14 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             # side-stream order = order of need: packed weights (normally already packed by the trainer) and window
             # layouts (encoder forward), the zero arena of everything after the VFE forward, then the targets (first read by the heads+loss
             # kernel, a whole forward later: they finish under the encoder, whose launches fill 105 of 256 CUs)
+            ops.mark("side:start")
             self.backbone._packed.refresh_if_stale()         # a no-op when the trainer packed after its optimizer step
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
-            ik_l, im_l = ik.long(), im.long()
-            feature_coors = seg.voxel_coors[:V]
-            coors_keep, coors_mask = feature_coors[ik_l], feature_coors[im_l]
-            layouts = self.backbone.build_layouts(coors_keep, coors_mask, batch_size)
+            ops.mark("side:mask")
+            coors_all, ik_l = ops.gather_token_coors(ik, im, seg.voxel_coors)
+            ops.mark("side:coors")
+            layouts = self.backbone.build_layouts(coors_all[:ik.numel()], None, batch_size, coors_all=coors_all)
+            ops.mark("side:layouts")
             layouts_ready = side.record_event()
             # buffers the main stream would otherwise allocate-and-fill between kernels of the critical path
             n_keep, n_mask = int(ik.numel()), int(im.numel())
@@ -170,6 +172,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
                         d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
             bufs["ready"] = side.record_event()
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
+            ops.mark("side:targets")
             tgt_ready = side.record_event()
         ops.mark("step_start")
         # the VFE forward's own arena is one fill on the main stream: a cross-queue wait costs as much as the fill

@@ -502,6 +502,19 @@ def random_mask(seg, keep_fraction, seed):
     return ids_keep[:n_keep], ids_mask[:V - n_keep], token_row[:V], counts
 
 
+def gather_token_coors(ids_keep, ids_mask, voxel_coors):
+    """-> coors [n_keep + n_mask, 4] int32 (kept rows, then masked rows), ids_keep as int64."""
+    _check_input(ids_keep, "ids_keep", torch.int32)
+    _check_input(ids_mask, "ids_mask", torch.int32)
+    _check_input(voxel_coors, "voxel_coors", torch.int32)
+    nk, nm = ids_keep.numel(), ids_mask.numel()
+    out = torch.empty((nk + nm, 4), dtype=torch.int32, device=voxel_coors.device)
+    ik64 = torch.empty(nk, dtype=torch.int64, device=voxel_coors.device)
+    check(_lib.load().geomae_gather_token_coors(_ptr(ids_keep), nk, _ptr(ids_mask), nm, _ptr(voxel_coors), _ptr(out),
+                                                _ptr(ik64), _stream()), "geomae_gather_token_coors")
+    return out, ik64
+
+
 def token_rows_from_ids(ids_keep, ids_mask, V):
     """token_row / counts for externally supplied ids (parity tests inject the reference's ids)."""
     dev = ids_keep.device

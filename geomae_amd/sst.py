@@ -438,10 +438,17 @@ class MultiMAESSTSPChoose(nn.Module):
     def forward_encoder(self, x, layouts, pos):
         return self._run_stack(self.encoder_blocks, "enc", x, pos, layouts)
 
-    def build_layouts(self, coors, coors_mask, batch_size):
+    def build_layouts(self, coors, coors_mask, batch_size, coors_all=None):
         """Window layouts of the encoder tokens (kept pillars) and of the decoder tokens (kept + masked): they depend
-        on coordinates only, so the detector builds them on a side stream under the VFE forward."""
+        on coordinates only, so the detector builds them on a side stream under the VFE forward.
+        coors_all: optional [n_keep + n_mask, 4] int32 = cat(coors, coors_mask) already in one buffer (then `coors` /
+        `coors_mask` may be None and `coors_all[:n_keep]` is passed as coors)."""
         ns = len(self.shifts_list)
+        if coors_all is not None and self.fused and 2 * ns <= 4:
+            c_enc = coors if coors is not None else coors_all
+            L = ops.window_build_batch([(c_enc, s) for s in range(ns)] + [(coors_all, s) for s in range(ns)], batch_size,
+                                       self._wcfg)
+            return L[:ns], L[ns:]
         if not self.fused or 2 * ns > 4:
             enc, _ = self.get_voxel_info(coors, batch_size)
             dec, _ = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
@@ -474,7 +481,8 @@ class MultiMAESSTSPChoose(nn.Module):
         this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream).
         bufs: optional dict prepared off the critical path by the caller (detector.train_step_explicit):
         "tokens" [n_keep + n_mask, 128] with the mask token already in rows n_keep.., zeroed "d_cen" / "d_den" of the
-        same shape, "ready" (event after which they may be used) and "side" (the stream for work nobody waits on
+        same shape, optionally "ready" (event after which they may be used; omitted when the caller's stream is already
+        ordered behind their preparation) and "side" (the stream for work nobody waits on
         until the optimizer: the mask-token gradient reduction)."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
         P, nh, pt = self._packed, self.nhead[0], self.pos_table
@@ -494,7 +502,8 @@ class MultiMAESSTSPChoose(nn.Module):
             tokens, d_out = bufs["tokens"], (bufs["d_cen"], bufs["d_den"])
             losses_buf = bufs.get("losses")
             _, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh, out=tokens[:n_keep])
-            cur.wait_event(bufs["ready"])
+            if bufs.get("ready") is not None:
+                cur.wait_event(bufs["ready"])
         ops.mark("enc_fwd_done")
         if self._streams is None:
             st = ops.side_streams()

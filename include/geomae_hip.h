@@ -101,6 +101,13 @@ int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double k
                        uint64_t seed, int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row,
                        int32_t* counts, geomaeStream_t stream);
 
+/* coors_out [num_keep + num_mask, 4] = voxel_coors rows of the kept pillars followed by the masked pillars (the
+ * decoder's token order; its head is the encoder's token list, bb.py:227-246 torch.cat of the two gathers), and
+ * optionally ids_keep widened to int64. */
+int geomae_gather_token_coors(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask, int32_t num_mask,
+                              const int32_t* voxel_coors /*[V,4]*/, int32_t* coors_out, int64_t* ids_keep_i64 /*or NULL*/,
+                              geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ A5,A7-A11 geometric targets */
 typedef struct GeomaeTargetConfig {
     int32_t grid_size[3];       /* top grid (z, y, x), z must be 1           (config grid_size)        */

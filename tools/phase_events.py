@@ -31,16 +31,24 @@ for i in range(K):
 torch.cuda.synchronize()
 wall = 1e3 * (time.perf_counter() - t0) / K
 marks, ops.PHASE_MARKS = ops.PHASE_MARKS, None
-names = [n for n, _ in marks[:9]]
-per = len(names)
-assert all(marks[k * per + j][0] == names[j] for k in range(K) for j in range(per)), names
+main = [(n, e) for n, e in marks if not n.startswith("side:")]
+sidem = [(n, e) for n, e in marks if n.startswith("side:")]
+per = len(main) // K
+names = [n for n, _ in main[:per]]
+assert all(main[k * per + j][0] == names[j] for k in range(K) for j in range(per)), names
 acc = {}
 for k in range(K):
-    ev = [e for _, e in marks[k * per:(k + 1) * per]]
+    ev = [e for _, e in main[k * per:(k + 1) * per]]
     for j in range(1, per):
         acc[names[j]] = acc.get(names[j], 0.0) + ev[j - 1].elapsed_time(ev[j])
     if k:
-        acc["between steps"] = acc.get("between steps", 0.0) + marks[k * per - 1][1].elapsed_time(ev[0])
-print(f"wall {wall:.3f} ms/step (with {per} event records per step)")
+        acc["between steps"] = acc.get("between steps", 0.0) + main[k * per - 1][1].elapsed_time(ev[0])
+print(f"wall {wall:.3f} ms/step (with {per} event records per step on the main stream)")
 for n, v in acc.items():
     print(f"  -> {n:16s} {1e3 * v / (K - 1 if n == 'between steps' else K):8.1f} us")
+ps = len(sidem) // K
+if ps:
+    print("side stream marks, offset from the same step's step_start mark:")
+    for j in range(ps):
+        tot = sum(main[k * per][1].elapsed_time(sidem[k * ps + j][1]) for k in range(K))
+        print(f"  @ {sidem[j][0]:16s} {1e3 * tot / K:8.1f} us")
