@@ -135,7 +135,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
     TARGETS_LATE = True
 
     @torch.no_grad()
-    def train_step_explicit(self, points, on_early_grads=None):
+    def train_step_explicit(self, points, on_early_grads=None, next_points=None):
         """forward_train_fused + backward as an explicit schedule: no autograd tape or engine.  Accumulates every
         parameter gradient into .grad and returns the loss dict (detached).  Used by Trainer for the fused path
         (the step was host-bound at ~3.3 ms of Python / autograd per 3.5 ms of GPU work)."""
@@ -171,6 +171,11 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             bufs = dict(tokens=tokens, d_cen=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
                         d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
             bufs["ready"] = side.record_event()
+        if next_points is not None:
+            # the following batch's voxelize / pillar sort / count readback: ahead of the targets (nobody reads those
+            # before the heads), so that the host may start enqueueing the next step ~0.25 ms into this one
+            self.prefetch(next_points, stream=side)
+        with torch.cuda.stream(side):
             tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
             ops.mark("side:targets")
             tgt_ready = side.record_event()
@@ -220,18 +225,24 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         return ops.random_mask(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
 
     @torch.no_grad()
-    def prefetch(self, points):
+    def prefetch(self, points, stream=None):
         """Stage 1 of `prepare` for a FUTURE batch: voxelize x3 + pillar segments are enqueued now and the
         pillar counts travel to pinned host memory asynchronously.  Call it for batch k+1 before enqueuing
         step k (Trainer.train_step(next_points=...)): when step k+1 starts the counts are already on the host,
         so the iteration's one device->host readback no longer drains the queue (the GPU idled ~0.3 ms per
-        step behind it, profiles/r01q_step_timeline.txt)."""
+        step behind it, profiles/r01q_step_timeline.txt).
+        stream: enqueue there without further ordering (the explicit schedule appends it to the geometry side stream
+        once that stream's work for the current step is enqueued: it idles for the rest of the step, and a fifth
+        stream would share a hardware queue with another one)."""
         main = torch.cuda.current_stream()
-        ps = getattr(self, "_prefetch_stream", None) or ops.side_streams()["prefetch"]
-        # its own stream: nothing in the current step depends on it.  Ordered after the work already enqueued on the
-        # main stream (the previous step), which also makes the allocator's reuse of this stream's freed blocks safe:
-        # their last readers (the previous step's kernels) are enqueued on `main` before this point.
-        ps.wait_stream(main)
+        if stream is not None:
+            ps = stream
+        else:
+            ps = getattr(self, "_prefetch_stream", None) or ops.prefetch_stream()
+            # its own stream: nothing in the current step depends on it.  Ordered after the work already enqueued on
+            # the main stream (the previous step), which also makes the allocator's reuse of this stream's freed
+            # blocks safe: their last readers (the previous step's kernels) are enqueued on `main` before this point.
+            ps.wait_stream(main)
         with torch.cuda.stream(ps):
             voxels, coors, sub_med, sub_low = self.voxelize_all(points)
             seg = ops.pillar_segment(coors, len(points), self.grid_size)

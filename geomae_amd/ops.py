@@ -229,24 +229,32 @@ _SIDE_STREAMS = {}
 
 
 def side_streams(device=None):
-    """The step's four side streams: {"geo", "dec_a", "dec_b", "prefetch"}, one set per device.
+    """The step's side streams {"geo", "dec_a", "dec_b"} (+ "prefetch" on first request), one set per device.
 
     ROCm multiplexes HIP streams onto a few hardware queues (4 by default) in the order in which the streams are
-    FIRST USED, so a fifth stream shares a queue with an earlier one.  Creating and touching them here in a fixed
-    order pins the sharing to the harmless pair: `prefetch` (the next batch's voxelization, independent of everything
-    in the current step) lands on the queue of the main stream.  With lazy creation the order was prefetch, geo,
-    dec_a, dec_b and the second decoder stack shared the main stream's queue: 3.83 instead of 3.31 ms/step."""
+    FIRST USED, so a fifth stream shares a queue with an earlier one.  Main + these three fill the four queues; they
+    are created and touched here in a fixed order.  The explicit training schedule needs no more (the next batch's
+    voxelization rides at the tail of "geo"); the autograd path's `prefetch` stream is created after them and then
+    shares the main stream's queue, the harmless pairing.  With lazy creation the order once was prefetch, geo, dec_a,
+    dec_b and the second decoder stack shared the main stream's queue: 3.83 instead of 3.31 ms/step."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
         st = {}
-        for name in ("geo", "dec_a", "dec_b", "prefetch"):
+        for name in ("geo", "dec_a", "dec_b"):
             st[name] = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st[name]):
                 torch.zeros(1, device=dev)                     # first use = queue assignment
         torch.cuda.synchronize(dev)
         _SIDE_STREAMS[key] = st
     return _SIDE_STREAMS[key]
+
+
+def prefetch_stream(device=None):
+    st = side_streams(device)
+    if "prefetch" not in st:
+        st["prefetch"] = torch.cuda.Stream(device=st["geo"].device)
+    return st["prefetch"]
 
 
 class PillarSegments:

@@ -279,9 +279,12 @@ class Trainer:
                 a, b, _ = self.flat.segments[0]
                 works.append((0, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
         early = early_ready if (world > 1 and len(self.flat.segments) > 1) else None
-        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early)) if explicit else \
+        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early, next_points=next_points)) if explicit else \
             (lambda p: self.model.forward_train(p, None, **kw))
-        if next_points is not None and hasattr(self.model, "prefetch"):
+        if explicit:
+            self.model._prefetched = keep
+            losses = run(points)                 # enqueues the next batch's stage 1 itself (on its side stream)
+        elif next_points is not None and hasattr(self.model, "prefetch"):
             self.model.prefetch(next_points)
             nxt = self.model._prefetched
             self.model._prefetched = keep

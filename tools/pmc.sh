@@ -1,17 +1,18 @@
 #!/bin/bash
 # usage: tools/pmc.sh <tag> "<counters>" <bench args...>  -- rocprofv3 PMC pass (kernel-trace only), aggregated per kernel
+# (PMC_BY_GRID=1: per kernel AND grid size, which separates encoder- from decoder-size launches)
 tag=$1; shift; ctrs=$1; shift
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_$tag
 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d /tmp/pmc_$tag -- python /root/repo/bench.py "$@" > /root/repo/gpurun_out/pmc_$tag.log 2>&1
 mkdir -p /root/repo/gpurun_out/pmc_$tag
 python - <<PY
-import csv, glob, collections
+import csv, glob, collections, os
 files = glob.glob('/tmp/pmc_$tag/**/*counter_collection.csv', recursive=True)
 agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
 for f in files:
     for r in csv.DictReader(open(f)):
-        k = r['Kernel_Name'][:48] + ' g' + r.get('Grid_Size', '?')
+        k = r['Kernel_Name'][:60] if not os.environ.get('PMC_BY_GRID') else r['Kernel_Name'][:48] + ' g' + r.get('Grid_Size', '?')
         agg[k][r['Counter_Name']] += float(r['Counter_Value'])
         cnt[(k, r['Counter_Name'])] += 1
 with open('/root/repo/gpurun_out/pmc_$tag/summary.csv', 'w') as out:
