@@ -32,6 +32,16 @@ inline int check_launch(const char* what) {
         }                                         \
     } while (0)
 
+// Layout flags (sst_layer.hip kLay*) that the SST layer / attention entry points apply to the tensors they exchange.
+// Per host thread, 0 = row-major everywhere (what the C ABI documents); only geomae_sst_stack_forward / _backward set
+// it, around their own calls, to keep their internal buffers in the tile-blocked layout (sst_device.h "Row layouts").
+void set_layer_layout(int flags);
+int layer_layout();
+struct LayerLayoutScope {
+    explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
+    ~LayerLayoutScope() { set_layer_layout(0); }
+};
+
 // Accumulator / atomics-target buffers are zeroed by the entry point that fills them (hipMemsetAsync: a ~5 us fill
 // kernel each, a dozen of them between dependent kernels of a training step) unless the calling thread declared, with
 // geomae_set_accumulators_prezeroed(1), that it hands in buffers that are already zero (one arena fill per step,

@@ -11,6 +11,9 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+static thread_local int g_layer_layout = 0;
+void set_layer_layout(int flags) { g_layer_layout = flags; }
+int layer_layout() { return g_layer_layout; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

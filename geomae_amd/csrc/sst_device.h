@@ -170,50 +170,83 @@ __device__ __forceinline__ f32x4 buf_load_f32x4(__amdgpu_buffer_rsrc_t r, int of
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// Row layouts.  Row-major [n, ld] is what the C ABI exchanges.  The T-layout access of a wave -- lane (t = l & 15,
+// g = l >> 4) touches 8 or 16 bytes of token t -- hits 16 different rows per instruction there: 64 separate
+// requests in the memory pipeline; tools/microbench_row_access.hip measures 64 such store instructions per wave at
+// 8.5 us against 3.0 us for row-contiguous ones (105 workgroups), and a layer kernel issues ~120 of them per wave.
+// The tensors that only these kernels exchange (inside geomae_sst_stack_*) therefore use the TILE-BLOCKED layout
+//     [n/16][ld/16][16 tokens][16 channels],
+// in which the 64 lanes of one access instruction cover one contiguous 512-byte (bf16) or 1-KB (fp32) block.  Both
+// layouts have the same tile stride (16 * ld elements); `blk` selects the in-tile strides at run time (wave-uniform:
+// scalar selects, and the per-tile step rides in the instruction's scalar offset).  Row-major relies on the buffer
+// range check for the tail rows of the last tile; blocked buffers are allocated for ceil16(n) rows, whose pad rows
+// hold finite-or-garbage values that never leave their own token (every per-token op is column-independent in the
+// T-layout; the two reductions over tokens mask them: ln_param_grads_t here, the token bound in dw_body).
+struct RowAddr {
+    __amdgpu_buffer_rsrc_t r;
+    int voff;        // byte offset of this lane's piece in tile ct = 0
+    int ct_stride;   // bytes between consecutive 16-channel tiles
+};
+template <int ELEM>
+__device__ __forceinline__ RowAddr row_addr(const void* base, int n, int tok, int ld, int col0, int lane, bool blk) {
+    RowAddr a;
+    const int rowb = ld * ELEM, g = lane >> 4;
+    a.r = rows_rsrc(base, blk ? ((n + 15) & ~15) : n, rowb);
+    a.voff = blk ? (tok >> 4) * (16 * rowb) + (col0 >> 4) * (256 * ELEM) + (tok & 15) * (16 * ELEM) + 4 * ELEM * g
+                 : tok * rowb + col0 * ELEM + 4 * ELEM * g;
+    a.ct_stride = blk ? 256 * ELEM : 16 * ELEM;
+    return a;
+}
+
 // lane (t = l & 15, g = l >> 4) holds channels 16 ct + 4 g + {0..3} of token `tok` (T-layout accumulator order)
 template <int C>
-__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int n, int tok, f32x4 (&v)[C / 16], int lane) {
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(src, n, C * 4);
-    const int off = tok * (C * 4) + 16 * (lane >> 4);
+__device__ __forceinline__ void load_rows_f32(const float* __restrict__ src, int n, int tok, f32x4 (&v)[C / 16], int lane,
+                                              bool blk = false) {
+    const RowAddr a = row_addr<4>(src, n, tok, C, 0, lane, blk);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) v[ct] = buf_load_f32x4(r, off + 64 * ct);
+    for (int ct = 0; ct < C / 16; ++ct)
+        v[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a.r, a.voff, ct * a.ct_stride, 0));
 }
 
 // C channels starting at column col0 of a [n, ld] bf16 matrix
 template <int C>
 __device__ __forceinline__ void load_rows_bf16(const bf16_t* __restrict__ src, int n, int tok, int ld, int col0,
-                                               uint2 (&v)[C / 16], int lane) {
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(src, n, ld * 2);
-    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
+                                               uint2 (&v)[C / 16], int lane, bool blk = false) {
+    const RowAddr a = row_addr<2>(src, n, tok, ld, col0, lane, blk);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) v[ct] = buf_load_b64(r, off + 32 * ct);
+    for (int ct = 0; ct < C / 16; ++ct) {
+        const u32x2 t = __builtin_amdgcn_raw_buffer_load_b64(a.r, a.voff, ct * a.ct_stride, 0);
+        v[ct] = make_uint2(t[0], t[1]);
+    }
 }
 
 template <int C>
-__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int n, int tok, const f32x4 (&v)[C / 16], int lane) {
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, C * 4);
-    const int off = tok * (C * 4) + 16 * (lane >> 4);
+__device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int n, int tok, const f32x4 (&v)[C / 16], int lane,
+                                               bool blk = false) {
+    const RowAddr a = row_addr<4>(dst, n, tok, C, 0, lane, blk);
 #pragma unroll
     for (int ct = 0; ct < C / 16; ++ct)
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ct]), r, off + 64 * ct, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ct]), a.r, a.voff, ct * a.ct_stride, 0);
 }
 
 template <int C>
 __device__ __forceinline__ void store_rows_packed(bf16_t* __restrict__ dst, int n, int tok, int ld, int col0,
-                                                  const uint2 (&v)[C / 16], int lane) {
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, ld * 2);
-    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
+                                                  const uint2 (&v)[C / 16], int lane, bool blk = false) {
+    const RowAddr a = row_addr<2>(dst, n, tok, ld, col0, lane, blk);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) buf_store_b64(r, off + 32 * ct, v[ct]);
+    for (int ct = 0; ct < C / 16; ++ct)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{v[ct].x, v[ct].y}, a.r, a.voff, ct * a.ct_stride, 0);
 }
 
 template <int C>
 __device__ __forceinline__ void store_rows_bf16(bf16_t* __restrict__ dst, int n, int tok, int ld, int col0,
-                                                const f32x4 (&v)[C / 16], int lane) {
-    const __amdgpu_buffer_rsrc_t r = rows_rsrc(dst, n, ld * 2);
-    const int off = tok * (ld * 2) + col0 * 2 + 8 * (lane >> 4);
+                                                const f32x4 (&v)[C / 16], int lane, bool blk = false) {
+    const RowAddr a = row_addr<2>(dst, n, tok, ld, col0, lane, blk);
 #pragma unroll
-    for (int ct = 0; ct < C / 16; ++ct) buf_store_b64(r, off + 32 * ct, pack4(v[ct]));
+    for (int ct = 0; ct < C / 16; ++ct) {
+        const uint2 p = pack4(v[ct]);
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{p.x, p.y}, a.r, a.voff, ct * a.ct_stride, 0);
+    }
 }
 
 // sum over the 128 channels of a token (spread over 8 tiles x 4 regs in-lane and the 4 lanes of group g)
@@ -321,13 +354,14 @@ constexpr int kRedWaveFloats = 2 * 16 * kRedLd;              // per wave: two te
 static_assert(4 * kRedWaveFloats * 4 <= kWeightLds * 2, "token-reduction scratch must fit the weight buffer");
 __device__ __forceinline__ void ln_param_grads_t(const f32x4 (&dy)[8], const f32x4 (&xhat)[8], float* __restrict__ scratch,
                                                  float (*red_wave)[128] /* [tensor][channel] of this wave */, int k0,
-                                                 int lane) {
+                                                 int lane, bool valid) {
     const int t = lane & 15, g = lane >> 4;
     float* row = scratch + t * kRedLd + 4 * g;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        *reinterpret_cast<f32x4*>(row + 16 * ct) = dy[ct] * xhat[ct];
-        *reinterpret_cast<f32x4*>(row + 16 * kRedLd + 16 * ct) = dy[ct];
+    for (int ct = 0; ct < 8; ++ct) {                 // rows past the token count contribute nothing (pad rows of a
+        *reinterpret_cast<f32x4*>(row + 16 * ct) = valid ? dy[ct] * xhat[ct] : zero;       // blocked buffer are not zero)
+        *reinterpret_cast<f32x4*>(row + 16 * kRedLd + 16 * ct) = valid ? dy[ct] : zero;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -354,7 +388,10 @@ struct DwTask {
     int rows_valid;          // only rows i < rows_valid of the 128-row block exist
 };
 constexpr int kMaxDwTasks = 12;
-struct DwTasks { DwTask t[kMaxDwTasks]; };
+struct DwTasks {
+    DwTask t[kMaxDwTasks];
+    int blocked = 0;         // operands A, B in the tile-blocked layout (the layer stacks' slabs) instead of row-major
+};
 int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t stream);
 // the next geomae_sst_weight_grad call of this host thread only records its tasks; the following
 // geomae_sst_ffn_backward launches them inside its own kernel (sst_ffn_bwd_dw_kernel)

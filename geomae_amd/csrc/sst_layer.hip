@@ -54,6 +54,11 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// layout flags of the layer kernels (sst_device.h "Row layouts"); 0 = everything row-major (the plain C-ABI calls)
+constexpr int kLayBlocked = 1;    // tensors only these kernels exchange: qkv, attn, the saved activations, the backward slabs
+constexpr int kLayXBlocked = 2;   // the layer input x (residual stream)
+constexpr int kLayZBlocked = 4;   // the layer output z
+
 struct LayerW {
     const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
     const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
@@ -66,7 +71,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
                                                                 const int32_t* __restrict__ tok_pos,
                                                                 const float* __restrict__ pos_table, LayerW W,
                                                                 int n, bf16_t* __restrict__ qkv,
-                                                                bf16_t* __restrict__ x_b, bf16_t* __restrict__ xp_b) {
+                                                                bf16_t* __restrict__ x_b, bf16_t* __restrict__ xp_b,
+                                                                int lay) {
+    const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
@@ -79,7 +86,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
     stage_issue<128, 256>(W.wqkv, s_qk);
     {
         f32x4 xv[8];
-        load_rows_f32<128>(x, n, tok, xv, lane);
+        load_rows_f32<128>(x, n, tok, xv, lane, lay & kLayXBlocked);
         const __amdgpu_buffer_rsrc_t pr = table_rsrc(pos_table);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -89,21 +96,21 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
         }
     }
     if (x_b) {                       // the bf16 operands of this layer's weight-gradient contraction (dW_qk, dW_v)
-        store_rows_packed<128>(x_b, n, tok, 128, 0, xb, lane);
-        store_rows_packed<128>(xp_b, n, tok, 128, 0, xpb, lane);
+        store_rows_packed<128>(x_b, n, tok, 128, 0, xb, lane, blk);
+        store_rows_packed<128>(xp_b, n, tok, 128, 0, xpb, lane, blk);
     }
     {
         f32x4 acc[16];
         load_bias<256>(W.bqkv, acc, lane);
         gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
         stage_issue<128, 128>(W.wqkv + 256 * 128, s_v);               // in flight under the q/k stores
-        store_rows_bf16<256>(qkv, n, tok, 384, 0, acc, lane);
+        store_rows_bf16<256>(qkv, n, tok, 384, 0, acc, lane, blk);
     }
     {
         f32x4 acc[8];
         load_bias<128>(W.bqkv + 256, acc, lane);
         gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
-        store_rows_bf16<128>(qkv, n, tok, 384, 256, acc, lane);
+        store_rows_bf16<128>(qkv, n, tok, 384, 256, acc, lane, blk);
     }
 }
 
@@ -131,7 +138,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
                                                                 float* __restrict__ xh1_out,
                                                                 float* __restrict__ xh2_out,
                                                                 bf16_t* __restrict__ hp_out,
-                                                                float* __restrict__ rstd_out, NextQkv N) {
+                                                                float* __restrict__ rstd_out, NextQkv N, int lay) {
+    const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
@@ -143,9 +151,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         WStage<128, 128> s_wo;
         stage_issue<128, 128>(W.wo, s_wo);
         uint2 ob[8];
-        load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane);
+        load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane, blk);
         f32x4 xr[8];
-        load_rows_f32<128>(x, n, tok, xr, lane);                      // needed after the GEMM: in flight under it
+        load_rows_f32<128>(x, n, tok, xr, lane, lay & kLayXBlocked);                 // needed after the GEMM: in flight under it
         load_bias<128>(W.bo, u, lane);
         gemm_staged<128, 128>(s_wo, smem, ob, u, lane);
         stage_issue<128, 256>(W.w1, s_w1);                            // lands under the LayerNorm arithmetic
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
     layer_norm_t(u, eps, &r1);
-    if (xh1_out) store_rows_f32<128>(xh1_out, n, tok, u, lane);
+    if (xh1_out) store_rows_f32<128>(xh1_out, n, tok, u, lane, blk);
     affine_t(u, W.g1, W.be1, y, lane);
     uint2 hb[16];
     WStage<256, 128> s_w2;
@@ -165,7 +173,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         load_bias<256>(W.b1, hp, lane);
         gemm_staged<128, 256>(s_w1, smem, yb, hp, lane);
         stage_issue<256, 128>(W.w2, s_w2);                            // lands under the GELU arithmetic
-        if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane);
+        if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane, blk);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
@@ -180,12 +188,12 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
     layer_norm_t(u, eps, &r2);
-    if (xh2_out) store_rows_f32<128>(xh2_out, n, tok, u, lane);
+    if (xh2_out) store_rows_f32<128>(xh2_out, n, tok, u, lane, blk);
     if (rstd_out && (lane >> 4) == 0)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
                                               tok * 8, 0, 0);
     affine_t(u, W.g2, W.be2, y, lane);
-    store_rows_f32<128>(z, n, tok, y, lane);
+    store_rows_f32<128>(z, n, tok, y, lane, lay & kLayZBlocked);
     if (!has_next) return;
     // ---- F1 of the next layer on z = y (registers)
     const int g = lane >> 4;
@@ -201,8 +209,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         }
     }
     if (N.x_b) {
-        store_rows_packed<128>(N.x_b, n, tok, 128, 0, xb, lane);
-        store_rows_packed<128>(N.xp_b, n, tok, 128, 0, xpb, lane);
+        store_rows_packed<128>(N.x_b, n, tok, 128, 0, xb, lane, blk);
+        store_rows_packed<128>(N.xp_b, n, tok, 128, 0, xpb, lane, blk);
     }
     WStage<128, 128> s_v;
     {
@@ -210,13 +218,13 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         load_bias<256>(N.bqkv, acc, lane);
         gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
         stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
-        store_rows_bf16<256>(N.qkv, n, tok, 384, 0, acc, lane);
+        store_rows_bf16<256>(N.qkv, n, tok, 384, 0, acc, lane, blk);
     }
     {
         f32x4 acc[8];
         load_bias<128>(N.bqkv + 256, acc, lane);
         gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
-        store_rows_bf16<128>(N.qkv, n, tok, 384, 256, acc, lane);
+        store_rows_bf16<128>(N.qkv, n, tok, 384, 256, acc, lane, blk);
     }
 }
 
@@ -239,21 +247,22 @@ struct FfnBwdArgs {
     const bf16_t* up_dqkv;            // [n,384] or nullptr (then dz is read from memory)
     const float* up_dx_res;           // [n,128]
     const bf16_t *up_wqkT, *up_wvT;   // packed transposed in-projection of layer l+1
+    int lay;                          // kLayBlocked: everything except dz (always row-major: it comes from outside)
 };
 
 // B1 arithmetic: acc = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv
 __device__ __forceinline__ void qkv_bwd_rows(const bf16_t* __restrict__ dqkv, const float* __restrict__ dx_res,
                                              const bf16_t* __restrict__ wqkT, const bf16_t* __restrict__ wvT, int n,
-                                             int tok, bf16_t* __restrict__ smem, f32x4 (&acc)[8], int lane) {
+                                             int tok, bf16_t* __restrict__ smem, f32x4 (&acc)[8], int lane, bool blk) {
     WStage<256, 128> s_qk;
     WStage<128, 128> s_v;
     stage_issue<256, 128>(wqkT, s_qk);
-    load_rows_f32<128>(dx_res, n, tok, acc, lane);
+    load_rows_f32<128>(dx_res, n, tok, acc, lane, blk);
     uint2 dv_rows[8];
     {
         uint2 d[16];
-        load_rows_bf16<256>(dqkv, n, tok, 384, 0, d, lane);
-        load_rows_bf16<128>(dqkv, n, tok, 384, 256, dv_rows, lane);   // operand of the second GEMM: in flight under the first
+        load_rows_bf16<256>(dqkv, n, tok, 384, 0, d, lane, blk);
+        load_rows_bf16<128>(dqkv, n, tok, 384, 256, dv_rows, lane, blk);  // operand of the second GEMM: in flight under the first
         stage_issue<128, 128>(wvT, s_v);
         gemm_staged<256, 128>(s_qk, smem, d, acc, lane);
     }
@@ -274,32 +283,33 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     const int g = lane >> 4;
     const int tile = block * (kLayerBlk / 64) + wave;
     const int tok = tile * 16 + (lane & 15);
+    const bool blk = A.lay & kLayBlocked, valid = tok < n;
     float* red_scratch = reinterpret_cast<float*>(smem) + wave * kRedWaveFloats;   // see ln_param_grads_t
     GEOMAE_STAMP(0);
     const uint2 rs = buf_load_b64(rows_rsrc(rstd_in, n, 8), tok * 8);
     const float r1 = __uint_as_float(rs.x), r2 = __uint_as_float(rs.y);
     f32x4 dv[8];
-    if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, n, tok, smem, dv, lane);
+    if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, n, tok, smem, dv, lane, blk);
     else load_rows_f32<128>(dz, n, tok, dv, lane);
     GEOMAE_STAMP(20);
     WStage<128, 256> s_w2T;
     // ---- LN2 backward
     {
         f32x4 xh2[8];
-        load_rows_f32<128>(xh2_in, n, tok, xh2, lane);
+        load_rows_f32<128>(xh2_in, n, tok, xh2, lane, blk);
         stage_issue<128, 256>(W.w2T, s_w2T);                          // lands under the LayerNorm arithmetic
         if (A.up_dqkv) __syncthreads();                               // B1's last matrix consumed by every wave
-        ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane);   // d gamma2, d beta2
+        ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane, valid);   // d gamma2, d beta2
         layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
     }
-    store_rows_bf16<128>(dv_b, n, tok, 128, 0, dv, lane);
+    store_rows_bf16<128>(dv_b, n, tok, 128, 0, dv, lane, blk);
     GEOMAE_STAMP(1);
     // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1
     uint2 dhpb[16];
     WStage<256, 128> s_w1T;
     {
         uint2 hpb[16];
-        load_rows_bf16<256>(hp_in, n, tok, 256, 0, hpb, lane);           // needed after the GEMM: in flight under it
+        load_rows_bf16<256>(hp_in, n, tok, 256, 0, hpb, lane, blk);           // needed after the GEMM: in flight under it
         uint2 dvb[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
@@ -309,8 +319,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         gemm_staged<128, 256>(s_w2T, smem, dvb, dh, lane, 2);
         GEOMAE_STAMP(5);
         stage_issue<256, 128>(W.w1T, s_w1T);                          // lands under the GELU arithmetic
-        const __amdgpu_buffer_rsrc_t h_r = rows_rsrc(h_b, n, 512), dhp_r = rows_rsrc(dhp_b, n, 512);
-        const int hoff = tok * 512 + 8 * g;
+        const RowAddr h_a = row_addr<2>(h_b, n, tok, 256, 0, lane, blk), dhp_a = row_addr<2>(dhp_b, n, tok, 256, 0, lane, blk);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             const f32x4 hp = unpack4(hpb[ct]);
@@ -318,24 +327,19 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float c, p;
-#ifdef GEOMAE_EXP_TRIVIAL_GELU
-                c = 0.5f; p = 0.1f * hp[r];
-#else
                 gelu_parts(hp[r], &c, &p);
-#endif
                 h[r] = hp[r] * c;
                 dh[ct][r] *= c + hp[r] * p;
             }
             dhpb[ct] = pack4(dh[ct]);
-#ifndef GEOMAE_EXP_NO_GELU_STORES
-            buf_store_b64(h_r, hoff + 32 * ct, pack4(h));
-            buf_store_b64(dhp_r, hoff + 32 * ct, dhpb[ct]);
-#endif
+            const uint2 hb2 = pack4(h);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{hb2.x, hb2.y}, h_a.r, h_a.voff, ct * h_a.ct_stride, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(u32x2{dhpb[ct].x, dhpb[ct].y}, dhp_a.r, dhp_a.voff, ct * dhp_a.ct_stride, 0);
         }
     }
     GEOMAE_STAMP(6);
     f32x4 xh1[8];
-    load_rows_f32<128>(xh1_in, n, tok, xh1, lane);                    // in flight under the GEMM
+    load_rows_f32<128>(xh1_in, n, tok, xh1, lane, blk);               // in flight under the GEMM
     gemm_staged<256, 128>(s_w1T, smem, dhpb, dv, lane, 7);            // dv now holds dy
     GEOMAE_STAMP(10);
     WStage<128, 128> s_woT;
@@ -345,14 +349,14 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         {
             f32x4 y[8];
             affine_t(xh1, W.g1, W.be1, y, lane);
-            store_rows_bf16<128>(y_b, n, tok, 128, 0, y, lane);
+            store_rows_bf16<128>(y_b, n, tok, 128, 0, y, lane, blk);
         }
         __syncthreads();                                              // w1T consumed by every wave
-        ln_param_grads_t(dv, xh1, red_scratch, red[wave], 2, lane);   // d gamma1, d beta1
+        ln_param_grads_t(dv, xh1, red_scratch, red[wave], 2, lane, valid);   // d gamma1, d beta1
         layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
     }
-    store_rows_f32<128>(dx_res, n, tok, dv, lane);
-    store_rows_bf16<128>(du_b, n, tok, 128, 0, dv, lane);
+    store_rows_f32<128>(dx_res, n, tok, dv, lane, blk);
+    store_rows_bf16<128>(du_b, n, tok, 128, 0, dv, lane, blk);
     GEOMAE_STAMP(11);
     {
         uint2 dub[8];
@@ -363,7 +367,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         for (int ct = 0; ct < 8; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
         gemm_staged<128, 128>(s_woT, smem, dub, da, lane, 12);
         GEOMAE_STAMP(15);
-        store_rows_bf16<128>(dattn, n, tok, 128, 0, da, lane);
+        store_rows_bf16<128>(dattn, n, tok, 128, 0, da, lane, blk);
     }
     GEOMAE_STAMP(16);
     // ---- flush LayerNorm parameter gradients (invalid rows contributed zeros: dz was loaded as 0)
@@ -390,14 +394,14 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
                                                                 const float* __restrict__ dx_res, LayerW W, int n,
-                                                                float* __restrict__ dx) {
+                                                                float* __restrict__ dx, int lay) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
     const int tok = tile * 16 + (lane & 15);
     f32x4 acc[8];
-    qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, n, tok, smem, acc, lane);
-    store_rows_f32<128>(dx, n, tok, acc, lane);
+    qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, n, tok, smem, acc, lane, lay & kLayBlocked);
+    store_rows_f32<128>(dx, n, tok, acc, lane);                       // the stack's output: row-major
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -419,8 +423,14 @@ __device__ __forceinline__ uint2 tr_read(const bf16_t* p) {
     return c.u;
 }
 
+// element offset of (token, column) in a [n, ld] bf16 operand: row-major or tile-blocked [n/16][ld/16][16][16]
+__device__ __forceinline__ int64_t dw_elem(int tok, int ld, int col, bool blk) {
+    return blk ? ((int64_t)(tok >> 4) * (ld >> 4) + (col >> 4)) * 256 + (tok & 15) * 16 + (col & 15)
+               : (int64_t)tok * ld + col;
+}
+
 __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int bx, bf16_t* __restrict__ As,
-                                        bf16_t* __restrict__ Bs, float (*bred)[128]) {
+                                        bf16_t* __restrict__ Bs, float (*bred)[128], bool blk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = lane & 15, g = lane >> 4;
     const int t_begin = bx * chunk;
@@ -444,8 +454,8 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
             ra[k] = u32x4{0u, 0u, 0u, 0u};
             rb[k] = ra[k];
             if (tok < t_end) {
-                ra[k] = *reinterpret_cast<const u32x4*>(T.A + (int64_t)tok * T.lda + T.a_col0 + 8 * cch);
-                rb[k] = *reinterpret_cast<const u32x4*>(T.B + (int64_t)tok * T.ldb + T.b_col0 + 8 * cch);
+                ra[k] = *reinterpret_cast<const u32x4*>(T.A + dw_elem(tok, T.lda, T.a_col0 + 8 * cch, blk));
+                rb[k] = *reinterpret_cast<const u32x4*>(T.B + dw_elem(tok, T.ldb, T.b_col0 + 8 * cch, blk));
             }
         }
     };
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
     __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
     __shared__ float bred[4][128];
-    dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred);
+    dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred, tasks.blocked != 0);
 }
 
 // Horizontal fusion for the backward of a layer stack: the data-gradient kernel of layer l and the weight-
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs
     } else {
         const int b = blockIdx.x - n_ffn;
         dw_body(tasks.t[b / dw_gx], dw_n, dw_chunk, b % dw_gx, smem, smem + kDwTok * kDwLd,
-                reinterpret_cast<float (*)[128]>(&red[0][0][0]));
+                reinterpret_cast<float (*)[128]>(&red[0][0][0]), tasks.blocked != 0);
     }
 }
 
@@ -612,7 +622,8 @@ extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, co
     GEOMAE_REQUIRE((x_bf16 == nullptr) == (xp_bf16 == nullptr), "sst_qkv_forward: pass both operand copies or none");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_qkv_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x, tok_pos,
-                       pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16, (bf16_t*)x_bf16, (bf16_t*)xp_bf16);
+                       pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16, (bf16_t*)x_bf16, (bf16_t*)xp_bf16,
+                       layer_layout());
     return check_launch("sst_qkv_fwd_kernel");
 }
 
@@ -639,7 +650,7 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
                        (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
-                       (bf16_t*)hp_bf16, rstd, N);
+                       (bf16_t*)hp_bf16, rstd, N, layer_layout());
     return check_launch("sst_ffn_fwd_kernel");
 }
 
@@ -672,7 +683,7 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
                           (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
                           (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b,
                           (const bf16_t*)up_dqkv_bf16, up_dx_res, up_w ? (const bf16_t*)up_w->wqkT_p : nullptr,
-                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr};
+                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout()};
     const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
     if (!g_pending_dw.active) {
         hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);
@@ -697,7 +708,7 @@ extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_re
     GEOMAE_REQUIRE(dqkv_bf16 && dx_res && dx, "sst_qkv_backward: null argument");
     const int tiles = cdiv(num_tokens, 16);
     hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,
-                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx);
+                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx, layer_layout());
     return check_launch("sst_qkv_bwd_kernel");
 }
 
@@ -714,6 +725,7 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
                  *du = (const bf16_t*)du_bf16, *at = (const bf16_t*)attn_bf16, *dhp = (const bf16_t*)dhp_bf16,
                  *y = (const bf16_t*)y_bf16, *dv = (const bf16_t*)dv_bf16, *h = (const bf16_t*)h_bf16;
     DwTasks T;
+    T.blocked = (layer_layout() & kLayBlocked) ? 1 : 0;
     //          A     lda a0   B   ldb b0  C        ldc  r0   c0  dbias     rows
     T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv, 128};   // dWq
     T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv, 128};   // dWk

@@ -35,8 +35,13 @@ static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 struct SavedOffsets {
     int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
 };
+// layout flags of sst_layer.hip (kLayBlocked / kLayXBlocked / kLayZBlocked)
+constexpr int kBlk = 1, kXBlk = 2, kZBlk = 4;
+
+// The stack's own buffers are tile-blocked ([n/16][C/16][16][16], sst_device.h "Row layouts"): sized for ceil16(n) rows
 static SavedOffsets saved_offsets(int64_t n, int heads) {
     SavedOffsets o;
+    n = (n + 15) / 16 * 16;
     int64_t p = 0;
     o.x = p;    p += al256(n * 128 * 4);
     o.qkv = p;  p += al256(n * 384 * 2);
@@ -60,6 +65,7 @@ struct ScratchOffsets {
 };
 static ScratchOffsets scratch_offsets(int64_t n) {
     ScratchOffsets o;
+    n = (n + 15) / 16 * 16;
     int64_t p = 0;
     o.dx_res = p; p += al256(n * 128 * 4);
     o.dattn = p;  p += al256(n * 128 * 2);
@@ -92,6 +98,21 @@ struct Timed {
         if (on) { hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
     }
 };
+
+// stack input: row-major [n,128] fp32 -> tile-blocked (pad rows of the last tile zero-filled).  One thread per
+// 16-byte piece, blocked address order: the writes are fully contiguous, the reads 64-byte row pieces.
+__global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* __restrict__ src, int n,
+                                                                  float* __restrict__ dst) {
+    const int64_t pieces = (int64_t)((n + 15) / 16) * 16 * 32;              // 32 float4 per row
+    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * 256) {
+        const int c4 = (int)(q & 3), t = (int)((q >> 2) & 15), cb = (int)((q >> 6) & 7);
+        const int64_t tile = q >> 9;
+        const int64_t tok = tile * 16 + t;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tok < n) v = *reinterpret_cast<const float4*>(src + tok * 128 + 16 * cb + 4 * c4);
+        reinterpret_cast<float4*>(dst)[q] = v;
+    }
+}
 
 }  // namespace geomae
 
@@ -150,13 +171,18 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         return GEOMAE_ERR_WORKSPACE;
     }
     char* base = (char*)saved;
-    GEOMAE_HIP(hipMemcpyAsync(base + so.x, x_in, (size_t)num_tokens * 128 * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(rows_to_blocked_f32_kernel, dim3(stream_grid((int64_t)cdiv(num_tokens, 16) * 512, 256)), dim3(256), 0,
+                       stream, x_in, num_tokens, (float*)(base + so.x));
+    if ((rc = check_launch("rows_to_blocked_f32_kernel"))) return rc;
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
     for (int l = 0; l < num_layers; ++l) {
         char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
         const float* x = (const float*)(sv + so.x);
         float* z = (l + 1 < num_layers) ? (float*)(sv + so.stride + so.x) : z_out;
+        const bool next = l + 1 < num_layers;
+        // everything between the stack's input copy and its output is tile-blocked; z of the last layer is the output
+        LayerLayoutScope lay(kBlk | kXBlk | (next ? kZBlk : 0));
         if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_FWD, stream);
             if ((rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, sv + so.xb,
@@ -172,7 +198,6 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         }
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
-            const bool next = l + 1 < num_layers;
             if ((rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
                                                  (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd),
                                                  next ? &layers[l + 1] : nullptr, next ? layouts[(l + 1) & 1].tok_pos : nullptr,
@@ -212,6 +237,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         const int set = l & 1;
         char* ws = w + sc.set0 + set * sc.set_bytes;
         const bool top = l + 1 == num_layers;
+        LayerLayoutScope lay(kBlk);                 // dz (top layer) and dx_out are the row-major boundary tensors
         const char* ws_up = w + sc.set0 + ((l + 1) & 1) * sc.set_bytes;       // slabs of the layer above
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch

@@ -217,14 +217,21 @@ constexpr int kStageIters = (kMaxT * 2 + kAttnBlk - 1) / kAttnBlk;   // 16-byte 
 
 // Head slice [T, 16] of a [n, ld] bf16 matrix (columns col0..col0+15): lane handles (row, half) pieces.
 // Loads for ALL slices are issued before any LDS write so that their latencies overlap.
+// element offset of (token, column) in a [n, ld] bf16 matrix: row-major, or the layer stacks' tile-blocked layout
+// [n/16][ld/16][16 tokens][16 channels] (sst_device.h "Row layouts"), where a head slice is one 32-byte block row
+__device__ __forceinline__ int64_t tok_elem(int tok, int ld, int col, bool blk) {
+    return blk ? ((int64_t)(tok >> 4) * (ld >> 4) + (col >> 4)) * 256 + (tok & 15) * 16 + (col & 15)
+               : (int64_t)tok * ld + col;
+}
+
 __device__ __forceinline__ void stage_load(const unsigned short* __restrict__ src, int ld, int col0,
-                                           const int* toks, int T, u32x4 (&v)[kStageIters]) {
+                                           const int* toks, int T, u32x4 (&v)[kStageIters], bool blk) {
 #pragma unroll
     for (int k = 0; k < kStageIters; ++k) {
         const int t = k * kAttnBlk + threadIdx.x;
         const int row = t >> 1, half = t & 1;
         v[k] = u32x4{0u, 0u, 0u, 0u};
-        if (row < T) v[k] = *reinterpret_cast<const u32x4*>(src + (int64_t)toks[row] * ld + col0 + half * 8);
+        if (row < T) v[k] = *reinterpret_cast<const u32x4*>(src + tok_elem(toks[row], ld, col0 + half * 8, blk));
     }
 }
 
@@ -250,13 +257,13 @@ __device__ __forceinline__ void stage_store(const u32x4 (&v)[kStageIters], int T
 
 // rows of an LDS tile rm[Tp][16] -> global [n, ld] at columns col0.. (16-byte stores)
 __device__ __forceinline__ void unstage_store(const unsigned short* rm, unsigned short* __restrict__ dst, int ld,
-                                              int col0, const int* toks, int T) {
+                                              int col0, const int* toks, int T, bool blk) {
 #pragma unroll
     for (int k = 0; k < kStageIters; ++k) {
         const int t = k * kAttnBlk + threadIdx.x;
         const int row = t >> 1, half = t & 1;
         if (row < T)
-            *reinterpret_cast<u32x4*>(dst + (int64_t)toks[row] * ld + col0 + half * 8) =
+            *reinterpret_cast<u32x4*>(dst + tok_elem(toks[row], ld, col0 + half * 8, blk)) =
                 *reinterpret_cast<const u32x4*>(rm + row * kDh + half * 8);
     }
 }
@@ -338,7 +345,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                                                           const int32_t* __restrict__ bun_start,
                                                           const int32_t* __restrict__ num_bundles, float scale,
                                                           unsigned short* __restrict__ out,
-                                                          float* __restrict__ lse) {
+                                                          float* __restrict__ lse, bool blk) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Vs[kMaxT * kDh];
@@ -356,9 +363,9 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
         __syncthreads();
         {
             u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters];
-            stage_load(qkv, 3 * C, h * kDh, toks, T, rq);
-            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk);
-            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
+            stage_load(qkv, 3 * C, h * kDh, toks, T, rq, blk);
+            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk, blk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv, blk);
             stage_store(rq, Tp, Qs, nullptr);
             stage_store(rk, Tp, Ks, nullptr);
             stage_store(rv, Tp, Vs, nullptr);
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
             if (g == 0 && iq < T) lse[(int64_t)toks[iq] * n_heads + h] = m + __logf(sum);
         }
         __syncthreads();
-        unstage_store(Os, out, C, h * kDh, toks, T);
+        unstage_store(Os, out, C, h * kDh, toks, T, blk);
         __syncthreads();
     }
 }
@@ -441,7 +448,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                                                           const int32_t* __restrict__ tok_win,
                                                           const int32_t* __restrict__ bun_start,
                                                           const int32_t* __restrict__ num_bundles, float scale,
-                                                          unsigned short* __restrict__ dqkv) {
+                                                          unsigned short* __restrict__ dqkv, bool blk) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
         dOs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short G1[kMaxT * kDh], G2[kMaxT * kDh];   // dQ, then dK / dV
@@ -461,11 +468,11 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         ATTN_STAMP(1);
         {
             u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters], rdo[kStageIters], ro[kStageIters];
-            stage_load(qkv, 3 * C, h * kDh, toks, T, rq);
-            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk);
-            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv);
-            stage_load(dout, C, h * kDh, toks, T, rdo);
-            stage_load(out, C, h * kDh, toks, T, ro);
+            stage_load(qkv, 3 * C, h * kDh, toks, T, rq, blk);
+            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk, blk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv, blk);
+            stage_load(dout, C, h * kDh, toks, T, rdo, blk);
+            stage_load(out, C, h * kDh, toks, T, ro, blk);
             stage_store(rq, Tp, Qs, nullptr);
             stage_store(rk, Tp, Ks, nullptr);
             stage_store(rv, Tp, Vs, nullptr);
@@ -517,7 +524,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         }
         __syncthreads();
         ATTN_STAMP(3);
-        unstage_store(G1, dqkv, 3 * C, h * kDh, toks, T);
+        unstage_store(G1, dqkv, 3 * C, h * kDh, toks, T, blk);
         __syncthreads();
         ATTN_STAMP(4);
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
@@ -561,8 +568,8 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         }
         __syncthreads();
         ATTN_STAMP(5);
-        unstage_store(G1, dqkv, 3 * C, C + h * kDh, toks, T);
-        unstage_store(G2, dqkv, 3 * C, 2 * C + h * kDh, toks, T);
+        unstage_store(G1, dqkv, 3 * C, C + h * kDh, toks, T, blk);
+        unstage_store(G2, dqkv, 3 * C, 2 * C + h * kDh, toks, T, blk);
         __syncthreads();
         ATTN_STAMP(6);
     }
@@ -751,7 +758,7 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
     const int grid = attn_grid(num_tokens, num_heads, max_bundles, max_window_tokens);
     hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
-                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse);
+                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse, (layer_layout() & 1) != 0);
     return check_launch("win_attn_fwd_kernel");
 }
 
@@ -771,7 +778,7 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
                        win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),
-                       (unsigned short*)dqkv_bf16);
+                       (unsigned short*)dqkv_bf16, (layer_layout() & 1) != 0);
     return check_launch("win_attn_bwd_kernel");
 }
 
