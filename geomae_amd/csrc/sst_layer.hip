@@ -441,8 +441,13 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging: 512 16-byte pieces per operand slab, two per thread: token = q >> 4, channel chunk = q & 15
-    const int cch = threadIdx.x & 15, tk0 = threadIdx.x >> 4;
+    // staging: 512 16-byte pieces per operand slab, two per thread (tokens tk0 and tk0 + 16, channel chunk cch).
+    // Row-major operands: token = q >> 4, chunk = q & 15 (16 threads read one 256-byte row piece).  Tile-blocked
+    // operands: [16-channel block][half][token]: 32 threads read one contiguous 512-byte block (with the row-major
+    // mapping they gathered 8 separate 32-byte pieces per token and the contraction ran 29 % slower), and the 16
+    // token lanes of a half write 16 LDS rows 4 banks apart (conflict-free; [block][token][half] was 2-way conflicted).
+    const int cch = blk ? ((threadIdx.x >> 5) & 7) * 2 + ((threadIdx.x >> 4) & 1) : (threadIdx.x & 15);
+    const int tk0 = blk ? threadIdx.x & 15 : threadIdx.x >> 4;
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
@@ -503,16 +508,26 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
             }
     if (T.dbias) {
         // column sums of A: thread holds 8 channels (chunk cch) of tokens tk0 + 16k (+32 per slab)
+        if (!blk) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float v = bsum[e];
-            v = rows4_sum(v);
-            if (lane < 16) bred[wave][8 * cch + e] = v;
+            for (int e = 0; e < 8; ++e) {
+                float v = bsum[e];
+                v = rows4_sum(v);
+                if (lane < 16) bred[wave][8 * cch + e] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 128 && threadIdx.x < T.rows_valid)
+                atomicAdd(T.dbias + T.c_row0 + threadIdx.x,
+                          bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
+        } else {                 // the 16 token lanes of a chunk are one DPP row, and each chunk lives in exactly one row
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = row16_sum(bsum[e]);
+                if ((lane & 15) == 0) bred[0][8 * cch + e] = v;
+            }
+            __syncthreads();
+            if (threadIdx.x < 128 && threadIdx.x < T.rows_valid) atomicAdd(T.dbias + T.c_row0 + threadIdx.x, bred[0][threadIdx.x]);
         }
-        __syncthreads();
-        if (threadIdx.x < 128 && threadIdx.x < T.rows_valid)
-            atomicAdd(T.dbias + T.c_row0 + threadIdx.x,
-                      bred[0][threadIdx.x] + bred[1][threadIdx.x] + bred[2][threadIdx.x] + bred[3][threadIdx.x]);
     }
 }
 
@@ -545,6 +560,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs
 
 // enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
 static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out) {
+    // 512 tokens per workgroup: every workgroup ends in 16 k float atomics, and halving the chunk at encoder size (twice
+    // the workgroups, twice the atomics) made the carrying ffn-backward launches 9 us slower
     int G = cdiv(num_tokens, 512);
     const int cap = num_tasks >= 8 ? 32 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
     if (G > cap) G = cap;
