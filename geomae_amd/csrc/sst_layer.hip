@@ -451,49 +451,62 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
-    u32x4 ra[2], rb[2];
-    auto fetch = [&](int t0) {
+    // Operand slabs travel global -> registers -> LDS.  A register ring of kDwStages slabs keeps kDwStages - 1 slabs
+    // of loads in flight: with a single stage the loads issued under one slab's MFMAs (~0.3 us) were needed one
+    // slab later and each slab paid most of the memory latency (~1.9 us per slab, 16 slabs per workgroup: the
+    // contraction, not the data-gradient chain, set the duration of the encoder's backward launches).
+    constexpr int kDwStages = 4;
+    u32x4 ra[kDwStages][2], rb[kDwStages][2];
+    auto fetch = [&](int t0, u32x4 (&qa)[2], u32x4 (&qb)[2]) {
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const int tok = t0 + tk0 + 16 * k;
-            ra[k] = u32x4{0u, 0u, 0u, 0u};
-            rb[k] = ra[k];
+            qa[k] = u32x4{0u, 0u, 0u, 0u};
+            qb[k] = qa[k];
             if (tok < t_end) {
-                ra[k] = *reinterpret_cast<const u32x4*>(T.A + dw_elem(tok, T.lda, T.a_col0 + 8 * cch, blk));
-                rb[k] = *reinterpret_cast<const u32x4*>(T.B + dw_elem(tok, T.ldb, T.b_col0 + 8 * cch, blk));
+                qa[k] = *reinterpret_cast<const u32x4*>(T.A + dw_elem(tok, T.lda, T.a_col0 + 8 * cch, blk));
+                qb[k] = *reinterpret_cast<const u32x4*>(T.B + dw_elem(tok, T.ldb, T.b_col0 + 8 * cch, blk));
             }
         }
     };
-    fetch(t_begin);
-    for (int t0 = t_begin; t0 < t_end; t0 += kDwTok) {
-        __syncthreads();      // previous slab fully consumed
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            *reinterpret_cast<u32x4*>(As + (tk0 + 16 * k) * kDwLd + 8 * cch) = ra[k];
-            *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = rb[k];
+    for (int st = 0; st < kDwStages - 1; ++st) fetch(t_begin + st * kDwTok, ra[st], rb[st]);
+    const int m = o;
+    const bf16_t* arow = As + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
+    const bf16_t* brow = Bs + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
+    for (int t0 = t_begin; t0 < t_end; t0 += kDwStages * kDwTok) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                bsum[2 * e] += bf_lo(ra[k][e]);
-                bsum[2 * e + 1] += bf_hi(ra[k][e]);
+        for (int st = 0; st < kDwStages; ++st) {
+            const int cur = t0 + st * kDwTok;
+            if (cur < t_end) {                                    // workgroup-uniform
+                // the slab kDwStages - 1 ahead goes into the stage consumed in the previous iteration
+                fetch(cur + (kDwStages - 1) * kDwTok, ra[(st + kDwStages - 1) % kDwStages], rb[(st + kDwStages - 1) % kDwStages]);
+                __syncthreads();      // previous slab fully consumed
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    *reinterpret_cast<u32x4*>(As + (tk0 + 16 * k) * kDwLd + 8 * cch) = ra[st][k];
+                    *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = rb[st][k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        bsum[2 * e] += bf_lo(ra[st][k][e]);
+                        bsum[2 * e + 1] += bf_hi(ra[st][k][e]);
+                    }
+                }
+                __syncthreads();
+                uint4 af[2];
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const uint2 lo = tr_read(arow + 32 * wave + 16 * it), hi = tr_read(arow + 4 * kDwLd + 32 * wave + 16 * it);
+                    af[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                }
+#pragma unroll
+                for (int jt = 0; jt < 8; ++jt) {
+                    const uint2 lo = tr_read(brow + 16 * jt), hi = tr_read(brow + 4 * kDwLd + 16 * jt);
+                    const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
+                }
             }
-        }
-        __syncthreads();
-        if (t0 + kDwTok < t_end) fetch(t0 + kDwTok);     // next slab's loads fly under the MFMAs
-        const int m = o;
-        const bf16_t* arow = As + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
-        const bf16_t* brow = Bs + (8 * g + (m >> 2)) * kDwLd + 4 * (m & 3);
-        uint4 af[2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const uint2 lo = tr_read(arow + 32 * wave + 16 * it), hi = tr_read(arow + 4 * kDwLd + 32 * wave + 16 * it);
-            af[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        }
-#pragma unroll
-        for (int jt = 0; jt < 8; ++jt) {
-            const uint2 lo = tr_read(brow + 16 * jt), hi = tr_read(brow + 4 * kDwLd + 16 * jt);
-            const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
-#pragma unroll
-            for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
         }
     }
     // C layout: row i = 32*wave + 16*it + 4*g + r, col j = 16*jt + o
