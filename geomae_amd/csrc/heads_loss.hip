@@ -38,7 +38,6 @@ struct HeadArgs {
     bf16_t* dl; bf16_t* cm_b; bf16_t* dm_b;   // [M,896], [M,128], [M,128]
 };
 
-__device__ __forceinline__ int kperm_inv(int k) { return (k & ~31) + 8 * ((k >> 2) & 3) + 4 * ((k >> 4) & 1) + (k & 3); }
 
 // BCE with logits against y in {0,1}: value and d/dx
 __device__ __forceinline__ void bce(float x, float y, float* l, float* d) {
@@ -51,25 +50,24 @@ __device__ __forceinline__ void bce(float x, float y, float* l, float* d) {
 
 // dX (normal-orientation C layout: lane (c = l&15, g) holds tokens 4g+r of channel tile ct) +=
 //   dl[16 x 128 outputs] * W[128 outputs x 128 channels], W read from the staged chunk (K-permuted columns)
+// The B operand is a COLUMN of the staged row-major chunk (8 output rows of one LDS column per lane): read with
+// ds_read_b64_tr_b16 (two per MFMA; it was eight 2-byte LDS reads plus their repacking).  LDS column j holds
+// channel kperm(j) (the chunk is staged K-permuted for the forward GEMM), so column c of accumulator tile ct is
+// channel kperm(16 ct + c): the caller un-permutes in its store index.
 __device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, const uint2 (&dlb)[8],
                                               f32x4 (&acc)[8], int lane) {
     constexpr int LD = 128 + kPad;
-    const int c = lane & 15, g = lane >> 4;
+    const int m = lane & 15, g = lane >> 4;
+    // lane m of a 16-lane group addresses row (m >> 2), columns 4 (m & 3).. of a [4 rows x 16 columns] block and
+    // receives column m of it: rows = this lane group's output rows 32 kk + 4 g + 0..3 (lo) and + 16 (hi)
+    const bf16_t* base = smem + (4 * g + (m >> 2)) * LD + 4 * (m & 3);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const uint4 a = make_uint4(dlb[2 * kk].x, dlb[2 * kk].y, dlb[2 * kk + 1].x, dlb[2 * kk + 1].y);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
-            const int col = kperm_inv(16 * ct + c);
-            unsigned int w[4];
-#pragma unroll
-            for (int e2 = 0; e2 < 4; ++e2) {
-                // element e = 2*e2, 2*e2+1 of this lane's k-slice: output row o = 32kk + 16(e>>2) + 4g + (e&3)
-                const int o0 = 32 * kk + 16 * ((2 * e2) >> 2) + 4 * g + ((2 * e2) & 3);
-                const unsigned int lo = smem[o0 * LD + col], hi = smem[(o0 + 1) * LD + col];
-                w[e2] = lo | (hi << 16);
-            }
-            acc[ct] = mfma32(a, make_uint4(w[0], w[1], w[2], w[3]), acc[ct]);
+            const uint2 lo = tr_read(base + (32 * kk) * LD + 16 * ct), hi = tr_read(base + (32 * kk + 16) * LD + 16 * ct);
+            acc[ct] = mfma32(a, make_uint4(lo.x, lo.y, hi.x, hi.y), acc[ct]);
         }
     }
 }
@@ -101,6 +99,8 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // weights of chunk c+1 are requested right after chunk c's matrix is in LDS: the loads fly under the loss
+    // arithmetic and the dX GEMM instead of stalling the next chunk's first MFMA
     for (int chunk = 0; chunk < 7; ++chunk) {
         if (chunk == 6) {
             // flush d_cen, switch the input to the density decoder
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-                    if (rr < A.M) A.d_cen[(A.n_keep + rr) * 128 + 16 * ct + (lane & 15)] = dx[ct][r];
+                    if (rr < A.M) A.d_cen[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
                 }
             f32x4 x[8];
             load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-            if (rr < A.M) A.d_den[(A.n_keep + rr) * 128 + 16 * ct + (lane & 15)] = dx[ct][r];
+            if (rr < A.M) A.d_den[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
         }
     // zero the padding columns of dl that dw_kernel will read: [771,896)
     if (valid)

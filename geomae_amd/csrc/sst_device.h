@@ -379,6 +379,18 @@ __device__ __forceinline__ void ln_param_grads_t(const f32x4 (&dy)[8], const f32
 
 
 
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+// ds_read_b64_tr_b16: within a 16-lane group, lane 4a+b receives element b of lanes a, 4+a, 8+a, 12+a.
+// With lane m pointing at row (m>>2), 4-element column chunk (m&3) of a row-major [4 x 16] block, lane c gets
+// column c of the block: 4 consecutive TOKENS of one channel -- the MFMA fragment of a token contraction,
+// read straight from the token-major slab (measured on gfx950, round 1).
+__device__ __forceinline__ uint2 tr_read(const bf16_t* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    union { s16x4 s; uint2 u; } c;
+    c.s = v;
+    return c.u;
+}
+
 // weight-gradient (token contraction) tasks, see dw_kernel in sst_layer.hip
 struct DwTask {
     const bf16_t* A; int lda, a_col0;

@@ -411,18 +411,6 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t*
 constexpr int kDwTok = 32;             // tokens per slab (= MFMA K)
 constexpr int kDwLd = 128 + 8;         // LDS row: 128 channels + 16 B pad (token-major, no transposition)
 
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-// ds_read_b64_tr_b16: within a 16-lane group, lane 4a+b receives element b of lanes a, 4+a, 8+a, 12+a.
-// With lane m pointing at row (m>>2), 4-element column chunk (m&3) of a row-major [4 x 16] block, lane c gets
-// column c of the block: 4 consecutive TOKENS of one channel -- the MFMA fragment of a token contraction,
-// read straight from the token-major slab (measured on gfx950, round 1).
-__device__ __forceinline__ uint2 tr_read(const bf16_t* p) {
-    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
-    union { s16x4 s; uint2 u; } c;
-    c.s = v;
-    return c.u;
-}
-
 // element offset of (token, column) in a [n, ld] bf16 operand: row-major or tile-blocked [n/16][ld/16][16][16]
 __device__ __forceinline__ int64_t dw_elem(int tok, int ld, int col, bool blk) {
     return blk ? ((int64_t)(tok >> 4) * (ld >> 4) + (col >> 4)) * 256 + (tok & 15) * 16 + (col & 15)
