@@ -29,7 +29,8 @@ namespace geomae {
 
 constexpr int kVfeBlk = 512;            // 8 waves share one LDS copy of W1: 2 waves per SIMD hide each other's latency
 constexpr int kVfeWaves = kVfeBlk / 64;
-constexpr int kW1Ld = 128 + 4;          // fp32 LDS row of W1 (+16 B pad)
+constexpr int kW1bLd = 128 + 8;         // bf16 LDS row of one half (hi or lo) of the split W1 (+16 B pad: conflict-free b128 reads)
+constexpr int kW1Ld = kW1bLd;           // the W1 buffer is declared as float [128][kW1Ld] = two bf16 [128][kW1bLd] halves
 constexpr int kTileLd = 128 + 4;        // fp32 LDS row of the per-wave [16 x 128] tile
 constexpr int kTile0Ld = 80 + 4;        // ... of the [16 x 64 (+16 features)] tile
 constexpr int kVfePts = 64;             // points per wave: 4 tiles of 16
@@ -120,34 +121,64 @@ __device__ __forceinline__ void layer0_linear(const float* __restrict__ W0s, con
     }
 }
 
-// y1[t][16*ot + 4g + r] = sum_k W1[.][k] gin[t][k]; W1s: LDS [128][kW1Ld] fp32 ; gin: 8 T-layout tiles.
-// NG output tiles starting at ot0 advance together over k (independent accumulators back to back: the
-// 16x16x4 f32 MFMA has a 40-cycle dependent latency against a 32-cycle issue).  The k order inside every
-// accumulator is fixed (ct, then r), so any grouping gives bit-identical results.
+// The 128 x 128 layer-1 GEMMs in "bf16 x 3": x = x_hi + x_lo and w = w_hi + w_lo with bf16 halves (x_lo =
+// bf16(x - x_hi): 16 mantissa bits together), y = w_hi x_hi + w_lo x_hi + w_hi x_lo accumulated in fp32 -- the dropped
+// w_lo x_lo term and the 2^-17 representation errors leave ~2^-16 relative error per product, far inside the fp32-
+// accumulation noise of a 128-term sum of O(1) terms times the test tolerance (2e-4).  Three 16x16x32 bf16 MFMAs
+// (32 cycles each) replace eight 16x16x4 fp32 MFMAs (32 cycles each) per 32-wide k step: 96 instead of 256 MFMA
+// issues per [16 x 128] tile, and these sweeps were MFMA-issue bound (272-528 fp32 MFMAs per tile).
+// Both the forward and the backward's recomputation call THIS function on the same operands, so the recomputed
+// activations stay bit-identical to the forward's (the max-pool backward routes gradients by equality).
+struct BSplit { uint4 h[4], l[4]; };     // B operand of a [16 tokens x 128 channels] T-layout tile: 4 k-steps of 32
+
+__device__ __forceinline__ void split2(float x, float y, unsigned int* hi, unsigned int* lo) {
+    const unsigned int h = pack2(x, y);
+    *hi = h;
+    *lo = pack2(x - bf_lo(h), y - bf_hi(h));
+}
+__device__ __forceinline__ BSplit split_operand(const f32x4 (&v)[8]) {
+    BSplit s;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        split2(v[2 * kk][0], v[2 * kk][1], &s.h[kk].x, &s.l[kk].x);
+        split2(v[2 * kk][2], v[2 * kk][3], &s.h[kk].y, &s.l[kk].y);
+        split2(v[2 * kk + 1][0], v[2 * kk + 1][1], &s.h[kk].z, &s.l[kk].z);
+        split2(v[2 * kk + 1][2], v[2 * kk + 1][3], &s.h[kk].w, &s.l[kk].w);
+    }
+    return s;
+}
+
+// y1[t][16*ot + 4g + r] = sum_k W1[.][k] gin[t][k]; W1s: the split, K-permuted LDS copy written by stage_w1.
+// NG output tiles starting at ot0 advance together over k (independent accumulators back to back).  The order of
+// the terms inside every accumulator is fixed (k step, then hi*hi, lo*hi, hi*lo), so any grouping gives
+// bit-identical results.
 template <int NG>
-__device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, const f32x4 (&gin)[8], int ot0,
-                                             f32x4 (&y)[NG], int lane) {
+__device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, const BSplit& x, int ot0, f32x4 (&y)[NG],
+                                             int lane) {
     const int o = lane & 15, g = lane >> 4;
+    const bf16_t* wh = reinterpret_cast<const bf16_t*>(W1s) + (16 * ot0 + o) * kW1bLd + 8 * g;
+    const bf16_t* wl = wh + 128 * kW1bLd;
 #pragma unroll
     for (int u = 0; u < NG; ++u) y[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ct = 0; ct < 8; ++ct) {
-        float4 a[NG];
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 ah[NG], al[NG];
 #pragma unroll
-        for (int u = 0; u < NG; ++u)
-            a[u] = *reinterpret_cast<const float4*>(W1s + (16 * (ot0 + u) + o) * kW1Ld + 4 * g + 16 * ct);
+        for (int u = 0; u < NG; ++u) {
+            ah[u] = *reinterpret_cast<const uint4*>(wh + 16 * u * kW1bLd + 32 * kk);
+            al[u] = *reinterpret_cast<const uint4*>(wl + 16 * u * kW1bLd + 32 * kk);
+        }
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].x, gin[ct][0], y[u]);
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.h[kk], y[u]);
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].y, gin[ct][1], y[u]);
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].z, gin[ct][2], y[u]);
-#pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma_f32(a[u].w, gin[ct][3], y[u]);
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
     }
 }
-__device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const f32x4 (&gin)[8], f32x4 (&y)[8], int lane) {
-    layer1_group<8>(W1s, gin, 0, y, lane);
+__device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const BSplit& x, f32x4 (&y)[8], int lane) {
+    layer1_group<4>(W1s, x, 0, reinterpret_cast<f32x4(&)[4]>(y[0]), lane);
+    layer1_group<4>(W1s, x, 4, reinterpret_cast<f32x4(&)[4]>(y[4]), lane);
 }
 
 template <int NT>
@@ -171,15 +202,29 @@ __device__ __forceinline__ void stage_w0(const float* __restrict__ w0, float* W0
         W0s[e] = c < 11 ? w0[r * 11 + c] : 0.f;
     }
 }
+// W1 [128 out][128 in] fp32 -> LDS, split into bf16 hi / lo halves, K-permuted for the MFMA operand order of the
+// T-layout (sst_device.h kperm): dst[o][p] = W1[o][kperm(p)], or with `transpose` (dg = dy1 W1: outputs are the
+// input channels) dst[k][p] = W1[kperm(p)][k].  kperm^-1(32 b + 16 h + 4 q + e) = 32 b + 8 q + 4 h + e: four
+// consecutive source columns stay consecutive.
 __device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1s, bool transpose) {
+    bf16_t* wh = reinterpret_cast<bf16_t*>(W1s);
+    bf16_t* wl = wh + 128 * kW1bLd;
     for (int e = threadIdx.x; e < 128 * 32; e += kVfeBlk) {
         const int r = e >> 5, c4 = (e & 31) * 4;
         const float4 v = *reinterpret_cast<const float4*>(w1 + r * 128 + c4);
+        unsigned int h01, l01, h23, l23;
+        split2(v.x, v.y, &h01, &l01);
+        split2(v.z, v.w, &h23, &l23);
         if (!transpose) {
-            *reinterpret_cast<float4*>(W1s + r * kW1Ld + c4) = v;
+            const int p = (c4 & ~31) + 8 * ((c4 >> 2) & 3) + 4 * ((c4 >> 4) & 1);
+            *reinterpret_cast<uint2*>(wh + r * kW1bLd + p) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(wl + r * kW1bLd + p) = make_uint2(l01, l23);
         } else {
-            W1s[(c4 + 0) * kW1Ld + r] = v.x; W1s[(c4 + 1) * kW1Ld + r] = v.y;
-            W1s[(c4 + 2) * kW1Ld + r] = v.z; W1s[(c4 + 3) * kW1Ld + r] = v.w;
+            const int p = (r & ~31) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3);
+            wh[(c4 + 0) * kW1bLd + p] = (bf16_t)(h01 & 0xffffu); wh[(c4 + 1) * kW1bLd + p] = (bf16_t)(h01 >> 16);
+            wh[(c4 + 2) * kW1bLd + p] = (bf16_t)(h23 & 0xffffu); wh[(c4 + 3) * kW1bLd + p] = (bf16_t)(h23 >> 16);
+            wl[(c4 + 0) * kW1bLd + p] = (bf16_t)(l01 & 0xffffu); wl[(c4 + 1) * kW1bLd + p] = (bf16_t)(l01 >> 16);
+            wl[(c4 + 2) * kW1bLd + p] = (bf16_t)(l23 & 0xffffu); wl[(c4 + 3) * kW1bLd + p] = (bf16_t)(l23 >> 16);
         }
     }
 }
@@ -481,10 +526,11 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
         const float* W1l = W1s + oz;
         f32x4 y0[4], gin[8];
         recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        const BSplit gs = split_operand(gin);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 y2[2];
-            layer1_group<2>(W1l, gin, ot0, y2, lane);
+            layer1_group<2>(W1l, gs, ot0, y2, lane);
             if (valid) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { s1[ot0 + u] += y2[u]; s2[ot0 + u] += y2[u] * y2[u]; }
@@ -523,7 +569,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
         const VfeW Wl = shifted(Ws, oz);
         f32x4 y0[4], gin[8], y1[8], h1[8];
         recompute_g(G, Wl, W0s + oz, m0, j, pid, valid, lane, y0, gin);
-        layer1_linear(W1s + oz, gin, y1, lane);
+        layer1_linear(W1s + oz, split_operand(gin), y1, lane);
         bn_relu<8>(y1, Wl.scale1, Wl.shift1, h1, lane);
         tile_store<8, kTileLd>(tile, h1, lane);
         if (g == 0) pids[wave][lane & 15] = pid;
@@ -589,11 +635,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
             const Bn1 bnl = shifted(bns, oz);
             f32x4 y0[4], gin[8];
             recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+            const BSplit gs = split_operand(gin);
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
                 const int ot0 = 4 * half + q;
                 f32x4 y4[2];
-                layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
+                layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 dh, yh;
@@ -650,10 +697,11 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         f32x4 y0[4], gin[8];
         recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
         store_rows_bf16<128>(g_b, R.j_hi, j, 128, 0, gin, lane);      // rows >= j_hi belong to the next wave: dropped
+        const BSplit gs = split_operand(gin);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
           f32x4 y4[2];
-          layer1_group<2>(W1s + oz, gin, ot0, y4, lane);
+          layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
             const int ot = ot0 + u;
@@ -684,10 +732,11 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         f32x4 dy1[8];
         load_rows_f32<128>(dy1_f, R.j_hi, j, dy1, lane);
         // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
+        const BSplit ds = split_operand(dy1);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 d2[2];
-            layer1_group<2>(W1l, dy1, ot0, d2, lane);
+            layer1_group<2>(W1l, ds, ot0, d2, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ct = ot0 + u;
