@@ -151,7 +151,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             # layouts (encoder forward), the zero arena of everything after the VFE forward, then the targets (first read by the heads+loss
             # kernel, a whole forward later: they finish under the encoder, whose launches fill 105 of 256 CUs)
             ops.mark("side:start")
-            self.backbone._packed.refresh_if_stale()         # a no-op when the trainer packed after its optimizer step
+            packed_ready = self.backbone._packed.refresh_if_stale()   # a no-op when the trainer packed after its optimizer step
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
             ops.mark("side:mask")
             coors_all, ik_l = ops.gather_token_coors(ik, im, seg.voxel_coors)
@@ -185,6 +185,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd)
         ops.mark("vfe_fwd_done")
         main.wait_event(layouts_ready)
+        if packed_ready is not None:
+            main.wait_event(packed_ready)                    # packed on another stream, long before this point
         if not self.TARGETS_LATE:
             main.wait_event(tgt_ready)
         ik = ik_l

@@ -106,6 +106,9 @@ class PackedLayers:
         if k != self.key:
             self._build(k[-1])
             self.key = k
+        ev, self.ready = getattr(self, "ready", None), None
+        if ev is not None:                   # an earlier pack-ahead on another stream: do not race it
+            torch.cuda.current_stream().wait_event(ev)
         ops.pack_weights(self.desc, self.n_desc, 384 * 128, self.packed, self.head_bias)
         self._prepacked = None
 
@@ -132,10 +135,13 @@ class PackedLayers:
         self._prepacked = None
 
     def refresh_if_stale(self):
+        """-> event to wait for before reading the packed copies (None: packed on the current stream)."""
         v, self._prepacked = getattr(self, "_prepacked", None), None
         if v is not None and self._key() == self.key and v == self._versions():
-            return
-        self.refresh()
+            ev, self.ready = getattr(self, "ready", None), None
+            return ev
+        self.refresh()                                       # (waits for a pending pack-ahead itself)
+        return None
 
     def grads(self, layer_index):
         """C struct of gradient pointers; allocates .grad where autograd has not yet."""

@@ -311,11 +311,14 @@ class Trainer:
             packed = getattr(getattr(self.model, "backbone", None), "_packed", None)
             if explicit and packed is not None:
                 # bf16 MFMA-layout copies of the updated weights for the next step, off its critical path
+                # (on a decoder stream: idle until the next step's decoders, while the geometry stream's chain of
+                # mask -> window layouts gates the next encoder and should start the moment the step does)
                 from . import ops
-                main, side = torch.cuda.current_stream(), ops.side_streams()["geo"]
+                main, side = torch.cuda.current_stream(), ops.side_streams()["dec_a"]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     packed.prepack()
+                    packed.ready = side.record_event()
                 self._prepack_flat_version = self.flat.flat._version
         else:
             allreduce_gradients(self.flat)
