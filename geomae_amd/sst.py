@@ -115,11 +115,14 @@ class PackedLayers:
     # ---- packing ahead: the copies depend on the weights only, so the trainer packs them right after the optimizer
     # step (on a side stream) and the next step's critical path does not contain the pack kernel
     def _sources(self):
-        srcs = [p for L in self.layers for p in L.parameters()]
-        if self.backbone is not None:
-            for n, _ in self.HEAD_ROWS:
-                lin = getattr(self.backbone, n)
-                srcs += [lin.weight, lin.bias]
+        srcs = getattr(self, "_srcs", None)
+        if srcs is None:                       # the Parameter objects are stable (only their .data / .grad move)
+            srcs = [p for L in self.layers for p in L.parameters()]
+            if self.backbone is not None:
+                for n, _ in self.HEAD_ROWS:
+                    lin = getattr(self.backbone, n)
+                    srcs += [lin.weight, lin.bias]
+            self._srcs = srcs
         return srcs
 
     def _versions(self):
@@ -164,8 +167,19 @@ class PackedLayers:
         return (GeomaeSstLayerWeights * count)(*self.structs[first:first + count])
 
     def grad_array(self, first, count):
+        """ctypes array of per-layer gradient-pointer structs; cached while the first and last gradient of the range
+        stay where they were (the trainer keeps every .grad as a view of one flat buffer)."""
         from ._lib import GeomaeSstLayerGrads
-        return (GeomaeSstLayerGrads * count)(*[self.grads(i) for i in range(first, first + count)])
+        cache = self.__dict__.setdefault("_grad_arrays", {})
+        a, b = self.layers[first].linear1.weight.grad, self.layers[first + count - 1].norm2.bias.grad
+        tag = (a.data_ptr(), b.data_ptr()) if (a is not None and b is not None) else None
+        hit = cache.get((first, count))
+        if hit is not None and tag is not None and hit[0] == tag:
+            return hit[1]
+        arr = (GeomaeSstLayerGrads * count)(*[self.grads(i) for i in range(first, first + count)])
+        a, b = self.layers[first].linear1.weight.grad, self.layers[first + count - 1].norm2.bias.grad
+        cache[(first, count)] = ((a.data_ptr(), b.data_ptr()), arr)
+        return arr
 
     def head_grads(self):
         from ._lib import GeomaeHeadGrads
