@@ -29,7 +29,7 @@ class GeomaeWindowConfig(ctypes.Structure):
 class GeomaeWindowBuildJob(ctypes.Structure):
     _fields_ = ([("coors", c_void_p), ("num_tokens", c_int32), ("shift_index", c_int32)]
                 + [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "bun_start",
-                                           "num_bundles")])
+                                           "num_bundles", "bun_tok", "pos_info")])
 
 
 class GeomaeSstLayerWeights(ctypes.Structure):
@@ -40,7 +40,7 @@ class GeomaeSstLayerWeights(ctypes.Structure):
 
 class GeomaeSstStackLayout(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "bun_start", "num_bundles")] + \
-               [("max_bundles", c_int32)]
+               [("max_bundles", c_int32), ("bun_tok", c_void_p), ("pos_info", c_void_p)]
 
 
 class GeomaeVfeArgs(ctypes.Structure):
@@ -130,9 +130,9 @@ SIGNATURES = {
     "geomae_window_build_batch": (ctypes.c_int, [POINTER(GeomaeWindowBuildJob), c_int32, c_int32,
                                                  POINTER(GeomaeWindowConfig), P, c_int64, P]),
     "geomae_window_attention_forward": (ctypes.c_int, [P, c_int32, c_int32, c_int32, P, P, P, P, P, c_int32,
-                                                       c_int32, P, P, P]),
+                                                       c_int32, P, P, P, P, P]),
     "geomae_window_attention_backward": (ctypes.c_int, [P, P, P, P, c_int32, c_int32, c_int32, P, P, P, P, P,
-                                                        c_int32, c_int32, P, P]),
+                                                        c_int32, c_int32, P, P, P, P]),
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
     "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_gather_token_coors": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, P, P]),

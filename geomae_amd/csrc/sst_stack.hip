@@ -193,7 +193,8 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
             Timed t(profiler, GEOMAE_KERNEL_ATTN_FWD, stream);
             if ((rc = geomae_window_attention_forward(sv + so.qkv, num_tokens, num_heads, 128 / num_heads, L.win_start,
                                                       L.win_tokens, L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
-                                                      max_window_tokens, sv + so.attn, (float*)(sv + so.lse), stream)))
+                                                      max_window_tokens, sv + so.attn, (float*)(sv + so.lse), L.bun_tok,
+                                                      L.pos_info, stream)))
                 return rc;
         }
         {
@@ -254,7 +255,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
             rc = geomae_window_attention_backward(sv + so.qkv, sv + so.attn, w + sc.dattn, (const float*)(sv + so.lse),
                                                   num_tokens, num_heads, 128 / num_heads, L.win_start, L.win_tokens,
                                                   L.tok_win, L.bun_start, L.num_bundles, L.max_bundles,
-                                                  max_window_tokens, ws + sc.dqkv, stream);
+                                                  max_window_tokens, ws + sc.dqkv, L.bun_tok, L.pos_info, stream);
         }
         if (rc) break;
         if (l == 0) {

@@ -59,6 +59,8 @@ struct WinJob {
     int n, slots, cap;
     WinGeom g;
     int32_t *table, *rank, *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
+    int32_t* bun_tok;        // optional attention plan (see bundle_setup): token position where each bundle starts
+    int4* pos_info;          // ... and per position of win_tokens: (token, window, window start, window end)
 };
 struct WinJobs { WinJob j[kMaxWinJobs]; };
 
@@ -132,8 +134,11 @@ __global__ __launch_bounds__(64) void win_sort_jobs_kernel(WinJobs J) {
                 int r = 0;
                 for (int u = 0; u < n; ++u) r += a[u] < v;
                 win_tokens[s + r] = v;
+                if (j.pos_info) j.pos_info[s + r] = make_int4(v, w, s, s + n);
             }
             __syncthreads();
+        } else if (j.pos_info) {
+            for (int t = threadIdx.x; t < n; t += 64) j.pos_info[s + t] = make_int4(win_tokens[s + t], w, s, s + n);
         }
     }
 }
@@ -170,10 +175,12 @@ __global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
     if (threadIdx.x == 0) {
         int nb = 0, w = 0;
         while (w < W) {
+            if (j.bun_tok) j.bun_tok[nb] = in_lds ? ws[w] : win_start[w];
             bun_start[nb++] = w;
             w = in_lds ? nx[w] : nxt_ws[w];
         }
         bun_start[nb] = W;
+        if (j.bun_tok) j.bun_tok[nb] = j.n;
         num_bundles[0] = nb;
     }
 }
@@ -295,32 +302,49 @@ struct BundleCtx {
     int s0, T, nt, Tp;
 };
 
-// loads the bundle's token list and each token's window (CSR index) into LDS
-__device__ __forceinline__ BundleCtx bundle_setup(int b, const int32_t* __restrict__ bun_start,
-                                                  const int32_t* __restrict__ win_start,
-                                                  const int32_t* __restrict__ win_tokens,
-                                                  const int32_t* __restrict__ tok_win, int* toks, int* wid) {
+// Loads the bundle's token list and, per token, its window (CSR index) and that window's position range into LDS.
+// From the CSR arrays this is a chain of four dependent global loads (bun_start -> win_start -> win_tokens ->
+// tok_win, then win_start again per tile) in front of the operand gather -- most of a workgroup's life at d_head =
+// 16.  The optional attention plan written by the window build (bun_tok [NB+1], pos_info [n] = (token, window, window
+// start, window end) per position) makes it two: bun_tok[b], then one 16-byte record per position.
+struct AttnPlan {
+    const int32_t *bun_start, *win_start, *win_tokens, *tok_win;     // CSR form (always valid)
+    const int32_t* bun_tok; const int4* pos_info;                    // plan form, or null
+};
+__device__ __forceinline__ BundleCtx bundle_setup(int b, const AttnPlan& P, int* toks, int* wid, int* wlo, int* whi) {
     BundleCtx c;
-    c.s0 = win_start[bun_start[b]];
-    c.T = win_start[bun_start[b + 1]] - c.s0;
+    if (P.pos_info) {
+        c.s0 = P.bun_tok[b];
+        c.T = P.bun_tok[b + 1] - c.s0;
+    } else {
+        c.s0 = P.win_start[P.bun_start[b]];
+        c.T = P.win_start[P.bun_start[b + 1]] - c.s0;
+    }
     c.nt = (c.T + 15) >> 4;
     c.Tp = c.nt * 16;
     for (int t = threadIdx.x; t < c.Tp; t += kAttnBlk) {
-        int tk = -1, w = -1 - t;                     // padded rows: a window id nothing else has
-        if (t < c.T) { tk = win_tokens[c.s0 + t]; w = tok_win[tk]; }
-        toks[t] = tk;
-        wid[t] = w;
+        int4 pi = make_int4(-1, -1 - t, 0, 0);            // padded rows: a window id nothing else has
+        if (t < c.T) {
+            if (P.pos_info) {
+                pi = P.pos_info[c.s0 + t];
+            } else {
+                pi.x = P.win_tokens[c.s0 + t];
+                pi.y = P.tok_win[pi.x];
+                pi.z = P.win_start[pi.y];
+                pi.w = P.win_start[pi.y + 1];
+            }
+        }
+        toks[t] = pi.x; wid[t] = pi.y; wlo[t] = pi.z; whi[t] = pi.w;
     }
     return c;
 }
 
 // key-tile range [lo, hi] that the windows touching query tile `it` span
-__device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int* wid,
-                                           const int32_t* __restrict__ win_start, int* lo, int* hi) {
+__device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int* wlo, const int* whi, int* lo, int* hi) {
     const int first = it * 16;
     const int last = (first + 15 < c.T ? first + 15 : c.T - 1);
-    *lo = (win_start[wid[first]] - c.s0) >> 4;
-    *hi = (win_start[wid[last] + 1] - 1 - c.s0) >> 4;
+    *lo = (wlo[first] - c.s0) >> 4;
+    *hi = (whi[last] - 1 - c.s0) >> 4;
 }
 
 // qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
@@ -345,12 +369,15 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                                                           const int32_t* __restrict__ bun_start,
                                                           const int32_t* __restrict__ num_bundles, float scale,
                                                           unsigned short* __restrict__ out,
-                                                          float* __restrict__ lse, bool blk) {
+                                                          float* __restrict__ lse, bool blk,
+                                                          const int32_t* __restrict__ bun_tok,
+                                                          const int4* __restrict__ pos_info) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Vs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short Os[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT];
+    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT], wlo[kMaxT], whi[kMaxT];
+    const AttnPlan P = {bun_start, win_start, win_tokens, tok_win, bun_tok, pos_info};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
@@ -358,7 +385,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
     for (int item = blockIdx.x; item < attn_items(NB, n_heads); item += gridDim.x) {
         int b, h;
         if (!attn_item(item, NB, n_heads, &b, &h)) continue;
-        const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
+        const BundleCtx B = bundle_setup(b, P, toks, wid, wlo, whi);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
         {
@@ -373,7 +400,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
         __syncthreads();
         for (int it = wave; it < nt; it += kAttnBlk / 64) {
             int jlo, jhi;
-            tile_range(B, it, wid, win_start, &jlo, &jhi);
+            tile_range(B, it, wlo, whi, &jlo, &jhi);
             // S^T tiles: A = K rows (keys), B = Q^T (queries): lane holds query i = it*16 + c,
             // keys j = jt*16 + 4*g + r
             const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
@@ -448,12 +475,15 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                                                           const int32_t* __restrict__ tok_win,
                                                           const int32_t* __restrict__ bun_start,
                                                           const int32_t* __restrict__ num_bundles, float scale,
-                                                          unsigned short* __restrict__ dqkv, bool blk) {
+                                                          unsigned short* __restrict__ dqkv, bool blk,
+                                                          const int32_t* __restrict__ bun_tok,
+                                                          const int4* __restrict__ pos_info) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
         dOs[kMaxT * kDh];
     __shared__ __attribute__((aligned(16))) unsigned short G1[kMaxT * kDh], G2[kMaxT * kDh];   // dQ, then dK / dV
     __shared__ __attribute__((aligned(16))) float Ls[kMaxT], Ds[kMaxT];
-    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT];
+    __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT], wlo[kMaxT], whi[kMaxT];
+    const AttnPlan P = {bun_start, win_start, win_tokens, tok_win, bun_tok, pos_info};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
@@ -462,7 +492,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         ATTN_STAMP(0);
         int b, h;
         if (!attn_item(item, NB, n_heads, &b, &h)) continue;
-        const BundleCtx B = bundle_setup(b, bun_start, win_start, win_tokens, tok_win, toks, wid);
+        const BundleCtx B = bundle_setup(b, P, toks, wid, wlo, whi);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         __syncthreads();
         ATTN_STAMP(1);
@@ -495,7 +525,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         // ---- pass 1: dQ.  S^T orientation: lane holds query i = it*16 + c, keys j = jt*16 + 4g + r
         for (int it = wave; it < nt; it += kAttnBlk / 64) {
             int jlo, jhi;
-            tile_range(B, it, wid, win_start, &jlo, &jhi);
+            tile_range(B, it, wlo, whi, &jlo, &jhi);
             const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
             const bf16x4 dob = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
             const float Li = Ls[it * 16 + c], Di = Ds[it * 16 + c];
@@ -530,7 +560,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
         for (int jt = wave; jt < nt; jt += kAttnBlk / 64) {
             int ilo, ihi;
-            tile_range(B, jt, wid, win_start, &ilo, &ihi);
+            tile_range(B, jt, wlo, whi, &ilo, &ihi);
             const bf16x4 kb = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
             const bf16x4 vb = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
             const int wk = wid[jt * 16 + c];
@@ -693,6 +723,8 @@ extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32
         j.coors = (const int4*)in.coors; j.n = in.num_tokens; j.slots = batch_size * sps; j.cap = j.g.wx * j.g.wy;
         j.win_start = in.win_start; j.win_tokens = in.win_tokens; j.tok_win = in.tok_win; j.tok_pos = in.tok_pos;
         j.num_windows = in.num_windows; j.bun_start = in.bun_start; j.num_bundles = in.num_bundles;
+        GEOMAE_REQUIRE((in.bun_tok == nullptr) == (in.pos_info == nullptr), "window_build: pass both attention-plan arrays or none");
+        j.bun_tok = in.bun_tok; j.pos_info = (int4*)in.pos_info;
         table_bytes += al((int64_t)j.slots * 4);
         need += al((int64_t)j.slots * 4) + al((int64_t)j.n * 4);
         if (j.n > max_n) max_n = j.n;
@@ -729,7 +761,7 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
                                    int32_t* num_windows, int32_t* bun_start, int32_t* num_bundles,
                                    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     GeomaeWindowBuildJob job = {coors, num_tokens, shift_index, win_start, win_tokens, tok_win, tok_pos,
-                                num_windows, bun_start, num_bundles};
+                                num_windows, bun_start, num_bundles, nullptr, nullptr};
     return geomae_window_build_batch(&job, 1, batch_size, cfg, workspace, workspace_bytes, stream);
 }
 
@@ -749,7 +781,8 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
                                                const int32_t* win_tokens, const int32_t* tok_win,
                                                const int32_t* bun_start, const int32_t* num_bundles,
                                                int32_t max_bundles, int32_t max_window_tokens, void* out_bf16,
-                                               float* lse, hipStream_t stream) {
+                                               float* lse, const int32_t* bun_tok, const int32_t* pos_info,
+                                               hipStream_t stream) {
     if (num_tokens <= 0 || max_bundles <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(qkv_bf16 && win_start && win_tokens && tok_win && bun_start && num_bundles && out_bf16 && lse,
                    "window_attention_forward: null argument");
@@ -758,7 +791,8 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
     const int grid = attn_grid(num_tokens, num_heads, max_bundles, max_window_tokens);
     hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
-                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse, (layer_layout() & 1) != 0);
+                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse, (layer_layout() & 1) != 0,
+                       pos_info ? bun_tok : nullptr, (const int4*)(bun_tok ? pos_info : nullptr));
     return check_launch("win_attn_fwd_kernel");
 }
 
@@ -768,7 +802,7 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
                                                 const int32_t* win_tokens, const int32_t* tok_win,
                                                 const int32_t* bun_start, const int32_t* num_bundles,
                                                 int32_t max_bundles, int32_t max_window_tokens, void* dqkv_bf16,
-                                                hipStream_t stream) {
+                                                const int32_t* bun_tok, const int32_t* pos_info, hipStream_t stream) {
     if (num_tokens <= 0 || max_bundles <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(qkv_bf16 && out_bf16 && dout_bf16 && lse && win_start && win_tokens && tok_win && bun_start &&
                    num_bundles && dqkv_bf16, "window_attention_backward: null argument");
@@ -778,7 +812,8 @@ extern "C" int geomae_window_attention_backward(const void* qkv_bf16, const void
     hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
                        (const unsigned short*)out_bf16, (const unsigned short*)dout_bf16, lse, num_heads, win_start,
                        win_tokens, tok_win, bun_start, num_bundles, 1.0f / sqrtf((float)head_dim),
-                       (unsigned short*)dqkv_bf16, (layer_layout() & 1) != 0);
+                       (unsigned short*)dqkv_bf16, (layer_layout() & 1) != 0, pos_info ? bun_tok : nullptr,
+                       (const int4*)(bun_tok ? pos_info : nullptr));
     return check_launch("win_attn_bwd_kernel");
 }
 

@@ -594,7 +594,7 @@ def make_window_config(window_shape, shift, bev_shape):
 class WindowLayout:
     """CSR grouping of tokens by window for one shift (replaces the flat2win index dictionaries)."""
     __slots__ = ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "max_windows", "n", "max_tokens",
-                 "bun_start", "num_bundles")
+                 "bun_start", "num_bundles", "bun_tok", "pos_info")
 
 
 def _new_window_layout(n, batch_size, wcfg, dev):
@@ -612,6 +612,7 @@ def _new_window_layout(n, batch_size, wcfg, dev):
     L.num_windows = torch.empty(1, dtype=torch.int32, device=dev)
     L.bun_start = torch.empty(L.max_windows + 1, dtype=torch.int32, device=dev)
     L.num_bundles = torch.empty(1, dtype=torch.int32, device=dev)
+    L.bun_tok = L.pos_info = None          # the attention plan: window_build_batch fills it
     return L
 
 
@@ -634,6 +635,9 @@ def window_build_batch(jobs, batch_size, wcfg):
         j.win_start, j.win_tokens, j.tok_win = L.win_start.data_ptr(), L.win_tokens.data_ptr(), L.tok_win.data_ptr()
         j.tok_pos, j.num_windows = L.tok_pos.data_ptr(), L.num_windows.data_ptr()
         j.bun_start, j.num_bundles = L.bun_start.data_ptr(), L.num_bundles.data_ptr()
+        L.bun_tok = torch.empty(L.max_windows + 1, dtype=torch.int32, device=coors.device)
+        L.pos_info = torch.empty((max(L.n, 1), 4), dtype=torch.int32, device=coors.device)
+        j.bun_tok, j.pos_info = L.bun_tok.data_ptr(), L.pos_info.data_ptr()
         ns[k] = L.n
     wsb = lib.geomae_window_build_batch_workspace_bytes(ns, len(jobs), batch_size, ctypes.byref(wcfg))
     if wsb < 0:
@@ -673,7 +677,7 @@ class _WindowAttention(torch.autograd.Function):
             check(_lib.load().geomae_window_attention_forward(
                 _ptr(qkv), n, num_heads, C // num_heads, _ptr(layout.win_start), _ptr(layout.win_tokens),
                 _ptr(layout.tok_win), _ptr(layout.bun_start), _ptr(layout.num_bundles), layout.max_windows,
-                layout.max_tokens, _ptr(out), _ptr(lse), _stream()),
+                layout.max_tokens, _ptr(out), _ptr(lse), _ptr(layout.bun_tok), _ptr(layout.pos_info), _stream()),
                 "geomae_window_attention_forward")
         ctx.layout, ctx.num_heads = layout, num_heads
         ctx.save_for_backward(qkv, out, lse)
@@ -690,7 +694,8 @@ class _WindowAttention(torch.autograd.Function):
             check(_lib.load().geomae_window_attention_backward(
                 _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), n, ctx.num_heads, c3 // 3 // ctx.num_heads,
                 _ptr(L.win_start), _ptr(L.win_tokens), _ptr(L.tok_win), _ptr(L.bun_start), _ptr(L.num_bundles),
-                L.max_windows, L.max_tokens, _ptr(dqkv), _stream()), "geomae_window_attention_backward")
+                L.max_windows, L.max_tokens, _ptr(dqkv), _ptr(L.bun_tok), _ptr(L.pos_info), _stream()),
+                "geomae_window_attention_backward")
         return dqkv, None, None
 
 
@@ -928,6 +933,8 @@ def _stack_layouts(layouts):
         a.win_start, a.win_tokens, a.tok_win = L.win_start.data_ptr(), L.win_tokens.data_ptr(), L.tok_win.data_ptr()
         a.tok_pos, a.bun_start, a.num_bundles = L.tok_pos.data_ptr(), L.bun_start.data_ptr(), L.num_bundles.data_ptr()
         a.max_bundles = L.max_windows
+        if L.bun_tok is not None and L.pos_info is not None:
+            a.bun_tok, a.pos_info = L.bun_tok.data_ptr(), L.pos_info.data_ptr()
     return arr
 
 

@@ -169,6 +169,10 @@ typedef struct GeomaeWindowBuildJob {
     const int32_t* coors;       /* [num_tokens, 4] (b, z, y, x) */
     int32_t num_tokens, shift_index;
     int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
+    /* optional "attention plan" (both or neither): bun_tok [min(n, slots) + 1] = position in win_tokens where each
+     * bundle starts, pos_info [n][4] = (token, window, window start, window end) per position.  The attention kernels
+     * then reach their operands through two dependent loads instead of five. */
+    int32_t *bun_tok, *pos_info;
 } GeomaeWindowBuildJob;
 int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens /*host [num_jobs]*/, int32_t num_jobs,
                                                   int32_t batch_size, const GeomaeWindowConfig* cfg);
@@ -186,13 +190,16 @@ int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, in
                                     const int32_t* win_tokens, const int32_t* tok_win,
                                     const int32_t* bun_start, const int32_t* num_bundles,
                                     int32_t max_bundles, int32_t max_window_tokens, void* out_bf16,
-                                    float* lse, geomaeStream_t stream);
+                                    float* lse, const int32_t* bun_tok /*or NULL*/,
+                                    const int32_t* pos_info /*or NULL: the build's attention plan*/,
+                                    geomaeStream_t stream);
 int geomae_window_attention_backward(const void* qkv_bf16, const void* out_bf16, const void* dout_bf16,
                                      const float* lse, int32_t num_tokens, int32_t num_heads,
                                      int32_t head_dim, const int32_t* win_start,
                                      const int32_t* win_tokens, const int32_t* tok_win,
                                      const int32_t* bun_start, const int32_t* num_bundles,
                                      int32_t max_bundles, int32_t max_window_tokens, void* dqkv_bf16,
+                                     const int32_t* bun_tok /*or NULL*/, const int32_t* pos_info /*or NULL*/,
                                      geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A19-A22 fused SST encoder layer
@@ -355,6 +362,7 @@ int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* b
 typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_build for one shift */
     const int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *bun_start, *num_bundles;
     int32_t max_bundles;
+    const int32_t *bun_tok, *pos_info;      /* the build's attention plan, or both NULL */
 } GeomaeSstStackLayout;
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);

@@ -281,6 +281,14 @@ def test_window_build_batch_equals_single(dev):
             assert torch.equal(L.win_start[:W + 1], R.win_start[:W + 1]) and torch.equal(L.bun_start[:NB + 1], R.bun_start[:NB + 1])
             for k in ("win_tokens", "tok_win", "tok_pos"):
                 assert torch.equal(getattr(L, k)[:n], getattr(R, k)[:n]), k
+            # the attention plan restates the CSR arrays per bundle / per position
+            ws = R.win_start[:W + 1].long()
+            assert torch.equal(L.bun_tok[:NB + 1].long(), ws[R.bun_start[:NB + 1].long()])
+            if n:
+                tok = R.win_tokens[:n].long()
+                w = R.tok_win[:n].long()[tok]
+                want = torch.stack([tok, w, ws[w], ws[w + 1]], dim=1).int()
+                assert torch.equal(L.pos_info[:n], want)
 
 
 def _ref_window_attention(qkv, win, nhead):

@@ -160,3 +160,20 @@ def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
     assert torch.equal(l1["loss"], l2["loss"])
     for a, b in zip(tr.flat.params, tr2.flat.params):
         assert torch.equal(a, b)
+
+
+def test_zero_arena_carves_aligned_zero_views():
+    """ops.ZeroArena: one zero-filled buffer handed out as typed, 256-byte aligned views (the accumulator buffers of a
+    training step); carving past the sized total is an error, not a silent overlap."""
+    from geomae_amd.ops import ZeroArena
+    specs = [((5, 3), torch.float32), ((7,), torch.float64), ((2, 128), torch.float32), ((6,), torch.int64)]
+    total = ZeroArena.nbytes(*specs)
+    assert total % 256 == 0 and total >= sum(torch.empty(s, dtype=d).numel() * torch.empty((), dtype=d).element_size() for s, d in specs)
+    arena = ZeroArena(total, "cpu")
+    views = [arena.take(s, d) for s, d in specs]
+    for v, (s, d) in zip(views, specs):
+        assert v.shape == torch.Size(s) and v.dtype == d and not v.any() and v.data_ptr() % 256 == arena.buf.data_ptr() % 256
+    views[0].fill_(1.0)                                   # views do not overlap
+    assert not views[1].any() and not views[2].any() and not views[3].any()
+    with pytest.raises(RuntimeError):
+        arena.take((1024,), torch.float32)
