@@ -172,16 +172,57 @@ __global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
         if (in_lds) nx[w] = lo; else nxt_ws[w] = lo;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int nb = 0, w = 0;
-        while (w < W) {
-            if (j.bun_tok) j.bun_tok[nb] = in_lds ? ws[w] : win_start[w];
-            bun_start[nb++] = w;
-            w = in_lds ? nx[w] : nxt_ws[w];
+    if (!in_lds) {                                       // huge window tables: the plain serial walk
+        if (threadIdx.x == 0) {
+            int nb = 0, w = 0;
+            while (w < W) {
+                if (j.bun_tok) j.bun_tok[nb] = win_start[w];
+                bun_start[nb++] = w;
+                w = nxt_ws[w];
+            }
+            bun_start[nb] = W;
+            if (j.bun_tok) j.bun_tok[nb] = j.n;
+            num_bundles[0] = nb;
         }
-        bun_start[nb] = W;
-        if (j.bun_tok) j.bun_tok[nb] = j.n;
-        num_bundles[0] = nb;
+        return;
+    }
+    // The walk 0 -> nx[0] -> nx[nx[0]] ... is one dependent LDS read per bundle (~300 at decoder size: most of this
+    // kernel's 27 us, on the chain that gates the encoder).  Four rounds of pointer doubling give the 16-hop map;
+    // one thread walks THAT (~20 reads) and records the anchors, then every anchor's thread fills its 16 bundles.
+    __shared__ int ja[8192 + 1];
+    __shared__ int jb[8192 + 1];
+    __shared__ int n_anchors;
+    if (threadIdx.x == 0) nx[W] = W;                      // sentinel: the walk stops at W
+    __syncthreads();
+    for (int w = threadIdx.x; w <= W; w += 1024) ja[w] = nx[nx[w]];          // 2 hops
+    __syncthreads();
+    for (int w = threadIdx.x; w <= W; w += 1024) jb[w] = ja[ja[w]];          // 4
+    __syncthreads();
+    for (int w = threadIdx.x; w <= W; w += 1024) ja[w] = jb[jb[w]];          // 8
+    __syncthreads();
+    for (int w = threadIdx.x; w <= W; w += 1024) jb[w] = ja[ja[w]];          // 16
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int na = 0, w = 0;
+        while (w < W) { ja[na++] = w; w = jb[w]; }        // ja is free again: it now holds the anchors
+        n_anchors = na;
+        if (na == 0) { bun_start[0] = W; if (j.bun_tok) j.bun_tok[0] = j.n; num_bundles[0] = 0; }
+    }
+    __syncthreads();
+    const int na = n_anchors;
+    for (int a = threadIdx.x; a < na; a += 1024) {
+        int w = ja[a], k = 0;
+        for (; k < 16 && w < W; ++k) {
+            bun_start[16 * a + k] = w;
+            if (j.bun_tok) j.bun_tok[16 * a + k] = ws[w];
+            w = nx[w];
+        }
+        if (a == na - 1) {                                // the last anchor's thread knows the bundle count
+            const int nb = 16 * a + k;
+            bun_start[nb] = W;
+            if (j.bun_tok) j.bun_tok[nb] = j.n;
+            num_bundles[0] = nb;
+        }
     }
 }
 

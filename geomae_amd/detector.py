@@ -181,8 +181,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             tgt_ready = side.record_event()
         ops.mark("step_start")
         # the VFE forward's own arena is one fill on the main stream: a cross-queue wait costs as much as the fill
-        zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V)), dev)
-        vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd)
+        prepared, self._prepared_points = self._prepared_points, None
+        zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V, prepared is not None)), dev)
+        vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd, prepared=prepared)
         ops.mark("vfe_fwd_done")
         main.wait_event(layouts_ready)
         if packed_ready is not None:
@@ -249,14 +250,20 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             voxels, coors, sub_med, sub_low = self.voxelize_all(points)
             seg = ops.pillar_segment(coors, len(points), self.grid_size)
             seg.start_readback()
+            # the weight-independent front of the fused VFE (pillar means, decorated features in pillar order) rides
+            # along: ~45 us of dependent small kernels that would otherwise open the step's critical path
+            prepared = self.voxel_encoder.prepare_points(voxels, seg) if getattr(self.voxel_encoder, "use_fused", True) \
+                and hasattr(self.voxel_encoder, "prepare_points") else None
             done = ps.record_event()
-        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done)
+        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared)
 
     def _stage1(self, points):
         """voxelize x3 + pillar segments: taken from `prefetch` when it ran for this batch."""
         pre, self._prefetched = getattr(self, "_prefetched", None), None
+        self._prepared_points = None
         if pre is not None and pre[0] is points:
             torch.cuda.current_stream().wait_event(pre[2])
+            self._prepared_points = pre[3] if len(pre) > 3 else None
             return pre[1]
         voxels, coors, sub_med, sub_low = self.voxelize_all(points)
         seg = ops.pillar_segment(coors, len(points), self.grid_size)

@@ -790,21 +790,34 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 
 
 # ------------------------------------------------------------------------------------ fused VFE
+def vfe_prepare_points(points, seg, voxel_size, center_offset, zeros=None):
+    """The weight-independent front of the fused VFE: pillar means and the decorated point features in pillar order
+    (-> (mean [cap,3], feat [N,16], pid [N])).  It needs only the points and their segments, not the pillar count on
+    the host, so a training loop can run it for the NEXT batch together with that batch's voxelization."""
+    lib = _lib.load()
+    dev, N = points.device, points.shape[0]
+    mean = segment_mean_xyz(points, seg, zeros)
+    feat = torch.empty((max(N, 1), 16), dtype=torch.float32, device=dev)
+    pid = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+    check(lib.geomae_vfe_prepare(_ptr(points), points.shape[1], N, _ptr(seg.order), _ptr(seg.inv), _ptr(mean),
+                                 _ptr(seg.voxel_coors), f3(voxel_size), f3(center_offset), _ptr(feat), _ptr(pid),
+                                 _stream()), "geomae_vfe_prepare")
+    return mean, feat, pid
+
+
 class VfePlan:
     """Per-batch state of the fused VFE sweeps: pillar mean, sorted point features, the argument struct."""
 
-    def __init__(self, points, seg, w0, w1, voxel_size, center_offset, zeros=None):
+    def __init__(self, points, seg, w0, w1, voxel_size, center_offset, zeros=None, prepared=None):
         from ._lib import GeomaeVfeArgs
-        lib = _lib.load()
         dev = points.device
         self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
-        self.mean = segment_mean_xyz(points, seg, zeros)
-        self.bn = torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)    # [layer][scale, shift, mean, invstd]
-        self.feat = torch.empty((max(self.N, 1), 16), dtype=torch.float32, device=dev)
-        self.pid = torch.empty(max(self.N, 1), dtype=torch.int32, device=dev)
-        check(lib.geomae_vfe_prepare(_ptr(points), points.shape[1], self.N, _ptr(seg.order), _ptr(seg.inv),
-                                     _ptr(self.mean), _ptr(seg.voxel_coors), f3(voxel_size), f3(center_offset),
-                                     _ptr(self.feat), _ptr(self.pid), _stream()), "geomae_vfe_prepare")
+        if prepared is None:
+            prepared = vfe_prepare_points(points, seg, voxel_size, center_offset, zeros)
+        self.mean, self.feat, self.pid = prepared
+        # [layer][scale, shift, mean, invstd]
+        self.bn = zeros.take((2, 4, 128), torch.float32) if zeros is not None else \
+            torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)
         a = GeomaeVfeArgs()
         a.feat_sorted, a.pid_sorted, a.seg_start = self.feat.data_ptr(), self.pid.data_ptr(), seg.seg_start.data_ptr()
         a.num_points, a.max_pillars = self.N, max(self.V, 1)
@@ -847,11 +860,13 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
         bn[2, :C].copy_(mom[:C])
 
 
-def vfe_forward_zero_specs(cap, V):
-    """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order."""
+def vfe_forward_zero_specs(cap, V, prepared=False):
+    """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order (prepared: the
+    pillar-mean workspace is not needed, vfe_prepare_points already ran)."""
     V1 = max(int(V), 1)
-    return [((max(int(cap), 1) * 3,), torch.int64), ((128,), torch.float64), ((V1, 64), torch.float32),
-            ((256,), torch.float64), ((V1, 128), torch.float32)]
+    front = [] if prepared else [((max(int(cap), 1) * 3,), torch.int64)]
+    return front + [((2, 4, 128), torch.float32), ((128,), torch.float64), ((V1, 64), torch.float32),
+                    ((256,), torch.float64), ((V1, 128), torch.float32)]
 
 
 def vfe_backward_zero_specs(V):

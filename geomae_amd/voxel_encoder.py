@@ -112,15 +112,22 @@ class DynamicScatterVFE(nn.Module):
 
     # ---- explicit (autograd-free) schedule of the fused path: detector.train_step_explicit
     @torch.no_grad()
-    def forward_explicit(self, features, seg, zeros=None):
-        """zeros: optional ops.ZeroArena sized by ops.vfe_forward_zero_specs(seg.cap, seg.V): the sweeps' accumulator
-        buffers come out of it and the library skips its own memsets."""
+    def prepare_points(self, features, seg):
+        """Weight-independent front of the fused path (pillar means, decorated features in pillar order): may run
+        ahead of time, e.g. with the next batch's voxelization (detector.prefetch)."""
+        return ops.vfe_prepare_points(features, seg, (self.vx, self.vy, self.vz), (self.x_offset, self.y_offset, self.z_offset))
+
+    @torch.no_grad()
+    def forward_explicit(self, features, seg, zeros=None, prepared=None):
+        """zeros: optional ops.ZeroArena sized by ops.vfe_forward_zero_specs(seg.cap, seg.V, prepared is not None): the
+        sweeps' accumulator buffers come out of it and the library skips its own memsets.  prepared: result of
+        prepare_points for this batch."""
         l0, l1 = self.vfe_layers
         world = _vfe_world(self)
         import contextlib
         with (ops.prezeroed() if zeros is not None else contextlib.nullcontext()):
             plan = ops.VfePlan(features, seg, l0.linear.weight, l1.linear.weight, (self.vx, self.vy, self.vz),
-                               (self.x_offset, self.y_offset, self.z_offset), zeros=zeros)
+                               (self.x_offset, self.y_offset, self.z_offset), zeros=zeros, prepared=prepared)
             vf, m0 = ops.vfe_forward(plan, l0.norm, l1.norm, world, zeros=zeros)
         return vf, (plan, m0, vf, world)
 
