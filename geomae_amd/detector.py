@@ -158,6 +158,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             ops.mark("side:coors")
             layouts = self.backbone.build_layouts(coors_all[:ik.numel()], None, batch_size, coors_all=coors_all)
             ops.mark("side:layouts")
+            if packed_ready is not None:
+                side.wait_event(packed_ready)                # one event for the main stream: each wait costs ~10 us there
             layouts_ready = side.record_event()
             # buffers the main stream would otherwise allocate-and-fill between kernels of the critical path
             n_keep, n_mask = int(ik.numel()), int(im.numel())
@@ -186,10 +188,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd, prepared=prepared)
         ops.mark("vfe_fwd_done")
         main.wait_event(layouts_ready)
-        if packed_ready is not None:
-            main.wait_event(packed_ready)                    # packed on another stream, long before this point
         if not self.TARGETS_LATE:
             main.wait_event(tgt_ready)
+        ops.mark("layouts_awaited")
         ik = ik_l
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
@@ -255,14 +256,17 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             prepared = self.voxel_encoder.prepare_points(voxels, seg) if getattr(self.voxel_encoder, "use_fused", True) \
                 and hasattr(self.voxel_encoder, "prepare_points") else None
             done = ps.record_event()
-        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared)
+        # stream given = the explicit schedule's geometry stream: the main stream waits on a LATER event of that stream
+        # (the targets' tgt_ready) in the same step, so the consumer of this batch needs no wait of its own
+        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared, stream is not None)
 
     def _stage1(self, points):
         """voxelize x3 + pillar segments: taken from `prefetch` when it ran for this batch."""
         pre, self._prefetched = getattr(self, "_prefetched", None), None
         self._prepared_points = None
         if pre is not None and pre[0] is points:
-            torch.cuda.current_stream().wait_event(pre[2])
+            if not (len(pre) > 4 and pre[4]):                # (on the geometry stream: ordered by its later events, see prefetch)
+                torch.cuda.current_stream().wait_event(pre[2])
             self._prepared_points = pre[3] if len(pre) > 3 else None
             return pre[1]
         voxels, coors, sub_med, sub_low = self.voxelize_all(points)

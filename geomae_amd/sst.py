@@ -528,12 +528,13 @@ class MultiMAESSTSPChoose(nn.Module):
         if self._streams is None:
             st = ops.side_streams()
             self._streams = (st["dec_a"], st["dec_b"])
-        sa_, sb_ = self._streams
-        sa_.wait_stream(cur)
+        # The two decoder stacks run concurrently: one on a side stream, the other on the current stream itself.  A
+        # cross-queue wait costs ~10 us of queue time even when its event has long fired (tools/phase_events.py), so
+        # the fork / join is one wait on each side instead of two.
+        _, sb_ = self._streams
         sb_.wait_stream(cur)
-        cen, s_cen = ops.sst_stack_forward(tokens, w_cen, dec_layouts, pt, nh, stream=sa_)
         den, s_den = ops.sst_stack_forward(tokens, w_den, dec_layouts, pt, nh, stream=sb_)
-        cur.wait_stream(sa_)
+        cen, s_cen = ops.sst_stack_forward(tokens, w_cen, dec_layouts, pt, nh)
         cur.wait_stream(sb_)
         if tgt_ready is not None:
             cur.wait_event(tgt_ready)
@@ -545,15 +546,13 @@ class MultiMAESSTSPChoose(nn.Module):
         g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
         n = tokens.shape[0]
         ops.mark("heads_done")
-        sa_.wait_stream(cur)
         sb_.wait_stream(cur)
-        dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, stream=sa_)
         dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
-        cur.wait_stream(sa_)
+        dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen)
         cur.wait_stream(sb_)
         ops.mark("dec_bwd_done")
         d_tok = dxa.add_(dxb)
-        del keep_a, keep_b
+        del keep_b
         if self.mask_token.grad is None:
             self.mask_token.grad = torch.zeros_like(self.mask_token)
         side = bufs["side"] if (bufs is not None and on_early_grads is None) else None
