@@ -101,7 +101,10 @@ struct Timed {
 
 // stack input: row-major [n,128] fp32 -> tile-blocked (pad rows of the last tile zero-filled).  One thread per
 // 16-byte piece, blocked address order: the writes are fully contiguous, the reads 64-byte row pieces.
-__global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* __restrict__ src, int n,
+// Rows [n_src, n) (if any) are copies of `fill_row` [128]: the decoder stacks' input is the encoder output followed
+// by one learned mask token per masked pillar (bb.py:239-246 repeat + cat), which is never materialised row-major.
+__global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* __restrict__ src, int n_src, int n,
+                                                                  const float* __restrict__ fill_row,
                                                                   float* __restrict__ dst) {
     const int64_t pieces = (int64_t)((n + 15) / 16) * 16 * 32;              // 32 float4 per row
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * 256) {
@@ -109,7 +112,8 @@ __global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* _
         const int64_t tile = q >> 9;
         const int64_t tok = tile * 16 + t;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tok < n) v = *reinterpret_cast<const float4*>(src + tok * 128 + 16 * cb + 4 * c4);
+        if (tok < n_src) v = *reinterpret_cast<const float4*>(src + tok * 128 + 16 * cb + 4 * c4);
+        else if (tok < n) v = *reinterpret_cast<const float4*>(fill_row + 16 * cb + 4 * c4);
         reinterpret_cast<float4*>(dst)[q] = v;
     }
 }
@@ -160,11 +164,14 @@ static int check_stack(const GeomaeSstLayerWeights* layers, int n_layers, const 
 extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                                         int32_t num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table,
                                         int32_t num_heads, int32_t max_window_tokens, void* saved, int64_t saved_bytes,
-                                        float* z_out, void* profiler, hipStream_t stream) {
+                                        float* z_out, int32_t num_input_rows, const float* fill_row, void* profiler,
+                                        hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_forward");
     if (rc) return rc;
     GEOMAE_REQUIRE(x_in && pos_table && saved && z_out, "sst_stack_forward: null argument");
+    if (!fill_row) num_input_rows = num_tokens;
+    GEOMAE_REQUIRE(num_input_rows >= 0 && num_input_rows <= num_tokens, "sst_stack_forward: num_input_rows out of range");
     const SavedOffsets so = saved_offsets(num_tokens, num_heads);
     if (saved_bytes < so.stride * num_layers) {
         set_error("sst_stack_forward: saved buffer %lld < %lld bytes", (long long)saved_bytes, (long long)(so.stride * num_layers));
@@ -172,7 +179,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     }
     char* base = (char*)saved;
     hipLaunchKernelGGL(rows_to_blocked_f32_kernel, dim3(stream_grid((int64_t)cdiv(num_tokens, 16) * 512, 256)), dim3(256), 0,
-                       stream, x_in, num_tokens, (float*)(base + so.x));
+                       stream, x_in, num_input_rows, num_tokens, fill_row, (float*)(base + so.x));
     if ((rc = check_launch("rows_to_blocked_f32_kernel"))) return rc;
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
     for (int l = 0; l < num_layers; ++l) {

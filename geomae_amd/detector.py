@@ -132,8 +132,6 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         self._loss_vector = losses                   # Trainer sums this once instead of adding six scalars
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
-    TARGETS_LATE = True
-
     @torch.no_grad()
     def train_step_explicit(self, points, on_early_grads=None, next_points=None):
         """forward_train_fused + backward as an explicit schedule: no autograd tape or engine.  Accumulates every
@@ -143,60 +141,64 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         voxels, coors, sub_med, sub_low, seg = self._stage1(points)
         V = seg.V
         main = torch.cuda.current_stream()
-        side = ops.side_streams()["geo"]
+        streams = ops.side_streams()
+        side, aux = streams["geo"], streams["dec_b"]
         side.wait_stream(main)
+        aux.wait_stream(main)
         dev = voxels.device
+        C = self.backbone.mask_token.shape[1]
+        f32 = torch.float32
+        # Everything that depends only on the points and the pillar coordinates runs beside the VFE forward, on two
+        # streams, arranged so that the main stream waits for other queues as rarely as possible (a cross-queue wait
+        # costs ~15 us of queue time even when its event fired long ago, tools/phase_events.py):
+        #   geometry stream : random mask -> token coordinates -> the four window layouts.  ONE event (layouts_ready) gates the encoder; the weights packed ahead
+        #                     by the trainer are chained into it.
+        #   decoder-B stream: idle until the decoders fork, so it first takes the step's zero arena, the NEXT batch's
+        #                     stage 1 (voxelize / pillar sort / count readback / VFE front) and the geometric targets.
+        #                     The main stream joins it after the decoder forward anyway: no wait of its own for any of
+        #                     them (the targets are first read by the heads+loss kernel).
         with torch.cuda.stream(side):
-            # side-stream order = order of need: packed weights (normally already packed by the trainer) and window
-            # layouts (encoder forward), the zero arena of everything after the VFE forward, then the targets (first read by the heads+loss
-            # kernel, a whole forward later: they finish under the encoder, whose launches fill 105 of 256 CUs)
             ops.mark("side:start")
             packed_ready = self.backbone._packed.refresh_if_stale()   # a no-op when the trainer packed after its optimizer step
             ik, im, token_row, counts = self.get_vanilla_mask_index(seg)
+            mask_done = side.record_event()
             ops.mark("side:mask")
+            n_keep, n_mask = int(ik.numel()), int(im.numel())
+            n = n_keep + n_mask
             coors_all, ik_l = ops.gather_token_coors(ik, im, seg.voxel_coors)
             ops.mark("side:coors")
-            layouts = self.backbone.build_layouts(coors_all[:ik.numel()], None, batch_size, coors_all=coors_all)
+            layouts = self.backbone.build_layouts(coors_all[:n_keep], None, batch_size, coors_all=coors_all)
             ops.mark("side:layouts")
             if packed_ready is not None:
-                side.wait_event(packed_ready)                # one event for the main stream: each wait costs ~10 us there
+                side.wait_event(packed_ready)
             layouts_ready = side.record_event()
-            # buffers the main stream would otherwise allocate-and-fill between kernels of the critical path
-            n_keep, n_mask = int(ik.numel()), int(im.numel())
-            C = self.backbone.mask_token.shape[1]
-            n = n_keep + n_mask
-            tokens = torch.empty((n, C), dtype=torch.float32, device=dev)
-            tokens[n_keep:] = self.backbone.mask_token.detach()
-            f32 = torch.float32
-            late = [((n, C), f32), ((n, C), f32), ((V, C), f32), ((6,), f32)] + ops.vfe_backward_zero_specs(V)
-            zeros_late = ops.ZeroArena(ops.ZeroArena.nbytes(*late), dev)
-            bufs = dict(tokens=tokens, d_cen=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
-                        d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
-            bufs["ready"] = side.record_event()
-        if next_points is not None:
-            # the following batch's voxelize / pillar sort / count readback: ahead of the targets (nobody reads those
-            # before the heads), so that the host may start enqueueing the next step ~0.25 ms into this one
-            self.prefetch(next_points, stream=side)
-        with torch.cuda.stream(side):
-            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=int(im.numel()))
-            ops.mark("side:targets")
-            tgt_ready = side.record_event()
         ops.mark("step_start")
         # the VFE forward's own arena is one fill on the main stream: a cross-queue wait costs as much as the fill
         prepared, self._prepared_points = self._prepared_points, None
         zeros_fwd = ops.ZeroArena(ops.ZeroArena.nbytes(*ops.vfe_forward_zero_specs(seg.cap, V, prepared is not None)), dev)
         vf, vfe_state = self.voxel_encoder.forward_explicit(voxels, seg, zeros=zeros_fwd, prepared=prepared)
         ops.mark("vfe_fwd_done")
+        vfe_done = main.record_event()
+        with torch.cuda.stream(aux):
+            # behind the VFE forward: its sweeps fill the chip, the encoder that follows leaves 150 of 256 CUs idle
+            aux.wait_event(vfe_done)
+            late = [((n, C), f32), ((n, C), f32), ((V, C), f32), ((6,), f32)] + ops.vfe_backward_zero_specs(V)
+            zeros_late = ops.ZeroArena(ops.ZeroArena.nbytes(*late), dev)
+            bufs = dict(d_cen=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
+                        d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
+        if next_points is not None:
+            self.prefetch(next_points, stream=aux)
+        with torch.cuda.stream(aux):
+            aux.wait_event(mask_done)
+            tgt = ops.geometry_targets(voxels, seg, sub_med, sub_low, self._tcfg, token_row, counts, n_rows=n_mask)
+            ops.mark("side:targets")
         main.wait_event(layouts_ready)
-        if not self.TARGETS_LATE:
-            main.wait_event(tgt_ready)
         ops.mark("layouts_awaited")
         ik = ik_l
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
-        losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], int(im.numel()), batch_size, tgt, w, layouts,
-                                                                 on_early_grads, packed_fresh=True, tgt_ready=tgt_ready,
-                                                                 bufs=bufs)
+        losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], n_mask, batch_size, tgt, w, layouts,
+                                                                 on_early_grads, packed_fresh=True, bufs=bufs)
         d_vf = bufs["d_vf"]
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
         self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late)
@@ -235,9 +237,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         step k (Trainer.train_step(next_points=...)): when step k+1 starts the counts are already on the host,
         so the iteration's one device->host readback no longer drains the queue (the GPU idled ~0.3 ms per
         step behind it, profiles/r01q_step_timeline.txt).
-        stream: enqueue there without further ordering (the explicit schedule appends it to the geometry side stream
-        once that stream's work for the current step is enqueued: it idles for the rest of the step, and a fifth
-        stream would share a hardware queue with another one)."""
+        stream: enqueue there without further ordering (the explicit schedule puts it on the decoder-B stream, which
+        idles until the decoders fork; a fifth stream would share a hardware queue with another one)."""
         main = torch.cuda.current_stream()
         if stream is not None:
             ps = stream
@@ -256,8 +257,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             prepared = self.voxel_encoder.prepare_points(voxels, seg) if getattr(self.voxel_encoder, "use_fused", True) \
                 and hasattr(self.voxel_encoder, "prepare_points") else None
             done = ps.record_event()
-        # stream given = the explicit schedule's geometry stream: the main stream waits on a LATER event of that stream
-        # (the targets' tgt_ready) in the same step, so the consumer of this batch needs no wait of its own
+        # stream given = the explicit schedule's decoder-B stream: the main stream joins that stream later in the same
+        # step (after the decoder forward), so the consumer of this batch needs no wait of its own
         self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared, stream is not None)
 
     def _stage1(self, points):

@@ -957,24 +957,33 @@ def _stream_of(stream):
     return _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
 
-def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None):
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None, tail=None):
     """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8).
     Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current).
-    out: optional preallocated contiguous [n,128] f32 destination of z (e.g. the head rows of a larger buffer)."""
+    out: optional preallocated contiguous [n,128] f32 destination of z.
+    tail = (fill_row [1,128] or [128] f32, count): the stack's input is x followed by `count` copies of fill_row (the
+    decoders' mask tokens), without materialising them; n = x.shape[0] + count."""
     lib = _lib.load()
     _check_input(x, "x", torch.float32)
-    n, nl = x.shape[0], len(weights)
+    n_in, nl = x.shape[0], len(weights)
+    fill, n = None, n_in
+    if tail is not None:
+        fill, extra = tail
+        _check_input(fill, "fill_row", torch.float32)
+        if fill.numel() != x.shape[1]:
+            raise RuntimeError("sst_stack_forward: fill_row must have one row of x's width")
+        n = n_in + int(extra)
     sb = lib.geomae_sst_stack_saved_bytes(n, nl, num_heads)
     saved = torch.empty(max(sb, 1), dtype=torch.uint8, device=x.device)
     if out is None:
-        z = torch.empty_like(x)
+        z = torch.empty((n, x.shape[1]), dtype=torch.float32, device=x.device)
     else:
         _check_input(out, "out", torch.float32)
-        if out.shape != x.shape:
-            raise RuntimeError("sst_stack_forward: out must have the shape of x")
+        if out.shape != (n, x.shape[1]):
+            raise RuntimeError("sst_stack_forward: out must be [n, width of x]")
         z = out
     check(lib.geomae_sst_stack_forward(_ptr(x), n, weights, nl, _stack_layouts(layouts), _ptr(pos_table), num_heads,
-                                       layouts[0].max_tokens, _ptr(saved), sb, _ptr(z),
+                                       layouts[0].max_tokens, _ptr(saved), sb, _ptr(z), n_in, _ptr(fill),
                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
           "geomae_sst_stack_forward")
     return z, saved

@@ -499,9 +499,8 @@ class MultiMAESSTSPChoose(nn.Module):
         (everything except the encoder), so that the caller can start exchanging them.
         packed_fresh: the caller already re-packed the bf16 weights for this step (on another stream, ordered before
         this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream).
-        bufs: optional dict prepared off the critical path by the caller (detector.train_step_explicit):
-        "tokens" [n_keep + n_mask, 128] with the mask token already in rows n_keep.., zeroed "d_cen" / "d_den" of the
-        same shape, optionally "ready" (event after which they may be used; omitted when the caller's stream is already
+        bufs: optional dict prepared off the critical path by the caller (detector.train_step_explicit): zeroed
+        "d_cen" / "d_den" [n_keep + n_mask, 128], "losses" [6], optionally "ready" (event after which they may be used; omitted when the caller's stream is already
         ordered behind their preparation) and "side" (the stream for work nobody waits on
         until the optimizer: the mask-token gradient reduction)."""
         assert self.fused and self.cls_sub_voxel and self.top and not self.low and not self.med
@@ -514,14 +513,14 @@ class MultiMAESSTSPChoose(nn.Module):
         w_enc = P.weight_array(self._stack_base["enc"], n_enc)
         w_cen, w_den = P.weight_array(self._stack_base["cen"], n_dec), P.weight_array(self._stack_base["den"], n_dec)
         cur = torch.cuda.current_stream()
+        # the decoders' input = encoder output followed by n_mask copies of the mask token: the stacks take that as
+        # (rows, tail) and never materialise the concatenation (bb.py:239-246)
+        z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
+        dec_tail = (self.mask_token.detach(), n_mask)
         if bufs is None:
-            z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
-            tokens = torch.cat([z_enc, self.mask_token.detach().expand(n_mask, -1)], dim=0)
             d_out = losses_buf = None
-        else:                       # the encoder writes straight into the decoder input: no concatenation copy
-            tokens, d_out = bufs["tokens"], (bufs["d_cen"], bufs["d_den"])
-            losses_buf = bufs.get("losses")
-            _, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh, out=tokens[:n_keep])
+        else:
+            d_out, losses_buf = (bufs["d_cen"], bufs["d_den"]), bufs.get("losses")
             if bufs.get("ready") is not None:
                 cur.wait_event(bufs["ready"])
         ops.mark("enc_fwd_done")
@@ -533,8 +532,8 @@ class MultiMAESSTSPChoose(nn.Module):
         # the fork / join is one wait on each side instead of two.
         _, sb_ = self._streams
         sb_.wait_stream(cur)
-        den, s_den = ops.sst_stack_forward(tokens, w_den, dec_layouts, pt, nh, stream=sb_)
-        cen, s_cen = ops.sst_stack_forward(tokens, w_cen, dec_layouts, pt, nh)
+        den, s_den = ops.sst_stack_forward(z_enc, w_den, dec_layouts, pt, nh, stream=sb_, tail=dec_tail)
+        cen, s_cen = ops.sst_stack_forward(z_enc, w_cen, dec_layouts, pt, nh, tail=dec_tail)
         cur.wait_stream(sb_)
         if tgt_ready is not None:
             cur.wait_event(tgt_ready)
@@ -544,7 +543,7 @@ class MultiMAESSTSPChoose(nn.Module):
         # ---------------- backward
         ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
         g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
-        n = tokens.shape[0]
+        n = n_keep + n_mask
         ops.mark("heads_done")
         sb_.wait_stream(cur)
         dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)

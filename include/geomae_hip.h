@@ -366,10 +366,13 @@ typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_b
 } GeomaeSstStackLayout;
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
+/* x_in holds num_input_rows rows; the remaining num_tokens - num_input_rows input rows are copies of fill_row [128]
+ * (the decoders' mask token, bb.py:239-246).  fill_row == NULL: x_in holds all num_tokens rows. */
 int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                              int32_t num_layers, const GeomaeSstStackLayout* layouts /*[2]*/,
                              const float* pos_table, int32_t num_heads, int32_t max_window_tokens, void* saved,
-                             int64_t saved_bytes, float* z_out, void* profiler /*or NULL*/, geomaeStream_t stream);
+                             int64_t saved_bytes, float* z_out, int32_t num_input_rows, const float* fill_row /*or NULL*/,
+                             void* profiler /*or NULL*/, geomaeStream_t stream);
 int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                               const GeomaeSstLayerGrads* grads, int32_t num_layers,
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
