@@ -229,19 +229,19 @@ _SIDE_STREAMS = {}
 
 
 def side_streams(device=None):
-    """The step's side streams {"geo", "dec_a", "dec_b"} (+ "prefetch" on first request), one set per device.
+    """The step's side streams {"geo", "dec_b"}, one set per device (+ "dec_a" / "prefetch" on request: extra_stream).
 
     ROCm multiplexes HIP streams onto a few hardware queues (4 by default) in the order in which the streams are
-    FIRST USED, so a fifth stream shares a queue with an earlier one.  Main + these three fill the four queues; they
-    are created and touched here in a fixed order.  The explicit training schedule needs no more (the next batch's
-    voxelization rides at the tail of "geo"); the autograd path's `prefetch` stream is created after them and then
-    shares the main stream's queue, the harmless pairing.  With lazy creation the order once was prefetch, geo, dec_a,
-    dec_b and the second decoder stack shared the main stream's queue: 3.83 instead of 3.31 ms/step."""
+    FIRST USED, so a fifth stream shares a queue with an earlier one -- with lazy creation the order once was prefetch,
+    geo, dec_a, dec_b, the second decoder stack shared the main stream's queue and a step took 3.83 instead of 3.31 ms.
+    The explicit training schedule therefore uses main + these TWO (created and touched here in a fixed order), which
+    leaves the fourth queue to the communication stream of torch.distributed's NCCL (= RCCL) backend whichever of them
+    is created first.  The autograd path's second decoder stream and its prefetch stream come after them."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
         st = {}
-        for name in ("geo", "dec_a", "dec_b"):
+        for name in ("geo", "dec_b"):
             st[name] = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st[name]):
                 torch.zeros(1, device=dev)                     # first use = queue assignment
@@ -250,11 +250,16 @@ def side_streams(device=None):
     return _SIDE_STREAMS[key]
 
 
-def prefetch_stream(device=None):
+def extra_stream(name, device=None):
+    """A further stream of the set ("dec_a", "prefetch"), created on first request (after the fixed ones)."""
     st = side_streams(device)
-    if "prefetch" not in st:
-        st["prefetch"] = torch.cuda.Stream(device=st["geo"].device)
-    return st["prefetch"]
+    if name not in st:
+        st[name] = torch.cuda.Stream(device=st["geo"].device)
+    return st[name]
+
+
+def prefetch_stream(device=None):
+    return extra_stream("prefetch", device)
 
 
 class PillarSegments:

@@ -525,8 +525,7 @@ class MultiMAESSTSPChoose(nn.Module):
                 cur.wait_event(bufs["ready"])
         ops.mark("enc_fwd_done")
         if self._streams is None:
-            st = ops.side_streams()
-            self._streams = (st["dec_a"], st["dec_b"])
+            self._streams = (None, ops.side_streams()["dec_b"])
         # The two decoder stacks run concurrently: one on a side stream, the other on the current stream itself.  A
         # cross-queue wait costs ~10 us of queue time even when its event has long fired (tools/phase_events.py), so
         # the fork / join is one wait on each side instead of two.
@@ -578,9 +577,8 @@ class MultiMAESSTSPChoose(nn.Module):
         if layouts is None:
             layouts, pos = self.get_voxel_info(torch.cat([coors, coors_mask], dim=0), batch_size)
         if self.fused and self.concurrent_decoders:
-            if self._streams is None:
-                st = ops.side_streams()
-                self._streams = (st["dec_a"], st["dec_b"])
+            if self._streams is None or self._streams[0] is None:
+                self._streams = (ops.extra_stream("dec_a"), ops.side_streams()["dec_b"])
             cen, den = _FusedDecoderPair.apply(tokens, self._packed, self._stack_base["cen"], self._stack_base["den"],
                                                2 * len(self.decoder_centroid_blocks), layouts, self.pos_table,
                                                self.nhead[0], self._streams)

@@ -305,10 +305,10 @@ class Trainer:
             packed = getattr(getattr(self.model, "backbone", None), "_packed", None)
             if explicit and packed is not None:
                 # bf16 MFMA-layout copies of the updated weights for the next step, off its critical path
-                # (on a decoder stream: idle until the next step's decoders, while the geometry stream's chain of
-                # mask -> window layouts gates the next encoder and should start the moment the step does)
+                # (on the decoder-B stream: idle until the next step's VFE forward is done, while the geometry stream's
+                # chain of mask -> window layouts gates the next encoder and should start the moment the step does)
                 from . import ops
-                main, side = torch.cuda.current_stream(), ops.side_streams()["dec_a"]
+                main, side = torch.cuda.current_stream(), ops.side_streams()["dec_b"]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     packed.prepack()
