@@ -540,7 +540,17 @@ class MultiMAESSTSPChoose(nn.Module):
         losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights,
                                                        d_out=d_out, losses=losses_buf)
         # ---------------- backward
-        ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
+        side = bufs["side"] if (bufs is not None and on_early_grads is None) else None
+        if side is None:
+            ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
+        else:
+            # the heads' weight-gradient contraction feeds nothing but the optimizer: off the main stream, beside the
+            # decoder backward (the stream is joined before the optimizer for the mask-token gradient anyway)
+            side.wait_stream(cur)
+            for t in saved_h:
+                t.record_stream(side)
+            with torch.cuda.stream(side):
+                ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
         g_cen, g_den = P.grad_array(self._stack_base["cen"], n_dec), P.grad_array(self._stack_base["den"], n_dec)
         n = n_keep + n_mask
         ops.mark("heads_done")
@@ -553,7 +563,6 @@ class MultiMAESSTSPChoose(nn.Module):
         del keep_b
         if self.mask_token.grad is None:
             self.mask_token.grad = torch.zeros_like(self.mask_token)
-        side = bufs["side"] if (bufs is not None and on_early_grads is None) else None
         if side is None:
             self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
         else:                       # nobody reads the mask-token gradient before the optimizer: reduce it off the main stream
