@@ -67,6 +67,7 @@ def main():
     share = os.environ.get("GEOMAE_BENCH_SHARE_GPU") == "1"
     if share:
         local_rank = 0
+        os.environ.setdefault("GEOMAE_SIDE_STREAMS", "3")      # see geomae_amd.ops.side_streams
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:

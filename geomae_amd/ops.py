@@ -241,7 +241,12 @@ def side_streams(device=None):
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
         st = {}
-        for name in ("geo", "dec_b"):
+        import os
+        # GEOMAE_SIDE_STREAMS=3: also create "dec_a" up front, so that a communication backend's streams wrap onto the
+        # main stream's queue.  Only for the test hook that runs several ranks on ONE GPU with gloo (bench.py
+        # GEOMAE_BENCH_SHARE_GPU, tests/test_gpu_multirank.py): two processes then own 8 queues on one device, and
+        # gloo's copy stream alone on the fourth queue of each waited ~100 ms per collective for a time slice.
+        for name in (("geo", "dec_a", "dec_b") if os.environ.get("GEOMAE_SIDE_STREAMS") == "3" else ("geo", "dec_b")):
             st[name] = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(st[name]):
                 torch.zeros(1, device=dev)                     # first use = queue assignment

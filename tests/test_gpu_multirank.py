@@ -25,6 +25,7 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("GEOMAE_SIDE_STREAMS", "3")          # two ranks on one GPU: see geomae_amd.ops.side_streams
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
