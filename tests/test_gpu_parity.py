@@ -775,6 +775,30 @@ def test_fused_layer_matches_composed_layer(dev):
     bad = {k: rel(pgrads[0][k], pgrads[1][k]) for k in pgrads[0] if rel(pgrads[0][k], pgrads[1][k]) > 4e-2}
     assert not bad, bad
 
+def test_stack_forward_tail_rows_equal_concatenated_input(dev):
+    """geomae_sst_stack_forward(x, tail = (fill_row, M)) == the same stack on cat([x, fill_row.repeat(M, 1)]): the
+    decoders' input (encoder output + one mask token per masked pillar, bb.py:239-246) is never materialised.
+    Same kernels on the same values: bit-identical."""
+    from geomae_amd import ops
+    model, _ = _build(dev, 1, 2, "bf16")
+    bb = model.backbone
+    frames = [synth.lidar_frame(31), synth.lidar_frame(32, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    n_in = n - n // 3 - 5                                   # ragged: the boundary falls inside a 16-token tile
+    x = torch.randn(n_in, 128, generator=torch.Generator().manual_seed(3)).to(dev)
+    fill = torch.randn(1, 128, generator=torch.Generator().manual_seed(4)).to(dev)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, 2)
+    nl = 2 * len(bb.decoder_centroid_blocks)
+    w = bb._packed.weight_array(bb._stack_base["cen"], nl)
+    za, _ = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0], tail=(fill, n - n_in))
+    zb, _ = ops.sst_stack_forward(torch.cat([x, fill.expand(n - n_in, -1)], dim=0).contiguous(), w, layouts, bb.pos_table,
+                                  bb.nhead[0])
+    assert za.shape == (n, 128) and torch.equal(za, zb)
+
+
 
 def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
     """forward_train (fused heads+loss kernel) vs extract_feat + forward_loss on the same model / mask:
