@@ -107,7 +107,7 @@ SIGNATURES = {
     "geomae_recover_bev_backward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P]),
     "geomae_grad_sumsq": (ctypes.c_int, [P, c_int64, P, P]),
     "geomae_adamw_step": (ctypes.c_int, [P, P, P, P, c_int64, c_int64, c_float, c_float, c_float, c_float, c_float,
-                                         c_int64, c_float, P, c_float, c_int32, P, P]),
+                                         c_int64, c_float, P, c_float, c_int32, P, c_int64, c_int64, P, P]),
     "geomae_bn_finalize": (ctypes.c_int, [P, c_double, P, c_int32, P, P, c_float, c_float, c_int32, P, P, P, P, P, P, P, P]),
     "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),
     "geomae_vfe_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),

@@ -53,6 +53,8 @@ struct AdamwArgs {
     float b2, one_minus_b2;
     float bc2_sqrt, eps, step_size;
     float max_norm, grad_scale;
+    int64_t nd2_start, nd2_end;  // a second no-decay range [start, end) (flat buffers made of two segments), or empty
+    double* zero_after;      // optional accumulator word to clear for the NEXT step (not read by this launch)
     const double* sumsq;     // of grad * grad_scale is sumsq * grad_scale^2
     float* gnorm_out;
     int zero_grad;
@@ -81,15 +83,17 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
             coef *= c < 1.0f ? c : 1.0f;
         }
     }
+    if (a.zero_after && blockIdx.x == 0 && threadIdx.x == 0) *a.zero_after = 0.0;
+    auto decays = [&](int64_t e) { return e >= a.n_no_decay && !(e >= a.nd2_start && e < a.nd2_end); };
     const int64_t n4 = a.n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
         float4 p = reinterpret_cast<float4*>(a.p)[i], m = reinterpret_cast<float4*>(a.m)[i], v = reinterpret_cast<float4*>(a.v)[i];
         const float4 g = reinterpret_cast<const float4*>(a.g)[i];
         const int64_t e = i << 2;
-        adamw_one(p.x, g.x, m.x, v.x, e + 0 >= a.n_no_decay, a, coef);
-        adamw_one(p.y, g.y, m.y, v.y, e + 1 >= a.n_no_decay, a, coef);
-        adamw_one(p.z, g.z, m.z, v.z, e + 2 >= a.n_no_decay, a, coef);
-        adamw_one(p.w, g.w, m.w, v.w, e + 3 >= a.n_no_decay, a, coef);
+        adamw_one(p.x, g.x, m.x, v.x, decays(e + 0), a, coef);
+        adamw_one(p.y, g.y, m.y, v.y, decays(e + 1), a, coef);
+        adamw_one(p.z, g.z, m.z, v.z, decays(e + 2), a, coef);
+        adamw_one(p.w, g.w, m.w, v.w, decays(e + 3), a, coef);
         reinterpret_cast<float4*>(a.p)[i] = p;
         reinterpret_cast<float4*>(a.m)[i] = m;
         reinterpret_cast<float4*>(a.v)[i] = v;
@@ -97,7 +101,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(AdamwArgs a) {
     }
     if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {
         const int64_t e = (n4 << 2) + threadIdx.x;
-        adamw_one(a.p[e], a.g[e], a.m[e], a.v[e], e >= a.n_no_decay, a, coef);
+        adamw_one(a.p[e], a.g[e], a.m[e], a.v[e], decays(e), a, coef);
         if (a.zero_grad) a.g[e] = 0.f;
     }
 }
@@ -122,9 +126,13 @@ extern "C" int geomae_grad_sumsq(const float* grad, int64_t num_elems, double* s
 extern "C" int geomae_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t num_elems,
                                  int64_t num_no_decay, float lr, float beta1, float beta2, float eps, float weight_decay,
                                  int64_t step, float max_norm, const double* grad_sumsq, float grad_scale,
-                                 int32_t zero_grad, float* grad_norm_out, hipStream_t stream) {
+                                 int32_t zero_grad, float* grad_norm_out, int64_t no_decay2_start,
+                                 int64_t no_decay2_count, double* zero_after, hipStream_t stream) {
     GEOMAE_REQUIRE(params && grads && exp_avg && exp_avg_sq && num_elems >= 0 && num_no_decay >= 0 && num_no_decay <= num_elems,
                    "adamw_step: bad argument");
+    GEOMAE_REQUIRE(no_decay2_count >= 0 && (no_decay2_count == 0 || (no_decay2_start >= num_no_decay &&
+                   no_decay2_start + no_decay2_count <= num_elems)), "adamw_step: second no-decay range out of bounds");
+    GEOMAE_REQUIRE(zero_after != grad_sumsq || !zero_after, "adamw_step: zero_after must not be the word being read");
     GEOMAE_REQUIRE(step >= 1, "adamw_step: step counts from 1");
     GEOMAE_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq) & 15) == 0,
                    "adamw_step: buffers must be 16-byte aligned");
@@ -133,6 +141,7 @@ extern "C" int geomae_adamw_step(float* params, float* grads, float* exp_avg, fl
     AdamwArgs a;
     a.p = params; a.g = grads; a.m = exp_avg; a.v = exp_avg_sq;
     a.n = num_elems; a.n_no_decay = num_no_decay;
+    a.nd2_start = no_decay2_start; a.nd2_end = no_decay2_start + no_decay2_count; a.zero_after = zero_after;
     // python-double scalars rounded to fp32 where torch hands them to an fp32 tensor op
     a.lr_wd_factor = (float)(1.0 - (double)lr * (double)weight_decay);
     a.w1 = (float)(1.0 - (double)beta1);

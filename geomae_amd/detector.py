@@ -143,8 +143,12 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         main = torch.cuda.current_stream()
         streams = ops.side_streams()
         side, aux = streams["geo"], streams["dec_b"]
-        side.wait_stream(main)
-        aux.wait_stream(main)
+        step_end, self._step_end_event = getattr(self, "_step_end_event", None), None
+        if step_end is not None:        # recorded by the trainer after its optimizer step; the decoder-B stream already
+            side.wait_event(step_end)   # waited for it (pack-ahead), and nothing was enqueued on the main stream since
+        else:
+            side.wait_stream(main)
+            aux.wait_stream(main)
         dev = voxels.device
         C = self.backbone.mask_token.shape[1]
         f32 = torch.float32

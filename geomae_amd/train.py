@@ -156,15 +156,17 @@ class FlatAdamW:
         main = torch.cuda.current_stream()
         with ops.prezeroed():
             _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
-        P = lambda t, o: ctypes.c_void_p(t.data_ptr() + 4 * o)
-        for start, end, n_nd in f.segments:                       # one launch per segment (its own no-decay prefix)
-            _lib.check(lib.geomae_adamw_step(P(f.flat, start), P(f.grad, start), P(self.exp_avg, start),
-                                             P(self.exp_avg_sq, start), end - start, n_nd, float(self.lr),
-                                             float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                             float(self.weight_decay), self.step_count, float(max_norm or 0.0),
-                                             _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)), _ptr(self._gnorm),
-                                             _stream()), "geomae_adamw_step")
-        self._sumsq_ring[1 - slot:2 - slot].zero_()               # a 3 us fill here beats a ~10 us cross-stream wait later
+        # one launch over the whole flat buffer: the segments (each [no-decay | decay]) only matter to the gradient
+        # exchange; the kernel takes the second segment's no-decay range and clears the other accumulator slot
+        segs = f.segments
+        assert len(segs) <= 2 and segs[0][0] == 0 and segs[-1][1] == n
+        nd2 = (segs[1][0], segs[1][2]) if len(segs) == 2 else (0, 0)
+        nxt = self._sumsq_ring[1 - slot:2 - slot]
+        _lib.check(lib.geomae_adamw_step(_ptr(f.flat), _ptr(f.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), n,
+                                         segs[0][2], float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                         float(self.eps), float(self.weight_decay), self.step_count,
+                                         float(max_norm or 0.0), _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)),
+                                         _ptr(self._gnorm), nd2[0], nd2[1], _ptr(nxt), _stream()), "geomae_adamw_step")
         ops.mark("optimizer_done")
         return self._gnorm[0]
 
@@ -309,10 +311,14 @@ class Trainer:
                 # chain of mask -> window layouts gates the next encoder and should start the moment the step does)
                 from . import ops
                 main, side = torch.cuda.current_stream(), ops.side_streams()["dec_b"]
-                side.wait_stream(main)
+                step_end = main.record_event()
+                side.wait_event(step_end)
                 with torch.cuda.stream(side):
                     packed.prepack()
                     packed.ready = side.record_event()
+                # the next step orders its side streams behind this same event instead of recording two more on the
+                # main stream (an event record is a packet of its own in the queue: ~5 us each between two steps)
+                self.model._step_end_event = step_end
                 self._prepack_flat_version = self.flat.flat._version
         else:
             allreduce_gradients(self.flat)

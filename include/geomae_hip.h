@@ -471,12 +471,16 @@ int geomae_points_pipeline(const float* raw_points, int64_t num_points, int32_t 
  * geomae_grad_sumsq: *sumsq = sum g^2 (fp64).  geomae_adamw_step: g *= grad_scale * min(1, max_norm / (norm + 1e-6))
  * with norm = grad_scale * sqrt(*grad_sumsq) (max_norm <= 0: no clipping, grad_sumsq may be NULL), then the
  * AdamW update of torch's single-tensor path op by op in fp32; `step` counts from 1; zero_grad != 0 clears the
- * gradient buffer in the same pass; grad_norm_out (or NULL) receives the pre-clip norm. */
+ * gradient buffer in the same pass; grad_norm_out (or NULL) receives the pre-clip norm.  A second no-decay range
+ * [no_decay2_start, + no_decay2_count) covers flat buffers laid out as two segments (each with its own no-decay
+ * prefix) in ONE launch; zero_after (or NULL) is a fp64 word cleared for the next step's geomae_grad_sumsq (two
+ * alternating words: no memset between the last backward kernel and the norm reduction). */
 int geomae_grad_sumsq(const float* grad, int64_t num_elems, double* sumsq, geomaeStream_t stream);
 int geomae_adamw_step(float* params, float* grads, float* exp_avg, float* exp_avg_sq, int64_t num_elems,
                       int64_t num_no_decay, float lr, float beta1, float beta2, float eps, float weight_decay,
                       int64_t step, float max_norm, const double* grad_sumsq, float grad_scale, int32_t zero_grad,
-                      float* grad_norm_out, geomaeStream_t stream);
+                      float* grad_norm_out, int64_t no_decay2_start, int64_t no_decay2_count, double* zero_after,
+                      geomaeStream_t stream);
 
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
