@@ -765,6 +765,7 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
 }
 
 void geomae::defer_next_weight_grad() { t_defer_weight_grad = true; }
+extern "C" int geomae_flush_weight_grad(hipStream_t stream) { return geomae::flush_pending_weight_grad(stream); }
 int geomae::flush_pending_weight_grad(hipStream_t stream) {
     t_defer_weight_grad = false;
     if (!g_pending_dw.active) return GEOMAE_OK;

@@ -222,7 +222,8 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
                                          const GeomaeSstLayerGrads* grads, int32_t num_layers,
                                          const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                                          int32_t max_window_tokens, const void* saved, void* scratch,
-                                         int64_t scratch_bytes, float* dx_out, void* profiler, hipStream_t stream) {
+                                         int64_t scratch_bytes, float* dx_out, int32_t defer_last_weight_grad,
+                                         void* profiler, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -275,11 +276,15 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         } else {
+            // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
+            // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
+            if (defer_last_weight_grad) defer_next_weight_grad();
             Timed t(profiler, GEOMAE_KERNEL_DW, stream);
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
-    if (flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK) rc = GEOMAE_ERR_HIP;   // error paths only
+    if (!(defer_last_weight_grad && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
+        rc = GEOMAE_ERR_HIP;                                                                         // error paths only
     return rc;
 }

@@ -1037,13 +1037,20 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     if (rc) return rc;
     Bn0 bn0;
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
-    GEOMAE_REQUIRE(dh0 && bsums0_global && dy1_bf16 && g_bf16 && dw0 && dw1 && n_eff > 0,
+    GEOMAE_REQUIRE(dh0 && bsums0_global && dw0 && n_eff > 0 && (!dw1 || (dy1_bf16 && g_bf16)),
                    "vfe_backward_layer0: null argument");
     GEOMAE_REQUIRE((d_beta0 == nullptr) == (d_gamma0 == nullptr), "vfe_backward_layer0: pass both BN gradients or none");
     hipLaunchKernelGGL(vfe_bwd_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, dh0, bn0, bsums0_global, n_eff,
                        dw0, d_beta0, d_gamma0);
     rc = check_launch("vfe_bwd_layer0_kernel");
-    if (rc) return rc;
+    if (rc || !dw1) return rc;                       // dw1 == NULL: the caller runs geomae_vfe_weight_grad1 itself
+    return geomae_vfe_weight_grad1(dy1_bf16, g_bf16, num_points, dw1, stream);
+}
+
+extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1,
+                                       hipStream_t stream) {
+    if (num_points <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(dy1_bf16 && g_bf16 && dw1, "vfe_weight_grad1: null argument");
     DwTasks T;
     T.t[0] = {(const bf16_t*)dy1_bf16, 128, 0, (const bf16_t*)g_bf16, 128, 0, dw1, 128, 0, 0, nullptr, 128};
     return launch_dw(T, 1, (int)num_points, stream);

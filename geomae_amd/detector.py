@@ -205,7 +205,10 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
                                                                  on_early_grads, packed_fresh=True, bufs=bufs)
         d_vf = bufs["d_vf"]
         d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
-        self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late)
+        join = bufs.get("join_side", False)          # work parked on the geometry stream: only the optimizer needs it
+        self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late, side=side if join else None)
+        if join:
+            main.wait_stream(side)
         ops.mark("vfe_bwd_done")
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 

@@ -899,9 +899,11 @@ def vfe_forward(plan, norm0, norm1, world=1, group=None, zeros=None):
     return vf[:plan.V], m0
 
 
-def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None):
+def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, side=None):
     """params: dict w0, w1, g0, b0, g1, b1 -> nn.Parameters whose .grad is accumulated into.
-    zeros: optional ZeroArena sized by vfe_backward_zero_specs (call under prezeroed())."""
+    zeros: optional ZeroArena sized by vfe_backward_zero_specs (call under prezeroed()).
+    side: optional stream for the layer-1 weight-gradient contraction (read only by the optimizer): it then runs beside
+    the layer-0 backward kernels; the caller joins `side` before the optimizer."""
     from torch import distributed as dist
     lib = _lib.load()
     dev = dvf.device
@@ -932,12 +934,19 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None):
                                          _ptr(dy1_b), _ptr(g_b), _ptr(dy1_f), _ptr(dh0), _ptr(dm0), _ptr(bs0),
                                          _ptr(params["b1"].grad) if fold else None,
                                          _ptr(params["g1"].grad) if fold else None, _stream()), "geomae_vfe_backward_layer1")
+    if side is not None:
+        side.wait_stream(torch.cuda.current_stream())
+        dy1_b.record_stream(side)
+        g_b.record_stream(side)
+        with torch.cuda.stream(side):
+            check(lib.geomae_vfe_weight_grad1(_ptr(dy1_b), _ptr(g_b), N, _ptr(params["w1"].grad), _stream()),
+                  "geomae_vfe_weight_grad1")
     if not fold:
         params["b0"].grad.add_(bs0[:64])
         params["g0"].grad.add_(bs0[64:])
         dist.all_reduce(bs0, group=group)
     check(lib.geomae_vfe_backward_layer0(a, ctypes.byref(bn), _ptr(dh0), _ptr(bs0), n_eff, N, _ptr(dy1_b), _ptr(g_b),
-                                         _ptr(params["w0"].grad), _ptr(params["w1"].grad),
+                                         _ptr(params["w0"].grad), None if side is not None else _ptr(params["w1"].grad),
                                          _ptr(params["b0"].grad) if fold else None,
                                          _ptr(params["g0"].grad) if fold else None, _stream()),
           "geomae_vfe_backward_layer0")
@@ -999,7 +1008,14 @@ def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, ou
     return z, saved
 
 
-def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None):
+def flush_weight_grad(stream=None):
+    """Launch the weight-gradient contraction a stack backward left recorded (defer_last=True) on `stream`."""
+    check(_lib.load().geomae_flush_weight_grad(_stream_of(stream)), "geomae_flush_weight_grad")
+
+
+def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, defer_last=False):
+    """defer_last: leave the first layer's weight-gradient contraction recorded (-> also returns the scratch buffer,
+    which must stay alive until flush_weight_grad's kernel ran)."""
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
@@ -1008,7 +1024,8 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
     dx = torch.empty_like(dz)
     check(lib.geomae_sst_stack_backward(_ptr(dz), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
+                                        int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
+                                        _stream_of(stream)),
           "geomae_sst_stack_backward")
     # `scratch` must outlive the kernels: a caller that runs the stack on a stream of its own keeps it until the join
-    return (dx, scratch) if stream is not None else dx
+    return (dx, scratch) if (stream is not None or defer_last) else dx

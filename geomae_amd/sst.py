@@ -573,10 +573,20 @@ class MultiMAESSTSPChoose(nn.Module):
         if on_early_grads is not None:
             on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
-        d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+        if side is None:
+            d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+        else:
+            # the first layer's weight-gradient contraction (the stack's last kernel) goes to the side stream, beside
+            # the VFE backward; the caller joins `side` before the optimizer (bufs["join_side"])
+            d_vf, keep = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh,
+                                                s_enc, defer_last=True)
+            side.wait_stream(cur)
+            keep.record_stream(side)
+            s_enc.record_stream(side)
+            with torch.cuda.stream(side):
+                ops.flush_weight_grad()
+            bufs["join_side"] = True
         ops.mark("enc_bwd_done")
-        if side is not None:
-            cur.wait_stream(side)
         return losses, d_vf
 
     def decode(self, visible_voxel_feat, coors, coors_mask, batch_size, layouts=None):

@@ -132,14 +132,14 @@ class DynamicScatterVFE(nn.Module):
         return vf, (plan, m0, vf, world)
 
     @torch.no_grad()
-    def backward_explicit(self, state, dvf, zeros=None):
+    def backward_explicit(self, state, dvf, zeros=None, side=None):
         plan, m0, vf, world = state
         l0, l1 = self.vfe_layers
         import contextlib
         with (ops.prezeroed() if zeros is not None else contextlib.nullcontext()):
             ops.vfe_backward(plan, m0, vf, dvf, dict(w0=l0.linear.weight, g0=l0.norm.weight, b0=l0.norm.bias,
                                                      w1=l1.linear.weight, g1=l1.norm.weight, b1=l1.norm.bias), world,
-                             zeros=zeros)
+                             zeros=zeros, side=side)
 
     def forward(self, features, coors, points=None, img_feats=None, img_metas=None, return_inv=False, seg=None):
         """features [N, C_in] fp32, coors [N, 4] int32 (b, z, y, x)."""

@@ -350,6 +350,11 @@ int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* b
                                const void* g_bf16, float* dw0 /*[64,11] +=*/, float* dw1 /*[128,128] +=*/,
                                float* d_beta0 /*[64] += or NULL*/, float* d_gamma0 /*[64] += or NULL*/,
                                geomaeStream_t stream);
+/* dw1 += dy1^T g (the layer-1 weight gradient): geomae_vfe_backward_layer0 runs it last unless its dw1 is NULL; a
+ * caller may instead launch it on another stream right after geomae_vfe_backward_layer1, beside the two kernels of
+ * the layer-0 backward (it is read only by the optimizer). */
+int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1 /*[128,128] +=*/,
+                            geomaeStream_t stream);
 /* d_beta / d_gamma (both or neither): single-process callers let the kernels add bsums (= d beta, d gamma) to the
  * BatchNorm parameter gradients; with naiveSyncBN1d the caller adds the LOCAL sums itself before all-reducing them. */
 
@@ -377,7 +382,12 @@ int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeS
                               const GeomaeSstLayerGrads* grads, int32_t num_layers,
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
-                              float* dx_out, void* profiler /*or NULL*/, geomaeStream_t stream);
+                              float* dx_out, int32_t defer_last_weight_grad, void* profiler /*or NULL*/,
+                              geomaeStream_t stream);
+/* defer_last_weight_grad != 0: the weight-gradient contraction of the stack's FIRST layer (the last kernel of the
+ * backward, read only by the optimizer) is recorded instead of launched; geomae_flush_weight_grad(other_stream)
+ * launches it there (order other_stream behind `stream` first), beside whatever the caller enqueues next on `stream`. */
+int geomae_flush_weight_grad(geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ N3 DynamicScatter native op
  * replaces the pybind functions dynamic_point_to_voxel_forward / _backward (ops/voxel/src/voxelization.h:112-154,
