@@ -555,8 +555,24 @@ class MultiMAESSTSPChoose(nn.Module):
         n = n_keep + n_mask
         ops.mark("heads_done")
         sb_.wait_stream(cur)
-        dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
-        dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen)
+        if side is None:
+            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
+            dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen)
+        else:
+            # each stack's last kernel, the first layer's weight-gradient contraction (~50 us at decoder size, read
+            # only by the optimizer), runs on the side stream instead of closing the decoder backward: it overlaps
+            # the encoder backward, whose launches leave most CUs idle
+            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_, defer_last=True)
+            side.wait_stream(sb_)
+            with torch.cuda.stream(side):
+                ops.flush_weight_grad()
+            dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, defer_last=True)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                ops.flush_weight_grad()
+            for t in (keep_a, keep_b, s_cen, s_den):
+                t.record_stream(side)
+            del keep_a
         cur.wait_stream(sb_)
         ops.mark("dec_bwd_done")
         d_tok = dxa.add_(dxb)
