@@ -233,9 +233,16 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         return pts, top
 
     @torch.no_grad()
-    def get_vanilla_mask_index(self, seg):
+    def _launch_mask(self, seg):
         self._iter += 1
-        return ops.random_mask(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
+        return ops.random_mask_launch(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
+
+    @torch.no_grad()
+    def get_vanilla_mask_index(self, seg):
+        raw, self._mask_raw = getattr(self, "_mask_raw", None), None
+        if raw is None or raw[0] is not seg:           # not drawn ahead by `prefetch` for this batch
+            raw = (seg, self._launch_mask(seg))
+        return ops.random_mask_finish(raw[1], seg)
 
     @torch.no_grad()
     def prefetch(self, points, stream=None):
@@ -263,10 +270,13 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             # along: ~45 us of dependent small kernels that would otherwise open the step's critical path
             prepared = self.voxel_encoder.prepare_points(voxels, seg) if getattr(self.voxel_encoder, "use_fused", True) \
                 and hasattr(self.voxel_encoder, "prepare_points") else None
+            # ... and so does the random mask of that batch: it needs the per-sample pillar offsets on the DEVICE only
+            # (one draw per batch, in batch order: the same sequence of seeds as drawing inside each step)
+            mask_raw = self._launch_mask(seg)
             done = ps.record_event()
         # stream given = the explicit schedule's decoder-B stream: the main stream joins that stream later in the same
         # step (after the decoder forward), so the consumer of this batch needs no wait of its own
-        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared, stream is not None)
+        self._prefetched = (points, (voxels, coors, sub_med, sub_low, seg), done, prepared, stream is not None, mask_raw)
 
     def _stage1(self, points):
         """voxelize x3 + pillar segments: taken from `prefetch` when it ran for this batch."""
@@ -276,6 +286,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             if not (len(pre) > 4 and pre[4]):                # (on the geometry stream: ordered by its later events, see prefetch)
                 torch.cuda.current_stream().wait_event(pre[2])
             self._prepared_points = pre[3] if len(pre) > 3 else None
+            self._mask_raw = (pre[1][4], pre[5]) if len(pre) > 5 else None
             return pre[1]
         voxels, coors, sub_med, sub_low = self.voxelize_all(points)
         seg = ops.pillar_segment(coors, len(points), self.grid_size)

@@ -504,20 +504,34 @@ class DynamicScatter(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ A6
-def random_mask(seg, keep_fraction, seed):
-    """-> ids_keep [n_keep], ids_mask [n_mask] (int64, ascending), token_row [V] int32, counts [2] int32."""
+def random_mask_launch(seg, keep_fraction, seed):
+    """Enqueue the mask kernel without needing the pillar counts on the host (buffers sized by the segment capacity):
+    a training loop runs it for the NEXT batch together with that batch's voxelization.  -> raw state for
+    random_mask_finish."""
     dev = seg.voxel_coors.device
-    starts = seg.sync_counts()
-    V = starts[-1]
-    n_keep = sum(int((starts[b + 1] - starts[b]) * keep_fraction) for b in range(seg.batch_size))
-    ids_keep = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
-    ids_mask = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
-    token_row = torch.empty(max(V, 1), dtype=torch.int32, device=dev)
+    cap = max(int(seg.cap), 1)
+    ids_keep = torch.empty(cap, dtype=torch.int32, device=dev)
+    ids_mask = torch.empty(cap, dtype=torch.int32, device=dev)
+    token_row = torch.empty(cap, dtype=torch.int32, device=dev)
     counts = torch.empty(2, dtype=torch.int32, device=dev)
     check(_lib.load().geomae_random_mask(_ptr(seg.sample_start), seg.batch_size, float(keep_fraction),
                                          int(seed) & (2 ** 64 - 1), _ptr(ids_keep), _ptr(ids_mask), _ptr(token_row),
                                          _ptr(counts), _stream()), "geomae_random_mask")
+    return ids_keep, ids_mask, token_row, counts, float(keep_fraction)
+
+
+def random_mask_finish(raw, seg):
+    """Slice the mask buffers with the host-side pillar counts (per sample int(L * keep_fraction) kept, as the kernel)."""
+    ids_keep, ids_mask, token_row, counts, keep_fraction = raw
+    starts = seg.sync_counts()
+    V = starts[-1]
+    n_keep = sum(int((starts[b + 1] - starts[b]) * keep_fraction) for b in range(seg.batch_size))
     return ids_keep[:n_keep], ids_mask[:V - n_keep], token_row[:V], counts
+
+
+def random_mask(seg, keep_fraction, seed):
+    """-> ids_keep [n_keep], ids_mask [n_mask] (int32, ascending), token_row [V] int32, counts [2] int32."""
+    return random_mask_finish(random_mask_launch(seg, keep_fraction, seed), seg)
 
 
 def gather_token_coors(ids_keep, ids_mask, voxel_coors):
