@@ -155,12 +155,13 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         # Everything that depends only on the points and the pillar coordinates runs beside the VFE forward, on two
         # streams, arranged so that the main stream waits for other queues as rarely as possible (a cross-queue wait
         # costs ~15 us of queue time even when its event fired long ago, tools/phase_events.py):
-        #   geometry stream : random mask -> token coordinates -> the four window layouts.  ONE event (layouts_ready) gates the encoder; the weights packed ahead
-        #                     by the trainer are chained into it.
+        #   geometry stream : (random mask, unless `prefetch` drew it in the previous step) -> token coordinates -> the
+        #                     four window layouts.  ONE event (layouts_ready) gates the encoder; the weights packed
+        #                     ahead by the trainer are chained into it.
         #   decoder-B stream: idle until the decoders fork, so it first takes the step's zero arena, the NEXT batch's
-        #                     stage 1 (voxelize / pillar sort / count readback / VFE front) and the geometric targets.
-        #                     The main stream joins it after the decoder forward anyway: no wait of its own for any of
-        #                     them (the targets are first read by the heads+loss kernel).
+        #                     stage 1 (voxelize / pillar sort / count readback / VFE front / random mask) and the
+        #                     geometric targets.  The main stream joins it after the decoder forward anyway: no wait of
+        #                     its own for any of them (the targets are first read by the heads+loss kernel).
         with torch.cuda.stream(side):
             ops.mark("side:start")
             packed_ready = self.backbone._packed.refresh_if_stale()   # a no-op when the trainer packed after its optimizer step
