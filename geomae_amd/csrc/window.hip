@@ -273,13 +273,13 @@ __device__ __forceinline__ int64_t tok_elem(int tok, int ld, int col, bool blk) 
 }
 
 __device__ __forceinline__ void stage_load(const unsigned short* __restrict__ src, int ld, int col0,
-                                           const int* toks, int T, u32x4 (&v)[kStageIters], bool blk) {
+                                           const int (&tk)[kStageIters], int T, u32x4 (&v)[kStageIters], bool blk) {
 #pragma unroll
     for (int k = 0; k < kStageIters; ++k) {
         const int t = k * kAttnBlk + threadIdx.x;
         const int row = t >> 1, half = t & 1;
         v[k] = u32x4{0u, 0u, 0u, 0u};
-        if (row < T) v[k] = *reinterpret_cast<const u32x4*>(src + tok_elem(toks[row], ld, col0 + half * 8, blk));
+        if (row < T) v[k] = *reinterpret_cast<const u32x4*>(src + tok_elem(tk[k], ld, col0 + half * 8, blk));
     }
 }
 
@@ -388,6 +388,18 @@ __device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int
     *hi = (whi[last] - 1 - c.s0) >> 4;
 }
 
+// this thread's staging rows -> their token ids.  With the build's attention plan they come straight from global
+// memory (one 16-byte record per position), so the operand gathers are issued without the LDS round trip and the
+// barrier behind bundle_setup; from the CSR arrays they are read back from `toks` after that barrier.
+__device__ __forceinline__ void stage_tokens(const AttnPlan& P, const BundleCtx& B, const int* toks, int (&tk)[kStageIters]) {
+    if (!P.pos_info) __syncthreads();                 // workgroup-uniform
+#pragma unroll
+    for (int k = 0; k < kStageIters; ++k) {
+        const int row = (k * kAttnBlk + threadIdx.x) >> 1;
+        tk[k] = row < B.T ? (P.pos_info ? P.pos_info[B.s0 + row].x : toks[row]) : -1;
+    }
+}
+
 // qkv: [n, 3*C] bf16 (q | k | v, C = heads*16);  out: [n, C] bf16;  lse: [n, heads] fp32
 // Work item -> (bundle, head), XCD-aware.  Workgroups are dealt round-robin to the 8 XCDs (item % 8), each with its
 // own L2.  A head reads 32-byte slices of the 768-byte qkv rows of its bundle's tokens, so the 8 heads of a bundle
@@ -428,12 +440,13 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
         if (!attn_item(item, NB, n_heads, &b, &h)) continue;
         const BundleCtx B = bundle_setup(b, P, toks, wid, wlo, whi);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
-        __syncthreads();
         {
+            int tk[kStageIters];
+            stage_tokens(P, B, toks, tk);
             u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters];
-            stage_load(qkv, 3 * C, h * kDh, toks, T, rq, blk);
-            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk, blk);
-            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv, blk);
+            stage_load(qkv, 3 * C, h * kDh, tk, T, rq, blk);
+            stage_load(qkv, 3 * C, C + h * kDh, tk, T, rk, blk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, tk, T, rv, blk);
             stage_store(rq, Tp, Qs, nullptr);
             stage_store(rk, Tp, Ks, nullptr);
             stage_store(rv, Tp, Vs, nullptr);
@@ -535,15 +548,16 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
         if (!attn_item(item, NB, n_heads, &b, &h)) continue;
         const BundleCtx B = bundle_setup(b, P, toks, wid, wlo, whi);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
-        __syncthreads();
         ATTN_STAMP(1);
         {
+            int tk[kStageIters];
+            stage_tokens(P, B, toks, tk);
             u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters], rdo[kStageIters], ro[kStageIters];
-            stage_load(qkv, 3 * C, h * kDh, toks, T, rq, blk);
-            stage_load(qkv, 3 * C, C + h * kDh, toks, T, rk, blk);
-            stage_load(qkv, 3 * C, 2 * C + h * kDh, toks, T, rv, blk);
-            stage_load(dout, C, h * kDh, toks, T, rdo, blk);
-            stage_load(out, C, h * kDh, toks, T, ro, blk);
+            stage_load(qkv, 3 * C, h * kDh, tk, T, rq, blk);
+            stage_load(qkv, 3 * C, C + h * kDh, tk, T, rk, blk);
+            stage_load(qkv, 3 * C, 2 * C + h * kDh, tk, T, rv, blk);
+            stage_load(dout, C, h * kDh, tk, T, rdo, blk);
+            stage_load(out, C, h * kDh, tk, T, ro, blk);
             stage_store(rq, Tp, Qs, nullptr);
             stage_store(rk, Tp, Ks, nullptr);
             stage_store(rv, Tp, Vs, nullptr);
@@ -557,7 +571,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                 d += dpp_mov<kDppXor1>(d);
                 if ((t & 1) == 0 && row < Tp) {
                     Ds[row] = d;                                                    // zero for padded rows
-                    Ls[row] = row < T ? lse[(int64_t)toks[row] * n_heads + h] : INFINITY;   // P = exp(s - inf) = 0
+                    Ls[row] = row < T ? lse[(int64_t)tk[k] * n_heads + h] : INFINITY;       // P = exp(s - inf) = 0
                 }
             }
         }
