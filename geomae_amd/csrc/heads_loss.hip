@@ -121,6 +121,32 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
             store_rows_bf16<128>(A.dm_b, A.M, (int)row, 128, 0, x, lane);
         }
         const int row0 = chunk < 6 ? 128 * chunk : 768;         // first output row of this chunk
+        // Targets of the five sub-voxel-low chunks (most of the kernel's target bytes), requested BEFORE the GEMM and
+        // unconditionally: inside the loss loop they were a mask load, a branch on it and a dependent target load per
+        // element, none of which could start before the logits existed (22 us of the kernel, measured by removing them).
+        f32x4 tl[8];                                            // chunks 0-2: regression targets of this lane's 32 outputs
+        unsigned int mk[8];                                     // per ct: two mask bytes (see below)
+        if (chunk < 5) {
+            const __amdgpu_buffer_rsrc_t mr = rows_rsrc(A.m_low, A.M, 128);
+            if (chunk < 3) {
+                const RowAddr ta = row_addr<4>(A.t_low, A.M, (int)row, 384, 128 * chunk, lane, false);
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {
+                    tl[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ta.r, ta.voff, ct * ta.ct_stride, 0));
+                    // outputs og .. og+3 belong to sub-voxels og/3 and (og+3)/3 (equal or consecutive)
+                    const int og = 128 * chunk + 16 * ct + 4 * g;
+                    const unsigned int b0 = __builtin_amdgcn_raw_buffer_load_b8(mr, (int)row * 128 + og / 3, 0, 0);
+                    const unsigned int b1 = __builtin_amdgcn_raw_buffer_load_b8(mr, (int)row * 128 + (og + 3) / 3, 0, 0);
+                    mk[ct] = b0 | (b1 << 8);
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < 8; ++ct) {                // class outputs og .. og+3: sub-voxels og/2, og/2 + 1
+                    const int og = 128 * (chunk - 3) + 16 * ct + 4 * g;
+                    mk[ct] = __builtin_amdgcn_raw_buffer_load_b16(mr, (int)row * 128 + (og >> 1), 0, 0);
+                }
+            }
+        }
         f32x4 z[8];
         if (chunk < 6) {
             load_bias<128>(A.bias + row0, z, lane);
@@ -145,14 +171,16 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
                     const float x = z[ct][r];
                     if (chunk < 3) {
                         const int og = 128 * chunk + o;
-                        if (A.m_low[row * 128 + og / 3]) {
-                            const float df = x - A.t_low[row * 384 + og];
+                        const unsigned int m = ((og / 3 == (og - r) / 3) ? mk[ct] : (mk[ct] >> 8)) & 0xffu;
+                        if (m) {
+                            const float df = x - tl[ct][r];
                             l_low += df * df * (1.f / 3.f);
                             d[r] = df * (2.f / 3.f) * inv_low;
                         }
                     } else if (chunk < 5) {
                         const int og = 128 * (chunk - 3) + o;
-                        const float y = ((int)A.m_low[row * 128 + (og >> 1)] == (og & 1)) ? 1.f : 0.f;
+                        const int cls = (int)((mk[ct] >> (8 * (r >> 1))) & 0xffu);
+                        const float y = (cls == (og & 1)) ? 1.f : 0.f;
                         float l, dd;
                         bce(x, y, &l, &dd);
                         l_cl += l;
