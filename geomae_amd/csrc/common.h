@@ -37,6 +37,14 @@ inline int check_launch(const char* what) {
 // it, around their own calls, to keep their internal buffers in the tile-blocked layout (sst_device.h "Row layouts").
 void set_layer_layout(int flags);
 int layer_layout();
+// Row map of the NEXT geomae_sst_qkv_backward of this host thread (set by geomae_sst_stack_backward around its last
+// kernel only): token t's gradient row goes to row rows[t] of a [num_rows_out, 128] buffer instead of row t.
+void set_output_rows(const int32_t* rows, int num_rows_out);
+const int32_t* output_rows(int* num_rows_out);
+// Second summand of the NEXT geomae_sst_ffn_backward's dz on this host thread (dz + dz2, row-major like dz): set by
+// geomae_sst_stack_backward around its top layer only.
+void set_dz_addend(const float* dz2);
+const float* dz_addend();
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

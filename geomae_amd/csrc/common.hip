@@ -14,6 +14,13 @@ void set_error(const char* fmt, ...) {
 static thread_local int g_layer_layout = 0;
 void set_layer_layout(int flags) { g_layer_layout = flags; }
 int layer_layout() { return g_layer_layout; }
+static thread_local const int32_t* g_out_rows = nullptr;
+static thread_local int g_out_rows_n = 0;
+void set_output_rows(const int32_t* rows, int num_rows_out) { g_out_rows = rows; g_out_rows_n = num_rows_out; }
+const int32_t* output_rows(int* num_rows_out) { *num_rows_out = g_out_rows_n; return g_out_rows; }
+static thread_local const float* g_dz_addend = nullptr;
+void set_dz_addend(const float* dz2) { g_dz_addend = dz2; }
+const float* dz_addend() { return g_dz_addend; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

@@ -248,6 +248,7 @@ struct FfnBwdArgs {
     const float* up_dx_res;           // [n,128]
     const bf16_t *up_wqkT, *up_wvT;   // packed transposed in-projection of layer l+1
     int lay;                          // kLayBlocked: everything except dz (always row-major: it comes from outside)
+    const float* dz_add;              // optional second summand of dz (the other decoder's input gradient), row-major
 };
 
 // B1 arithmetic: acc = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv
@@ -290,7 +291,15 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     const float r1 = __uint_as_float(rs.x), r2 = __uint_as_float(rs.y);
     f32x4 dv[8];
     if (A.up_dqkv) qkv_bwd_rows(A.up_dqkv, A.up_dx_res, A.up_wqkT, A.up_wvT, n, tok, smem, dv, lane, blk);
-    else load_rows_f32<128>(dz, n, tok, dv, lane);
+    else {
+        load_rows_f32<128>(dz, n, tok, dv, lane);
+        if (A.dz_add) {
+            f32x4 d2[8];
+            load_rows_f32<128>(A.dz_add, n, tok, d2, lane);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) dv[ct] += d2[ct];
+        }
+    }
     GEOMAE_STAMP(20);
     WStage<128, 256> s_w2T;
     // ---- LN2 backward
@@ -394,14 +403,20 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
                                                                 const float* __restrict__ dx_res, LayerW W, int n,
-                                                                float* __restrict__ dx, int lay) {
+                                                                float* __restrict__ dx, int lay,
+                                                                const int32_t* __restrict__ out_rows, int n_out) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
     const int tok = tile * 16 + (lane & 15);
     f32x4 acc[8];
     qkv_bwd_rows(dqkv, dx_res, W.wqkT, W.wvT, n, tok, smem, acc, lane, lay & kLayBlocked);
-    store_rows_f32<128>(dx, n, tok, acc, lane);                       // the stack's output: row-major
+    if (!out_rows) {
+        store_rows_f32<128>(dx, n, tok, acc, lane);                   // the stack's output: row-major
+    } else {                                                          // ... scattered: token t -> row out_rows[t] of [n_out, 128]
+        const int orow = tok < n ? out_rows[tok] : n_out;             // (past the end: dropped by the range check)
+        store_rows_f32<128>(dx, n_out, orow, acc, lane);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -701,7 +716,7 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
                           (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
                           (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b,
                           (const bf16_t*)up_dqkv_bf16, up_dx_res, up_w ? (const bf16_t*)up_w->wqkT_p : nullptr,
-                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout()};
+                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout(), dz ? dz_addend() : nullptr};
     const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
     if (!g_pending_dw.active) {
         hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);
@@ -725,8 +740,10 @@ extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_re
     GEOMAE_CHECK_TOKENS(num_tokens, "sst_qkv_backward");
     GEOMAE_REQUIRE(dqkv_bf16 && dx_res && dx, "sst_qkv_backward: null argument");
     const int tiles = cdiv(num_tokens, 16);
+    int n_out = 0;
+    const int32_t* orows = output_rows(&n_out);
     hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,
-                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx, layer_layout());
+                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx, layer_layout(), orows, n_out);
     return check_launch("sst_qkv_bwd_kernel");
 }
 

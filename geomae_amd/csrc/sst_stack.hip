@@ -105,6 +105,7 @@ struct Timed {
 // by one learned mask token per masked pillar (bb.py:239-246 repeat + cat), which is never materialised row-major.
 __global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* __restrict__ src, int n_src, int n,
                                                                   const float* __restrict__ fill_row,
+                                                                  const int32_t* __restrict__ src_rows,
                                                                   float* __restrict__ dst) {
     const int64_t pieces = (int64_t)((n + 15) / 16) * 16 * 32;              // 32 float4 per row
     for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * 256) {
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* _
         const int64_t tile = q >> 9;
         const int64_t tok = tile * 16 + t;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tok < n_src) v = *reinterpret_cast<const float4*>(src + tok * 128 + 16 * cb + 4 * c4);
+        if (tok < n_src) v = *reinterpret_cast<const float4*>(src + (src_rows ? (int64_t)src_rows[tok] : tok) * 128 + 16 * cb + 4 * c4);
         else if (tok < n) v = *reinterpret_cast<const float4*>(fill_row + 16 * cb + 4 * c4);
         reinterpret_cast<float4*>(dst)[q] = v;
     }
@@ -164,13 +165,13 @@ static int check_stack(const GeomaeSstLayerWeights* layers, int n_layers, const 
 extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                                         int32_t num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table,
                                         int32_t num_heads, int32_t max_window_tokens, void* saved, int64_t saved_bytes,
-                                        float* z_out, int32_t num_input_rows, const float* fill_row, void* profiler,
-                                        hipStream_t stream) {
+                                        float* z_out, int32_t num_input_rows, const float* fill_row,
+                                        const int32_t* input_rows, void* profiler, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_forward");
     if (rc) return rc;
     GEOMAE_REQUIRE(x_in && pos_table && saved && z_out, "sst_stack_forward: null argument");
-    if (!fill_row) num_input_rows = num_tokens;
+    if (!fill_row && !input_rows) num_input_rows = num_tokens;
     GEOMAE_REQUIRE(num_input_rows >= 0 && num_input_rows <= num_tokens, "sst_stack_forward: num_input_rows out of range");
     const SavedOffsets so = saved_offsets(num_tokens, num_heads);
     if (saved_bytes < so.stride * num_layers) {
@@ -179,7 +180,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     }
     char* base = (char*)saved;
     hipLaunchKernelGGL(rows_to_blocked_f32_kernel, dim3(stream_grid((int64_t)cdiv(num_tokens, 16) * 512, 256)), dim3(256), 0,
-                       stream, x_in, num_input_rows, num_tokens, fill_row, (float*)(base + so.x));
+                       stream, x_in, num_input_rows, num_tokens, fill_row, input_rows, (float*)(base + so.x));
     if ((rc = check_launch("rows_to_blocked_f32_kernel"))) return rc;
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
     for (int l = 0; l < num_layers; ++l) {
@@ -218,12 +219,13 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     return GEOMAE_OK;
 }
 
-extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                                          const GeomaeSstLayerGrads* grads, int32_t num_layers,
                                          const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                                          int32_t max_window_tokens, const void* saved, void* scratch,
-                                         int64_t scratch_bytes, float* dx_out, int32_t defer_last_weight_grad,
-                                         void* profiler, hipStream_t stream) {
+                                         int64_t scratch_bytes, float* dx_out, const int32_t* output_rows,
+                                         int32_t num_output_rows, int32_t defer_last_weight_grad, void* profiler,
+                                         hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -251,11 +253,13 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
+            if (top) set_dz_addend(dz_add);
             rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
                                          (const float*)(sv + so.rstd), top ? dz : nullptr, &layers[l], num_tokens,
                                          (float*)(w + sc.dx_res), w + sc.dattn, ws + sc.du, ws + sc.dv, ws + sc.dhp,
                                          ws + sc.y, ws + sc.h, &grads[l], top ? nullptr : ws_up + sc.dqkv,
                                          top ? nullptr : (const float*)(w + sc.dx_res), top ? nullptr : &layers[l + 1], stream);
+            set_dz_addend(nullptr);
         }
         if (rc) break;
         {
@@ -268,7 +272,9 @@ extern "C" int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, co
         if (rc) break;
         if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_BWD, stream);
+            set_output_rows(output_rows, num_output_rows);
             rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), &layers[0], num_tokens, dx_out, stream);
+            set_output_rows(nullptr, 0);
             if (rc) break;
         }
         if (l > 0) {

@@ -170,7 +170,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             ops.mark("side:mask")
             n_keep, n_mask = int(ik.numel()), int(im.numel())
             n = n_keep + n_mask
-            coors_all, ik_l = ops.gather_token_coors(ik, im, seg.voxel_coors)
+            coors_all, _ = ops.gather_token_coors(ik, im, seg.voxel_coors)
             ops.mark("side:coors")
             layouts = self.backbone.build_layouts(coors_all[:n_keep], None, batch_size, coors_all=coors_all)
             ops.mark("side:layouts")
@@ -199,13 +199,12 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
             ops.mark("side:targets")
         main.wait_event(layouts_ready)
         ops.mark("layouts_awaited")
-        ik = ik_l
         w = (self.loss_ratio_low_nor, self.loss_ratio_low, self.loss_ratio_med, self.loss_ratio_top,
              self.cls_loss_ratio_low, self.cls_loss_ratio_med)
-        losses, d_keep = self.backbone.losses_and_grads_explicit(vf[ik], n_mask, batch_size, tgt, w, layouts,
-                                                                 on_early_grads, packed_fresh=True, bufs=bufs)
-        d_vf = bufs["d_vf"]
-        d_vf.index_copy_(0, ik, d_keep)                    # ids_keep are distinct rows: masked pillars get no gradient
+        # the gather of the kept pillars and the scatter of their gradients (ids_keep are distinct rows: masked pillars
+        # get no gradient) are folded into the encoder's first / last kernel
+        losses, d_vf = self.backbone.losses_and_grads_explicit(vf, n_mask, batch_size, tgt, w, layouts, on_early_grads,
+                                                               packed_fresh=True, bufs=bufs, keep_rows=ik)
         join = bufs.get("join_side", False)          # work parked on the geometry stream: only the optimizer needs it
         self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late, side=side if join else None)
         if join:

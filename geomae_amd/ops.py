@@ -990,15 +990,19 @@ def _stream_of(stream):
     return _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
 
-def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None, tail=None):
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None, tail=None, rows=None):
     """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8).
     Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current).
     out: optional preallocated contiguous [n,128] f32 destination of z.
     tail = (fill_row [1,128] or [128] f32, count): the stack's input is x followed by `count` copies of fill_row (the
-    decoders' mask tokens), without materialising them; n = x.shape[0] + count."""
+    decoders' mask tokens), without materialising them; n = x.shape[0] + count.
+    rows: optional int32 [m] row indices into x: the stack's input is x[rows] (gathered by its input conversion)."""
     lib = _lib.load()
     _check_input(x, "x", torch.float32)
     n_in, nl = x.shape[0], len(weights)
+    if rows is not None:
+        _check_input(rows, "rows", torch.int32)
+        n_in = rows.numel()
     fill, n = None, n_in
     if tail is not None:
         fill, extra = tail
@@ -1016,7 +1020,7 @@ def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, ou
             raise RuntimeError("sst_stack_forward: out must be [n, width of x]")
         z = out
     check(lib.geomae_sst_stack_forward(_ptr(x), n, weights, nl, _stack_layouts(layouts), _ptr(pos_table), num_heads,
-                                       layouts[0].max_tokens, _ptr(saved), sb, _ptr(z), n_in, _ptr(fill),
+                                       layouts[0].max_tokens, _ptr(saved), sb, _ptr(z), n_in, _ptr(fill), _ptr(rows),
                                        ctypes.c_void_p(PROFILER) if PROFILER else None, _stream_of(stream)),
           "geomae_sst_stack_forward")
     return z, saved
@@ -1027,18 +1031,35 @@ def flush_weight_grad(stream=None):
     check(_lib.load().geomae_flush_weight_grad(_stream_of(stream)), "geomae_flush_weight_grad")
 
 
-def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, defer_last=False):
+def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, defer_last=False,
+                       scatter=None, dz_add=None):
     """defer_last: leave the first layer's weight-gradient contraction recorded (-> also returns the scratch buffer,
-    which must stay alive until flush_weight_grad's kernel ran)."""
+    which must stay alive until flush_weight_grad's kernel ran).
+    scatter = (rows int32 [n], dst [m,128] f32): the input gradient of token t is written to dst[rows[t]] (the
+    transpose of sst_stack_forward's `rows`; dst's other rows are left as they are) and dst is returned as dx.
+    dz_add: optional second summand of the output gradient (>= n rows; the stack reads dz + dz_add)."""
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
     wb = lib.geomae_sst_stack_scratch_bytes(n)
     scratch = torch.empty(max(wb, 1), dtype=torch.uint8, device=dz.device)
-    dx = torch.empty_like(dz)
-    check(lib.geomae_sst_stack_backward(_ptr(dz), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
+    rows, n_out = None, 0
+    if scatter is not None:
+        rows, dx = scatter
+        _check_input(rows, "rows", torch.int32)
+        _check_input(dx, "dst", torch.float32)
+        if rows.numel() != n or dx.dim() != 2 or dx.shape[1] != dz.shape[1]:
+            raise RuntimeError("sst_stack_backward: scatter needs one row index per token and a [m, width] destination")
+        n_out = dx.shape[0]
+    else:
+        dx = dz.new_empty((n,) + tuple(dz.shape[1:]))
+    if dz_add is not None:
+        _check_input(dz_add, "dz_add", torch.float32)
+        if dz_add.shape[0] < n or dz_add.shape[1:] != dz.shape[1:]:
+            raise RuntimeError("sst_stack_backward: dz_add must hold at least n rows of dz's width")
+    check(lib.geomae_sst_stack_backward(_ptr(dz), _ptr(dz_add), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
+                                        _ptr(rows), n_out, int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
                                         _stream_of(stream)),
           "geomae_sst_stack_backward")
     # `scratch` must outlive the kernels: a caller that runs the stack on a stream of its own keeps it until the join

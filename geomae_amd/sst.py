@@ -493,8 +493,11 @@ class MultiMAESSTSPChoose(nn.Module):
     # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
     @torch.no_grad()
     def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None,
-                                  packed_fresh=False, tgt_ready=None, bufs=None):
+                                  packed_fresh=False, tgt_ready=None, bufs=None, keep_rows=None):
         """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad.
+        keep_rows (int32 ids_keep): voxel_feat is then ALL pillars' features [V,128] and the encoder gathers / its
+        backward scatters the kept rows itself (bb.py:178); the gradient comes back as [V,128] in bufs["d_vf"]
+        (zeroed by the caller: masked pillars get no gradient).
         on_early_grads(): called once the gradients of the heads, both decoders and the mask token are enqueued
         (everything except the encoder), so that the caller can start exchanging them.
         packed_fresh: the caller already re-packed the bf16 weights for this step (on another stream, ordered before
@@ -508,14 +511,15 @@ class MultiMAESSTSPChoose(nn.Module):
         if not packed_fresh:
             P.refresh()
         enc_layouts, dec_layouts = layouts
-        n_keep = voxel_feat.shape[0]
+        n_keep = voxel_feat.shape[0] if keep_rows is None else keep_rows.numel()
+        scatter = None if keep_rows is None else (keep_rows, bufs["d_vf"])
         n_enc, n_dec = 2 * len(self.encoder_blocks), 2 * len(self.decoder_centroid_blocks)
         w_enc = P.weight_array(self._stack_base["enc"], n_enc)
         w_cen, w_den = P.weight_array(self._stack_base["cen"], n_dec), P.weight_array(self._stack_base["den"], n_dec)
         cur = torch.cuda.current_stream()
         # the decoders' input = encoder output followed by n_mask copies of the mask token: the stacks take that as
         # (rows, tail) and never materialise the concatenation (bb.py:239-246)
-        z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh)
+        z_enc, s_enc = ops.sst_stack_forward(voxel_feat.float().contiguous(), w_enc, enc_layouts, pt, nh, rows=keep_rows)
         dec_tail = (self.mask_token.detach(), n_mask)
         if bufs is None:
             d_out = losses_buf = None
@@ -575,27 +579,30 @@ class MultiMAESSTSPChoose(nn.Module):
             del keep_a
         cur.wait_stream(sb_)
         ops.mark("dec_bwd_done")
-        d_tok = dxa.add_(dxb)
+        # the token gradient is dxa + dxb: its kept rows are summed by the encoder backward's first kernel (dz_add), its
+        # masked rows reduce into the mask-token gradient
         del keep_b
         if self.mask_token.grad is None:
             self.mask_token.grad = torch.zeros_like(self.mask_token)
         if side is None:
-            self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+            self.mask_token.grad.add_((dxa[n_keep:] + dxb[n_keep:]).sum(dim=0, keepdim=True))
         else:                       # nobody reads the mask-token gradient before the optimizer: reduce it off the main stream
             side.wait_stream(cur)
-            d_tok.record_stream(side)
+            dxa.record_stream(side)
+            dxb.record_stream(side)
             with torch.cuda.stream(side):
-                self.mask_token.grad.add_(d_tok[n_keep:].sum(dim=0, keepdim=True))
+                self.mask_token.grad.add_((dxa[n_keep:] + dxb[n_keep:]).sum(dim=0, keepdim=True))
         if on_early_grads is not None:
             on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
         if side is None:
-            d_vf = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc)
+            d_vf = ops.sst_stack_backward(dxa, n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc, scatter=scatter,
+                                          dz_add=dxb)
         else:
             # the first layer's weight-gradient contraction (the stack's last kernel) goes to the side stream, beside
             # the VFE backward; the caller joins `side` before the optimizer (bufs["join_side"])
-            d_vf, keep = ops.sst_stack_backward(d_tok[:n_keep].contiguous(), n_keep, w_enc, g_enc, enc_layouts, pt, nh,
-                                                s_enc, defer_last=True)
+            d_vf, keep = ops.sst_stack_backward(dxa, n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc, defer_last=True,
+                                                scatter=scatter, dz_add=dxb)
             side.wait_stream(cur)
             keep.record_stream(side)
             s_enc.record_stream(side)

@@ -372,18 +372,24 @@ typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_b
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
 /* x_in holds num_input_rows rows; the remaining num_tokens - num_input_rows input rows are copies of fill_row [128]
- * (the decoders' mask token, bb.py:239-246).  fill_row == NULL: x_in holds all num_tokens rows. */
+ * (the decoders' mask token, bb.py:239-246).  fill_row == NULL: x_in holds all num_tokens rows.
+ * input_rows != NULL: token t (t < num_input_rows) reads row input_rows[t] of x_in (the gather of the kept voxels,
+ * bb.py:178, folded into the stack's input conversion). */
 int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                              int32_t num_layers, const GeomaeSstStackLayout* layouts /*[2]*/,
                              const float* pos_table, int32_t num_heads, int32_t max_window_tokens, void* saved,
                              int64_t saved_bytes, float* z_out, int32_t num_input_rows, const float* fill_row /*or NULL*/,
-                             void* profiler /*or NULL*/, geomaeStream_t stream);
-int geomae_sst_stack_backward(const float* dz, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
+                             const int32_t* input_rows /*or NULL*/, void* profiler /*or NULL*/, geomaeStream_t stream);
+/* output_rows != NULL: token t's input-gradient row is written to row output_rows[t] of dx_out [num_output_rows, 128]
+ * (rows not named keep their contents: the caller zeroes them), the transpose of input_rows above. */
+/* dz_add != NULL: the output gradient is dz + dz_add (two consumers of the stack's output, e.g. the two decoders on
+ * the encoder's), summed in the top layer's first kernel instead of by the caller. */
+int geomae_sst_stack_backward(const float* dz, const float* dz_add /*or NULL*/, int32_t num_tokens, const GeomaeSstLayerWeights* layers,
                               const GeomaeSstLayerGrads* grads, int32_t num_layers,
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
-                              float* dx_out, int32_t defer_last_weight_grad, void* profiler /*or NULL*/,
-                              geomaeStream_t stream);
+                              float* dx_out, const int32_t* output_rows /*or NULL*/, int32_t num_output_rows,
+                              int32_t defer_last_weight_grad, void* profiler /*or NULL*/, geomaeStream_t stream);
 /* defer_last_weight_grad != 0: the weight-gradient contraction of the stack's FIRST layer (the last kernel of the
  * backward, read only by the optimizer) is recorded instead of launched; geomae_flush_weight_grad(other_stream)
  * launches it there (order other_stream behind `stream` first), beside whatever the caller enqueues next on `stream`. */

@@ -799,6 +799,46 @@ def test_stack_forward_tail_rows_equal_concatenated_input(dev):
     assert za.shape == (n, 128) and torch.equal(za, zb)
 
 
+def test_stack_row_gather_and_gradient_scatter_equal_indexing(dev):
+    """geomae_sst_stack_forward(x_all, rows) == the stack on x_all[rows] (the kept pillars, bb.py:178) and
+    geomae_sst_stack_backward(scatter = (rows, dst)) == dst.index_copy_(0, rows, dx): bit-identical, rows not named
+    keep their contents."""
+    from geomae_amd import ops
+    model, _ = _build(dev, 1, 2, "bf16")
+    bb = model.backbone
+    frames = [synth.lidar_frame(33), synth.lidar_frame(34, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    V = n + n // 2 + 3
+    gen = torch.Generator().manual_seed(5)
+    x_all = torch.randn(V, 128, generator=gen).to(dev)
+    rows = torch.randperm(V, generator=gen)[:n].int().to(dev)
+    dz = torch.randn(n, 128, generator=gen).to(dev)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, 2)
+    nl = 2 * len(bb.decoder_centroid_blocks)
+    w = bb._packed.weight_array(bb._stack_base["cen"], nl)
+    for p in bb.parameters():
+        p.grad = None
+    g = bb._packed.grad_array(bb._stack_base["cen"], nl)
+    za, sa = ops.sst_stack_forward(x_all, w, layouts, bb.pos_table, bb.nhead[0], rows=rows)
+    zb, sb = ops.sst_stack_forward(x_all[rows.long()].contiguous(), w, layouts, bb.pos_table, bb.nhead[0])
+    assert torch.equal(za, zb)
+    dst = torch.full((V, 128), 7.0, device=dev)
+    out = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], sa, scatter=(rows, dst))
+    assert out is dst
+    dx = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], sb)
+    want = torch.full((V, 128), 7.0, device=dev).index_copy_(0, rows.long(), dx)
+    assert torch.equal(dst, want)
+    # dz_add: the stack reads dz + dz_add (both may hold more rows than the stack has tokens)
+    extra = torch.randn(n + 9, 128, generator=gen).to(dev)
+    dz_long = torch.cat([dz, torch.ones(9, 128, device=dev)]).contiguous()
+    da = ops.sst_stack_backward(dz_long, n, w, g, layouts, bb.pos_table, bb.nhead[0], sb, dz_add=extra)
+    db = ops.sst_stack_backward((dz + extra[:n]).contiguous(), n, w, g, layouts, bb.pos_table, bb.nhead[0], sb)
+    assert da.shape == (n, 128) and torch.equal(da, db)
+
+
 
 def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
     """forward_train (fused heads+loss kernel) vs extract_feat + forward_loss on the same model / mask:
