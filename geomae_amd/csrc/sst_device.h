@@ -153,11 +153,21 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&a
 // immediate.  Host side guarantees n * 768 < 2^31 (geomae_sst_* entry points).
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// Every descriptor in these kernels is wave-uniform (kernel arguments, or a task picked by blockIdx), but the compiler
+// loses that whenever a component passes through a select / phi it keeps in VGPRs (the `blk ? .. : ..` row counts, a
+// task struct indexed by blockIdx.y): it then wraps EVERY buffer access in a waterfall loop (4 v_readfirstlane +
+// 2 v_cmp + s_and_saveexec + branch; 193 of them in sst_ffn_bwd_dw_kernel).  Pinning base and size to SGPRs here
+// removes the loops.
+__device__ __forceinline__ void* uniform_ptr(const void* p) {
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<void*>(((uint64_t)hi << 32) | lo);
+}
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* base, int n, int row_bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, n * row_bytes, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(base), 0, __builtin_amdgcn_readfirstlane(n * row_bytes), 0x00020000);
 }
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* base) {   // no bound known / needed
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, -1, 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(base), 0, -1, 0x00020000);
 }
 __device__ __forceinline__ uint2 buf_load_b64(__amdgpu_buffer_rsrc_t r, int off) {
     const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);

@@ -1,11 +1,13 @@
 """Digest of one training step from a rocprofv3 kernel trace (tools/trace.sh): start (us), duration, gap to the
-latest previous end over all queues, queue, workgroups, kernel.  usage: timeline_digest.py kernel_trace.csv [step_index_from_end]"""
+latest previous end over all queues, queue, workgroups, kernel.  usage: timeline_digest.py kernel_trace.csv [step_index_from_end | +step_index_from_start]
+(bench.py's last steps are its untimed extra passes, whose batches are not prefetched: pick a step of the timed region,
+e.g. +10 with --warmup 6)"""
 import csv
 import re
 import sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
-back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+sel = sys.argv[2] if len(sys.argv) > 2 else "2"
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 ends = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
 # a step = after the last adamw launch of step k-1 ... last adamw launch of step k (two launches per step: segments)
@@ -15,7 +17,7 @@ for i in ends:
     if prev is not None and i - prev > 5:
         steps.append((prev + 1, i))
     prev = i
-lo, hi = steps[-back]
+lo, hi = steps[int(sel[1:])] if sel.startswith("+") else steps[-int(sel)]
 t0 = int(rows[lo]["Start_Timestamp"])
 last_end = t0
 busy = 0.0
