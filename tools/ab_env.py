@@ -22,7 +22,7 @@ for rep in range(2):
     for i in range(40): l, _ = step(i)
     torch.cuda.synchronize(); print(f"{1e3*(time.perf_counter()-t0)/40:.3f} ms/step loss {float(sum(l.values())):.4f}")
 '''
-for val in (None, "1", None, "1"):
+for val in ((None, "1", None, "1") if len(sys.argv) < 3 else (None,) + tuple(sys.argv[2:]) + (None,) + tuple(sys.argv[2:])):
     env = dict(os.environ)
     if val is not None: env[var] = val
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
