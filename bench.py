@@ -73,6 +73,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)

@@ -544,7 +544,7 @@ class MultiMAESSTSPChoose(nn.Module):
         losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights,
                                                        d_out=d_out, losses=losses_buf)
         # ---------------- backward
-        side = bufs["side"] if (bufs is not None and on_early_grads is None) else None
+        side = bufs.get("side") if bufs is not None else None
         if side is None:
             ops.heads_weight_grad(n_mask, *saved_h, P.head_grads())
         else:
@@ -593,7 +593,15 @@ class MultiMAESSTSPChoose(nn.Module):
             with torch.cuda.stream(side):
                 self.mask_token.grad.add_((dxa[n_keep:] + dxb[n_keep:]).sum(dim=0, keepdim=True))
         if on_early_grads is not None:
-            on_early_grads()
+            if side is None:
+                on_early_grads()
+            else:
+                # every gradient of the heads, the decoders and the mask token is complete in the geometry stream's
+                # order (it waited for both decoder backwards before the two flushes and carries the heads' contraction
+                # and the mask-token reduction itself): the collective is ordered behind THAT stream, the main stream
+                # never waits for it
+                with torch.cuda.stream(side):
+                    on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)
         if side is None:
             d_vf = ops.sst_stack_backward(dxa, n_keep, w_enc, g_enc, enc_layouts, pt, nh, s_enc, scatter=scatter,

@@ -302,6 +302,9 @@ class Trainer:
                         works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
                 for _, w in works:
                     w.wait()
+                tap = getattr(self, "on_reduced_grad", None)
+                if tap is not None:                  # test tap: the summed gradient buffer the optimizer is about to read
+                    tap(self.flat.grad)
             gnorm = self.opt.fused_clip_step(self.grad_clip.get("max_norm", 0.0), 1.0 / world, zero_grad=True)
             self._grads_clean = True
             packed = getattr(getattr(self.model, "backbone", None), "_packed", None)
