@@ -879,9 +879,8 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
         dist.all_reduce(mom, group=group)
         mom.mul_(1.0 / world)
         check(lib.geomae_bn_finalize(None, float(plan.N), _ptr(mom), *common, 0, _ptr(norm.running_mean),
-                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), None,
+                                     _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), _ptr(bn[2]),
                                      _ptr(norm.num_batches_tracked), _stream()), "geomae_bn_finalize")
-        bn[2, :C].copy_(mom[:C])
 
 
 def vfe_forward_zero_specs(cap, V, prepared=False):
