@@ -133,7 +133,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         return {k: losses[i] for i, k in enumerate(self.LOSS_KEYS)}
 
     @torch.no_grad()
-    def train_step_explicit(self, points, on_early_grads=None, next_points=None):
+    def train_step_explicit(self, points, on_early_grads=None, next_points=None, on_encoder_grads=None):
         """forward_train_fused + backward as an explicit schedule: no autograd tape or engine.  Accumulates every
         parameter gradient into .grad and returns the loss dict (detached).  Used by Trainer for the fused path
         (the step was host-bound at ~3.3 ms of Python / autograd per 3.5 ms of GPU work)."""
@@ -204,7 +204,8 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         # the gather of the kept pillars and the scatter of their gradients (ids_keep are distinct rows: masked pillars
         # get no gradient) are folded into the encoder's first / last kernel
         losses, d_vf = self.backbone.losses_and_grads_explicit(vf, n_mask, batch_size, tgt, w, layouts, on_early_grads,
-                                                               packed_fresh=True, bufs=bufs, keep_rows=ik)
+                                                               packed_fresh=True, bufs=bufs, keep_rows=ik,
+                                                               on_encoder_grads=on_encoder_grads)
         join = bufs.get("join_side", False)          # work parked on the geometry stream: only the optimizer needs it
         self.voxel_encoder.backward_explicit(vfe_state, d_vf, zeros=zeros_late, side=side if join else None)
         if join:

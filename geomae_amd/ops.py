@@ -860,10 +860,17 @@ class VfePlan:
         return b
 
 
+# Process group of the fused VFE's BatchNorm collectives when the caller passes none (None = the default group).  The
+# trainer installs one of its own at world > 1: on the default group's communicator the [2C]-word all-reduces of the VFE
+# backward would queue behind the encoder segment's gradient all-reduce that was started just before it.
+BN_GROUP = None
+
+
 def _bn_finalize(plan, layer, sums, norm, world, group):
     """Training-mode statistics -> folded scale/shift (+ running stats), with naiveSyncBN1d's equal-weight
     cross-rank average of (mean, mean of squares) when world > 1 (mmdet3d/ops/norm.py:64-76)."""
     from torch import distributed as dist
+    group = BN_GROUP if group is None else group
     lib = _lib.load()
     C = 64 if layer == 0 else 128
     bn = plan.bn[layer]
@@ -932,6 +939,7 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, sid
     # d beta / d gamma = the LOCAL sums: one process lets the next kernel add them; with naiveSyncBN1d they are added
     # here, before the sums are all-reduced for the input gradient
     fold = world == 1
+    group = BN_GROUP if group is None else group
     if not fold:
         params["b1"].grad.add_(bs1[:128])
         params["g1"].grad.add_(bs1[128:])

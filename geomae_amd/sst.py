@@ -493,13 +493,14 @@ class MultiMAESSTSPChoose(nn.Module):
     # above; no tape, no engine thread, no gradient seeds / index_add / cat nodes.
     @torch.no_grad()
     def losses_and_grads_explicit(self, voxel_feat, n_mask, batch_size, tgt, loss_weights, layouts, on_early_grads=None,
-                                  packed_fresh=False, tgt_ready=None, bufs=None, keep_rows=None):
+                                  packed_fresh=False, tgt_ready=None, bufs=None, keep_rows=None, on_encoder_grads=None):
         """-> ([6] losses, d_voxel_feat [n_keep,128]); parameter gradients are accumulated into .grad.
         keep_rows (int32 ids_keep): voxel_feat is then ALL pillars' features [V,128] and the encoder gathers / its
         backward scatters the kept rows itself (bb.py:178); the gradient comes back as [V,128] in bufs["d_vf"]
         (zeroed by the caller: masked pillars get no gradient).
         on_early_grads(): called once the gradients of the heads, both decoders and the mask token are enqueued
-        (everything except the encoder), so that the caller can start exchanging them.
+        (everything except the encoder), so that the caller can start exchanging them; on_encoder_grads(): likewise
+        once the encoder's are.  Both are called with the stream current behind which those gradients are complete.
         packed_fresh: the caller already re-packed the bf16 weights for this step (on another stream, ordered before
         this call's stream).  tgt_ready: event after which `tgt` may be read (targets built on a side stream).
         bufs: optional dict prepared off the critical path by the caller (detector.train_step_explicit): zeroed
@@ -616,7 +617,11 @@ class MultiMAESSTSPChoose(nn.Module):
             s_enc.record_stream(side)
             with torch.cuda.stream(side):
                 ops.flush_weight_grad()
+                if on_encoder_grads is not None:          # (the flush was the encoder's last gradient kernel)
+                    on_encoder_grads()
             bufs["join_side"] = True
+        if side is None and on_encoder_grads is not None:
+            on_encoder_grads()
         ops.mark("enc_bwd_done")
         return losses, d_vf
 

@@ -30,22 +30,41 @@ class FlatParams:
     def __init__(self, model, no_decay_keys=("norm",), late_keys=()):
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         is_nd = lambda n: any(k in n for k in no_decay_keys)
-        is_late = lambda n: any(n.startswith(k) for k in late_keys)
-        groups = [[(n, p) for n, p in named if not is_late(n)], [(n, p) for n, p in named if is_late(n)]]
+        # late_keys: name prefixes, or tuples of prefixes, one entry per later segment (in the order their gradients
+        # become complete during the backward); everything else forms segment 0
+        late_groups = [(k,) if isinstance(k, str) else tuple(k) for k in late_keys]
+        if late_groups and all(isinstance(k, str) for k in late_keys):
+            late_groups = [tuple(late_keys)]                        # a flat tuple of prefixes = ONE late segment
+        which = lambda n: next((i + 1 for i, ks in enumerate(late_groups) if any(n.startswith(k) for k in ks)), 0)
+        groups = [[(n, p) for n, p in named if which(n) == gi] for gi in range(len(late_groups) + 1)]
         groups = [g for g in groups if g]
-        self.names, self.params, self.offsets, self.segments = [], [], [], []
+        self.names, self.params, self.offsets, self.segments, self.nd_ranges = [], [], [], [], []
         off = 0
-        for g in groups:
+        for gi, g in enumerate(groups):
             nd = [(n, p) for n, p in g if is_nd(n)]
             dc = [(n, p) for n, p in g if not is_nd(n)]
+            # segments alternate [no-decay | decay], [decay | no-decay], ...: the no-decay parts of segments 1 and 2 are
+            # then adjacent and the whole buffer has at most two no-decay ranges for up to three segments (the fused
+            # AdamW pass takes a prefix range and one more)
+            nd_first = gi % 2 == 0
             start = off
-            for n, p in nd + dc:
+            n_nd = sum(p.numel() for _, p in nd)
+            n_dc = sum(p.numel() for _, p in dc)
+            for n, p in (nd + dc if nd_first else dc + nd):
                 self.names.append(n)
                 self.params.append(p)
                 self.offsets.append(off)
                 off += p.numel()
-            n_nd = sum(p.numel() for _, p in nd)
-            off = (off + 3) // 4 * 4                                # keep every segment 16-byte aligned
+            a = start if nd_first else start + n_dc
+            if n_nd:
+                if self.nd_ranges and self.nd_ranges[-1][1] == a:
+                    self.nd_ranges[-1] = (self.nd_ranges[-1][0], a + n_nd)
+                else:
+                    self.nd_ranges.append((a, a + n_nd))
+            end = (off + 3) // 4 * 4                                # keep every segment 16-byte aligned
+            if not nd_first and n_nd and end != off:
+                self.nd_ranges[-1] = (self.nd_ranges[-1][0], end)   # the padding (zeros, zero gradients) joins the range
+            off = end
             self.segments.append((start, off, n_nd))
         total = off
         self.n_no_decay = self.segments[0][2] if len(self.segments) == 1 else None
@@ -64,7 +83,14 @@ class FlatParams:
 
     def decay_ranges(self):
         """[(start, end)] of the elements that take weight decay."""
-        return [(s + nd, e) for s, e, nd in self.segments]
+        out, pos = [], 0
+        for a, b in self.nd_ranges:
+            if a > pos:
+                out.append((pos, a))
+            pos = b
+        if pos < self.total:
+            out.append((pos, self.total))
+        return out
 
     def check_storage(self):
         """load_state_dict copies in place, so every parameter must still be a view of the flat buffer."""
@@ -158,12 +184,14 @@ class FlatAdamW:
             _lib.check(lib.geomae_grad_sumsq(_ptr(f.grad), n, _ptr(self._sumsq), _stream()), "geomae_grad_sumsq")
         # one launch over the whole flat buffer: the segments (each [no-decay | decay]) only matter to the gradient
         # exchange; the kernel takes the second segment's no-decay range and clears the other accumulator slot
-        segs = f.segments
-        assert len(segs) <= 2 and segs[0][0] == 0 and segs[-1][1] == n
-        nd2 = (segs[1][0], segs[1][2]) if len(segs) == 2 else (0, 0)
+        segs, nds = f.segments, list(f.nd_ranges)
+        assert segs[0][0] == 0 and segs[-1][1] == n
+        prefix = nds.pop(0)[1] if nds and nds[0][0] == 0 else 0
+        assert len(nds) <= 1, "the fused AdamW pass takes a no-decay prefix and one more range"
+        nd2 = (nds[0][0], nds[0][1] - nds[0][0]) if nds else (0, 0)
         nxt = self._sumsq_ring[1 - slot:2 - slot]
         _lib.check(lib.geomae_adamw_step(_ptr(f.flat), _ptr(f.grad), _ptr(self.exp_avg), _ptr(self.exp_avg_sq), n,
-                                         segs[0][2], float(self.lr), float(self.betas[0]), float(self.betas[1]),
+                                         prefix, float(self.lr), float(self.betas[0]), float(self.betas[1]),
                                          float(self.eps), float(self.weight_decay), self.step_count,
                                          float(max_norm or 0.0), _ptr(self._sumsq), float(grad_scale), int(bool(zero_grad)),
                                          _ptr(self._gnorm), nd2[0], nd2[1], _ptr(nxt), _stream()), "geomae_adamw_step")
@@ -236,8 +264,16 @@ class Trainer:
         self.model = model
         # gradients of the decoders / heads are complete before the encoder backward starts: they form the early
         # segment, whose all-reduce overlaps the rest of the backward (explicit schedule, world > 1)
-        late = ("backbone.encoder_blocks.", "voxel_encoder.") if hasattr(model, "train_step_explicit") else ()
+        # ... and the encoder's before the voxel encoder's backward: three segments [decoders + heads | encoder | VFE];
+        # only the last, small one (70 KB) is exchanged with nothing left to hide it
+        late = (("backbone.encoder_blocks.",), ("voxel_encoder.",)) if hasattr(model, "train_step_explicit") else ()
         self.flat = FlatParams(model, no_decay_keys=keys or ("\0",), late_keys=late)
+        if late and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from . import ops
+            if ops.BN_GROUP is None:
+                # a communicator of its own for the SyncBN statistics (every rank builds its trainer: new_group is a
+                # collective call): they must not queue behind a gradient all-reduce in flight (ops.BN_GROUP)
+                ops.BN_GROUP = dist.new_group()
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
@@ -268,14 +304,17 @@ class Trainer:
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         works = []
 
-        def early_ready():
-            # called by the model when every gradient of segment 0 has been enqueued: start its all-reduce now, under
-            # the encoder / voxel-encoder backward (RCCL runs it on its own stream after the kernels enqueued so far)
-            if world > 1 and len(self.flat.segments) > 1:
-                a, b, _ = self.flat.segments[0]
-                works.append((0, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
-        early = early_ready if (world > 1 and len(self.flat.segments) > 1) else None
-        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early, next_points=next_points)) if explicit else \
+        def segment_ready(i):
+            # called by the model when every gradient of segment i has been enqueued (with the stream current that
+            # carries its last writer): start its all-reduce now, under the rest of the backward (RCCL runs it on its own
+            # stream after the kernels enqueued so far on the current one)
+            a, b, _ = self.flat.segments[i]
+            works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+        nseg = len(self.flat.segments)
+        early = (lambda: segment_ready(0)) if (world > 1 and nseg > 1) else None
+        enc_ready = (lambda: segment_ready(1)) if (world > 1 and nseg > 2) else None
+        run = (lambda p: self.model.train_step_explicit(p, on_early_grads=early, next_points=next_points,
+                                                        on_encoder_grads=enc_ready)) if explicit else \
             (lambda p: self.model.forward_train(p, None, **kw))
         if explicit:
             self.model._prefetched = keep

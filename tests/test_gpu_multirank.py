@@ -80,7 +80,7 @@ def _worker(rank, world, port, tmp):
         tr_auto.train_step(pts)
         losses, gnorm = tr.train_step(pts)
         tr.on_reduced_grad = None
-        assert len(tr.flat.segments) == 2                      # i.e. the early all-reduce did run
+        assert len(tr.flat.segments) == 3                      # i.e. both early all-reduces did run
         worst = (0.0, "")
         for name, off, p in zip(tr.flat.names, tr.flat.offsets, tr.flat.params):
             ge, ga = taps["explicit"][off:off + p.numel()], taps["autograd"][off:off + p.numel()]

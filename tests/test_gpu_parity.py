@@ -702,10 +702,12 @@ def test_pillar_segment_drops_invalid_rows(dev):
     assert sorted(seg.order[:n_ok].cpu().tolist()) == np.nonzero(ok)[0].tolist()
 
 
+@pytest.mark.parametrize("late", [(), ("b.", "norm2."), (("b.", "norm2."), ("c.", "norm3."))])
 @pytest.mark.parametrize("max_norm", [10.0, 0.05])
-def test_fused_clip_adamw_matches_torch(dev, max_norm):
+def test_fused_clip_adamw_matches_torch(dev, max_norm, late):
     """geomae_grad_sumsq + geomae_adamw_step vs torch.nn.utils.clip_grad_norm_ + torch.optim.AdamW (the optimizer
-    configs/_base_/schedules/cosine_2x.py selects), 5 steps, with the 'norm' no-decay split; max_norm 0.05 forces clipping."""
+    configs/_base_/schedules/cosine_2x.py selects), 5 steps, with the 'norm' no-decay split; max_norm 0.05 forces clipping.
+    late: the flat buffer in 1 / 2 / 3 gradient-exchange segments (their no-decay parts laid out as Trainer does)."""
     import torch.nn as nn
     from geomae_amd.train import FlatAdamW, FlatParams
 
@@ -715,11 +717,17 @@ def test_fused_clip_adamw_matches_torch(dev, max_norm):
             self.a = nn.Linear(37, 53)
             self.norm1 = nn.LayerNorm(53)
             self.b = nn.Linear(53, 11, bias=False)
+            self.norm2 = nn.LayerNorm(11)
+            self.c = nn.Linear(11, 7)
+            self.norm3 = nn.LayerNorm(7)
     torch.manual_seed(3)
     m1 = M().to(dev)
     import copy
     m2 = copy.deepcopy(m1)
-    flat = FlatParams(m1, no_decay_keys=("norm",))
+    flat = FlatParams(m1, no_decay_keys=("norm",), late_keys=late)
+    assert len(flat.segments) == (1 if not late else (2 if isinstance(late[0], str) else 3)) and len(flat.nd_ranges) <= 2
+    nd_elems = sum(b - a for a, b in flat.nd_ranges)
+    assert 0 <= nd_elems - sum(p.numel() for n, p in m1.named_parameters() if "norm" in n) < 4 * len(flat.segments)
     opt = FlatAdamW(flat, lr=3e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
     named = dict(m2.named_parameters())
     ref = torch.optim.AdamW([dict(params=[p], weight_decay=0.0 if "norm" in n else 0.05) for n, p in named.items()],

@@ -24,16 +24,19 @@ class Toy(nn.Module):
         return self.out(self.norm(torch.relu(self.lin(x))))
 
 
-def test_flat_adamw_matches_torch_adamw():
+@pytest.mark.parametrize("late", [(), ("norm.", "out."), (("norm.",), ("out.",))])
+def test_flat_adamw_matches_torch_adamw(late):
     torch.manual_seed(0)
     a, b = Toy(), Toy()
     b.load_state_dict(a.state_dict())
-    flat = FlatParams(a, no_decay_keys=("norm",))
+    flat = FlatParams(a, no_decay_keys=("norm",), late_keys=late)
     opt = FlatAdamW(flat, lr=1e-2, weight_decay=0.05)
     nd = [p for n, p in b.named_parameters() if "norm" in n]
     dc = [p for n, p in b.named_parameters() if "norm" not in n]
     ref = torch.optim.AdamW([dict(params=nd, weight_decay=0.0), dict(params=dc, weight_decay=0.05)], lr=1e-2)
-    assert flat.n_no_decay == sum(p.numel() for p in nd)
+    assert late or flat.n_no_decay == sum(p.numel() for p in nd)
+    covered = sum(e - s for s, e in flat.decay_ranges()) + sum(e - s for s, e in flat.nd_ranges)
+    assert covered == flat.total and len(flat.nd_ranges) <= 2
     for it in range(5):
         x = torch.randn(16, 6)
         flat.zero_grad()
