@@ -273,7 +273,11 @@ class Trainer:
             if ops.BN_GROUP is None:
                 # a communicator of its own for the SyncBN statistics (every rank builds its trainer: new_group is a
                 # collective call): they must not queue behind a gradient all-reduce in flight (ops.BN_GROUP)
-                ops.BN_GROUP = dist.new_group()
+                try:
+                    ops.BN_GROUP = dist.new_group()
+                except Exception as e:                       # stay on the default group: correct, only less overlapped
+                    import warnings
+                    warnings.warn(f"geomae_amd: no separate process group for SyncBN ({e!r}); using the default group")
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
