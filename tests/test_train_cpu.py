@@ -59,6 +59,8 @@ def _worker(rank, world, port, tmp):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")          # the container's hostname may not resolve
     os.environ["MASTER_PORT"] = str(port)
+    import faulthandler
+    faulthandler.dump_traceback_later(240, exit=True)          # a stuck rank reports where and leaves
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         torch.manual_seed(0)
