@@ -278,6 +278,19 @@ class Trainer:
                 except Exception as e:                       # stay on the default group: correct, only less overlapped
                     import warnings
                     warnings.warn(f"geomae_amd: no separate process group for SyncBN ({e!r}); using the default group")
+            if self.flat.flat.is_cuda:
+                # ROCm maps a process's streams onto 4 hardware queues in first-use order and a 5th stream shares the
+                # first one's queue.  Fix that order here: main stream, the default group's
+                # communication stream (the gradient all-reduces must not sit in the main stream's queue: they would run
+                # in order with its kernels instead of beside them), geometry, decoder-B; the SyncBN group's stream, if
+                # the backend uses one for blocking collectives at all, comes 5th and shares the main stream's queue --
+                # harmless, the main stream waits for those collectives anyway.
+                t = torch.zeros(1, device=self.flat.flat.device)
+                dist.all_reduce(t, async_op=True).wait()
+                ops.side_streams(t.device)
+                if ops.BN_GROUP is not None:
+                    dist.all_reduce(t, group=ops.BN_GROUP)
+                torch.cuda.synchronize(t.device)
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step
