@@ -148,9 +148,19 @@ __global__ __launch_bounds__(256) void occ_count_kernel(const uint8_t* __restric
                                                         const uint8_t* __restrict__ mask_med, int64_t n_med_bytes,
                                                         int32_t* __restrict__ occ_counts) {
     __shared__ int sm[2][4];
-    int a = 0, b = 0;
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n_low_bytes; i += (int64_t)gridDim.x * 256) a += mask_low[i];
-    for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n_med_bytes; i += (int64_t)gridDim.x * 256) b += mask_med[i];
+    // the arrays hold 0 / 1 bytes: 16 of them per load, counted with popcount (byte loads made this a 17 us kernel)
+    auto count = [&](const uint8_t* __restrict__ m, int64_t n) {
+        int c = 0;
+        const int64_t n16 = ((uintptr_t)m & 15) == 0 ? n >> 4 : 0;
+        const uint4* m16 = reinterpret_cast<const uint4*>(m);
+        for (int64_t i = blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+            const uint4 v = m16[i];
+            c += __builtin_popcount(v.x) + __builtin_popcount(v.y) + __builtin_popcount(v.z) + __builtin_popcount(v.w);
+        }
+        for (int64_t i = (n16 << 4) + blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) c += m[i];
+        return c;
+    };
+    int a = count(mask_low, n_low_bytes), b = count(mask_med, n_med_bytes);
     a = wave_sum(a);
     b = wave_sum(b);
     if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = a; sm[1][threadIdx.x >> 6] = b; }
@@ -197,12 +207,45 @@ __device__ void eig3(const double a_in[6], double w[3], double v[3][3]) {
     w[0] = a[0][0]; w[1] = a[1][1]; w[2] = a[2][2];
 }
 
+// eigen-decomposition of one pillar's 3x3 scatter matrix -> unit normal (canonical sign) and the curvature triple
+__device__ __forceinline__ void normal_curv_from_cov(const float (&c)[6], int64_t row, float* __restrict__ normal,
+                                                     double* __restrict__ curv) {
+    const double a[6] = {c[0], c[1], c[2], c[3], c[4], c[5]};
+    double w[3], v[3][3];
+    eig3(a, w, v);
+    // singular values of the PSD scatter matrix = |eigenvalues|, descending
+    int idx[3] = {0, 1, 2};
+    double s[3] = {fabs(w[0]), fabs(w[1]), fabs(w[2])};
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2 - i; ++j)
+            if (s[j] < s[j + 1]) {
+                double ts = s[j]; s[j] = s[j + 1]; s[j + 1] = ts;
+                int ti = idx[j]; idx[j] = idx[j + 1]; idx[j + 1] = ti;
+            }
+    float nz = (float)v[0][idx[2]], ny = (float)v[1][idx[2]], nx = (float)v[2][idx[2]];
+    const float len = sqrtf(nz * nz + ny * ny + nx * nx);
+    nz /= len; ny /= len; nx /= len;
+    // canonical sign: the component of largest magnitude is positive (ties: lowest index)
+    const float az = fabsf(nz), ay = fabsf(ny), ax = fabsf(nx);
+    const float lead = (az >= ay && az >= ax) ? nz : (ay >= ax ? ny : nx);
+    if (lead < 0.0f) { nz = -nz; ny = -ny; nx = -nx; }
+    normal[(int64_t)row * 3 + 0] = nz;
+    normal[(int64_t)row * 3 + 1] = ny;
+    normal[(int64_t)row * 3 + 2] = nx;
+    // est_curv = (S.double() + 1e-9) / sum  (ssl.py:604-607); S is fp32 in the reference
+    const double e0 = (double)(float)s[0] + 1e-9, e1 = (double)(float)s[1] + 1e-9, e2 = (double)(float)s[2] + 1e-9;
+    const double tot = e0 + e1 + e2;
+    curv[(int64_t)row * 3 + 0] = e0 / tot;
+    curv[(int64_t)row * 3 + 1] = e1 / tot;
+    curv[(int64_t)row * 3 + 2] = e2 / tot;
+}
+
 __global__ __launch_bounds__(64) void normal_curv_kernel(
     const int32_t* __restrict__ num_pillars, const int4* __restrict__ voxel_coors,
     const int32_t* __restrict__ cell_table, const int32_t* __restrict__ token_row,
     const int32_t* __restrict__ mask_counts, TargetCfg cfg, int n_batch, const float* __restrict__ top_raw,
     const float* __restrict__ med_raw, const uint8_t* __restrict__ med_raw_mask, float* __restrict__ normal,
-    double* __restrict__ curv, float* __restrict__ cov_out) {
+    double* __restrict__ curv, float* __restrict__ cov_out, int cov_only) {
     const int lane = threadIdx.x;
     const int V = num_pillars[0];
     const int n_med = cfg.rm[0] * cfg.rm[1] * cfg.rm[2];
@@ -229,40 +272,30 @@ __global__ __launch_bounds__(64) void normal_curv_kernel(
         c00 = wave_sum(c00); c01 = wave_sum(c01); c02 = wave_sum(c02);
         c11 = wave_sum(c11); c12 = wave_sum(c12); c22 = wave_sum(c22);
         if (lane == 0) {
-            const double a[6] = {c00, c01, c02, c11, c12, c22};
-            double w[3], v[3][3];
-            eig3(a, w, v);
-            // singular values of the PSD scatter matrix = |eigenvalues|, descending
-            int idx[3] = {0, 1, 2};
-            double s[3] = {fabs(w[0]), fabs(w[1]), fabs(w[2])};
-            for (int i = 0; i < 2; ++i)
-                for (int j = 0; j < 2 - i; ++j)
-                    if (s[j] < s[j + 1]) {
-                        double ts = s[j]; s[j] = s[j + 1]; s[j + 1] = ts;
-                        int ti = idx[j]; idx[j] = idx[j + 1]; idx[j + 1] = ti;
-                    }
-            float nz = (float)v[0][idx[2]], ny = (float)v[1][idx[2]], nx = (float)v[2][idx[2]];
-            const float len = sqrtf(nz * nz + ny * ny + nx * nx);
-            nz /= len; ny /= len; nx /= len;
-            // canonical sign: the component of largest magnitude is positive (ties: lowest index)
-            const float az = fabsf(nz), ay = fabsf(ny), ax = fabsf(nx);
-            const float lead = (az >= ay && az >= ax) ? nz : (ay >= ax ? ny : nx);
-            if (lead < 0.0f) { nz = -nz; ny = -ny; nx = -nx; }
-            normal[(int64_t)row * 3 + 0] = nz;
-            normal[(int64_t)row * 3 + 1] = ny;
-            normal[(int64_t)row * 3 + 2] = nx;
-            // est_curv = (S.double() + 1e-9) / sum  (ssl.py:604-607); S is fp32 in the reference
-            const double e0 = (double)(float)s[0] + 1e-9, e1 = (double)(float)s[1] + 1e-9, e2 = (double)(float)s[2] + 1e-9;
-            const double tot = e0 + e1 + e2;
-            curv[(int64_t)row * 3 + 0] = e0 / tot;
-            curv[(int64_t)row * 3 + 1] = e1 / tot;
-            curv[(int64_t)row * 3 + 2] = e2 / tot;
+            const float c[6] = {c00, c01, c02, c11, c12, c22};
+            if (!cov_only) normal_curv_from_cov(c, row, normal, curv);
             if (cov_out) {
                 float* co = cov_out + (int64_t)row * 6;
                 co[0] = c00; co[1] = c01; co[2] = c02; co[3] = c11; co[4] = c12; co[5] = c22;
             }
         }
     }
+}
+
+// Second half of the normal / curvature targets when the scatter matrices went through memory (cov_only above): one
+// THREAD per target row.  In the fused kernel lane 0 of every pillar's wave runs the fp64 Jacobi iteration alone --
+// ~11 k issue cycles with 63 lanes idle, 15 k waves: that was the kernel's whole duration (53 us), and it ran beside the
+// latency-bound encoder forward.  Same arithmetic per pillar, so the results are bit-identical.
+__global__ __launch_bounds__(64) void normal_eig_kernel(const int32_t* __restrict__ num_pillars,
+                                                        const int32_t* __restrict__ mask_counts,
+                                                        const float* __restrict__ cov, float* __restrict__ normal,
+                                                        double* __restrict__ curv) {
+    const int rows = mask_counts ? mask_counts[1] : num_pillars[0];
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= rows) return;
+    const float* co = cov + (int64_t)row * 6;
+    const float c[6] = {co[0], co[1], co[2], co[3], co[4], co[5]};
+    normal_curv_from_cov(c, row, normal, curv);
 }
 
 static int fill_cfg(TargetCfg& c, const GeomaeTargetConfig* g) {
@@ -320,9 +353,13 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
                        seg_start, num_pillars, (const int4*)voxel_coors, (const int4*)coors_med,
                        (const int4*)coors_low, token_row, mask_counts, c, centroid_low, mask_low, centroid_med,
                        mask_med, centroid_top, top_raw, med_raw, med_raw_mask);
+    // with a scatter-matrix buffer from the caller the eigen-decompositions run one per thread in a second launch
     hipLaunchKernelGGL(normal_curv_kernel, dim3(grid), dim3(64), 0, stream, num_pillars, (const int4*)voxel_coors,
                        cell_table, token_row, mask_counts, c, batch_size, top_raw, med_raw, med_raw_mask, normal, curv,
-                       cov_out);
+                       cov_out, cov_out ? 1 : 0);
+    if (cov_out)
+        hipLaunchKernelGGL(normal_eig_kernel, dim3((max_pillars + 63) / 64), dim3(64), 0, stream, num_pillars,
+                           mask_counts, (const float*)cov_out, normal, curv);
     if (occ_counts) {
         // rows: masked pillars (device count) or all pillars; the host-side upper bound is max_pillars,
         // rows beyond the real count were never written, so count over the rows the caller allocated

@@ -591,7 +591,9 @@ def geometry_targets(points, seg, coors_med, coors_low, cfg, token_row=None, cou
         top_raw=torch.empty((max(V, 1), 3), dtype=f32, device=dev),
         med_raw=torch.empty((max(V, 1), s_med, 3), dtype=f32, device=dev),
         med_raw_mask=torch.empty((max(V, 1), s_med), dtype=u8, device=dev),
-        cov=torch.empty((M, 6), dtype=f32, device=dev) if want_cov else None,
+        # the scatter matrices always go through memory: with this buffer the library runs the eigen-decompositions one
+        # per thread in a second launch (targets.hip normal_eig_kernel) instead of on lane 0 of each pillar's wave
+        cov=torch.empty((max(M, 1), 6), dtype=f32, device=dev),
         occ_counts=torch.empty(2, dtype=torch.int32, device=dev))
     check(_lib.load().geomae_geometry_targets(
         _ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start), _ptr(seg.num_pillars), V,

@@ -127,7 +127,9 @@ typedef struct GeomaeTargetConfig {
  *   centroid_low [M,S_low,3] f32   mask_low [M,S_low] u8   centroid_med [M,S_med,3]   mask_med [M,S_med]
  *   centroid_top [M,3]   normal [M,3] f32 (canonical sign)   curv [M,3] f64
  *   top_raw [cap,3], med_raw [cap,S_med,3], med_raw_mask [cap,S_med]: un-normalised centroids of
- *   every pillar (also scratch for the neighbourhood pass);  cov_out [M,6] optional (may be NULL) */
+ *   every pillar (also scratch for the neighbourhood pass);  cov_out [M,6] optional (may be NULL): the 3x3 scatter
+ *   matrices (upper triangle) of cal_regular_voxel_nor_and_curv; when given, the eigen-decompositions run in a second
+ *   launch, one per thread, instead of on one lane of each pillar's wave (same results, 5x shorter) */
 int geomae_geometry_targets(const float* points, int32_t num_features, const int32_t* order,
                             const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
                             const int32_t* voxel_coors, const int32_t* coors_med,
