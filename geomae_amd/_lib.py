@@ -90,6 +90,7 @@ SIGNATURES = {
     "geomae_pillar_segment_nd": (ctypes.c_int, [P, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P,
                                                 P, P, P, c_int64, P]),
     "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, c_int32, P, P, P]),
+    "geomae_segment_mean_xyz_sorted": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P]),
     "geomae_vfe_prepare": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, P, F3, F3, P, P, P]),
     "geomae_dynamic_point_to_voxel_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "geomae_dynamic_point_to_voxel_forward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,

@@ -322,12 +322,12 @@ def pillar_segment(coors, batch_size, grid_zyx, cap=None):
 
 
 def segment_mean_xyz(points, seg, zeros=None):
-    """zeros: optional ZeroArena for the sum workspace (call under prezeroed())."""
+    """Pillar means of the xyz columns from the pillar-sorted point list (no atomics, no workspace; `zeros` is unused and
+    kept for callers of the former atomic version)."""
     mean = torch.empty((max(seg.cap, 1), 3), dtype=torch.float32, device=points.device)
-    ws = _zeros_or_empty(zeros, max(seg.cap, 1) * 3, torch.int64, points.device)
-    check(_lib.load().geomae_segment_mean_xyz(_ptr(points), points.shape[1], points.shape[0], _ptr(seg.inv),
-                                              _ptr(seg.seg_start), _ptr(seg.num_pillars), seg.cap, _ptr(ws), _ptr(mean),
-                                              _stream()), "geomae_segment_mean_xyz")
+    check(_lib.load().geomae_segment_mean_xyz_sorted(_ptr(points), points.shape[1], _ptr(seg.order), _ptr(seg.seg_start),
+                                                     _ptr(seg.num_pillars), seg.cap, _ptr(mean), _stream()),
+          "geomae_segment_mean_xyz_sorted")
     return mean
 
 
@@ -893,11 +893,9 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
 
 
 def vfe_forward_zero_specs(cap, V, prepared=False):
-    """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order (prepared: the
-    pillar-mean workspace is not needed, vfe_prepare_points already ran)."""
+    """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order."""
     V1 = max(int(V), 1)
-    front = [] if prepared else [((max(int(cap), 1) * 3,), torch.int64)]
-    return front + [((2, 4, 128), torch.float32), ((128,), torch.float64), ((V1, 64), torch.float32),
+    return [((2, 4, 128), torch.float32), ((128,), torch.float64), ((V1, 64), torch.float32),
                     ((256,), torch.float64), ((V1, 128), torch.float32)]
 
 

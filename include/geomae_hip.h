@@ -83,6 +83,10 @@ int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int64_t num_poi
 int geomae_segment_mean_xyz(const float* points, int32_t num_features, int64_t num_points, const int32_t* inv,
                             const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
                             void* sum_workspace, float* mean, geomaeStream_t stream);
+/* The same means (bit-identical) from the pillar-sorted point list of geomae_pillar_segment: no atomics, no workspace. */
+int geomae_segment_mean_xyz_sorted(const float* points, int32_t num_features, const int32_t* order,
+                                   const int32_t* seg_start, const int32_t* num_pillars, int32_t max_pillars,
+                                   float* mean, geomaeStream_t stream);
 /* torch_scatter.scatter_max (voxel_encoder.py:407): feat [N, C] in point order -> out [cap, C],
  * argmax [cap, C] (point index); backward routes grad_out to the arg-max rows: grad_feat [N, C]. */
 int geomae_segment_max_forward(const float* feat, int32_t channels, const int32_t* order,

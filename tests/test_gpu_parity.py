@@ -1,5 +1,6 @@
 """GPU parity: the HIP path (through the C ABI, via geomae_amd.ops) against the CPU oracle and the
 reference-generated golden fixtures.  Run on the MI355X box with `pytest -m gpu`."""
+import ctypes
 import os
 
 import numpy as np
@@ -125,6 +126,16 @@ def test_segment_reductions(dev):
     mean = ops.segment_mean_xyz(torch.as_tensor(pts, device=dev), seg)[:V].cpu()
     want = O.segment_mean(torch.as_tensor(pts[:, :3]).double(), torch.as_tensor(inv), V)
     np.testing.assert_allclose(mean.numpy(), want.float().numpy(), rtol=0, atol=4e-6)
+    # the atomic entry point (fixed-point int64 sums per point) gives the same bits as the sorted-segment one above
+    from geomae_amd import _lib
+    lib, P = _lib.load(), (lambda t: ctypes.c_void_p(t.data_ptr()))
+    pd = torch.as_tensor(pts, device=dev)
+    ws = torch.zeros(seg.cap * 3, dtype=torch.int64, device=dev)
+    mean_a = torch.empty((seg.cap, 3), dtype=torch.float32, device=dev)
+    _lib.check(lib.geomae_segment_mean_xyz(P(pd), pd.shape[1], pd.shape[0], P(seg.inv), P(seg.seg_start), P(seg.num_pillars),
+                                           seg.cap, P(ws), P(mean_a), None), "geomae_segment_mean_xyz")
+    torch.cuda.synchronize()
+    assert torch.equal(mean_a[:V].cpu(), mean)
     feat = torch.randn(pts.shape[0], 64, generator=torch.Generator().manual_seed(0))
     f = feat.to(dev).requires_grad_(True)
     out = ops.segment_max(f, seg)
