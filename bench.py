@@ -48,8 +48,8 @@ def cpu_baseline(seed=1000):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-gpu", type=int, default=4)
     ap.add_argument("--sweeps", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
