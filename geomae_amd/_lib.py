@@ -153,7 +153,7 @@ SIGNATURES = {
     "geomae_sst_stack_forward": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, c_int32, c_int32, P, c_int64, P, c_int32, P,
                                                 P, P, P]),
     "geomae_sst_stack_backward": (ctypes.c_int, [P, P, c_int32, P, P, c_int32, P, P, c_int32, c_int32, P, P, c_int64, P,
-                                                 P, c_int32, c_int32, P, P]),
+                                                 P, c_int32, P, c_int32, c_int32, P, P]),
     "geomae_flush_weight_grad": (ctypes.c_int, [P]),
     "geomae_vfe_weight_grad1": (ctypes.c_int, [P, P, c_int64, P, P]),
     "geomae_profiler_create": (c_void_p, [c_int32, c_int32]),

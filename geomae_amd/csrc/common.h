@@ -45,6 +45,10 @@ const int32_t* output_rows(int* num_rows_out);
 // geomae_sst_stack_backward around its top layer only.
 void set_dz_addend(const float* dz2);
 const float* dz_addend();
+// Column sums of the rows >= from_row of the NEXT geomae_sst_qkv_backward's output on this host thread, ADDED into
+// sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).
+void set_tail_sum(float* sum, int from_row);
+float* tail_sum(int* from_row);
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

@@ -21,6 +21,10 @@ const int32_t* output_rows(int* num_rows_out) { *num_rows_out = g_out_rows_n; re
 static thread_local const float* g_dz_addend = nullptr;
 void set_dz_addend(const float* dz2) { g_dz_addend = dz2; }
 const float* dz_addend() { return g_dz_addend; }
+static thread_local float* g_tail_sum = nullptr;
+static thread_local int g_tail_from = 0;
+void set_tail_sum(float* sum, int from_row) { g_tail_sum = sum; g_tail_from = from_row; }
+float* tail_sum(int* from_row) { *from_row = g_tail_from; return g_tail_sum; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

@@ -404,7 +404,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A)
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t* __restrict__ dqkv,
                                                                 const float* __restrict__ dx_res, LayerW W, int n,
                                                                 float* __restrict__ dx, int lay,
-                                                                const int32_t* __restrict__ out_rows, int n_out) {
+                                                                const int32_t* __restrict__ out_rows, int n_out,
+                                                                float* __restrict__ tail_sum, int tail_from) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
@@ -416,6 +417,27 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t*
     } else {                                                          // ... scattered: token t -> row out_rows[t] of [n_out, 128]
         const int orow = tok < n ? out_rows[tok] : n_out;             // (past the end: dropped by the range check)
         store_rows_f32<128>(dx, n_out, orow, acc, lane);
+    }
+    // column sums of the rows >= tail_from (the mask tokens' rows: their gradient is one shared row, bb.py:239-246)
+    if (tail_sum && (int)(blockIdx.x + 1) * kLayerBlk / 4 > tail_from) {            // workgroup-uniform
+        __syncthreads();                                              // every wave is done with the weights in smem
+        float* red = reinterpret_cast<float*>(smem);                  // [waves][128]
+        const bool in_tail = tok >= tail_from && tok < n;
+        const int g = lane >> 4, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float s = row16_sum(in_tail ? acc[ct][r] : 0.0f);
+                if ((lane & 15) == 0) red[wave * 128 + 16 * ct + 4 * g + r] = s;
+            }
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            float s = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kLayerBlk / 64; ++w) s += red[w * 128 + threadIdx.x];
+            atomicAdd(tail_sum + threadIdx.x, s);
+        }
     }
 }
 
@@ -742,8 +764,10 @@ extern "C" int geomae_sst_qkv_backward(const void* dqkv_bf16, const float* dx_re
     const int tiles = cdiv(num_tokens, 16);
     int n_out = 0;
     const int32_t* orows = output_rows(&n_out);
+    int tail_from = 0;
+    float* tsum = tail_sum(&tail_from);
     hipLaunchKernelGGL(sst_qkv_bwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream,
-                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx, layer_layout(), orows, n_out);
+                       (const bf16_t*)dqkv_bf16, dx_res, to_layer(w), num_tokens, dx, layer_layout(), orows, n_out, tsum, tail_from);
     return check_launch("sst_qkv_bwd_kernel");
 }
 

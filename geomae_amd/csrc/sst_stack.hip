@@ -224,8 +224,8 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
                                          const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                                          int32_t max_window_tokens, const void* saved, void* scratch,
                                          int64_t scratch_bytes, float* dx_out, const int32_t* output_rows,
-                                         int32_t num_output_rows, int32_t defer_last_weight_grad, void* profiler,
-                                         hipStream_t stream) {
+                                         int32_t num_output_rows, float* tail_sum, int32_t tail_from,
+                                         int32_t defer_last_weight_grad, void* profiler, hipStream_t stream) {
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -273,8 +273,10 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_BWD, stream);
             set_output_rows(output_rows, num_output_rows);
+            set_tail_sum(tail_sum, tail_from);
             rc = geomae_sst_qkv_backward(ws + sc.dqkv, (const float*)(w + sc.dx_res), &layers[0], num_tokens, dx_out, stream);
             set_output_rows(nullptr, 0);
+            set_tail_sum(nullptr, 0);
             if (rc) break;
         }
         if (l > 0) {

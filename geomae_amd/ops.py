@@ -1039,12 +1039,14 @@ def flush_weight_grad(stream=None):
 
 
 def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, defer_last=False,
-                       scatter=None, dz_add=None):
+                       scatter=None, dz_add=None, tail_sum=None):
     """defer_last: leave the first layer's weight-gradient contraction recorded (-> also returns the scratch buffer,
     which must stay alive until flush_weight_grad's kernel ran).
     scatter = (rows int32 [n], dst [m,128] f32): the input gradient of token t is written to dst[rows[t]] (the
     transpose of sst_stack_forward's `rows`; dst's other rows are left as they are) and dst is returned as dx.
-    dz_add: optional second summand of the output gradient (>= n rows; the stack reads dz + dz_add)."""
+    dz_add: optional second summand of the output gradient (>= n rows; the stack reads dz + dz_add).
+    tail_sum = (acc [128] or [1,128] f32, from_row): the column sums of dx[from_row:] are ADDED into acc (the gradient of
+    sst_stack_forward's fill row)."""
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
@@ -1060,13 +1062,19 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
         n_out = dx.shape[0]
     else:
         dx = dz.new_empty((n,) + tuple(dz.shape[1:]))
+    tsum, tfrom = None, 0
+    if tail_sum is not None:
+        tsum, tfrom = tail_sum
+        _check_input(tsum, "tail_sum", torch.float32)
+        if tsum.numel() != dz.shape[1] or not 0 <= int(tfrom) <= n:
+            raise RuntimeError("sst_stack_backward: tail_sum needs one accumulator per channel and 0 <= from_row <= n")
     if dz_add is not None:
         _check_input(dz_add, "dz_add", torch.float32)
         if dz_add.shape[0] < n or dz_add.shape[1:] != dz.shape[1:]:
             raise RuntimeError("sst_stack_backward: dz_add must hold at least n rows of dz's width")
     check(lib.geomae_sst_stack_backward(_ptr(dz), _ptr(dz_add), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        _ptr(rows), n_out, int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
+                                        _ptr(rows), n_out, _ptr(tsum), int(tfrom), int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
                                         _stream_of(stream)),
           "geomae_sst_stack_backward")
     # `scratch` must outlive the kernels: a caller that runs the stack on a stream of its own keeps it until the join

@@ -560,18 +560,25 @@ class MultiMAESSTSPChoose(nn.Module):
         n = n_keep + n_mask
         ops.mark("heads_done")
         sb_.wait_stream(cur)
+        # the masked rows of both decoders' input gradients sum into the mask-token gradient: each stack's last data
+        # kernel adds its rows' column sums (tail_sum), nobody materialises or reduces dxa + dxb
+        if self.mask_token.grad is None:
+            self.mask_token.grad = torch.zeros_like(self.mask_token)
+        mt = (self.mask_token.grad, n_keep)
         if side is None:
-            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_)
-            dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen)
+            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_, tail_sum=mt)
+            dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, tail_sum=mt)
         else:
             # each stack's last kernel, the first layer's weight-gradient contraction (~50 us at decoder size, read
             # only by the optimizer), runs on the side stream instead of closing the decoder backward: it overlaps
             # the encoder backward, whose launches leave most CUs idle
-            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_, defer_last=True)
+            dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_, defer_last=True,
+                                                 tail_sum=mt)
             side.wait_stream(sb_)
             with torch.cuda.stream(side):
                 ops.flush_weight_grad()
-            dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, defer_last=True)
+            dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, defer_last=True,
+                                                 tail_sum=mt)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 ops.flush_weight_grad()
@@ -580,27 +587,16 @@ class MultiMAESSTSPChoose(nn.Module):
             del keep_a
         cur.wait_stream(sb_)
         ops.mark("dec_bwd_done")
-        # the token gradient is dxa + dxb: its kept rows are summed by the encoder backward's first kernel (dz_add), its
-        # masked rows reduce into the mask-token gradient
+        # the token gradient is dxa + dxb: its kept rows are summed by the encoder backward's first kernel (dz_add)
         del keep_b
-        if self.mask_token.grad is None:
-            self.mask_token.grad = torch.zeros_like(self.mask_token)
-        if side is None:
-            self.mask_token.grad.add_((dxa[n_keep:] + dxb[n_keep:]).sum(dim=0, keepdim=True))
-        else:                       # nobody reads the mask-token gradient before the optimizer: reduce it off the main stream
-            side.wait_stream(cur)
-            dxa.record_stream(side)
-            dxb.record_stream(side)
-            with torch.cuda.stream(side):
-                self.mask_token.grad.add_((dxa[n_keep:] + dxb[n_keep:]).sum(dim=0, keepdim=True))
         if on_early_grads is not None:
             if side is None:
                 on_early_grads()
             else:
                 # every gradient of the heads, the decoders and the mask token is complete in the geometry stream's
-                # order (it waited for both decoder backwards before the two flushes and carries the heads' contraction
-                # and the mask-token reduction itself): the collective is ordered behind THAT stream, the main stream
-                # never waits for it
+                # order (it waited for both decoder backwards, whose last kernels also add up the mask-token gradient,
+                # before the two flushes, and carries the heads' contraction itself): the collective is ordered behind
+                # THAT stream, the main stream never waits for it
                 with torch.cuda.stream(side):
                     on_early_grads()
         g_enc = P.grad_array(self._stack_base["enc"], n_enc)

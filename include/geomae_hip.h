@@ -395,7 +395,10 @@ int geomae_sst_stack_backward(const float* dz, const float* dz_add /*or NULL*/, 
                               const GeomaeSstStackLayout* layouts, const float* pos_table, int32_t num_heads,
                               int32_t max_window_tokens, const void* saved, void* scratch, int64_t scratch_bytes,
                               float* dx_out, const int32_t* output_rows /*or NULL*/, int32_t num_output_rows,
-                              int32_t defer_last_weight_grad, void* profiler /*or NULL*/, geomaeStream_t stream);
+                              float* tail_sum /*or NULL*/, int32_t tail_from, int32_t defer_last_weight_grad,
+                              void* profiler /*or NULL*/, geomaeStream_t stream);
+/* tail_sum != NULL: the column sums of the input-gradient rows >= tail_from are ADDED into tail_sum[128] (atomics) by
+ * the stack's last data kernel: the gradient of the fill row of geomae_sst_stack_forward (the decoders' mask token). */
 /* defer_last_weight_grad != 0: the weight-gradient contraction of the stack's FIRST layer (the last kernel of the
  * backward, read only by the optimizer) is recorded instead of launched; geomae_flush_weight_grad(other_stream)
  * launches it there (order other_stream behind `stream` first), beside whatever the caller enqueues next on `stream`. */

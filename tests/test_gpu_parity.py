@@ -856,6 +856,13 @@ def test_stack_row_gather_and_gradient_scatter_equal_indexing(dev):
     da = ops.sst_stack_backward(dz_long, n, w, g, layouts, bb.pos_table, bb.nhead[0], sb, dz_add=extra)
     db = ops.sst_stack_backward((dz + extra[:n]).contiguous(), n, w, g, layouts, bb.pos_table, bb.nhead[0], sb)
     assert da.shape == (n, 128) and torch.equal(da, db)
+    # tail_sum: column sums of dx[from_row:] are added into an accumulator (the mask-token gradient)
+    for from_row in (0, n // 3 + 7, n):
+        acc = torch.full((1, 128), 0.5, device=dev)
+        dt = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], sb, tail_sum=(acc, from_row))
+        assert torch.equal(dt, dx)
+        want = 0.5 + dx[from_row:].double().sum(0)
+        assert torch.allclose(acc[0].double(), want, rtol=1e-4, atol=1e-4 * float(dx.abs().max())), from_row
 
 
 
