@@ -44,13 +44,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) aux[dst + e] = flat[src + e];
         return;
     }
-    const int64_t K = tr ? rows : cols;
-    for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t r = e / K;
-        const int p = (int)(e - r * K);
-        const int k = kperm(p);
-        const float v = tr ? flat[src + (int64_t)k * cols + r] : flat[src + r * cols + k];
-        packed[dst + e] = (bf16_t)f2bf_bits(v);
+    // 32-bit index arithmetic (a matrix has at most 384 x 256 elements): the 64-bit division per element was most of
+    // this kernel's 20 us, which it spends beside the next step's first (latency-bound) kernels
+    const int K = (int)(tr ? rows : cols), C = (int)cols, T = (int)total;
+    const float* __restrict__ w = flat + src;
+    bf16_t* __restrict__ out = packed + dst;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < T; e += gridDim.x * 256) {
+        const int r = e / K;
+        const int k = kperm(e - r * K);
+        const float v = tr ? w[k * C + r] : w[r * C + k];
+        out[e] = (bf16_t)f2bf_bits(v);
     }
 }
 
@@ -653,7 +656,7 @@ extern "C" int geomae_debug_read_stamps(unsigned long long* host, int clear) {
 extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc,
                                    int64_t max_elems, void* packed_bf16, float* aux_f32, hipStream_t stream) {
     if (num_desc <= 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE(desc && packed_bf16 && max_elems > 0, "pack_weights: bad argument");
+    GEOMAE_REQUIRE(desc && packed_bf16 && max_elems > 0 && max_elems < (1ll << 30), "pack_weights: bad argument");
     int gx = (int)((max_elems + 255) / 256);
     if (gx > 128) gx = 128;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, num_desc), dim3(256), 0, stream, flat_params, desc,
