@@ -74,6 +74,31 @@ class GeomaeSstLayerGrads(ctypes.Structure):
                                         "ln2_w", "ln2_b")]
 
 
+class GeomaePretrainConfig(ctypes.Structure):
+    _fields_ = [("batch_size", c_int32), ("num_features", c_int32), ("targets", GeomaeTargetConfig),
+                ("window", GeomaeWindowConfig), ("num_heads", c_int32), ("encoder_layers", c_int32),
+                ("decoder_layers", c_int32), ("keep_fraction", c_double), ("mask_seed", c_uint64),
+                ("loss_weights", c_float * 6), ("vfe_voxel_size", c_float * 3), ("vfe_center_offset", c_float * 3),
+                ("bn_eps", c_float), ("bn_momentum", c_float), ("beta1", c_float), ("beta2", c_float),
+                ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32)]
+
+
+class GeomaePretrainModel(ctypes.Structure):
+    _fields_ = ([("layers", c_void_p), ("layer_grads", c_void_p), ("head_grads", GeomaeHeadGrads),
+                 ("head_w_packed", c_void_p), ("head_bias", c_void_p), ("pos_table", c_void_p), ("mask_token", c_void_p),
+                 ("mask_token_grad", c_void_p), ("pack_desc", c_void_p), ("num_pack_desc", c_int32),
+                 ("pack_max_elems", c_int64), ("packed", c_void_p), ("pack_aux", c_void_p),
+                 ("vfe_w0", c_void_p), ("vfe_w1", c_void_p), ("vfe_dw0", c_void_p), ("vfe_dw1", c_void_p),
+                 ("bn_gamma", c_void_p * 2), ("bn_beta", c_void_p * 2), ("bn_dgamma", c_void_p * 2),
+                 ("bn_dbeta", c_void_p * 2), ("bn_running_mean", c_void_p * 2), ("bn_running_var", c_void_p * 2),
+                 ("bn_num_batches", c_void_p * 2), ("params", c_void_p), ("grads", c_void_p), ("exp_avg", c_void_p),
+                 ("exp_avg_sq", c_void_p), ("num_params", c_int64), ("no_decay_prefix", c_int64),
+                 ("no_decay2_start", c_int64), ("no_decay2_count", c_int64), ("bn_sync_moments0", c_void_p),
+                 ("bn_sync_moments1", c_void_p), ("bn_sync_bsums1", c_void_p), ("bn_sync_bsums0", c_void_p)])
+
+
+PRETRAIN_HOOK = ctypes.CFUNCTYPE(None, c_void_p, c_int32, c_void_p)
+
 F3 = POINTER(c_float)
 P = c_void_p
 # name -> (restype, argtypes).  Every symbol declared in include/geomae_hip.h is listed here;
@@ -156,6 +181,23 @@ SIGNATURES = {
                                                  P, c_int32, P, c_int32, c_int32, P, P]),
     "geomae_flush_weight_grad": (ctypes.c_int, [P]),
     "geomae_vfe_weight_grad1": (ctypes.c_int, [P, P, c_int64, P, P]),
+    "geomae_bn_param_grad_add": (ctypes.c_int, [P, c_int32, P, P, P]),
+    "geomae_pretrain_workspace_bytes": (c_int64, [POINTER(GeomaePretrainConfig), c_int64, c_int32]),
+    "geomae_pretrain_create": (c_void_p, [POINTER(GeomaePretrainConfig), POINTER(GeomaePretrainModel), P, c_int64, c_int64,
+                                          c_int32, POINTER(c_void_p)]),
+    "geomae_pretrain_destroy": (None, [c_void_p]),
+    "geomae_pretrain_set_hook": (ctypes.c_int, [c_void_p, PRETRAIN_HOOK, c_void_p]),
+    "geomae_pretrain_set_profiler": (ctypes.c_int, [c_void_p, c_void_p]),
+    "geomae_pretrain_set_phase_timing": (ctypes.c_int, [c_void_p, c_int32]),
+    "geomae_pretrain_phase_times": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
+    "geomae_pretrain_invalidate_packed": (ctypes.c_int, [c_void_p]),
+    "geomae_pretrain_submit": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), P]),
+    "geomae_pretrain_step": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_float, c_float, c_int32, P]),
+    "geomae_pretrain_optimizer": (ctypes.c_int, [c_void_p, c_float, c_float, P]),
+    "geomae_pretrain_result_offset": (c_int64, [c_void_p, c_int32]),
+    "geomae_pretrain_host_times": (ctypes.c_int, [c_void_p, POINTER(c_double)]),
+    "geomae_pretrain_set_optimizer_steps": (ctypes.c_int, [c_void_p, c_int64]),
+    "geomae_pretrain_last_sizes": (ctypes.c_int, [c_void_p, POINTER(c_int64)]),
     "geomae_profiler_create": (c_void_p, [c_int32, c_int32]),
     "geomae_profiler_read": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
     "geomae_profiler_destroy": (None, [c_void_p]),

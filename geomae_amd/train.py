@@ -297,11 +297,56 @@ class Trainer:
         self.iter = 0
         self.fused_optimizer = self.flat.flat.is_cuda
         self.explicit_schedule = self.flat.flat.is_cuda
+        # the whole step as one C call (geomae_amd/engine.py, csrc/engine.hip); False = the Python explicit schedule
+        # (same kernels, same order: kept as the A/B reference of the engine)
+        self.use_engine = self.flat.flat.is_cuda
+        self.engine = None
+
+    def _engine_step(self, points, next_points, world):
+        from .detector import MultiSubVoxelDynamicVoxelNetSSL as Det
+        from .engine import PretrainEngine
+        eng = self.engine
+        if eng is None:
+            eng = self.engine = PretrainEngine(self.model, self.flat, self.opt, self.grad_clip.get("max_norm", 0.0), world)
+        if not getattr(self, "_grads_clean", False):
+            self.flat.zero_grad()
+        if self.lr_schedule is not None:
+            self.opt.lr = self.lr_schedule.lr_at(self.iter)
+        if getattr(self, "_engine_flat_version", None) not in (None, self.flat.flat._version):
+            eng.invalidate_packed()                    # someone wrote the flat parameter buffer since the last step
+        works = []
+        if world > 1:
+            def segment_ready(i):
+                a, b, _ = self.flat.segments[i]
+                works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+            eng.on_segment = segment_ready if len(self.flat.segments) > 2 else None
+        losses, gnorm = eng.step(points, next_points, self.opt.lr, run_optimizer=(world == 1))
+        if world > 1:
+            done = {i for i, _ in works}
+            for i, (a, b, _) in enumerate(self.flat.segments):
+                if i not in done:
+                    works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+            for _, w in works:
+                w.wait()
+            tap = getattr(self, "on_reduced_grad", None)
+            if tap is not None:
+                tap(self.flat.grad)
+            gnorm = eng.optimizer_step(self.opt.lr)
+        self._grads_clean = True
+        self._engine_flat_version = self.flat.flat._version
+        self.opt.step_count = eng._opt_steps
+        self.iter += 1
+        return {k: losses[i] for i, k in enumerate(Det.LOSS_KEYS)}, gnorm
 
     def train_step(self, points, next_points=None, **kw):
         """next_points: the batch of the FOLLOWING step (the same list object must be passed as `points`
         then); its voxelization / pillar sort is enqueued ahead of this step so that its count readback is
         off the critical path (detector.prefetch)."""
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if self.use_engine and self.explicit_schedule and not kw and hasattr(self.model, "train_step_explicit"):
+            from . import engine as _engine
+            if _engine.supported(self.model):
+                return self._engine_step(points, next_points, world)
         if not getattr(self, "_grads_clean", False):
             self.flat.zero_grad()
         self._grads_clean = False
@@ -400,5 +445,8 @@ class Trainer:
         self.flat.check_storage()
         if ck.get("optimizer"):
             self.opt.load_state_dict(ck["optimizer"])
+        if self.engine is not None:                      # the parameters and Adam's counter changed under the engine
+            self.engine.invalidate_packed()
+            self.engine.set_optimizer_steps(self.opt.step_count)
         self.iter = int(ck.get("meta", {}).get("iter", 0))
         return ck.get("meta", {})

@@ -507,6 +507,109 @@ int geomae_adamw_step(float* params, float* grads, float* exp_avg, float* exp_av
                       float* grad_norm_out, int64_t no_decay2_start, int64_t no_decay2_count, double* zero_after,
                       geomaeStream_t stream);
 
+/* BatchNorm parameter gradients from the LOCAL backward sums of the fused VFE (naiveSyncBN1d at world > 1: they are
+ * added before the sums are all-reduced for the input gradient): d_beta[c] += bsums[c], d_gamma[c] += bsums[C + c]. */
+int geomae_bn_param_grad_add(const double* bsums /*[2C]*/, int32_t channels, float* d_beta, float* d_gamma,
+                             geomaeStream_t stream);
+
+/* ------------------------------------------------------------------ A24 the whole pre-training step in ONE call
+ * replaces the loop body of mmcv's EpochBasedRunner for this detector: MultiSubVoxelDynamicVoxelNetSSL.forward_train
+ * (ssl.py:126-242) + backward + OptimizerHook (clip 10, AdamW; configs/_base_/schedules/cosine_2x.py:1-17).  The
+ * per-op entry points above stay the operator-level boundary; the engine is the step-level one: the host enqueues
+ * ~140 launches on three HIP streams per step, and doing that from Python cost 1.5 ms of a 2.4 ms step (the step was
+ * host-bound on any slower CPU).  geomae_pretrain_step issues the same kernels in the same order from C.
+ *
+ * Memory: ONE caller-allocated workspace (geomae_pretrain_workspace_bytes for the largest batch: max_points points,
+ * max_pillars non-empty pillars), carved by the engine per step with the actual sizes; a step that does not fit
+ * returns GEOMAE_ERR_WORKSPACE before anything is enqueued.  Host-side state (events, pinned staging buffers for the
+ * batch offsets and the per-sample pillar counts) belongs to the engine object.
+ * Schedule: stage 1 of batch k+1 (concatenation, voxelize x3, pillar sort, count readback, VFE front, random mask) is
+ * enqueued inside step k (`next_*` arguments); the only host wait of a step is that readback's event. */
+typedef struct GeomaePretrainConfig {
+    int32_t batch_size;              /* frames per step                                                     */
+    int32_t num_features;            /* columns of a point row (5)                                          */
+    GeomaeTargetConfig targets;      /* grid (z,y,x), sub-voxel ratios, the three voxel sizes, range        */
+    GeomaeWindowConfig window;
+    int32_t num_heads;               /* 8                                                                   */
+    int32_t encoder_layers;          /* 12 (= 2 x encoder_num_blocks)                                       */
+    int32_t decoder_layers;          /* 4 per decoder stack                                                 */
+    double keep_fraction;            /* 1 - random_mask_ratio                                               */
+    uint64_t mask_seed;              /* batch i draws its mask with seed (mask_seed << 32) + i + 1          */
+    float loss_weights[6];           /* curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med */
+    float vfe_voxel_size[3];         /* DynamicScatterVFE (vx, vy, vz)                                      */
+    float vfe_center_offset[3];      /* v / 2 + range_min                                                   */
+    float bn_eps, bn_momentum;
+    float beta1, beta2, adam_eps, weight_decay, max_grad_norm;
+    int32_t world_size;              /* > 1: naiveSyncBN1d statistics + gradient exchange through `hook`    */
+} GeomaePretrainConfig;
+
+/* Device pointers of the model (parameters and gradients are views of the flat buffers; all of them must stay where
+ * they are for the life of the engine).  layers / layer_grads: HOST arrays, order encoder | centroid decoder |
+ * density decoder.  bn_sync_*: caller-owned communication buffers of naiveSyncBN1d (world_size > 1 only). */
+typedef struct GeomaePretrainModel {
+    const GeomaeSstLayerWeights* layers;
+    const GeomaeSstLayerGrads* layer_grads;
+    GeomaeHeadGrads head_grads;
+    const void* head_w_packed;  const float* head_bias;
+    const float* pos_table;
+    const float* mask_token;    float* mask_token_grad;
+    const int64_t* pack_desc;   int32_t num_pack_desc;   int64_t pack_max_elems;   void* packed;   float* pack_aux;
+    const float *vfe_w0, *vfe_w1;   float *vfe_dw0, *vfe_dw1;
+    const float *bn_gamma[2], *bn_beta[2];   float *bn_dgamma[2], *bn_dbeta[2];
+    float *bn_running_mean[2], *bn_running_var[2];   int64_t* bn_num_batches[2];
+    float *params, *grads, *exp_avg, *exp_avg_sq;   int64_t num_params;
+    int64_t no_decay_prefix, no_decay2_start, no_decay2_count;
+    float *bn_sync_moments0 /*[128]*/, *bn_sync_moments1 /*[256]*/;
+    double *bn_sync_bsums1 /*[256]*/, *bn_sync_bsums0 /*[128]*/;
+} GeomaePretrainModel;
+
+/* hook(user, what, stream): called from inside geomae_pretrain_step at world_size > 1, with the stream behind which
+ * the named data is complete.  BN_*: all-reduce (sum) the matching bn_sync_* buffer on `stream` before returning (the
+ * engine divides by world_size itself); GRADS_*: the gradient segment is complete in `stream`'s order -- start its
+ * exchange (the engine does not wait for it; the caller does, before geomae_pretrain_optimizer). */
+enum { GEOMAE_HOOK_BN_FWD0 = 0, GEOMAE_HOOK_BN_FWD1 = 1, GEOMAE_HOOK_BN_BWD1 = 2, GEOMAE_HOOK_BN_BWD0 = 3,
+       GEOMAE_HOOK_GRADS_EARLY = 4, GEOMAE_HOOK_GRADS_ENCODER = 5 };
+typedef void (*GeomaePretrainHook)(void* user, int32_t what, geomaeStream_t stream);
+
+int64_t geomae_pretrain_workspace_bytes(const GeomaePretrainConfig* cfg, int64_t max_points, int32_t max_pillars);
+/* side_streams[2]: the geometry stream and the decoder-B stream (created by the caller, first used in this order) */
+void* geomae_pretrain_create(const GeomaePretrainConfig* cfg, const GeomaePretrainModel* model, void* workspace,
+                             int64_t workspace_bytes, int64_t max_points, int32_t max_pillars,
+                             const geomaeStream_t* side_streams);
+void geomae_pretrain_destroy(void* engine);
+int geomae_pretrain_set_hook(void* engine, GeomaePretrainHook hook, void* user);
+/* kernel profiler of the stack calls (geomae_profiler_create) or NULL; phase timing on/off: HIP events with timing at
+ * the phase boundaries of the main stream (VFE forward | wait for the window layouts | encoder | decoders | heads+loss |
+ * decoders backward | encoder backward | VFE backward | clip+AdamW); geomae_pretrain_phase_times waits for the last
+ * step's final event and returns the phase durations in ms (up to 9) */
+int geomae_pretrain_set_profiler(void* engine, void* profiler);
+int geomae_pretrain_set_phase_timing(void* engine, int32_t enabled);
+int32_t geomae_pretrain_phase_times(void* engine, float* ms_out /*host*/, int32_t capacity);
+/* the bf16 MFMA-layout weight copies are re-packed by the engine after its own optimizer step; call this after
+ * anything else wrote the parameters (load_state_dict ...) */
+int geomae_pretrain_invalidate_packed(void* engine);
+/* stage 1 of a batch, on `stream`, without a step to hide behind (the first batch of a run).  frame_points: HOST
+ * array of batch_size DEVICE pointers ([n_b, num_features] fp32 each), frame_sizes: HOST array of row counts. */
+int geomae_pretrain_submit(void* engine, const float* const* frame_points, const int64_t* frame_sizes,
+                           geomaeStream_t stream);
+/* one training step on the batch submitted last (by geomae_pretrain_submit or as the previous step's next_*):
+ * forward, backward and -- run_optimizer != 0 -- clip + AdamW with learning rate lr and gradients scaled by
+ * grad_scale (1 / world_size).  next_frame_points / next_frame_sizes (or NULL): the following batch.
+ * Byte offsets of the step's results inside the workspace: geomae_pretrain_result_offset. */
+int geomae_pretrain_step(void* engine, const float* const* next_frame_points, const int64_t* next_frame_sizes,
+                         float lr, float grad_scale, int32_t run_optimizer, geomaeStream_t stream);
+int geomae_pretrain_optimizer(void* engine, float lr, float grad_scale, geomaeStream_t stream);
+/* what: 0 = losses of the LAST step ([6] f32; one of 4 ring slots: valid until three more steps were enqueued),
+ * 1 = pre-clip gradient norm ([1] f32), 2 = ids_keep, 3 = ids_mask of the last step ([n_keep] / [n_mask] int32) */
+int64_t geomae_pretrain_result_offset(void* engine, int32_t what);
+/* measurement: cumulative host wall time (seconds) spent inside geomae_pretrain_step calls, the part of it spent
+ * waiting for the pillar-count readback, and the number of steps: out[0..2] */
+int geomae_pretrain_host_times(void* engine, double* out /*host [3]*/);
+/* AdamW's step counter (bias correction): set it when optimizer state is loaded from a checkpoint */
+int geomae_pretrain_set_optimizer_steps(void* engine, int64_t steps_taken);
+/* host-side sizes of the last step: out[0..4] = N, V, n_keep, n_mask, optimizer steps taken */
+int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [5]*/);
+
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
 enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_FWD = 3, GEOMAE_KERNEL_FFN_BWD = 4,

@@ -1,0 +1,113 @@
+"""The C-level step engine (csrc/engine.hip, geomae_pretrain_step) against the Python explicit schedule it replaces:
+same kernels in the same order, so losses and the gradient buffer must agree to the float-atomics noise floor.
+The schedule's math is pinned to the reference by tests/test_gpu_parity.py (through the Python path)."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(enc=2, dec=1):
+    import geomae_amd
+    from geomae_amd.configs import mae_sst_model
+    torch.manual_seed(3)
+    cfg = mae_sst_model(encoder_num_blocks=enc, decoder_num_blocks=dec)
+    cfg["backbone"]["compute_dtype"] = "bf16"
+    return geomae_amd.build_model(cfg).cuda().train()
+
+
+def _batches(k, B=2, base=500):
+    from geomae_amd import synth
+    return [[torch.as_tensor(synth.lidar_frame(base + 10 * i + b, beams=16, n_az=500 + 30 * b), device="cuda")
+             for b in range(B)] for i in range(k)]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp(min=1e-30))
+
+
+def test_engine_gradients_match_python_explicit_schedule():
+    from geomae_amd.train import Trainer
+    from geomae_amd.engine import PretrainEngine
+    m_py = _build()
+    m_c = copy.deepcopy(m_py)
+    tr_py, tr_c = Trainer(m_py), Trainer(m_c)
+    pts = _batches(1)[0]
+    # Python explicit schedule: gradients accumulate into the flat buffer (mask seed (0 << 32) + 1)
+    tr_py.flat.zero_grad()
+    losses_py = m_py.train_step_explicit(pts)
+    torch.cuda.synchronize()
+    g_py = tr_py.flat.grad.clone()
+    # the engine, without its optimizer pass (same seed sequence: first batch drawn = seed 1)
+    eng = PretrainEngine(m_c, tr_c.flat, tr_c.opt, 10.0)
+    tr_c.flat.zero_grad()
+    losses_c, _ = eng.step(pts, None, 1e-5, run_optimizer=False)
+    torch.cuda.synchronize()
+    g_c = tr_c.flat.grad.clone()
+    ik, im = eng.last_ids()
+    s = eng.last_sizes()
+    assert s["n_keep"] + s["n_mask"] == s["V"] and ik.numel() == s["n_keep"] and im.numel() == s["n_mask"]
+    assert torch.equal(torch.sort(torch.cat([ik, im])).values, torch.arange(s["V"], dtype=torch.int32, device="cuda"))
+    lp = torch.stack([losses_py[k] for k in m_py.LOSS_KEYS])
+    # run-to-run noise of EITHER path (fp64 atomics order in the BatchNorm sums -> one-ulp scale differences -> bf16
+    # rounding flips): losses 2.3e-4 relative, per-parameter gradients <= 8e-4 (tools/engine_noise.py); bound = 6x that
+    assert torch.allclose(losses_c, lp, rtol=1.5e-3, atol=1e-6), (losses_c, lp)
+    worst = (0.0, "")
+    for name, off, p in zip(tr_py.flat.names, tr_py.flat.offsets, tr_py.flat.params):
+        a, b = g_c[off:off + p.numel()], g_py[off:off + p.numel()]
+        worst = max(worst, (_rel(a, b), name))
+    print(f"largest engine-vs-python gradient difference: {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < 5e-3, worst
+    # BatchNorm running statistics moved identically
+    for (k, a), (_, b) in zip(m_c.voxel_encoder.named_buffers(), m_py.voxel_encoder.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
+
+
+def test_engine_training_steps_match_python_trainer():
+    from geomae_amd.train import Trainer
+    m_py = _build()
+    m_c = copy.deepcopy(m_py)
+    tr_py, tr_c = Trainer(m_py), Trainer(m_c)
+    tr_py.use_engine = False
+    assert tr_c.use_engine
+    pool = _batches(3)
+    for i in range(4):
+        l_py, g_py = tr_py.train_step(pool[i % 3], next_points=pool[(i + 1) % 3])
+        l_c, g_c = tr_c.train_step(pool[i % 3], next_points=pool[(i + 1) % 3])
+        a = torch.stack([l_c[k] for k in m_py.LOSS_KEYS]).clone()
+        b = torch.stack([l_py[k] for k in m_py.LOSS_KEYS])
+        assert torch.allclose(a, b, rtol=2e-3, atol=1e-5), (i, a, b)
+        assert abs(float(g_c) - float(g_py)) <= 2e-3 * float(g_py), (i, float(g_c), float(g_py))
+    assert tr_c.engine is not None and tr_c.engine.last_sizes()["optimizer_steps"] == 4 and tr_c.opt.step_count == 4
+    # AdamW's first steps are sign-like (|update| ~ lr): compare against that scale
+    d = (tr_c.flat.flat - tr_py.flat.flat).abs().max()
+    assert float(d) <= 4 * 2 * 1e-5, float(d)
+    assert torch.isfinite(tr_c.flat.flat).all()
+    # the engine zeroes the gradient buffer in its AdamW pass
+    assert float(tr_c.flat.grad.abs().max()) == 0.0
+
+
+def test_engine_grows_its_workspace_and_times_phases():
+    from geomae_amd.train import Trainer
+    from geomae_amd.engine import PretrainEngine, PHASES
+    m = _build(1, 1)
+    tr = Trainer(m)
+    pool = _batches(2)
+    n = sum(p.shape[0] for p in pool[0])
+    eng = PretrainEngine(m, tr.flat, tr.opt, 10.0, max_points=n + 4096, max_pillars=64)   # far too few pillars
+    eng.set_phase_timing(True)
+    losses, gnorm = eng.step(pool[0], pool[1], 1e-5)
+    assert eng.max_pillars > 64
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses).all() and torch.isfinite(gnorm)
+    t = eng.phase_times()
+    assert list(t) == list(PHASES) and all(v > 0 for v in t.values()), t
+    losses2, _ = eng.step(pool[1], None, 1e-5)
+    torch.cuda.synchronize()
+    assert torch.isfinite(losses2).all()
+    host_s, blocked_s, steps = eng.host_times()
+    assert steps >= 2 and 0 <= blocked_s <= host_s
+    with pytest.raises(RuntimeError, match="CUDA float32"):
+        eng.step([p.double() for p in pool[0]], None, 1e-5)
