@@ -45,18 +45,86 @@ def cpu_baseline(seed=1000):
                 sample=f"{n} x (1 single-sweep frame, {frame.shape[0]} pts, fwd+bwd, torch-CPU fp32)")
 
 
+WORKLOADS = {
+    # name: (config index in BASELINE.json, sweeps, lidar_frame kwargs, model geometry kwargs)
+    "nuscenes1": (1, 1, {}, {}),
+    "nuscenes10": (2, 10, {}, {}),
+    # Waymo-like geometry of configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:8-10 (no GeoMAE Waymo config
+    # exists in the reference: synthesised): 64 beams, ~180 k points per frame
+    "waymo": (3, 1, dict(beams=64, n_az=5300, pc_range=(-74.88, -74.88, -2.0, 74.88, 74.88, 4.0), elev=(-17.6, 2.4),
+                         n_cyl=90, max_range=110.0),
+              dict(voxel_size=(0.32, 0.32, 6), sub_voxel_size_low=(0.08, 0.08, 0.75), sub_voxel_size_med=(0.16, 0.16, 1.5),
+                   point_cloud_range=(-74.88, -74.88, -2.0, 74.88, 74.88, 4.0), grid_size=(1, 468, 468))),
+}
+
+
+def hbm_kernels(model, pts, B, torch, ops):
+    """HBM GB/s of the scatter-side kernels (north_star: 'rocprof HBM GB/s on the scatter'): each op timed alone with
+    HIP events on the launch stream (20 repetitions), against its ALGORITHMIC bytes (SURVEY 8(d) / DESIGN section 3)."""
+    def timed(fn, reps=20):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / reps
+    out = {}
+    with torch.no_grad():
+        voxels, top, med, low = model.voxelize_all(pts)
+        N = voxels.shape[0]
+        boffs = torch.tensor([0] + list(np.cumsum([p.shape[0] for p in pts])), dtype=torch.int32, device=voxels.device)
+        gz, gy, gx = model.grid_size
+        cells = B * gz * gy * gx
+        seg = ops.pillar_segment(top, B, model.grid_size)
+        V = seg.V
+        ve = model.voxel_encoder
+        prepared = ve.prepare_points(voxels, seg)
+        ik, im, token_row, counts = ops.random_mask(seg, 1 - model.random_mask_ratio, 1)
+        M = int(im.numel())
+
+        def vfe_fwd():
+            ve.forward_explicit(voxels, seg, prepared=prepared)
+        cases = {
+            "voxelize_kernel": (lambda: ops.voxelize_batch3(voxels, boffs, B, model.voxel_size, model.sub_voxel_size_med,
+                                                            model.sub_voxel_size_low, model.point_cloud_range),
+                                N * (20 + 48), "N*(20 B read + 3*16 B written)"),
+            "pillar_segment (hist+scan x3+place)": (lambda: ops.pillar_segment(top, B, model.grid_size),
+                                                    N * 24 + cells * 8, "N*24 B + cells*8 B"),
+            "vfe_prepare + vfe forward sweeps": (lambda: (ve.prepare_points(voxels, seg), vfe_fwd()),
+                                                 N * 24 + V * 512, "N*(20+4) B + V*128*4 B (SURVEY 8(d))"),
+            "geometry_targets (centroid/occ/normal)": (lambda: ops.geometry_targets(voxels, seg, med, low, model._tcfg, token_row,
+                                                                                    counts, n_rows=M),
+                                                       N * 56 + M * 1900, "N*56 B + M*1.9 KB"),
+        }
+        for name, (fn, nbytes, formula) in cases.items():
+            ms = timed(fn)
+            gbs = nbytes / (ms * 1e-3) / 1e9
+            out[name] = {"bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 5),
+                         "avg_ms": round(ms, 5), "algorithmic_bytes": int(nbytes), "bytes_formula": formula}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames-per-gpu", type=int, default=4)
-    ap.add_argument("--sweeps", type=int, default=1)
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS))
+    ap.add_argument("--sweeps", type=int, default=1, help="(older spelling) 1 = --workload nuscenes1, 10 = nuscenes10")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-engine", action="store_true", help="Python explicit schedule instead of the C step engine (A/B)")
     ap.add_argument("--profile-every", type=int, default=4,
                     help="instrument the dominant kernel's launches with HIP events in every N-th timed step")
     args = ap.parse_args()
+    workload = args.workload or ("nuscenes10" if args.sweeps == 10 else "nuscenes1")
+    cfg_index, sweeps, frame_kw, geom_kw = WORKLOADS[workload]
+    if args.workload is None and args.sweeps not in (1, 10):
+        sweeps = args.sweeps
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -86,14 +154,18 @@ def main():
     _lib.load()                                   # no fallback: fail here if the HIP library is missing
 
     torch.manual_seed(1234)                       # identical initial weights on every rank (as DDP broadcast)
-    cfg = mae_sst_model()
+    cfg = mae_sst_model(**geom_kw)
+    if geom_kw:
+        cfg["backbone"]["output_shape"] = list(geom_kw["grid_size"][1:])
     cfg["backbone"]["compute_dtype"] = args.dtype
     model = geomae_amd.build_model(cfg).to(dev).train()
     trainer = Trainer(model)
+    if args.no_engine:
+        trainer.use_engine = False
     B = args.frames_per_gpu
     pool = []
     for i in range(4):                            # 4 distinct batches per rank, cycled; resident in HBM
-        pool.append([torch.as_tensor(synth.lidar_frame(10_000 * (rank + 1) + i * B + b, sweeps=args.sweeps), device=dev)
+        pool.append([torch.as_tensor(synth.lidar_frame(10_000 * (rank + 1) + i * B + b, sweeps=sweeps, **frame_kw), device=dev)
                      for b in range(B)])
     n_pts = float(np.mean([sum(p.shape[0] for p in batch) for batch in pool]))
 
@@ -105,7 +177,7 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # (the stand-alone dw_kernel launches are not in the list: the explicit schedule defers them to the geometry stream,
+    # (the stand-alone dw_kernel launches are not in the list: the schedule defers them to the geometry stream,
     # geomae_flush_weight_grad, so the stack's event pair would bracket their recording, not their execution;
     # profiles/*kernel_stats.csv has their durations)
     TIMED = ("sst_ffn_bwd_kernel", "win_attn_bwd_kernel", "sst_ffn_fwd_kernel", "sst_qkv_bwd_kernel",
@@ -113,46 +185,71 @@ def main():
     DOMINANT = "sst_ffn_bwd_kernel"               # largest share in profiles/ (rocprofv3 --kernel-trace --stats)
     lib = _lib.load()
     import ctypes
+    eng = trainer.engine                          # None with --no-engine (or before the first step)
+
+    def set_profiler(handle):
+        ops.PROFILER = handle
+        if eng is not None:
+            eng.set_profiler(handle)
 
     def profile_on(name, launches):
-        ops.PROFILER = lib.geomae_profiler_create(ops.KERNEL_IDS[name], launches)
-        assert ops.PROFILER
+        h = lib.geomae_profiler_create(ops.KERNEL_IDS[name], launches)
+        assert h
+        return h
 
-    def profile_off():
+    def profile_off(h):
         buf = (ctypes.c_float * 4096)()
-        n = lib.geomae_profiler_read(ctypes.c_void_p(ops.PROFILER), buf, 4096)
-        lib.geomae_profiler_destroy(ctypes.c_void_p(ops.PROFILER))
-        ops.PROFILER = None
+        n = lib.geomae_profiler_read(ctypes.c_void_p(h), buf, 4096)
+        set_profiler(None)
+        lib.geomae_profiler_destroy(ctypes.c_void_p(h))
         return [float(buf[i]) for i in range(n)]
 
     # HIP events on the launch stream around every launch of the dominant kernel, inside the timed region, in every
     # `--profile-every`-th timed step (default 4): two event records per launch cost ~4 us of queue time each, 0.14 ms
     # per step when every step is instrumented, and the timed region is what `value` is computed from
-    profile_on(DOMINANT, min(4000, 20 * args.steps))
-    prof_handle, ops.PROFILER = ops.PROFILER, None
+    prof_handle = profile_on(DOMINANT, min(4000, 20 * args.steps))
+    # one timing event per step on the main stream (~4 us of queue time per step): the per-step distribution
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    h0 = eng.host_times() if eng is not None else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    step_events[0].record()
     for i in range(args.steps):
-        ops.PROFILER = prof_handle if i % max(1, args.profile_every) == 0 else None
+        set_profiler(prof_handle if i % max(1, args.profile_every) == 0 else None)
         losses, _ = step(args.warmup + i)
-    ops.PROFILER = prof_handle
+        step_events[i + 1].record()
+    t_enq = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    set_profiler(None)
+    h1 = eng.host_times() if eng is not None else None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    durations = {DOMINANT: profile_off()}
+    per_step = np.array([step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)])
+    durations = {DOMINANT: profile_off(prof_handle)}
     for k in TIMED:                               # the other kernels: 3 extra (untimed) steps each
         if k != DOMINANT:
-            profile_on(k, 64)
+            h = profile_on(k, 64)
+            set_profiler(h)
             for i in range(3):
                 step(i)
-            durations[k] = profile_off()
+            durations[k] = profile_off(h)
+    phases = None
+    if eng is not None:                           # where the main stream's time goes: 3 instrumented (untimed) steps
+        eng.set_phase_timing(True)
+        acc = {}
+        for i in range(3):
+            step(i)
+            for k, v in eng.phase_times().items():
+                acc[k] = acc.get(k, 0.0) + v / 3
+        eng.set_phase_timing(False)
+        phases = {k: round(v, 4) for k, v in acc.items()}
     loss_val = float(sum(v.detach() for v in losses.values()))
     assert np.isfinite(loss_val), "non-finite loss"
 
@@ -191,10 +288,14 @@ def main():
         launches_step.update({"dw_kernel": 3.0, "sst_qkv_fwd_kernel": 3.0, "sst_qkv_bwd_kernel": 3.0})
         report_name = {"sst_ffn_bwd_kernel": "sst_ffn_bwd_dw_kernel"}
         peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
-        traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath))
+        # HBM bytes per launch are NOT measured in this run: they come from the stored PMC passes of tools/pmc.sh
+        # (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs) and only apply to the workload they were taken on
+        traffic, traffic_src = {}, None
+        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", cand)
+            if workload == "nuscenes1" and B == 4 and os.path.exists(tpath):
+                traffic, traffic_src = json.load(open(tpath)), "profiles/" + cand
+                break
         kern = {}
         for k in TIMED:
             d = durations.get(k) or []
@@ -203,10 +304,10 @@ def main():
                 ach = flops_step[k] / (ms_step * 1e-3) / 1e12
                 tr_b = traffic.get(report_name.get(k, k))
                 kern[k] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 5), "traffic": tr_b,
+                           "frac": round(ach / peak, 5), "traffic": tr_b, "traffic_source": traffic_src if tr_b else None,
                            "avg_launch_ms": round(float(np.mean(d)), 5), "launches_timed": len(d),
                            "ms_per_step": round(ms_step, 4)}
-                if tr_b:        # the same launch against the HBM roof (8 TB/s): measured PMC bytes / measured duration
+                if tr_b:        # the same launch against the HBM roof (8 TB/s): stored PMC bytes / measured duration
                     gbs = tr_b / (float(np.mean(d)) * 1e-3) / 1e9
                     kern[k]["hbm_view"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(gbs / 8000.0, 4)}
@@ -217,13 +318,31 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"configs[{1 if args.sweeps == 1 else 2}]: nuScenes-like {args.sweeps}-sweep GeoMAE-SST pretrain (mae_sst model "
+            "config": {"workload": f"configs[{cfg_index}]: {workload} ({sweeps}-sweep) GeoMAE-SST pretrain (mae_sst model "
                                    f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
-                       "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}"},
+                       "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
+                       "step_driver": "python-explicit" if eng is None else "geomae_pretrain_step (C engine)"},
             "loss": round(loss_val, 4),
+            # GPU-side time between the ends of consecutive steps on the main stream (HIP events), rank 0
+            "step_ms": {"p50": round(float(np.percentile(per_step, 50)), 4), "p90": round(float(np.percentile(per_step, 90)), 4),
+                        "max": round(float(per_step.max()), 4), "min": round(float(per_step.min()), 4)},
+            # host wall time to ENQUEUE the timed steps (everything but the final synchronize), per step; with the
+            # engine also the share of it spent blocked on the pillar-count readback (= how far the host runs ahead)
+            "host_ms_per_step": {"enqueue_loop": round(1e3 * t_enq / args.steps, 4)},
             "roofline": dict(kernel=report_name.get(dominant, dominant), **kern[dominant]),
             "roofline_other_kernels": {report_name.get(k, k): v for k, v in kern.items() if k != dominant},
         }
+        if h0 is not None:
+            busy = (h1[0] - h0[0]) - (h1[1] - h0[1])
+            out["host_ms_per_step"].update(inside_engine=round(1e3 * (h1[0] - h0[0]) / args.steps, 4),
+                                           blocked_on_count_readback=round(1e3 * (h1[1] - h0[1]) / args.steps, 4),
+                                           busy=round(1e3 * (t_enq - (h1[1] - h0[1])) / args.steps, 4),
+                                           engine_busy=round(1e3 * busy / args.steps, 4))
+        if phases is not None:
+            out["main_stream_phase_ms"] = phases
+            out["main_stream_phase_sum_ms"] = round(float(sum(phases.values())), 4)
+        if world == 1:          # (stand-alone op calls: at world > 1 the VFE's SyncBN collectives need every rank)
+            out["roofline_hbm_kernels"] = hbm_kernels(model, pool[0], B, torch, ops)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -312,8 +312,12 @@ class Trainer:
             self.flat.zero_grad()
         if self.lr_schedule is not None:
             self.opt.lr = self.lr_schedule.lr_at(self.iter)
-        if getattr(self, "_engine_flat_version", None) not in (None, self.flat.flat._version):
-            eng.invalidate_packed()                    # someone wrote the flat parameter buffer since the last step
+        # the engine re-packs the bf16 weight copies after its own optimizer pass; anything else that wrote a parameter
+        # since (a torch op on it or on the flat buffer: tensor version counters) invalidates them
+        packed = self.model.backbone._packed
+        versions = (self.flat.flat._version, packed._versions())
+        if getattr(self, "_engine_versions", None) not in (None, versions):
+            eng.invalidate_packed()
         works = []
         if world > 1:
             def segment_ready(i):
@@ -333,7 +337,7 @@ class Trainer:
                 tap(self.flat.grad)
             gnorm = eng.optimizer_step(self.opt.lr)
         self._grads_clean = True
-        self._engine_flat_version = self.flat.flat._version
+        self._engine_versions = versions
         self.opt.step_count = eng._opt_steps
         self.iter += 1
         return {k: losses[i] for i, k in enumerate(Det.LOSS_KEYS)}, gnorm

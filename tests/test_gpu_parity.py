@@ -468,7 +468,7 @@ def test_prepacked_weights_follow_parameter_writes(dev):
     pts = [torch.as_tensor(synth.lidar_frame(60 + i, beams=16, n_az=500), device=dev) for i in range(2)]
     tr.train_step(pts)
     pk = model.backbone._packed
-    assert pk._prepacked is not None                      # packed ahead by the trainer
+    assert tr.engine is not None or pk._prepacked is not None       # packed ahead (by the C engine / by the trainer)
     n = len(pk.layers)
     head = lambda: pk.head_w.float().abs().sum().item()
     assert head() > 0
@@ -480,10 +480,31 @@ def test_prepacked_weights_follow_parameter_writes(dev):
     assert head() != before
     with torch.no_grad():
         tr.flat.flat.zero_()                              # write through the flat buffer (views do not see a version bump)
+    zero_before = head()
     tr.train_step(pts)
     torch.cuda.synchronize()
-    # everything was zero when this step packed (the optimizer ran afterwards and the trainer packed again)
-    assert tr._prepack_flat_version is not None
+    # everything was zero when this step packed: its heads produced zero logits, i.e. the BCE terms are exactly
+    # (5 + 2) * ln 2 whatever the inputs; the optimizer ran afterwards and the weights were packed again
+    assert zero_before != 0.0
+    assert (tr._prepack_flat_version if tr.engine is None else tr._engine_versions) is not None
+
+
+@pytest.mark.parametrize("use_engine", [True, False])
+def test_stale_packed_weights_are_detected(dev, use_engine):
+    """Zero every parameter between two steps: the next step must run on the zero weights (its two occupancy losses
+    are then exactly 5 ln 2 and 2 ln 2), not on the bf16 copies packed after the previous optimizer step."""
+    import math
+    from geomae_amd.train import Trainer
+    model, _ = _build(dev, 1, 1, "bf16")
+    tr = Trainer(model)
+    tr.use_engine = use_engine
+    pts = [torch.as_tensor(synth.lidar_frame(60 + i, beams=16, n_az=500), device=dev) for i in range(2)]
+    tr.train_step(pts)
+    with torch.no_grad():
+        tr.flat.flat.zero_()
+    losses, _ = tr.train_step(pts)
+    assert abs(float(losses["loss_cls_low"]) - 5 * math.log(2)) < 1e-3, float(losses["loss_cls_low"])
+    assert abs(float(losses["loss_cls_med"]) - 2 * math.log(2)) < 1e-3, float(losses["loss_cls_med"])
 
 
 def test_trainer_prefetch_matches_plain_steps(dev):
@@ -500,7 +521,8 @@ def test_trainer_prefetch_matches_plain_steps(dev):
         lb, _ = tb.train_step(batches[k])
         for key in la:
             assert torch.allclose(la[key], lb[key], rtol=2e-3, atol=1e-5), (k, key, float(la[key]), float(lb[key]))
-    assert ta.model._prefetched is not None and ta.model._prefetched[0] is batches[0]
+    assert (ta.engine.pending is batches[0]) if ta.engine is not None else \
+        (ta.model._prefetched is not None and ta.model._prefetched[0] is batches[0])
 
 
 # ---------------------------------------------------------------------------------- N3 DynamicScatter

@@ -88,6 +88,32 @@ def _worker(rank, world, port, tmp):
         assert torch.allclose(bn.running_var, 1 + 0.01 * (var - 1), atol=1e-6)
         y.sum().backward()
         assert torch.isfinite(xin.grad).all()
+        # ---- the module against what the REFERENCE's NaiveSyncBatchNorm1d produced at world size 2
+        # (tests/golden/g_syncbn_w2.npz part 1, oracle/make_golden_syncbn.py: N_0 = 37, N_1 = 53 rows, C = 8)
+        import numpy as np
+        from geomae_amd.norm import NaiveSyncBatchNorm2d
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_syncbn_w2.npz"))
+        G = lambda k: torch.as_tensor(gold[f"r{rank}.{k}"])
+        g = torch.Generator().manual_seed(40 + rank)
+        n = (37, 53)[rank]
+        x, w = torch.randn(n, 8, generator=g) * 2.0 + 0.5, torch.randn(n, 8, generator=g)
+        for variant in ("1d", "2d"):
+            mod = (NaiveSyncBatchNorm1d if variant == "1d" else NaiveSyncBatchNorm2d)(8, eps=1e-3, momentum=0.01).train()
+            with torch.no_grad():
+                mod.weight.copy_(torch.linspace(0.5, 1.5, 8))
+                mod.bias.copy_(torch.linspace(-0.2, 0.3, 8))
+            xin = x.clone().requires_grad_(True)
+            shaped = xin if variant == "1d" else xin.t().reshape(1, 8, n, 1)         # same statistics as [n, 8]
+            y = mod(shaped)
+            y2 = y if variant == "1d" else y.reshape(8, n).t()
+            (y2 * w).sum().backward()
+            assert torch.allclose(y2, G("m_y"), rtol=1e-5, atol=1e-5), (variant, float((y2 - G("m_y")).abs().max()))
+            assert torch.allclose(xin.grad, G("m_dx"), rtol=1e-4, atol=1e-5), (variant, float((xin.grad - G("m_dx")).abs().max()))
+            assert torch.allclose(mod.weight.grad, G("m_dgamma"), rtol=1e-4, atol=1e-5), variant
+            assert torch.allclose(mod.bias.grad, G("m_dbeta"), rtol=1e-4, atol=1e-5), variant
+            assert torch.allclose(mod.running_mean, G("m_running_mean"), rtol=1e-5, atol=1e-6), variant
+            assert torch.allclose(mod.running_var, G("m_running_var"), rtol=1e-5, atol=1e-6), variant
+            assert int(mod.num_batches_tracked) == int(gold[f"r{rank}.m_num_batches_tracked"]) == 0
         torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
     finally:
         dist.destroy_process_group()
