@@ -181,6 +181,9 @@ SIGNATURES = {
                                                  P, c_int32, P, c_int32, c_int32, P, P]),
     "geomae_flush_weight_grad": (ctypes.c_int, [P]),
     "geomae_vfe_weight_grad1": (ctypes.c_int, [P, P, c_int64, P, P]),
+    "geomae_window_rank": (ctypes.c_int, [P, P, P, c_int64, P, P, P]),
+    "geomae_rows_scatter": (ctypes.c_int, [P, P, c_int64, c_int32, P, P]),
+    "geomae_rows_gather": (ctypes.c_int, [P, P, c_int64, c_int32, P, P]),
     "geomae_bn_param_grad_add": (ctypes.c_int, [P, c_int32, P, P, P]),
     "geomae_pretrain_workspace_bytes": (c_int64, [POINTER(GeomaePretrainConfig), c_int64, c_int32]),
     "geomae_pretrain_create": (c_void_p, [POINTER(GeomaePretrainConfig), POINTER(GeomaePretrainModel), P, c_int64, c_int64,

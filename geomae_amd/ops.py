@@ -158,7 +158,19 @@ class Voxelization(nn.Module):
                 f"{self.point_cloud_range}, max_num_points={self.max_num_points}, max_voxels={self.max_voxels})")
 
 
-Voxelization_with_flag = Voxelization   # constructed by the config (hard_sub_voxel_layer_*), never called on this path
+class Voxelization_with_flag(Voxelization):
+    """mmdet3d.ops.Voxelization_with_flag (ops/voxel/voxelize.py:126-244): hard voxelization that also returns
+    voxels_flag [M, max_points] bool, True for the slots that hold a point (assign_flag_to_voxel,
+    voxelization_cuda.cu:110-127, sets the slot of every kept point).  The mae_sst config constructs two of these
+    (hard_sub_voxel_layer_low / _med) and never calls them."""
+
+    def forward(self, input):
+        out = super().forward(input)
+        if not isinstance(out, tuple):
+            return out                                   # dynamic mode: coors only, as the reference
+        voxels, coors, num = out
+        slots = torch.arange(self.max_num_points, device=num.device, dtype=num.dtype)
+        return voxels, slots[None, :] < num[:, None], coors, num
 
 
 def voxelize_batch3(points, batch_offsets, batch_size, vs_top, vs_med, vs_low, coors_range):
@@ -318,6 +330,32 @@ def pillar_segment(coors, batch_size, grid_zyx, cap=None):
     check(lib.geomae_pillar_segment(_ptr(coors), n, batch_size, gz, gy, gx, _ptr(s.cell_table), _ptr(s.voxel_coors),
                                     _ptr(s.inv), _ptr(s.order), _ptr(s.seg_start), _ptr(s.sample_start),
                                     _ptr(s.num_pillars), _ptr(ws), wsb, _stream()), "geomae_pillar_segment")
+    return s
+
+
+def pillar_segment_nd(coors, batch_size, grid_zyx):
+    """pillar_segment for coors [N, 3] (z,y,x; batch_size 1) or [N, 4]: rows outside the grid are dropped (inv = -1)."""
+    _check_input(coors, "coors", torch.int32)
+    n, ndim = coors.shape
+    gz, gy, gx = [int(g) for g in grid_zyx]
+    cells = batch_size * gz * gy * gx
+    cap = max(min(n, cells), 1)
+    dev, lib = coors.device, _lib.load()
+    s = PillarSegments()
+    s.cell_table = torch.empty(cells, dtype=torch.int32, device=dev)
+    s.voxel_coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)        # always (b, z, y, x) rows
+    s.inv = torch.empty(n, dtype=torch.int32, device=dev)
+    s.order = torch.empty(n, dtype=torch.int32, device=dev)
+    s.seg_start = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+    s.sample_start = torch.empty(batch_size + 1, dtype=torch.int32, device=dev)
+    s.num_pillars = torch.empty(1, dtype=torch.int32, device=dev)
+    s.cap, s.grid, s.batch_size, s.num_points, s._host = cap, (gz, gy, gx), batch_size, n, None
+    s._pinned = s._event = None
+    wsb = lib.geomae_pillar_segment_workspace_bytes(n, batch_size, gz, gy, gx)
+    ws = torch.empty(max(wsb, 1), dtype=torch.uint8, device=dev)
+    check(lib.geomae_pillar_segment_nd(_ptr(coors), ndim, n, batch_size, gz, gy, gx, _ptr(s.cell_table), _ptr(s.voxel_coors),
+                                       _ptr(s.inv), _ptr(s.order), _ptr(s.seg_start), _ptr(s.sample_start),
+                                       _ptr(s.num_pillars), _ptr(ws), wsb, _stream()), "geomae_pillar_segment_nd")
     return s
 
 
@@ -728,6 +766,121 @@ class _WindowAttention(torch.autograd.Function):
 def window_attention(qkv_bf16, layout, num_heads):
     """softmax(q k^T / sqrt(d)) v inside every window; qkv [n, 3C] bf16 -> [n, C] bf16."""
     return _WindowAttention.apply(qkv_bf16, layout, num_heads)
+
+
+# ------------------------------------------------------------------------------------ operator-level window API
+# mmdet3d/ops/__init__.py:22-26 exports these five names; other reference modules (SSTInputLayer, SST backbones) import
+# them.  Same signatures and results as ops/sst/sst_ops.py; the index work is the pillar-segment counting sort and two
+# row-copy kernels (csrc/winops.hip) instead of torch.sort / unique / bincount / cumsum chains.
+def _window_rank(win_inds):
+    """-> (continuous ids, rank inside the window), both int64 [N], on win_inds' device."""
+    if win_inds.dim() != 1:
+        raise RuntimeError("window indices must be a 1-d tensor")
+    if not win_inds.is_cuda:
+        raise RuntimeError("win_inds must be a CUDA tensor (geomae_amd has no CPU path)")
+    n = win_inds.shape[0]
+    dev = win_inds.device
+    conti = torch.empty(n, dtype=torch.int64, device=dev)
+    inner = torch.empty(n, dtype=torch.int64, device=dev)
+    if n == 0:
+        return conti, inner
+    top = int(win_inds.max().item())                     # (the reference syncs for the same number, sst_ops.py:380)
+    if int(win_inds.min().item()) < 0 or top >= 2 ** 31 - 1:
+        raise RuntimeError("window indices must be in [0, 2^31 - 1)")
+    coors = torch.zeros((n, 3), dtype=torch.int32, device=dev)
+    coors[:, 2] = win_inds
+    seg = pillar_segment_nd(coors, 1, (1, 1, top + 1))
+    check(_lib.load().geomae_window_rank(_ptr(seg.order), _ptr(seg.inv), _ptr(seg.seg_start), n, _ptr(conti), _ptr(inner),
+                                         _stream()), "geomae_window_rank")
+    return conti, inner
+
+
+@torch.no_grad()
+def make_continuous_inds(inds):
+    """sst_ops.py:371-388: relabel ids to 0..W-1 in ascending order of the original ids."""
+    return _window_rank(inds)[0].to(inds.dtype)
+
+
+@torch.no_grad()
+def get_inner_win_inds(win_inds):
+    """sst_ops.py:271-319: for the M tokens that share a window, a permutation of 0..M-1 (the reference's order follows
+    an unstable sort, "might output different results" :280; any ranking is valid)."""
+    return _window_rank(win_inds)[1].to(win_inds.dtype)
+
+
+@torch.no_grad()
+def get_flat2win_inds(batch_win_inds, voxel_drop_lvl, drop_info, debug=True):
+    """sst_ops.py:57-96: {level: (flat2window_inds [n_l], (positions of the level's tokens,))}."""
+    out = {}
+    for dl in drop_info:
+        dl_mask = voxel_drop_lvl == dl
+        if not dl_mask.any():
+            continue
+        conti, inner = _window_rank(batch_win_inds[dl_mask].contiguous())
+        max_tokens = drop_info[dl]["max_tokens"]
+        flat2window_inds = (conti * max_tokens + inner).to(batch_win_inds.dtype)
+        out[dl] = (flat2window_inds, torch.where(dl_mask))
+        if debug:
+            assert int(inner.max()) < max_tokens, f"Max inner inds({int(inner.max())}) larger(equal) than {max_tokens}"
+    return out
+
+
+class _RowsCopy(torch.autograd.Function):
+    """dst = zeros(rows_out); scatter: dst[idx[i]] = src[i]   |   gather: dst[i] = src[idx[i]]  (idx without repeats)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, rows_out, scatter):
+        src = src.contiguous()
+        idx = idx.contiguous().long()
+        if not src.is_cuda:
+            raise RuntimeError("feat must be a CUDA tensor (geomae_amd has no CPU path)")
+        n, row = idx.shape[0], src[0].numel() if src.shape[0] else int(torch.tensor(src.shape[1:]).prod())
+        shape = (rows_out,) + tuple(src.shape[1:])
+        dst = torch.zeros(shape, dtype=src.dtype, device=src.device) if scatter else \
+            torch.empty(shape, dtype=src.dtype, device=src.device)
+        fn = _lib.load().geomae_rows_scatter if scatter else _lib.load().geomae_rows_gather
+        check(fn(_ptr(src), _ptr(idx), n, row * src.element_size(), _ptr(dst), _stream()), "geomae_rows_copy")
+        ctx.save_for_backward(idx)
+        ctx.rows_in, ctx.scatter = src.shape[0], scatter
+        return dst
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        return _RowsCopy.apply(g, idx, ctx.rows_in, not ctx.scatter), None, None, None
+
+
+def flat2window(feat, voxel_drop_lvl, flat2win_inds_dict, drop_info):
+    """sst_ops.py:98-135: {level: zero-padded [num_windows, max_tokens, C]} (differentiable in feat)."""
+    out = {}
+    for dl in drop_info:
+        dl_mask = voxel_drop_lvl == dl
+        if not dl_mask.any():
+            continue
+        this_inds, where = flat2win_inds_dict[dl]
+        max_tokens = drop_info[dl]["max_tokens"]
+        num_windows = int((this_inds // max_tokens).max().item()) + 1
+        rows = _RowsCopy.apply(feat, where[0], where[0].shape[0], False)                 # feat[dl_mask]
+        feat_3d = _RowsCopy.apply(rows, this_inds, num_windows * max_tokens, True)
+        out[dl] = feat_3d.reshape((num_windows, max_tokens) + tuple(feat.shape[1:]))
+    return out
+
+
+def window2flat(feat_3d_dict, inds_dict):
+    """sst_ops.py:225-251: the inverse of flat2window -> [N, C]."""
+    num_all = sum(inds_dict[dl][0].shape[0] for dl in inds_dict)
+    first = feat_3d_dict[next(iter(feat_3d_dict))]
+    out = None
+    covered = 0
+    for dl in feat_3d_dict:
+        feat = feat_3d_dict[dl]
+        inds, flat_pos = inds_dict[dl]
+        rows = _RowsCopy.apply(feat.reshape(-1, feat.shape[-1]), inds, inds.shape[0], False)
+        part = _RowsCopy.apply(rows, flat_pos[0], num_all, True)
+        out = part if out is None else out + part
+        covered += inds.shape[0]
+    assert covered == num_all, "window2flat: some voxels belong to no level"          # the reference's check_feat
+    return out if out is not None else first.new_zeros((num_all, first.shape[-1]))
 
 
 # ------------------------------------------------------------------------------------ N1 fine-tune pieces

@@ -77,7 +77,10 @@ class GpuTrainPipeline:
         d.scale = float(rng.uniform(self.scale_ratio_range[0], self.scale_ratio_range[1]))             # :730
         d.translation = [float(v) for v in np.atleast_1d(rng.normal(scale=self.translation_std, size=3))]   # :663
         if self.mmdet_flip_draw:
-            rng.choice(2)
+            # mmdet 2.20 RandomFlip.__call__: np.random.choice([direction, None], p=[ratio, 1 - ratio]) -- with p the
+            # draw is one uniform double (a plain choice(2) would consume the stream differently; pinned by
+            # tests/golden/g_input_pipeline.npz, where the following two rand() calls are the reference's)
+            rng.choice(2, p=[self.flip_h, 1.0 - self.flip_h])
         d.flip_horizontal = bool(rng.rand() < self.flip_h)                                             # :144
         d.flip_vertical = bool(rng.rand() < self.flip_v)                                               # :148
         d.shuffle_seed = int(rng.randint(1, 2 ** 31 - 1)) * (2 ** 31) + int(rng.randint(1, 2 ** 31 - 1)) if self.shuffle else 0

@@ -186,6 +186,21 @@ int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs /*host [num_jobs]
                               int32_t batch_size, const GeomaeWindowConfig* cfg /*host*/, void* workspace,
                               int64_t workspace_bytes, geomaeStream_t stream);
 
+/* Operator-level window plumbing (mmdet3d/ops/__init__.py:22-26; ops/sst/sst_ops.py:57-135, 225-251, 271-319, 371-388):
+ * the hot path works on the CSR layout above and never calls these; they back the reference's function names
+ * (geomae_amd.ops.get_inner_win_inds / make_continuous_inds / get_flat2win_inds / flat2window / window2flat).
+ * geomae_window_rank: given geomae_pillar_segment_nd over the window ids as (z,y,x) = (0,0,id) -- order, inv,
+ * seg_start -- writes continuous_inds[t] = rank of token t's window among the occupied ids (make_continuous_inds) and
+ * inner_inds[t] = a ranking 0..n_w-1 of the tokens of each window (get_inner_win_inds: any order is valid, the
+ * reference's follows an unstable sort).  geomae_rows_scatter: dst[row_index[i]] = src[i]; geomae_rows_gather:
+ * dst[i] = src[row_index[i]]; rows of row_bytes bytes, any element type (flat2window / window2flat copies). */
+int geomae_window_rank(const int32_t* order, const int32_t* inv, const int32_t* seg_start, int64_t num_tokens,
+                       int64_t* continuous_inds, int64_t* inner_inds, geomaeStream_t stream);
+int geomae_rows_scatter(const void* src, const int64_t* row_index, int64_t num_rows, int32_t row_bytes, void* dst,
+                        geomaeStream_t stream);
+int geomae_rows_gather(const void* src, const int64_t* row_index, int64_t num_rows, int32_t row_bytes, void* dst,
+                       geomaeStream_t stream);
+
 /* ------------------------------------------------------------------ A19 windowed attention core
  * replaces flat2window -> nn.MultiheadAttention(key_padding_mask) -> window2flat
  * (sst_basic_block.py:36-59) between the in-projection and the out-projection.

@@ -695,6 +695,24 @@ def test_gpu_input_pipeline_matches_oracle(dev, shuffle):
     assert all(torch.equal(a, b) for a, b in zip(outs, again))
 
 
+def test_gpu_input_pipeline_matches_reference_fixture(dev):
+    """geomae_points_pipeline against the output of the REFERENCE's own pipeline classes (tests/golden/
+    g_input_pipeline.npz, oracle/make_golden_pipeline.py), given the reference's random decisions: same rows in the
+    same (concatenation) order; intensity / time lag bit-exact, xyz within 2e-5 m (the sweep transform is an fp64
+    BLAS product in the reference, three fp64 FMAs per coordinate here)."""
+    from test_pipeline_cpu import fixture_cases
+    from geomae_amd.pipeline import GpuTrainPipeline
+    n = 0
+    for tag, b, fr, d, sweeps_num, want, _, _ in fixture_cases():
+        pipe = GpuTrainPipeline(RANGE, sweeps_num=sweeps_num, shuffle=False)
+        got = pipe([fr], dev, draws=[d])[0].cpu().numpy()
+        assert got.shape == want.shape, (tag, b, got.shape, want.shape)
+        assert np.array_equal(got[:, 3:], want[:, 3:]), (tag, b)
+        assert np.abs(got[:, :3] - want[:, :3]).max() < 2e-5, (tag, b, float(np.abs(got[:, :3] - want[:, :3]).max()))
+        n += 1
+    assert n == 4
+
+
 @pytest.mark.parametrize("name", ["lidar", "dense", "clamp"])
 def test_hard_voxelize_bit_exact_vs_reference_fixture(dev, golden_dir, name):
     """mmdet3d.ops.Voxelization in hard mode vs the reference's compiled CPU hard_voxelize (fixture) and the oracle:
