@@ -39,6 +39,7 @@ class FlatParams:
         groups = [[(n, p) for n, p in named if which(n) == gi] for gi in range(len(late_groups) + 1)]
         groups = [g for g in groups if g]
         self.names, self.params, self.offsets, self.segments, self.nd_ranges = [], [], [], [], []
+        model_names = [n for n, _ in named]
         off = 0
         for gi, g in enumerate(groups):
             nd = [(n, p) for n, p in g if is_nd(n)]
@@ -67,6 +68,8 @@ class FlatParams:
             off = end
             self.segments.append((start, off, n_nd))
         total = off
+        where = {n: j for j, n in enumerate(self.names)}
+        self.model_order = [where[n] for n in model_names]      # flat index of the i-th parameter of the model
         self.n_no_decay = self.segments[0][2] if len(self.segments) == 1 else None
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -143,10 +146,12 @@ class FlatAdamW:
         self.exp_avg_sq = torch.zeros_like(flat.flat)
         self.step_count = 0
         self._sumsq = self._gnorm = None
+        self._sumsq_zeroed = False
 
     @torch.no_grad()
     def step(self):
         f = self.flat
+        self._sumsq_zeroed = False
         self.step_count += 1
         b1, b2 = self.betas
         g = f.grad
@@ -171,13 +176,18 @@ class FlatAdamW:
         lib, f = _lib.load(), self.flat
         if self._sumsq is None:
             self._sumsq_ring = torch.zeros(2, dtype=torch.float64, device=f.flat.device)
-            self._sumsq_zeroed = None
+            self._sumsq_zeroed, self._sumsq_slot = True, 0
             self._gnorm = torch.zeros(1, dtype=torch.float32, device=f.flat.device)
+        if not self._sumsq_zeroed:                   # state was loaded / another path stepped: do not trust the ring
+            self._sumsq_ring.zero_()
+            self._sumsq_zeroed = True
         self.step_count += 1
         n = f.flat.numel()
-        # two accumulator slots: this step sums into one (already zero), the other is zeroed on a side stream for the
-        # next step -- no fill kernel between the last backward kernel and the norm reduction
-        slot = self.step_count & 1
+        # two accumulator slots: this step sums into one (already zero), the other is zeroed by this step's update
+        # pass for the next step -- no fill kernel between the last backward kernel and the norm reduction.  The slot
+        # has its own toggle (not step_count's parity: load_state_dict / a composed step() change that)
+        slot = self._sumsq_slot
+        self._sumsq_slot = 1 - slot
         self._sumsq = self._sumsq_ring[slot:slot + 1]
         main = torch.cuda.current_stream()
         with ops.prezeroed():
@@ -200,10 +210,16 @@ class FlatAdamW:
 
     # ---- torch.optim.AdamW-shaped state (what mmcv's checkpoint hook stores under 'optimizer'): mmcv's
     # DefaultOptimizerConstructor with a paramwise_cfg makes ONE param group per parameter
+    def _model_order(self):
+        """(param, flat offset) in model.named_parameters() order -- the index mmcv's DefaultOptimizerConstructor and
+        torch.optim use for 'state' / 'param_groups' -- whatever the flat buffer's segment layout is."""
+        f = self.flat
+        return [(f.params[j], f.offsets[j]) for j in f.model_order]
+
     def state_dict(self):
         f, state, groups = self.flat, {}, []
         decayed = f.decay_ranges()
-        for i, (p, off) in enumerate(zip(f.params, f.offsets)):
+        for i, (p, off) in enumerate(self._model_order()):
             n = p.numel()
             wd = self.weight_decay if any(a <= off < b for a, b in decayed) else 0.0
             state[i] = dict(step=torch.tensor(float(self.step_count)),
@@ -214,14 +230,22 @@ class FlatAdamW:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        f = self.flat
-        for i, (p, off) in enumerate(zip(f.params, f.offsets)):
+        order = self._model_order()
+        extra = [k for k in sd["state"] if not (isinstance(k, int) and 0 <= k < len(order))]
+        if extra:
+            raise ValueError(f"optimizer state has entries for parameters this model does not have: {extra[:4]}")
+        for i, (p, off) in enumerate(order):
             n = p.numel()
             st = sd["state"].get(i)
             if st is not None:
+                for key in ("exp_avg", "exp_avg_sq"):
+                    if tuple(st[key].shape) != tuple(p.shape):
+                        raise ValueError(f"optimizer state {i}: {key} has shape {tuple(st[key].shape)}, the parameter "
+                                         f"{tuple(p.shape)} (the checkpoint is from a different model or parameter order)")
                 self.exp_avg[off:off + n].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
+        self._sumsq_zeroed = False                   # the accumulator ring is re-zeroed by the next fused step
         if sd.get("param_groups"):
             self.lr = sd["param_groups"][0]["lr"]
             self.base_lr = sd["param_groups"][0].get("initial_lr", self.base_lr)
@@ -291,6 +315,14 @@ class Trainer:
                 if ops.BN_GROUP is not None:
                     dist.all_reduce(t, group=ops.BN_GROUP)
                 torch.cuda.synchronize(t.device)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # what MMDistributedDataParallel does at construction: every replica starts from rank 0's parameters AND
+            # buffers (BatchNorm running statistics, counters) whatever the ranks seeded or loaded; afterwards only
+            # gradients (and the SyncBN statistics) are exchanged
+            dist.broadcast(self.flat.flat, src=0)
+            for b in model.buffers():
+                if b.numel():
+                    dist.broadcast(b, src=0)
         self.opt = FlatAdamW(self.flat, **ocfg)
         self.grad_clip = dict(GRAD_CLIP if grad_clip is None else grad_clip)
         self.lr_schedule = lr_schedule          # e.g. CyclicLr(base_lr, max_iters): lr set before every step

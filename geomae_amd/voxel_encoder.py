@@ -155,6 +155,11 @@ class DynamicScatterVFE(nn.Module):
             seg = ops.pillar_segment(coors.contiguous().int(), batch_size, (gz, gy, gx))
         V = seg.V
         inv = seg.inv.long()
+        if bool((inv < 0).any()):
+            # pillar_segment marks points outside the grid with inv = -1 (csrc/segment.hip); the fused path never sees
+            # them (they are not in `order`).  Indexing with -1 would wrap to the last pillar: refuse instead
+            raise RuntimeError("DynamicScatterVFE (composed path): points outside the voxel grid; filter them first "
+                               "(PointsRangeFilter) or use the fused path")
         feats = [features]
         if self._with_cluster_center:
             with torch.no_grad():

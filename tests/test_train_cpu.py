@@ -176,8 +176,12 @@ def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
     ck = torch.load(path, weights_only=False)
     assert set(ck) == {"meta", "state_dict", "optimizer"} and ck["meta"]["epoch"] == 1 and ck["meta"]["iter"] == 3
     groups = ck["optimizer"]["param_groups"]
-    assert len(groups) == 4 and [g["weight_decay"] for g in groups] == [0.0, 0.0, 0.05, 0.05]      # norm.* first, undecayed
-    ref = torch.optim.AdamW([dict(params=[nn.Parameter(torch.zeros_like(p))]) for p in tr.flat.params])   # loads into torch's own
+    assert len(groups) == 4
+    # ... in model.named_parameters() order (what mmcv / torch.optim index by), NOT the flat buffer's segment order
+    model_params = [p for _, p in tr.model.named_parameters()]
+    assert [tuple(ck["optimizer"]["state"][i]["exp_avg"].shape) for i in range(4)] == [tuple(p.shape) for p in model_params]
+    assert [g["weight_decay"] for g in groups] == [0.05, 0.05, 0.0, 0.0]           # lin.weight, lin.bias, norm.weight, norm.bias
+    ref = torch.optim.AdamW([dict(params=[nn.Parameter(torch.zeros_like(p))]) for p in model_params])   # loads into torch's own
     ref.load_state_dict(dict(state=ck["optimizer"]["state"],
                              param_groups=[dict(g, maximize=False, foreach=None, capturable=False, differentiable=False,
                                                 fused=None, decoupled_weight_decay=True) for g in groups]))
@@ -192,6 +196,31 @@ def test_checkpoint_roundtrip_mmcv_layout(tmp_path):
     assert torch.equal(l1["loss"], l2["loss"])
     for a, b in zip(tr.flat.params, tr2.flat.params):
         assert torch.equal(a, b)
+    # torch.optim.AdamW built on the MODEL's parameter list continues identically from the same checkpoint
+    torch.manual_seed(2)
+    m3 = Tiny()
+    m3.load_state_dict(ck["state_dict"])
+    ps = list(m3.parameters())
+    o3 = torch.optim.AdamW([dict(params=[p], weight_decay=g["weight_decay"]) for p, g in zip(ps, groups)], lr=groups[0]["lr"])
+    sd3 = o3.state_dict()
+    sd3["state"] = {i: {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for i, st in ck["optimizer"]["state"].items()}
+    o3.load_state_dict(sd3)
+    torch.manual_seed(1)
+    tr4 = Trainer(Tiny())
+    tr4.load_checkpoint(path)
+    out = m3.forward_train(x, None)["loss"]
+    out.backward()
+    torch.nn.utils.clip_grad_norm_(ps, tr4.grad_clip["max_norm"])
+    o3.step()
+    tr4.train_step(x)
+    for (n, a), b in zip(tr4.model.named_parameters(), ps):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), n
+    # a checkpoint of another parameter order / model is refused, not silently mis-assigned
+    bad = dict(ck["optimizer"])
+    bad["state"] = {0: ck["optimizer"]["state"][2], 1: ck["optimizer"]["state"][1], 2: ck["optimizer"]["state"][0],
+                    3: ck["optimizer"]["state"][3]}
+    with pytest.raises(ValueError, match="shape"):
+        tr4.opt.load_state_dict(bad)
 
 
 def test_zero_arena_carves_aligned_zero_views():
