@@ -51,7 +51,7 @@ WORKLOADS = {
     "nuscenes10": (2, 10, {}, {}),
     # Waymo-like geometry of configs/sst_refactor/sst_waymoD5_1x_3class_8heads_v2.py:8-10 (no GeoMAE Waymo config
     # exists in the reference: synthesised): 64 beams, ~180 k points per frame
-    "waymo": (3, 1, dict(beams=64, n_az=5300, pc_range=(-74.88, -74.88, -2.0, 74.88, 74.88, 4.0), elev=(-17.6, 2.4),
+    "waymo": (3, 1, dict(beams=64, n_az=3100, pc_range=(-74.88, -74.88, -2.0, 74.88, 74.88, 4.0), elev=(-17.6, 2.4),
                          n_cyl=90, max_range=110.0),
               dict(voxel_size=(0.32, 0.32, 6), sub_voxel_size_low=(0.08, 0.08, 0.75), sub_voxel_size_med=(0.16, 0.16, 1.5),
                    point_cloud_range=(-74.88, -74.88, -2.0, 74.88, 74.88, 4.0), grid_size=(1, 468, 468))),

@@ -396,8 +396,12 @@ def test_vfe_forward_backward(dev, golden_dir, fused):
         assert off.mean() < 0.05, (k, off.mean())
 
 
-@pytest.mark.parametrize("tag,compute_dtype,tol", [("tiny", "fp32", 2e-2), ("full", "fp32", 4e-2), ("full", "bf16", 8e-2)])
-def test_forward_train_losses_and_grads(dev, golden_dir, tag, compute_dtype, tol):
+# (loss, gradient-norm, full-gradient Frobenius) tolerances ~2x the measured maxima this test prints with
+# GEOMAE_TEST_VERBOSE=1; the full-size versions of the same comparison are tests/test_gpu_fullsize.py
+# measured: fp32 composed path (attention core in bf16) 8.0e-4 / 9.1e-4 / 1.9e-3, bf16 fused path 2.5e-3 / 4.7e-3 / 1.4e-2
+@pytest.mark.parametrize("tag,compute_dtype,tols", [("tiny", "fp32", (2e-3, 2e-3, 4e-3)), ("full", "fp32", (2e-3, 2e-3, 4e-3)),
+                                                    ("full", "bf16", (6e-3, 1.2e-2, 3e-2))])
+def test_forward_train_losses_and_grads(dev, golden_dir, tag, compute_dtype, tols):
     g = np.load(os.path.join(golden_dir, f"g_pipeline_{tag}.npz"))
     enc, dec = (1, 1) if tag == "tiny" else (6, 2)
     model, params = _build(dev, enc, dec, compute_dtype)
@@ -407,23 +411,28 @@ def test_forward_train_losses_and_grads(dev, golden_dir, tag, compute_dtype, tol
     losses = model.forward_train(pts, None, ids_keep=ik, ids_mask=im)
     ref = dict(zip([str(n) for n in g["loss_names"]], g["loss_vals"]))
     assert set(losses) == set(ref)
-    for k, v in losses.items():
-        assert abs(float(v) - ref[k]) <= tol * max(1.0, abs(ref[k])), (k, float(v), ref[k])
+    tol_l, tol_n, tol_f = tols
+    e_loss = max(abs(float(v.detach()) - ref[k]) / max(1.0, abs(ref[k])) for k, v in losses.items())
     sum(losses.values()).backward()
     named = dict(model.named_parameters())
     gn = dict(zip([str(n) for n in g["grad_names"]], g["grad_norms"]))
-    bad = []
+    e_norm, worst = 0.0, ""
     for k, p in named.items():
-        got = float(p.grad.double().norm())
-        if abs(got - gn[k]) > 3 * tol * max(gn[k], 1e-2):
-            bad.append((k, got, gn[k]))
-    assert not bad, bad[:8]
-    ref_g = g["grad_pred_top_w"]
-    got_g = named["backbone.decoder_pred_top.weight"].grad.cpu().numpy()
-    assert np.linalg.norm(got_g - ref_g) / np.linalg.norm(ref_g) < 2 * tol
-    ref_g = g["grad_vfe0"]
-    got_g = named["voxel_encoder.vfe_layers.0.linear.weight"].grad.cpu().numpy()
-    assert np.linalg.norm(got_g - ref_g) / np.linalg.norm(ref_g) < 3 * tol
+        e = abs(float(p.grad.double().norm()) - gn[k]) / max(gn[k], 1e-2)
+        if e > e_norm:
+            e_norm, worst = e, k
+    e_full = {}
+    for key, name in (("grad_pred_top_w", "backbone.decoder_pred_top.weight"), ("grad_vfe0", "voxel_encoder.vfe_layers.0.linear.weight"),
+                      ("grad_mask_token", "backbone.mask_token"),
+                      ("grad_enc0_inproj_bias", "backbone.encoder_blocks.0.encoder_list.0.win_attn.self_attn.in_proj_bias")):
+        a, b = named[name].grad.detach().double().cpu().numpy(), g[key].astype(np.float64)
+        e_full[key] = float(np.linalg.norm(a - b) / np.linalg.norm(b))
+    if os.environ.get("GEOMAE_TEST_VERBOSE"):
+        print(f"\n{tag} {compute_dtype}: loss err {e_loss:.2e}, worst grad-norm err {e_norm:.2e} ({worst}), full-gradient "
+              f"Frobenius errs {({k: f'{v:.1e}' for k, v in e_full.items()})}", flush=True)
+    assert e_loss <= tol_l, (e_loss, {k: (float(v), ref[k]) for k, v in losses.items()})
+    assert e_norm <= tol_n, (e_norm, worst)
+    assert max(e_full.values()) <= tol_f, e_full
 
 
 def test_forward_train_random_mask_runs_and_is_finite(dev):
