@@ -13,5 +13,6 @@ from .voxel_encoder import DynamicScatterVFE  # noqa: F401
 from .sst import BasicShiftBlock, EncoderLayer, MultiMAESSTSPChoose, WindowAttention  # noqa: F401
 from .detector import MultiSubVoxelDynamicVoxelNetSSL  # noqa: F401
 from .finetune import DynamicVoxelNet, SECONDFPN, SSTInputLayer, SSTSecondPretrainedv1  # noqa: F401
+from .dense_head import Anchor3DHead  # noqa: F401
 
 __version__ = "0.1.0"

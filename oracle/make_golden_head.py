@@ -1,0 +1,319 @@
+"""Generate tests/golden/g_head.npz from the REFERENCE's Anchor3DHead (build container only; TEST INFRASTRUCTURE ONLY).
+
+Loaded by path from /root/reference: models/dense_heads/anchor3d_head.py + train_mixins.py (targets, losses assembly),
+core/anchor/anchor_3d_generator.py, core/bbox/coders/delta_xyzwhlr_bbox_coder.py, core/bbox/iou_calculators/
+iou3d_calculator.py, core/bbox/structures/{utils,base_box3d,lidar_box3d}.py -- configured as the fine-tune config
+(configs/_base_/models/sst_base_nus.py:13-65 + configs/pre_sst/m_sst_nus_second_pointpillar_fpn355_222_*.py:134-161).
+Un-vendored mmdet / mmcv pieces are stand-ins restating their published behaviour (the same restatements the product
+uses, geomae_amd/dense_head.py: parity with mmdet itself is unpinned): MaxIoUAssigner, PseudoSampler, bbox_overlaps,
+FocalLoss, SmoothL1Loss, CrossEntropyLoss, multi_apply, images_to_levels, the build_* registries.
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden_head.py"""
+import importlib.util
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = os.environ.get("GEOMAE_REFERENCE", "/root/reference")
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    m.__path__ = []
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, relpath, package=None):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, relpath))
+    m = importlib.util.module_from_spec(spec)
+    if package:
+        m.__package__ = package
+    sys.modules[name] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+class _Registry:
+    def __init__(self):
+        self.m = {}
+
+    def register_module(self, *a, **k):
+        def deco(cls):
+            self.m[cls.__name__] = cls
+            return cls
+        return deco
+
+    def build(self, cfg):
+        cfg = dict(cfg)
+        return self.m[cfg.pop("type")](**cfg)
+
+
+class AttrDict(dict):
+    __getattr__ = dict.__getitem__
+
+
+def multi_apply(func, *args, **kwargs):
+    pfunc = partial(func, **kwargs) if kwargs else func
+    return tuple(map(list, zip(*map(pfunc, *args))))
+
+
+def images_to_levels(target, num_levels):
+    target = torch.stack(target, 0)
+    out, start = [], 0
+    for n in num_levels:
+        out.append(target[:, start:start + n])
+        start += n
+    return out
+
+
+def bbox_overlaps(b1, b2, mode="iou", is_aligned=False, eps=1e-6):
+    assert mode == "iou" and not is_aligned
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[..., 0] * wh[..., 1]
+    union = torch.max(a1[:, None] + a2[None, :] - ov, ov.new_tensor([eps]))
+    return ov / union
+
+
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+
+class MaxIoUAssigner:
+    """mmdet 2.20 core/bbox/assigners/max_iou_assigner.py restated (assign + assign_wrt_overlaps)."""
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1, iou_calculator=None):
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
+        self.gt_max_assign_all, self.match_low_quality = gt_max_assign_all, match_low_quality
+        self.iou_calculator = IOU_CALCULATORS.build(iou_calculator)
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        overlaps = self.iou_calculator(gt_bboxes, bboxes)
+        num_gts, num_bboxes = overlaps.shape
+        assigned = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+        max_ov, argmax_ov = overlaps.max(dim=0)
+        gt_max, _ = overlaps.max(dim=1)
+        assigned[(max_ov >= 0) & (max_ov < self.neg_iou_thr)] = 0
+        pos = max_ov >= self.pos_iou_thr
+        assigned[pos] = argmax_ov[pos] + 1
+        if self.match_low_quality:
+            for i in range(num_gts):
+                if gt_max[i] >= self.min_pos_iou:
+                    if self.gt_max_assign_all:
+                        assigned[overlaps[i, :] == gt_max[i]] = i + 1
+                    else:
+                        assigned[overlaps[i].argmax()] = i + 1
+        labels = assigned.new_full((num_bboxes,), -1)
+        p = torch.nonzero(assigned > 0, as_tuple=False).squeeze()
+        if p.numel() > 0:
+            labels[p] = gt_labels[assigned[p] - 1]
+        return AssignResult(num_gts, assigned, max_ov, labels)
+
+
+class SamplingResult:
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :] if gt_bboxes.numel() else gt_bboxes.view(-1, gt_bboxes.shape[-1])
+
+
+class PseudoSampler:
+    def sample(self, assign_result, bboxes, gt_bboxes, **kw):
+        pos = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        return SamplingResult(pos, neg, bboxes, gt_bboxes, assign_result)
+
+
+class FocalLoss(nn.Module):
+    def __init__(self, use_sigmoid=True, gamma=2.0, alpha=0.25, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.gamma, self.alpha, self.loss_weight = gamma, alpha, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        C = pred.size(1)
+        t = F.one_hot(target, num_classes=C + 1)[:, :C].type_as(pred)
+        p = pred.sigmoid()
+        pt = (1 - p) * t + p * (1 - t)
+        fw = (self.alpha * t + (1 - self.alpha) * (1 - t)) * pt.pow(self.gamma)
+        loss = F.binary_cross_entropy_with_logits(pred, t, reduction="none") * fw
+        loss = loss * weight.view(-1, 1)
+        return self.loss_weight * loss.sum() / avg_factor
+
+
+class SmoothL1Loss(nn.Module):
+    def __init__(self, beta=1.0, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        self.beta, self.loss_weight = beta, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        d = torch.abs(pred - target)
+        loss = torch.where(d < self.beta, 0.5 * d * d / self.beta, d - 0.5 * self.beta)
+        return self.loss_weight * (loss * weight).sum() / avg_factor
+
+
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, use_sigmoid=False, reduction="mean", loss_weight=1.0):
+        super().__init__()
+        assert not use_sigmoid
+        self.loss_weight = loss_weight
+
+    def forward(self, pred, label, weight=None, avg_factor=None):
+        loss = F.cross_entropy(pred, label, reduction="none") * weight.float()
+        return self.loss_weight * loss.sum() / avg_factor
+
+
+ANCHOR_GENERATORS, BBOX_CODERS, IOU_CALCULATORS, HEADS = _Registry(), _Registry(), _Registry(), _Registry()
+LOSSES = dict(FocalLoss=FocalLoss, SmoothL1Loss=SmoothL1Loss, CrossEntropyLoss=CrossEntropyLoss)
+
+
+def build_loss(cfg):
+    cfg = dict(cfg)
+    return LOSSES[cfg.pop("type")](**cfg)
+
+
+def setup():
+    class BaseModule(nn.Module):
+        def __init__(self, init_cfg=None):
+            super().__init__()
+
+    ident = lambda *a, **k: (a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f))
+    _mod("mmcv", is_list_of=lambda seq, t: isinstance(seq, list) and all(isinstance(v, t) for v in seq))
+    _mod("mmcv.runner", BaseModule=BaseModule, force_fp32=ident)
+    _mod("mmcv.cnn", build_norm_layer=None)
+    _mod("mmcv.utils", build_from_cfg=None)
+    _mod("mmdet")
+    _mod("mmdet.core", build_anchor_generator=ANCHOR_GENERATORS.build, build_assigner=lambda cfg: MaxIoUAssigner(**{k: v for k, v in cfg.items() if k != "type"}),
+         build_bbox_coder=BBOX_CODERS.build, build_sampler=None, multi_apply=multi_apply, images_to_levels=images_to_levels)
+    _mod("mmdet.core.anchor", ANCHOR_GENERATORS=ANCHOR_GENERATORS)
+    _mod("mmdet.core.bbox", BaseBBoxCoder=object, bbox_overlaps=bbox_overlaps)
+    _mod("mmdet.core.bbox.builder", BBOX_CODERS=BBOX_CODERS)
+    _mod("mmdet.core.bbox.iou_calculators")
+    _mod("mmdet.core.bbox.iou_calculators.builder", IOU_CALCULATORS=IOU_CALCULATORS)
+    _mod("mmdet.models", HEADS=HEADS)
+    _mod("mmdet3d")
+    _mod("mmdet3d.ops", points_in_boxes_batch=None, points_in_boxes_gpu=None)
+    _mod("mmdet3d.ops.iou3d", iou3d_cuda=None)
+    _mod("mmdet3d.ops.iou3d.iou3d_utils", nms_gpu=None, nms_normal_gpu=None, nms_weighted_gpu=None)
+    _mod("mmdet3d.ops.roiaware_pool3d", points_in_boxes_gpu=None, points_in_boxes_batch=None)
+    core = _mod("mmdet3d.core")
+    bbox = _mod("mmdet3d.core.bbox")
+    st = _mod("mmdet3d.core.bbox.structures")
+    _mod("mmdet3d.core.points", BasePoints=type("BasePoints", (), {}))
+    utils = _load("mmdet3d.core.bbox.structures.utils", "mmdet3d/core/bbox/structures/utils.py", "mmdet3d.core.bbox.structures")
+    base = _load("mmdet3d.core.bbox.structures.base_box3d", "mmdet3d/core/bbox/structures/base_box3d.py", "mmdet3d.core.bbox.structures")
+    lidar = _load("mmdet3d.core.bbox.structures.lidar_box3d", "mmdet3d/core/bbox/structures/lidar_box3d.py", "mmdet3d.core.bbox.structures")
+    st.LiDARInstance3DBoxes, st.limit_period = lidar.LiDARInstance3DBoxes, utils.limit_period
+    st.get_box_type = lambda t: (lidar.LiDARInstance3DBoxes, 0)
+    bbox.structures = st
+    core.PseudoSampler, core.box3d_multiclass_nms, core.box3d_multiclass_wnms = PseudoSampler, None, None
+    core.limit_period, core.xywhr2xyxyr = utils.limit_period, utils.xywhr2xyxyr
+    _mod("mmdet3d.core.bbox.iou_calculators")
+    _mod("mmdet3d.core.bbox.coders")
+    _mod("mmdet3d.core.anchor")
+    _mod("mmdet3d.models")
+    _mod("mmdet3d.models.builder", build_loss=build_loss)
+    _mod("mmdet3d.models.dense_heads")
+    _load("mmdet3d.core.anchor.anchor_3d_generator", "mmdet3d/core/anchor/anchor_3d_generator.py", "mmdet3d.core.anchor")
+    _load("mmdet3d.core.bbox.coders.delta_xyzwhlr_bbox_coder", "mmdet3d/core/bbox/coders/delta_xyzwhlr_bbox_coder.py", "mmdet3d.core.bbox.coders")
+    _load("mmdet3d.core.bbox.iou_calculators.iou3d_calculator", "mmdet3d/core/bbox/iou_calculators/iou3d_calculator.py",
+          "mmdet3d.core.bbox.iou_calculators")
+    _load("mmdet3d.models.dense_heads.train_mixins", "mmdet3d/models/dense_heads/train_mixins.py", "mmdet3d.models.dense_heads")
+    head = _load("mmdet3d.models.dense_heads.anchor3d_head", "mmdet3d/models/dense_heads/anchor3d_head.py", "mmdet3d.models.dense_heads")
+    return head, lidar
+
+
+# the merged bbox_head / train_cfg of the fine-tune config
+HEAD_CFG = dict(
+    num_classes=10, in_channels=384, feat_channels=384, use_direction_classifier=True,
+    anchor_generator=dict(
+        type="AlignedAnchor3DRangeGenerator",
+        ranges=[[-49.6, -49.6, -1.80032795, 49.6, 49.6, -1.80032795], [-49.6, -49.6, -1.74440365, 49.6, 49.6, -1.74440365],
+                [-49.6, -49.6, -1.68526504, 49.6, 49.6, -1.68526504], [-49.6, -49.6, -1.67339111, 49.6, 49.6, -1.67339111],
+                [-49.6, -49.6, -1.61785072, 49.6, 49.6, -1.61785072], [-49.6, -49.6, -1.80984986, 49.6, 49.6, -1.80984986],
+                [-49.6, -49.6, -1.763965, 49.6, 49.6, -1.763965]],
+        sizes=[[4.60718145, 1.95017717, 1.72270761], [6.73778078, 2.4560939, 2.73004906], [12.01320693, 2.87427237, 3.81509561],
+               [1.68452161, 0.60058911, 1.27192197], [0.7256437, 0.66344886, 1.75748069], [0.40359262, 0.39694519, 1.06232151],
+               [0.48578221, 2.49008838, 0.98297065]],
+        custom_values=[0, 0], rotations=[0, 1.57], reshape_out=True),
+    assigner_per_size=False, diff_rad_by_sin=True, dir_offset=-0.7854,
+    bbox_coder=dict(type="DeltaXYZWLHRBBoxCoder", code_size=9),
+    loss_cls=dict(type="FocalLoss", use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+    loss_bbox=dict(type="SmoothL1Loss", beta=1.0 / 9.0, loss_weight=1.0),
+    loss_dir=dict(type="CrossEntropyLoss", use_sigmoid=False, loss_weight=0.2))
+TRAIN_CFG = dict(assigner=dict(type="MaxIoUAssigner", iou_calculator=dict(type="BboxOverlapsNearest3D"), pos_iou_thr=0.6,
+                               neg_iou_thr=0.3, min_pos_iou=0.3, ignore_iof_thr=-1),
+                 allowed_border=0, code_weight=[1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0, 0.2, 0.2], pos_weight=-1, debug=False)
+
+
+def inputs(seed=17, B=2, H=40, W=40):
+    """Seeded head input [B, 384, H, W], ground-truth boxes (9-d: x y z w l h r vx vy) matched to the 7 anchor sizes so
+    that some anchors clear the 0.6 IoU threshold, and labels."""
+    g = torch.Generator().manual_seed(seed)
+    feat = torch.randn(B, 384, H, W, generator=g) * 0.5
+    sizes = torch.tensor(HEAD_CFG["anchor_generator"]["sizes"])
+    gts, labels = [], []
+    for b in range(B):
+        n = 6 + 3 * b
+        cls = torch.randint(0, 7, (n,), generator=g)
+        xy = (torch.rand(n, 2, generator=g) - 0.5) * 90
+        z = torch.full((n, 1), -1.7) + torch.randn(n, 1, generator=g) * 0.05
+        dims = sizes[cls] * (1 + 0.08 * torch.randn(n, 3, generator=g))
+        rot = torch.where(torch.rand(n, 1, generator=g) < 0.5, torch.zeros(n, 1), torch.full((n, 1), 1.57)) + 0.1 * torch.randn(n, 1, generator=g)
+        vel = torch.randn(n, 2, generator=g)
+        gts.append(torch.cat([xy, z, dims, rot, vel], dim=1))
+        labels.append(torch.randint(0, 10, (n,), generator=g))
+    return feat, gts, labels
+
+
+def main():
+    head_mod, lidar = setup()
+    head = head_mod.Anchor3DHead(train_cfg=AttrDict(TRAIN_CFG), test_cfg=None, **HEAD_CFG)
+    sd = {}
+    for k, v in head.state_dict().items():
+        sd[k] = torch.randn(v.shape, generator=torch.Generator().manual_seed(sum(map(ord, k)))) * (0.05 if v.dim() > 1 else 0.5)
+    head.load_state_dict(sd)
+    feat, gts, labels = inputs()
+    x = feat.clone().requires_grad_(True)
+    outs = head([x])
+    gt_boxes = [lidar.LiDARInstance3DBoxes(g, box_dim=9) for g in gts]
+    losses = head.loss(*outs, gt_boxes, labels, [dict() for _ in gts])
+    total = sum(sum(v) for v in losses.values())
+    total.backward()
+    # targets of image 0 for a direct check of the assignment
+    anchors = head.anchor_generator.grid_anchors([feat.shape[-2:]], device="cpu")
+    t = head.anchor_target_3d([anchors for _ in gts], gt_boxes, [dict() for _ in gts], gt_labels_list=labels,
+                              num_classes=head.num_classes, label_channels=head.cls_out_channels, sampling=False)
+    out = dict(anchors_sample=anchors[0][::997].numpy(), num_anchors=np.int64(anchors[0].shape[0]),
+               labels0=t[0][0][0].numpy().astype(np.int8), dir_targets0=t[4][0][0].numpy().astype(np.int8),
+               bbox_targets_pos0=t[2][0][0][t[3][0][0].sum(-1) > 0].numpy(), num_total_pos=np.int64(t[6]),
+               loss_cls=np.float64(losses["loss_cls"][0]), loss_bbox=np.float64(losses["loss_bbox"][0]),
+               loss_dir=np.float64(losses["loss_dir"][0]), dx_sum=x.grad.double().sum(dim=(0, 2, 3)).numpy(),
+               dx_abs=np.float64(x.grad.double().abs().sum()))
+    for k, p in head.named_parameters():
+        out["grad." + k] = p.grad.numpy()
+    dst = os.path.join(ROOT, "tests", "golden", "g_head.npz")
+    np.savez_compressed(dst, **out)
+    print("wrote", dst, os.path.getsize(dst), "losses", {k: float(v[0]) for k, v in losses.items()}, "num_pos", int(t[6]),
+          "anchors", anchors[0].shape)
+
+
+if __name__ == "__main__":
+    main()

@@ -67,17 +67,30 @@ def test_pos_table_matches_oracle():
 FT_CFG = "/root/reference/configs/pre_sst/m_sst_nus_second_pointpillar_fpn355_222_curv_07_ssl_data_wo_dbsampler_6x_1e-5.py"
 
 
+def _plain(x):
+    if isinstance(x, dict):
+        return {k: _plain(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_plain(v) for v in x]
+    return x
+
+
 @pytest.mark.skipif(not os.path.exists(FT_CFG), reason="reference not mounted (GPU box)")
 def test_finetune_config_builds_and_takes_pretrained_encoder():
-    """N1: the fine-tune config resolves (detector, middle encoder, backbone, neck; the Anchor3DHead of its base config is
-    mmdet3d machinery outside this package and is skipped), and the pre-trained backbone.encoder_blocks.* keys load into it."""
+    """N1: the fine-tune config file resolves unchanged -- detector, middle encoder, backbone, neck AND the Anchor3DHead
+    of its base config -- it equals the restated dict the GPU tests use, and the pre-trained backbone.encoder_blocks.*
+    keys load into it."""
+    from geomae_amd.configs import pre_sst_model
     cfg = Config.fromfile(FT_CFG)
     m = dict(cfg.model)
     assert m["type"] == "DynamicVoxelNet" and m["middle_encoder"]["type"] == "SSTInputLayer"
     assert m["backbone"]["type"] == "SSTSecondPretrainedv1" and m["neck"]["type"] == "SECONDFPN"
-    m["bbox_head"] = None
+    assert _plain(m) == _plain(pre_sst_model())
     model = geomae_amd.build_model(m)
     assert len(model.backbone.encoder_blocks) == 6 and len(model.backbone.conv_blocks) == 3
+    head = model.bbox_head
+    assert type(head).__name__ == "Anchor3DHead" and head.num_anchors == 14 and head.box_code_size == 9
+    assert head.conv_cls.out_channels == 140 and head.conv_reg.out_channels == 126 and head.conv_dir_cls.out_channels == 28
     pre = geomae_amd.build_model(mae_sst_model())
     src = {k: v for k, v in pre.state_dict().items() if k.startswith("backbone.encoder_blocks.")}
     missing = model.load_state_dict(src, strict=False)

@@ -704,6 +704,41 @@ def test_gpu_input_pipeline_matches_oracle(dev, shuffle):
     assert all(torch.equal(a, b) for a, b in zip(outs, again))
 
 
+def test_finetune_step_runs_end_to_end(dev):
+    """BASELINE config 5 (fine-tune sanity): the pre_sst model -- dynamic voxelization, fused VFE,
+    SSTInputLayer region batching, 6 pre-trained SST blocks on the fused stack kernels, recover_bev, conv stack, SECONDFPN
+    and the plain-torch Anchor3DHead with its target assignment -- takes the pre-trained encoder, returns the three
+    detection losses and back-propagates into every trainable parameter.  (mAP / NDS need the dataset: out of reach.)"""
+    import geomae_amd
+    from geomae_amd.configs import mae_sst_model, pre_sst_model
+    torch.manual_seed(0)
+    model = geomae_amd.build_model(pre_sst_model()).to(dev).train()
+    pre = geomae_amd.build_model(mae_sst_model())
+    missing = model.load_state_dict({k: v for k, v in pre.state_dict().items() if k.startswith("backbone.encoder_blocks.")},
+                                    strict=False)
+    assert not missing.unexpected_keys
+    rng_ = (-50.0, -50.0, -5.0, 50.0, 50.0, 3.0)
+    pts = [torch.as_tensor(synth.lidar_frame(90 + i, pc_range=rng_), device=dev) for i in range(2)]
+    g = torch.Generator().manual_seed(4)
+    gts, labels = [], []
+    for b in range(2):
+        n = 5 + b
+        xy = (torch.rand(n, 2, generator=g) - 0.5) * 80
+        box = torch.cat([xy, torch.full((n, 1), -1.7), torch.tensor([[4.6, 1.95, 1.72]]).repeat(n, 1) * (1 + 0.05 * torch.randn(n, 3, generator=g)),
+                         0.1 * torch.randn(n, 1, generator=g), torch.zeros(n, 2)], dim=1)
+        gts.append(box.to(dev))
+        labels.append(torch.zeros(n, dtype=torch.long, device=dev))
+    losses = model.forward_train(pts, [dict(), dict()], gts, labels)
+    assert set(losses) == {"loss_cls", "loss_bbox", "loss_dir"}
+    total = sum(sum(v) for v in losses.values())
+    assert torch.isfinite(total) and float(losses["loss_bbox"][0]) > 0            # some anchors were assigned
+    total.backward()
+    no_grad = [k for k, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not no_grad, no_grad[:6]
+    assert float(model.backbone.encoder_blocks[0].encoder_list[0].linear1.weight.grad.abs().sum()) > 0
+    assert float(model.voxel_encoder.vfe_layers[0].linear.weight.grad.abs().sum()) > 0
+
+
 def test_gpu_input_pipeline_matches_reference_fixture(dev):
     """geomae_points_pipeline against the output of the REFERENCE's own pipeline classes (tests/golden/
     g_input_pipeline.npz, oracle/make_golden_pipeline.py), given the reference's random decisions: same rows in the

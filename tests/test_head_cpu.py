@@ -1,0 +1,67 @@
+"""Anchor3DHead (fine-tune config) in plain torch vs the reference's own head run under stubs
+(tests/golden/g_head.npz, oracle/make_golden_head.py): anchors, target assignment, the three losses and every gradient.
+The head is torch-only by design (SURVEY: "leave to MIOpen/PyTorch"), so this runs on CPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "oracle"))
+
+
+def _setup():
+    from make_golden_head import HEAD_CFG, TRAIN_CFG, inputs          # config dicts + seeded inputs (no reference import)
+    from geomae_amd.dense_head import Anchor3DHead
+    head = Anchor3DHead(train_cfg=dict(TRAIN_CFG), test_cfg=None, **HEAD_CFG)
+    sd = {k: torch.randn(v.shape, generator=torch.Generator().manual_seed(sum(map(ord, k)))) * (0.05 if v.dim() > 1 else 0.5)
+          for k, v in head.state_dict().items()}
+    head.load_state_dict(sd)
+    return head, inputs()
+
+
+def test_anchor3d_head_matches_reference_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g_head.npz"))
+    head, (feat, gts, labels) = _setup()
+    anchors = head.anchor_generator.grid_anchors([feat.shape[-2:]], device="cpu")[0]
+    assert anchors.shape[0] == int(g["num_anchors"]) and head.num_anchors == 14
+    assert np.array_equal(anchors[::997].numpy(), g["anchors_sample"])
+    t = head.targets_single(anchors, gts[0], labels[0])
+    assert np.array_equal(t[0].numpy().astype(np.int8), g["labels0"])
+    assert np.array_equal(t[4].numpy().astype(np.int8), g["dir_targets0"])
+    assert np.allclose(t[2][t[3].sum(-1) > 0].numpy(), g["bbox_targets_pos0"], rtol=1e-6, atol=1e-6)
+    x = feat.clone().requires_grad_(True)
+    losses = head.forward_train([x], None, gts, labels)
+    assert set(losses) == {"loss_cls", "loss_bbox", "loss_dir"} and all(len(v) == 1 for v in losses.values())
+    for k in losses:
+        assert abs(float(losses[k][0].detach()) - float(g[k])) <= 1e-5 * max(1.0, abs(float(g[k]))), (k, float(losses[k][0]), float(g[k]))
+    sum(sum(v) for v in losses.values()).backward()
+    assert np.allclose(x.grad.double().sum(dim=(0, 2, 3)).numpy(), g["dx_sum"], rtol=1e-4, atol=1e-5)
+    assert abs(float(x.grad.double().abs().sum()) - float(g["dx_abs"])) <= 1e-4 * float(g["dx_abs"])
+    for k, p in head.named_parameters():
+        ref = g["grad." + k]
+        assert np.linalg.norm(p.grad.numpy() - ref) <= 1e-4 * max(np.linalg.norm(ref), 1e-6), k
+
+
+def test_anchor3d_head_without_ground_truth_and_config_errors():
+    head, (feat, gts, labels) = _setup()
+    empty = [torch.zeros((0, 9)) for _ in gts]
+    losses = head.forward_train([feat], None, empty, [torch.zeros(0, dtype=torch.long) for _ in gts])
+    assert float(losses["loss_bbox"][0]) == 0.0 and float(losses["loss_dir"][0]) == 0.0 and torch.isfinite(losses["loss_cls"][0])
+    from geomae_amd.dense_head import Anchor3DHead
+    with pytest.raises(NotImplementedError):
+        Anchor3DHead(10, 8, anchor_generator=dict(type="Anchor3DRangeGenerator", ranges=[[0, 0, 0, 1, 1, 1]]))
+    with pytest.raises(NotImplementedError):
+        Anchor3DHead(10, 8, assigner_per_size=True)
+
+
+def test_max_iou_assigner_semantics():
+    """pos >= 0.6, neg < 0.3, in between ignored (-1); every gt keeps its best anchor if that reaches min_pos_iou."""
+    from geomae_amd.dense_head import max_iou_assign
+    ov = torch.tensor([[0.7, 0.2, 0.45, 0.10, 0.35],
+                       [0.1, 0.25, 0.5, 0.05, 0.35]])
+    a = max_iou_assign(ov, 0.6, 0.3, 0.3)
+    assert a.tolist() == [1, 0, 2, 0, -1]         # anchor 2: best anchor of gt 1 (0.5 >= min_pos_iou); anchor 4: 0.35 is neither
+    a = max_iou_assign(ov, 0.6, 0.3, 0.55)
+    assert a.tolist() == [1, 0, -1, 0, -1]
