@@ -338,6 +338,15 @@ def main():
                                            blocked_on_count_readback=round(1e3 * (h1[1] - h0[1]) / args.steps, 4),
                                            busy=round(1e3 * (t_enq - (h1[1] - h0[1])) / args.steps, 4),
                                            engine_busy=round(1e3 * busy / args.steps, 4))
+        # north_star: "MFMA utilisation on the bucketed attention".  Not measurable from inside this process (PMC needs
+        # rocprofv3): the stored pass of tools/r2_profile.sh for this workload, labelled as such
+        upath = os.path.join(ROOT, "profiles", "r02_mfma_util.json")
+        if workload == "nuscenes1" and B == 4 and os.path.exists(upath):
+            u = json.load(open(upath))
+            out["mfma_busy_stored"] = {"source": "profiles/r02_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
+                                       **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
+                                                                              "sst_ffn_fwd_kernel", "sst_ffn_bwd_dw_kernel",
+                                                                              "vfe_layer1_kernel") if k in u}}
         if phases is not None:
             out["main_stream_phase_ms"] = phases
             out["main_stream_phase_sum_ms"] = round(float(sum(phases.values())), 4)

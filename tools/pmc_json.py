@@ -1,4 +1,4 @@
-"""profiles/r01_pmc_traffic.json from the two PMC summaries written by tools/pmc.sh (FETCH_SIZE and WRITE_SIZE passes).
+"""profiles/rNN_pmc_traffic.json from the two PMC summaries written by tools/pmc.sh (FETCH_SIZE and WRITE_SIZE passes).
 bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: counter unit KB, gfx950 correction of MI355X_MICROARCH.md
 (FETCH_SIZE reports half of a wide coalesced read stream)."""
 import csv, json, sys
@@ -11,12 +11,16 @@ def load(path, col):
     return d
 f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
 res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh, bench.py "
-                   "--steps 2 --warmup 1, B=4 single-sweep frames, mean over all launches of the kernel). Counter unit KB; "
+                   "--steps 3 --warmup 2, B=4 single-sweep frames, mean over all launches of the kernel). Counter unit KB; "
                    "corrected as MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024. "
                    "Regenerate: tools/pmc.sh fetch2 FETCH_SIZE ...; tools/pmc.sh write2 WRITE_SIZE ...; tools/pmc_json.py",
        "_raw_kb": {}}
 for k in sorted(set(f) & set(w)):
-    if not (k.startswith("sst_") or k.startswith("win_attn") or k.startswith("vfe_") or k in ("dw_kernel", "heads_loss_kernel", "adamw_kernel")):
+    if not (k.startswith("sst_") or k.startswith("win_") or k.startswith("vfe_") or k.startswith("voxelize") or
+            k.startswith("scan_") or k in ("dw_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
+                                            "centroid_targets_kernel", "normal_curv_kernel", "normal_eig_kernel",
+                                            "occ_count_kernel", "random_mask_kernel", "grad_sumsq_kernel",
+                                            "pack_weights_kernel", "rows_to_blocked_f32_kernel", "gather_token_coors_kernel")):
         continue
     res[k] = int((2 * f[k][0] + w[k][0]) * 1024)
     res["_raw_kb"][k] = [f[k][0], w[k][0], f[k][1]]
