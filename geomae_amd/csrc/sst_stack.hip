@@ -92,10 +92,10 @@ struct Timed {
     Profiler* p; hipStream_t s; bool on;
     Timed(void* prof, int id, hipStream_t st) : p((Profiler*)prof), s(st) {
         on = p && p->kernel_id == id && p->used + 2 <= (int)p->ev.size();
-        if (on) hipEventRecord(p->ev[p->used], s);
+        if (on) (void)hipEventRecord(p->ev[p->used], s);
     }
     ~Timed() {
-        if (on) { hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
+        if (on) { (void)hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
     }
 };
 
@@ -136,8 +136,8 @@ extern "C" int32_t geomae_profiler_read(void* prof, float* ms_out, int32_t capac
     if (!p) return 0;
     const int n = p->used / 2 < capacity ? p->used / 2 : capacity;
     for (int i = 0; i < n; ++i) {
-        hipEventSynchronize(p->ev[2 * i + 1]);
-        hipEventElapsedTime(&ms_out[i], p->ev[2 * i], p->ev[2 * i + 1]);
+        (void)hipEventSynchronize(p->ev[2 * i + 1]);
+        (void)hipEventElapsedTime(&ms_out[i], p->ev[2 * i], p->ev[2 * i + 1]);
     }
     p->used = 0;
     return n;
@@ -145,7 +145,7 @@ extern "C" int32_t geomae_profiler_read(void* prof, float* ms_out, int32_t capac
 extern "C" void geomae_profiler_destroy(void* prof) {
     Profiler* p = (Profiler*)prof;
     if (!p) return;
-    for (auto& e : p->ev) hipEventDestroy(e);
+    for (auto& e : p->ev) (void)hipEventDestroy(e);
     delete p;
 }
 

@@ -44,6 +44,7 @@ class PretrainEngine:
         self._profiler = None
         self._phase_timing = False
         self._opt_steps = int(opt.step_count)
+        self._hook_error = None
 
     # ------------------------------------------------------------------ binding
     def _config(self):
@@ -144,6 +145,14 @@ class PretrainEngine:
 
     # ------------------------------------------------------------------ hooks (world > 1)
     def _hook(self, user, what, stream):
+        # an exception escaping a ctypes callback is only printed: keep it and re-raise after the C call returned
+        try:
+            self._hook_body(what)
+        except BaseException as e:                       # noqa: BLE001
+            if self._hook_error is None:
+                self._hook_error = e
+
+    def _hook_body(self, what):
         group = self.bn_group if self.bn_group is not None else ops.BN_GROUP
         if what == HOOK_BN_FWD0:
             dist.all_reduce(self.sync["mom0"], group=group)
@@ -196,6 +205,10 @@ class PretrainEngine:
         for attempt in range(4):
             rc = self.lib.geomae_pretrain_step(ctypes.c_void_p(self.handle), nxt[0] if nxt else None, nxt[1] if nxt else None,
                                                float(lr), 1.0 / self.world, int(bool(run_optimizer)), ops._stream())
+            if self._hook_error is not None:
+                err, self._hook_error = self._hook_error, None
+                raise RuntimeError("geomae_pretrain_step: a collective issued from the engine's hook failed; the step's "
+                                   "results are invalid") from err
             if rc != ERR_WORKSPACE:
                 break
             # more pillars than the workspace was sized for: nothing was enqueued; grow and resubmit

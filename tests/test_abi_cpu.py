@@ -55,6 +55,33 @@ def test_host_side_argument_checks_need_no_gpu():
     assert rc == 0                                            # empty input is a no-op
 
 
+def test_pretrain_engine_argument_checks_need_no_gpu():
+    """The step-level entry points validate their host-side arguments before touching the device."""
+    import ctypes
+    from geomae_amd import _lib
+    lib = _lib.load()
+    c = _lib.GeomaePretrainConfig()
+    assert lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 1000, 100) == -1          # all-zero config
+    c.batch_size, c.num_features, c.num_heads, c.encoder_layers, c.decoder_layers = 4, 5, 8, 12, 4
+    c.targets.grid_size[:] = [1, 400, 400]
+    c.targets.ratio_low[:], c.targets.ratio_med[:] = [8, 4, 4], [4, 2, 2]
+    c.window.window_shape[:], c.window.shift[:], c.window.bev_shape[:] = [12, 12], [6, 6], [400, 400]
+    c.keep_fraction = 0.3
+    small = lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 110_000, 30_000)
+    big = lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 1_100_000, 120_000)
+    assert 0 < small < big < 64 * 2 ** 30                      # ~2 GB for a single-sweep batch, well inside 288 GB
+    assert lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 0, 10) == -1
+    c.keep_fraction = 1.5
+    assert lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 1000, 100) == -1 and b"keep_fraction" in lib.geomae_last_error()
+    c.keep_fraction = 0.3
+    c.targets.grid_size[:] = [2, 400, 400]
+    assert lib.geomae_pretrain_workspace_bytes(ctypes.byref(c), 1000, 100) == -1 and b"top grid" in lib.geomae_last_error()
+    assert not lib.geomae_pretrain_create(ctypes.byref(c), None, None, 0, 1000, 100, None)
+    assert lib.geomae_pretrain_step(None, None, None, 1e-5, 1.0, 1, None) < 0 and b"null engine" in lib.geomae_last_error()
+    assert lib.geomae_pretrain_result_offset(None, 0) == -1
+    lib.geomae_pretrain_destroy(None)                          # a no-op, like free(NULL)
+
+
 def test_missing_library_fails_loudly(tmp_path):
     from geomae_amd import _lib
     with pytest.raises(_lib.GeomaeLibraryError):

@@ -111,3 +111,35 @@ def test_engine_grows_its_workspace_and_times_phases():
     assert steps >= 2 and 0 <= blocked_s <= host_s
     with pytest.raises(RuntimeError, match="CUDA float32"):
         eng.step([p.double() for p in pool[0]], None, 1e-5)
+
+
+def test_engine_handles_ragged_batches_and_empty_frames():
+    """Batch sizes that change from step to step (1.8x more points -> the engine re-creates itself), a frame with no
+    points, B = 1; every step must stay finite and the pillar / token bookkeeping consistent."""
+    from geomae_amd import synth
+    from geomae_amd.train import Trainer
+    m = _build(1, 1)
+    tr = Trainer(m)
+    small = _batches(1, B=2)[0]
+    big = [torch.as_tensor(synth.lidar_frame(700 + b, beams=32, n_az=700), device="cuda") for b in range(2)]
+    holed = [small[0], torch.empty((0, 5), device="cuda")]
+    seq = [small, big, small, holed, small]
+    for i, pts in enumerate(seq):
+        nxt = seq[i + 1] if i + 1 < len(seq) else None
+        losses, gnorm = tr.train_step(pts, next_points=nxt)
+        torch.cuda.synchronize()
+        s = tr.engine.last_sizes()
+        assert s["N"] == sum(p.shape[0] for p in pts) and s["n_keep"] + s["n_mask"] == s["V"] > 0, (i, s)
+        assert all(torch.isfinite(v) for v in losses.values()) and torch.isfinite(gnorm), i
+    assert tr.engine.last_sizes()["optimizer_steps"] == len(seq)
+    # another batch size: a new engine for B = 1
+    m1 = _build(1, 1)
+    tr1 = Trainer(m1)
+    one = [small[0]]
+    for _ in range(2):
+        losses, _ = tr1.train_step(one, next_points=one)
+    torch.cuda.synchronize()
+    assert tr1.engine._B == 1 and all(torch.isfinite(v) for v in losses.values())
+    # an entirely empty batch is refused before anything is enqueued
+    with pytest.raises(RuntimeError, match="empty"):
+        tr1.train_step([torch.empty((0, 5), device="cuda")])
