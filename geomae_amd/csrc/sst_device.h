@@ -61,11 +61,14 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 #ifndef GEOMAE_STAMP_MAX_GRID
 #define GEOMAE_STAMP_MAX_GRID 1000000     // -DGEOMAE_STAMP_MAX_GRID=300: only encoder-size launches leave stamps
 #endif
+#ifndef GEOMAE_STAMP_MIN_GRID
+#define GEOMAE_STAMP_MIN_GRID 0           // -DGEOMAE_STAMP_MIN_GRID=300: only decoder-size launches leave stamps
+#endif
 static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
 #define GEOMAE_STAMP(i)                                                                                   \
     do {                                                                                                  \
         if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x && (i) >= 0 &&              \
-            gridDim.x <= GEOMAE_STAMP_MAX_GRID)                                                           \
+            gridDim.x <= GEOMAE_STAMP_MAX_GRID && gridDim.x >= GEOMAE_STAMP_MIN_GRID)                              \
             geomae_stamps[(blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS + (i)] = clock64();     \
     } while (0)
 #else
