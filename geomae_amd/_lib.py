@@ -80,7 +80,7 @@ class GeomaePretrainConfig(ctypes.Structure):
                 ("decoder_layers", c_int32), ("keep_fraction", c_double), ("mask_seed", c_uint64),
                 ("loss_weights", c_float * 6), ("vfe_voxel_size", c_float * 3), ("vfe_center_offset", c_float * 3),
                 ("bn_eps", c_float), ("bn_momentum", c_float), ("beta1", c_float), ("beta2", c_float),
-                ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32)]
+                ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32), ("sync_bn", c_int32)]
 
 
 class GeomaePretrainModel(ctypes.Structure):

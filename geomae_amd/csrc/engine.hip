@@ -317,7 +317,7 @@ int bn_forward(Engine* e, int layer, const double* sums, double count, float* sc
     const GeomaePretrainConfig& c = e->cfg;
     const GeomaePretrainModel& m = e->m;
     const int C = layer == 0 ? 64 : 128;
-    if (c.world_size <= 1)
+    if (c.world_size <= 1 || !c.sync_bn)
         return geomae_bn_finalize(sums, count, nullptr, C, m.bn_gamma[layer], m.bn_beta[layer], c.bn_eps, c.bn_momentum, 1,
                                   m.bn_running_mean[layer], m.bn_running_var[layer], scale, shift, invstd, moments,
                                   m.bn_num_batches[layer], s);
@@ -557,7 +557,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     GeomaeBnState bn;
     bn.scale0 = bn_scale0; bn.shift0 = bn_shift0; bn.mean0 = bn_mom0; bn.invstd0 = bn_invstd0;
     bn.scale1 = bn_scale1; bn.shift1 = bn_shift1; bn.mean1 = bn_mom1; bn.invstd1 = bn_invstd1;
-    const bool fold = c.world_size <= 1;
+    const bool fold = c.world_size <= 1 || !c.sync_bn;
     double* use_bs1 = fold ? bs1 : m.bn_sync_bsums1;
     double* use_bs0 = fold ? bs0 : m.bn_sync_bsums0;
     if (!fold) {

@@ -66,6 +66,8 @@ class PretrainEngine:
         c.beta1, c.beta2 = float(self.opt.betas[0]), float(self.opt.betas[1])
         c.adam_eps, c.weight_decay, c.max_grad_norm = float(self.opt.eps), float(self.opt.weight_decay), self.max_norm
         c.world_size = self.world
+        from .norm import NaiveSyncBatchNorm1d
+        c.sync_bn = int(isinstance(n0, NaiveSyncBatchNorm1d))          # a config with plain 'BN1d' keeps local statistics
         return c
 
     def _model_struct(self):
@@ -100,7 +102,7 @@ class PretrainEngine:
         assert len(nds) <= 1, "the fused AdamW pass takes a no-decay prefix and one more range"
         m.no_decay_prefix = prefix
         m.no_decay2_start, m.no_decay2_count = (nds[0][0], nds[0][1] - nds[0][0]) if nds else (0, 0)
-        if self.world > 1:
+        if self.world > 1:                                              # (allocated even without sync_bn: 3 KB)
             z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.dev)
             self.sync = dict(mom0=z(128, torch.float32), mom1=z(256, torch.float32), bs1=z(256, torch.float64),
                              bs0=z(128, torch.float64))
@@ -202,6 +204,8 @@ class PretrainEngine:
                 next_points = None                      # does not fit this engine: submitted (and re-sized) next step
             else:
                 nxt = self._frames(next_points)
+                for t in next_points:                   # read by copies enqueued on the decoder-B stream during this step
+                    t.record_stream(self.aux)
         for attempt in range(4):
             rc = self.lib.geomae_pretrain_step(ctypes.c_void_p(self.handle), nxt[0] if nxt else None, nxt[1] if nxt else None,
                                                float(lr), 1.0 / self.world, int(bool(run_optimizer)), ops._stream())

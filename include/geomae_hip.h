@@ -555,7 +555,9 @@ typedef struct GeomaePretrainConfig {
     float vfe_center_offset[3];      /* v / 2 + range_min                                                   */
     float bn_eps, bn_momentum;
     float beta1, beta2, adam_eps, weight_decay, max_grad_norm;
-    int32_t world_size;              /* > 1: naiveSyncBN1d statistics + gradient exchange through `hook`    */
+    int32_t world_size;              /* > 1: gradient-segment hooks; with sync_bn also naiveSyncBN1d's exchanges */
+    int32_t sync_bn;                 /* the VFE's norm layers are naiveSyncBN1d (cross-rank statistics at world_size > 1);
+                                        0 = plain BatchNorm1d statistics of the local batch whatever the world size */
 } GeomaePretrainConfig;
 
 /* Device pointers of the model (parameters and gradients are views of the flat buffers; all of them must stay where
