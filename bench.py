@@ -41,7 +41,15 @@ def cpu_baseline(seed=1000):
         dt = time.perf_counter() - t0
         if dt > 10.0 or n >= 3:
             break
-    return dict(value=round(n / dt, 4), unit="frames/s", cores=cores, kind="port",
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return dict(value=round(n / dt, 4), unit="frames/s", cores=cores, kind="port", cpu_model=model,
                 sample=f"{n} x (1 single-sweep frame, {frame.shape[0]} pts, fwd+bwd, torch-CPU fp32)")
 
 
