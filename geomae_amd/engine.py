@@ -40,6 +40,12 @@ class PretrainEngine:
         self.bn_group = None
         st = ops.side_streams(self.dev)
         self.geo, self.aux = st["geo"], st["dec_b"]
+        import os
+        if os.environ.get("GEOMAE_ENGINE_SERIAL") == "1":
+            # diagnostic: the whole schedule on the caller's stream (every cross-stream wait then refers to an event
+            # recorded earlier in the same stream).  What a step costs WITHOUT any overlap between hardware queues --
+            # the bound for a box whose stream -> queue mapping defeats the three-stream schedule.
+            self.geo = self.aux = torch.cuda.current_stream(self.dev)
         self._hook_c = _lib.PRETRAIN_HOOK(self._hook)
         self._profiler = None
         self._phase_timing = False
