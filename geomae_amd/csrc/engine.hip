@@ -79,8 +79,8 @@ struct WinLayout {
     int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles, *bun_tok, *pos_info;
 };
 
-enum Ev { kStepEnd, kMaskDone, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kForkBwd, kAuxBwd, kMainDecBwd,
-          kEncBwd, kVfeL1, kGeoDone, kPacked, kFirstMain, kNumEv };
+enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
+          kPacked, kFirstMain, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -115,6 +115,8 @@ struct Engine {
     int64_t off_losses = 0, off_ids_keep = 0, off_ids_mask = 0;
     int32_t cells = 0, gz = 1, gy = 1, gx = 1, s_low = 1, s_med = 1;
     double host_step_s = 0.0, host_blocked_s = 0.0;      // cumulative wall time inside step calls / in the readback wait
+    // a step that fails AFTER its first launch leaves streams, events and the workspace in an undefined state
+    bool enqueue_started = false, poisoned = false;
 };
 
 inline double now_s() {
@@ -461,6 +463,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     const int max_tokens = c.window.window_shape[0] * c.window.window_shape[1];
 
     // ---------------- side streams start behind the previous step's optimizer
+    e->enqueue_started = true;
     if (e->have_step_end) {
         GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kStepEnd], 0));      // (dec_b waited for it when it packed ahead)
     } else {
@@ -749,9 +752,12 @@ extern "C" int geomae_pretrain_step(void* engine, const float* const* next_frame
                                     float lr, float grad_scale, int32_t run_opt, hipStream_t stream) {
     Engine* e = (Engine*)engine;
     GEOMAE_REQUIRE(e, "pretrain: null engine");
+    GEOMAE_REQUIRE(!e->poisoned, "pretrain_step: an earlier step failed after its first launch; destroy this engine");
     const double t0 = now_s();
+    e->enqueue_started = false;
     const int rc = run_step(e, next_frame_points, next_frame_sizes, lr, grad_scale, run_opt, stream);
     e->host_step_s += now_s() - t0;
+    if (rc != GEOMAE_OK && e->enqueue_started) e->poisoned = true;      // (failures before the first launch are clean)
     return rc;
 }
 

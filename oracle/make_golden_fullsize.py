@@ -115,7 +115,7 @@ def run(case):
 
 def main():
     which = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-    dst = os.path.join(ROOT, "tests", "golden", "g_fullsize.npz")
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_fullsize.npz")
     out = dict(np.load(dst)) if os.path.exists(dst) else {}
     for case in which:
         out.update(run(case))

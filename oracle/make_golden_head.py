@@ -309,7 +309,7 @@ def main():
                dx_abs=np.float64(x.grad.double().abs().sum()))
     for k, p in head.named_parameters():
         out["grad." + k] = p.grad.numpy()
-    dst = os.path.join(ROOT, "tests", "golden", "g_head.npz")
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_head.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "losses", {k: float(v[0]) for k, v in losses.items()}, "num_pos", int(t[6]),
           "anchors", anchors[0].shape)

@@ -203,7 +203,7 @@ def main():
                 out[k + "shuffled_rowsum"] = np.sort(shuffled.astype(np.float64).sum(1))
                 print(tag, b, "sweeps", len(fr["sweeps"]), "->", pts.shape, "rng", names, "rot", float(uni[0]),
                       "flip", bool(res["pcd_horizontal_flip"]), bool(res["pcd_vertical_flip"]))
-    dst = os.path.join(ROOT, "tests", "golden", "g_input_pipeline.npz")
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_input_pipeline.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), "bytes")
 

@@ -109,7 +109,7 @@ def main():
             d = np.load(os.path.join(tmp, f"r{r}.npz"))
             for k in d.files:
                 merged[f"r{r}.{k}"] = d[k]
-    dst = os.path.join(ROOT, "tests", "golden", "g_syncbn_w2.npz")
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_syncbn_w2.npz")
     np.savez_compressed(dst, **merged)
     print("wrote", dst, os.path.getsize(dst), "bytes;", {k: v.shape for k, v in merged.items() if k.startswith("r0.") and v.ndim})
     assert np.array_equal(merged["r0.v_buf.vfe_layers.1.norm.running_var"], merged["r1.v_buf.vfe_layers.1.norm.running_var"])

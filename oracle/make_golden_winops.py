@@ -58,7 +58,7 @@ def main():
         out[f"l{dl}.shape"] = np.array(t.shape)
         out[f"l{dl}.sorted_rowsums"] = np.sort(t.double().sum(-1).numpy(), axis=1)
         out[f"l{dl}.nonzero_rows"] = (t.abs().sum(-1) > 0).sum(1).numpy()
-    dst = os.path.join(ROOT, "tests", "golden", "g_winops.npz")
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_winops.npz")
     np.savez_compressed(dst, **out)
     print("wrote", dst, os.path.getsize(dst), {k: v.shape for k, v in out.items() if hasattr(v, "shape") and v.ndim})
 
