@@ -114,6 +114,37 @@ def _worker(rank, world, port, tmp):
             assert torch.allclose(mod.running_mean, G("m_running_mean"), rtol=1e-5, atol=1e-6), variant
             assert torch.allclose(mod.running_var, G("m_running_var"), rtol=1e-5, atol=1e-6), variant
             assert int(mod.num_batches_tracked) == int(gold[f"r{rank}.m_num_batches_tracked"]) == 0
+        # ---- Trainer construction makes the replicas identical (what MMDistributedDataParallel's constructor does):
+        # parameters AND buffers come from rank 0 whatever each rank seeded
+        from geomae_amd.train import Trainer
+
+        class WithBuffer(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.lin = nn.Linear(6, 5)
+                self.bn = nn.BatchNorm1d(5)
+
+            def forward_train(self, x, metas, **kw):
+                return dict(loss=self.bn(self.lin(x)).pow(2).mean())
+
+        torch.manual_seed(1000 + rank)                       # DIFFERENT initial weights per rank
+        mb = WithBuffer()
+        with torch.no_grad():
+            mb.bn.running_mean.fill_(float(rank + 1))
+            mb.bn.num_batches_tracked.fill_(7 * (rank + 1))
+        tr = Trainer(mb)
+        mine = torch.cat([tr.flat.flat, mb.bn.running_mean, mb.bn.num_batches_tracked.float().reshape(1)])
+        both = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(both, mine)
+        assert torch.equal(both[0], both[1]) and float(mb.bn.running_mean[0]) == 1.0 and int(mb.bn.num_batches_tracked) == 7
+        # ... and stay identical through training steps on different data (gradients averaged, same update)
+        for it in range(3):
+            xs_ = torch.randn(12, 6, generator=torch.Generator().manual_seed(10 * it + rank))
+            tr.train_step(xs_)
+        mine = tr.flat.flat.clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.allclose(gathered[0], gathered[1], rtol=0, atol=0)
         torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
     finally:
         dist.destroy_process_group()
