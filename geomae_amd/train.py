@@ -309,12 +309,18 @@ class Trainer:
                 # in order with its kernels instead of beside them), geometry, decoder-B; the SyncBN group's stream, if
                 # the backend uses one for blocking collectives at all, comes 5th and shares the main stream's queue --
                 # harmless, the main stream waits for those collectives anyway.
-                t = torch.zeros(1, device=self.flat.flat.device)
-                dist.all_reduce(t, async_op=True).wait()
-                ops.side_streams(t.device)
-                if ops.BN_GROUP is not None:
-                    dist.all_reduce(t, group=ops.BN_GROUP)
-                torch.cuda.synchronize(t.device)
+                try:
+                    t = torch.zeros(1, device=self.flat.flat.device)
+                    dist.all_reduce(t, async_op=True).wait()
+                    ops.side_streams(t.device)
+                    if ops.BN_GROUP is not None:
+                        dist.all_reduce(t, group=ops.BN_GROUP)
+                    torch.cuda.synchronize(t.device)
+                except Exception as e:                       # only the ORDER of stream creation is lost: still correct
+                    import warnings
+                    warnings.warn(f"geomae_amd: could not prime the communication streams ({e!r}); the step stays correct, "
+                                  "its side streams may share a hardware queue with the collectives")
+                    ops.side_streams(self.flat.flat.device)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # what MMDistributedDataParallel does at construction: every replica starts from rank 0's parameters AND
             # buffers (BatchNorm running statistics, counters) whatever the ranks seeded or loaded; afterwards only
