@@ -154,7 +154,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     const int64_t s_med = (int64_t)c.targets.ratio_med[0] * c.targets.ratio_med[1] * c.targets.ratio_med[2];
     const int64_t n = V < 1 ? 1 : V, M = n, nk = n;
     int64_t b = 0;
-    b += al256(256 * 8) + al256(128 * 8) + 2 * al256(n * 512) + al256(n * 512) + al256(n * 256);          // zeros_late
+    b += al256(256 * 8) + al256(128 * 8) + 3 * al256(n * 512) + al256(n * 512) + al256(n * 256);          // zeros_late
     b += 6 * al256(128 * 4) + al256(256 * 4) * 2 + al256(128 * 8) + al256(n * 256) + al256(256 * 8) + al256(n * 512);  // zeros_fwd
     b += al256(n * 16);                                                                                    // coors_all
     b += 2 * window_layout_bytes(c, nk) + 2 * window_layout_bytes(c, n);
@@ -387,6 +387,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     double* bs1 = a.take<double>(256);
     double* bs0 = a.take<double>(128);
     float* d_cen = a.take<float>((int64_t)n * 128);
+    float* d_cen2 = a.take<float>((int64_t)n * 128);       // second summand of d_cen (geomae_heads_loss_split_accumulate)
     float* d_den = a.take<float>((int64_t)n * 128);
     float* d_vf = a.take<float>((int64_t)V * 128);
     float* dm0 = a.take<float>((int64_t)V * 64);
@@ -529,9 +530,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
                                       m.mask_token, nullptr, e->profiler, main));
     ENG_CALL(order_after(e, kJoinDecFwd, aux, main));
     mark(e, pDecFwd, main);
-    ENG_CALL(geomae_heads_loss_accumulate(cen, den, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed, t_mmed,
-                                          t_ctop, t_normal, t_occ, c.loss_weights, losses, d_cen, d_den, h_dl, h_cm, h_dm,
-                                          main));
+    ENG_CALL(geomae_heads_loss_split_accumulate(cen, den, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed,
+                                                t_mmed, t_ctop, t_normal, t_occ, c.loss_weights, losses, d_cen, d_cen2, d_den,
+                                                h_dl, h_cm, h_dm, main));
     // ---------------- backward.  Contractions that only the optimizer reads go to the geometry stream.
     ENG_CALL(order_after(e, kHeads, main, geo));
     ENG_CALL(geomae_heads_weight_grad(nm, h_dl, h_cm, h_dm, &m.head_grads, geo));
@@ -542,7 +543,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     GEOMAE_HIP(hipEventRecord(e->ev[kAuxBwd], aux));
     GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kAuxBwd], 0));
     ENG_CALL(geomae_flush_weight_grad(geo));
-    ENG_CALL(geomae_sst_stack_backward(d_cen, nullptr, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
+    ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
                                        w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
     ENG_CALL(order_after(e, kMainDecBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));

@@ -35,6 +35,7 @@ struct HeadArgs {
     float w_low, w_med, w_top, w_nor, w_cls_low, w_cls_med;
     float* loss;                              // [6] curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med
     float* d_cen; float* d_den;               // [n,128], rows >= n_keep written (others pre-zeroed by caller)
+    float* d_cen2;                            // split mode (see heads_loss_kernel): second summand of d_cen, or nullptr
     bf16_t* dl; bf16_t* cm_b; bf16_t* dm_b;   // [M,896], [M,128], [M,128]
 };
 
@@ -72,9 +73,16 @@ __device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, c
     }
 }
 
-__global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
-    __shared__ float red[4][6];
+// MODE 0: all seven 128-output chunks in one workgroup (the original form).  MODE 1 / 2: the two halves of the split
+// form -- chunks 0-2 (the 384 low-level regression outputs) and chunks 3-6 (class logits, med / top outputs, the
+// density decoder's normal head).  At 15 k masked pillars the single form is 241 workgroups of one wave per SIMD, each a
+// 72 us chain of 7 x (GEMM -> loss arithmetic -> dX GEMM); the split form is 482 workgroups, two per CU, each half as
+// long.  Both halves contribute to d(centroid decoder output): they write SEPARATE zero-initialised buffers (d_cen,
+// d_cen2) that the decoder's backward sums while loading (geomae_sst_stack_backward dz + dz_add) -- no atomics.
+template <int MODE>
+__device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __restrict__ smem, float (*red)[6]) {
+    constexpr int kFirst = MODE == 2 ? 3 : 0, kLast = MODE == 1 ? 3 : 7;
+    float* const d_cen_out = MODE == 2 ? A.d_cen2 : A.d_cen;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
         load_rows_f32<128>(A.cen, A.n_keep + A.M, (int)tok, x, lane);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) xb[ct] = pack4(x[ct]);
-        store_rows_bf16<128>(A.cm_b, A.M, (int)row, 128, 0, x, lane);
+        if (MODE != 2) store_rows_bf16<128>(A.cm_b, A.M, (int)row, 128, 0, x, lane);
     }
     f32x4 dx[8];
 #pragma unroll
@@ -101,7 +109,8 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 
     // weights of chunk c+1 are requested right after chunk c's matrix is in LDS: the loads fly under the loss
     // arithmetic and the dX GEMM instead of stalling the next chunk's first MFMA
-    for (int chunk = 0; chunk < 7; ++chunk) {
+#pragma unroll
+    for (int chunk = kFirst; chunk < kLast; ++chunk) {
         if (chunk == 6) {
             // flush d_cen, switch the input to the density decoder
 #pragma unroll
@@ -109,7 +118,7 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-                    if (rr < A.M) A.d_cen[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
+                    if (rr < A.M) d_cen_out[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
                 }
             f32x4 x[8];
             load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
@@ -217,15 +226,16 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
         }
         accumulate_dx(smem, dlb, dx, lane);
     }
+    float* const d_last = MODE == 1 ? A.d_cen : A.d_den;       // MODE 1 ends on the centroid decoder's chunks
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-            if (rr < A.M) A.d_den[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
+            if (rr < A.M) d_last[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
         }
     // zero the padding columns of dl that dw_kernel will read: [771,896)
-    if (valid)
+    if (valid && MODE != 1)
         for (int cidx = 800 + 4 * g; cidx < kDlLd; cidx += 16)
             *reinterpret_cast<uint2*>(A.dl + row * kDlLd + cidx) = make_uint2(0u, 0u);
     // ---- losses: wave reduce, block reduce, one atomic per loss
@@ -240,18 +250,25 @@ __global__ __launch_bounds__(kLayerBlk) void heads_loss_kernel(HeadArgs A) {
                                                           red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
+__global__ __launch_bounds__(kLayerBlk, 2) void heads_loss_kernel(HeadArgs A) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ float red[4][6];
+    if (A.d_cen2 == nullptr) heads_loss_body<0>(A, smem, red);
+    else if (blockIdx.y == 0) heads_loss_body<1>(A, smem, red);
+    else heads_loss_body<2>(A, smem, red);
+}
+
 }  // namespace geomae
 
 using namespace geomae;
 
-// `losses` is ACCUMULATED into (atomics): the caller zeroes it, e.g. off the critical path
-extern "C" int geomae_heads_loss_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
-                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
-                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
-                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
-                                 const int32_t* occ_counts, const float* loss_weights, float* losses,
-                                 float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
-                                 void* dm_bf16, hipStream_t stream) {
+static int heads_loss_launch(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                             int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                             const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                             const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                             const int32_t* occ_counts, const float* loss_weights, float* losses,
+                             float* d_dec_centroid, float* d_dec_centroid2, float* d_dec_density, void* dlogits_bf16,
+                             void* cm_bf16, void* dm_bf16, hipStream_t stream) {
     if (num_mask <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(dec_centroid && dec_density && head_w_packed && head_bias && centroid_low && mask_low &&
                    centroid_med && mask_med && centroid_top && normal && occ_counts && loss_weights && losses &&
@@ -263,11 +280,41 @@ extern "C" int geomae_heads_loss_accumulate(const float* dec_centroid, const flo
     A.t_top = centroid_top; A.t_nor = normal; A.occ = occ_counts;
     A.w_nor = loss_weights[0]; A.w_low = loss_weights[1]; A.w_med = loss_weights[2]; A.w_top = loss_weights[3];
     A.w_cls_low = loss_weights[4]; A.w_cls_med = loss_weights[5];
-    A.loss = losses; A.d_cen = d_dec_centroid; A.d_den = d_dec_density;
+    A.loss = losses; A.d_cen = d_dec_centroid; A.d_den = d_dec_density; A.d_cen2 = d_dec_centroid2;
     A.dl = (bf16_t*)dlogits_bf16; A.cm_b = (bf16_t*)cm_bf16; A.dm_b = (bf16_t*)dm_bf16;
     const int tiles = cdiv(num_mask, 16);
-    hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, A);
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64), d_dec_centroid2 ? 2 : 1), dim3(kLayerBlk), 0,
+                       stream, A);
     return check_launch("heads_loss_kernel");
+}
+
+// `losses` is ACCUMULATED into (atomics): the caller zeroes it, e.g. off the critical path
+extern "C" int geomae_heads_loss_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                 const int32_t* occ_counts, const float* loss_weights, float* losses,
+                                 float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
+                                 void* dm_bf16, hipStream_t stream) {
+    return heads_loss_launch(dec_centroid, dec_density, num_keep, num_mask, head_w_packed, head_bias, centroid_low, mask_low,
+                             centroid_med, mask_med, centroid_top, normal, occ_counts, loss_weights, losses, d_dec_centroid,
+                             nullptr, d_dec_density, dlogits_bf16, cm_bf16, dm_bf16, stream);
+}
+
+// split form: twice the workgroups, each half the chain.  d_dec_centroid and d_dec_centroid2 (both [n,128], zeroed by
+// the caller) are the two summands of the centroid decoder's output gradient: hand them to
+// geomae_sst_stack_backward as dz and dz_add.
+extern "C" int geomae_heads_loss_split_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                 int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                 const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                 const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                 const int32_t* occ_counts, const float* loss_weights, float* losses,
+                                 float* d_dec_centroid, float* d_dec_centroid2, float* d_dec_density, void* dlogits_bf16,
+                                 void* cm_bf16, void* dm_bf16, hipStream_t stream) {
+    GEOMAE_REQUIRE(d_dec_centroid2, "heads_loss_split: null d_dec_centroid2");
+    return heads_loss_launch(dec_centroid, dec_density, num_keep, num_mask, head_w_packed, head_bias, centroid_low, mask_low,
+                             centroid_med, mask_med, centroid_top, normal, occ_counts, loss_weights, losses, d_dec_centroid,
+                             d_dec_centroid2, d_dec_density, dlogits_bf16, cm_bf16, dm_bf16, stream);
 }
 
 extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep,

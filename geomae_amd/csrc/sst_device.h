@@ -129,6 +129,69 @@ __device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __re
     }
 }
 
+// Column-split form (the "pair" kernels of sst_layer.hip): two waves share one 16-token tile, wave half h computes the
+// output tiles [h * N/32, (h + 1) * N/32) from the FULL-K operand -- half the MFMA chain and half the LDS fragment reads
+// per wave.  Same staging copy and barriers as gemm_staged; same accumulation order over K, so the results are
+// bit-identical to gemm_staged's.
+template <int K, int N>
+__device__ __forceinline__ void gemm_staged_half(const WStage<K, N>& st, bf16_t* __restrict__ smem,
+                                                 const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 32], int lane, int h) {
+    constexpr int LD = K + kPad;
+    constexpr int CH = K / 8;
+    constexpr int PASSES = N * CH / kLayerBlk;
+    static_assert(N * LD <= kWeightLds, "LDS weight buffer too small");
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < PASSES; ++p) {
+        const int c = p * kLayerBlk + threadIdx.x;
+        *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = st.r[p];
+    }
+    __syncthreads();
+    const int o = lane & 15, g = lane >> 4;
+    const bf16_t* base = smem + h * (N / 2) * LD + o * LD + 8 * g;
+    constexpr int NH = N / 32;
+    constexpr int GRP = NH < 4 ? NH : 4;
+#pragma unroll
+    for (int ot0 = 0; ot0 < NH; ot0 += GRP) {
+#pragma unroll
+        for (int kk = 0; kk < K / 32; ++kk) {
+            const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
+#pragma unroll
+            for (int u = 0; u < GRP; ++u) {
+                const uint4 a = *reinterpret_cast<const uint4*>(base + 16 * (ot0 + u) * LD + 32 * kk);
+                acc[ot0 + u] = mfma32(a, b, acc[ot0 + u]);
+            }
+        }
+    }
+}
+
+// The two waves of a pair (wave w and w ^ 2 of the 4-wave workgroup) swap NV 16-byte values per lane through LDS:
+// lane l of one wave receives what lane l of the other wrote.  `xch` holds 4 waves x NV x 64 lanes x 16 B.  The caller
+// keeps a workgroup barrier between two exchanges (every gemm_staged* has two).
+template <int NV>
+__device__ __forceinline__ void pair_exchange(uint4* __restrict__ xch, int wave, int lane, const uint4 (&mine)[NV],
+                                              uint4 (&theirs)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xch[(wave * NV + i) * 64 + lane] = mine[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) theirs[i] = xch[((wave ^ 2) * NV + i) * 64 + lane];
+}
+// full[NT tiles of half 0 | NT tiles of half 1] from this wave's half (h) and its partner's
+template <int NT>
+__device__ __forceinline__ void join_halves(const f32x4 (&mine)[NT], const f32x4 (&theirs)[NT], int h, f32x4 (&full)[2 * NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        full[i] = h ? theirs[i] : mine[i];
+        full[NT + i] = h ? mine[i] : theirs[i];
+    }
+}
+template <int NT, typename T>
+__device__ __forceinline__ void half_of(const T (&full)[2 * NT], int h, T (&mine)[NT]) {
+#pragma unroll
+    for (int i = 0; i < NT; ++i) mine[i] = h ? full[NT + i] : full[i];
+}
+
 template <int K, int N>
 __device__ __forceinline__ void gemm_t(const bf16_t* __restrict__ Wp, bf16_t* __restrict__ smem,
                                        const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
@@ -237,6 +300,24 @@ template <int C>
 __device__ __forceinline__ void store_rows_f32(float* __restrict__ dst, int n, int tok, const f32x4 (&v)[C / 16], int lane,
                                                bool blk = false) {
     const RowAddr a = row_addr<4>(dst, n, tok, C, 0, lane, blk);
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ct]), a.r, a.voff, ct * a.ct_stride, 0);
+}
+
+// C channels starting at column col0 of a [n, ld] fp32 matrix
+template <int C>
+__device__ __forceinline__ void load_rows_f32_cols(const float* __restrict__ src, int n, int tok, int ld, int col0,
+                                                   f32x4 (&v)[C / 16], int lane, bool blk = false) {
+    const RowAddr a = row_addr<4>(src, n, tok, ld, col0, lane, blk);
+#pragma unroll
+    for (int ct = 0; ct < C / 16; ++ct)
+        v[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(a.r, a.voff, ct * a.ct_stride, 0));
+}
+template <int C>
+__device__ __forceinline__ void store_rows_f32_cols(float* __restrict__ dst, int n, int tok, int ld, int col0,
+                                                    const f32x4 (&v)[C / 16], int lane, bool blk = false) {
+    const RowAddr a = row_addr<4>(dst, n, tok, ld, col0, lane, blk);
 #pragma unroll
     for (int ct = 0; ct < C / 16; ++ct)
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[ct]), a.r, a.voff, ct * a.ct_stride, 0);

@@ -231,6 +231,156 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     }
 }
 
+// Pair form of F3 (+ the fused F1) for SMALL token counts.  At encoder size (6.5 k kept tokens) the kernel above is 102
+// workgroups of one wave per SIMD on a 256-CU chip: 60 % of the CUs idle while each wave walks a ~50 k-cycle dependent
+// chain (256 MFMAs + the elementwise phases of 16 tokens x 128..384 channels).  Here a workgroup takes 32 tokens and two
+// waves share each 16-token tile: wave half h computes half of every GEMM's output channels from the full-K operand and
+// does the elementwise work (GELU, loads, stores) of its half; the halves meet through LDS three times (the two
+// pre-LayerNorm sums in fp32, the GELU output in bf16), after which both hold the full row for the LayerNorm
+// statistics and the next GEMM's operand.  Twice the workgroups, half the chain per wave; every value is computed by
+// the same instruction sequence as in the single-wave form, so the outputs are bit-identical to it.
+__global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const float* __restrict__ x,
+                                                                     const bf16_t* __restrict__ attn, LayerW W, int n,
+                                                                     float eps, float* __restrict__ z,
+                                                                     float* __restrict__ xh1_out,
+                                                                     float* __restrict__ xh2_out,
+                                                                     bf16_t* __restrict__ hp_out,
+                                                                     float* __restrict__ rstd_out, NextQkv N, int lay) {
+    const bool blk = lay & kLayBlocked;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ uint4 xch[4 * 4 * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = wave >> 1;                                          // which half of the output channels
+    const int tile = blockIdx.x * 2 + (wave & 1);
+    const int tok = tile * 16 + (lane & 15);
+    f32x4 u[8], y[8];
+    float r1, r2;
+    WStage<128, 256> s_w1;
+    {
+        WStage<128, 128> s_wo;
+        stage_issue<128, 128>(W.wo, s_wo);
+        uint2 ob[8];
+        load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane, blk);
+        f32x4 xr[4], uh[4], other[4];
+        load_rows_f32_cols<64>(x, n, tok, 128, 64 * h, xr, lane, lay & kLayXBlocked);
+        load_bias<64>(W.bo + 64 * h, uh, lane);
+        gemm_staged_half<128, 128>(s_wo, smem, ob, uh, lane, h);
+        stage_issue<128, 256>(W.w1, s_w1);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) uh[ct] += xr[ct];
+        pair_exchange<4>(xch, wave, lane, reinterpret_cast<const uint4(&)[4]>(uh), reinterpret_cast<uint4(&)[4]>(other));
+        join_halves<4>(uh, other, h, u);
+    }
+    layer_norm_t(u, eps, &r1);
+    if (xh1_out) {
+        f32x4 mine[4];
+        half_of<4>(u, h, mine);
+        store_rows_f32_cols<64>(xh1_out, n, tok, 128, 64 * h, mine, lane, blk);
+    }
+    affine_t(u, W.g1, W.be1, y, lane);
+    uint2 hb[16];
+    WStage<256, 128> s_w2;
+    {
+        uint2 yb[8];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
+        f32x4 hp[8];
+        load_bias<128>(W.b1 + 128 * h, hp, lane);
+        gemm_staged_half<128, 256>(s_w1, smem, yb, hp, lane, h);
+        stage_issue<256, 128>(W.w2, s_w2);
+        if (hp_out) store_rows_bf16<128>(hp_out, n, tok, 256, 128 * h, hp, lane, blk);
+        uint4 mine[4], other[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 a, b;
+            {
+                const f32x4 v = hp[2 * i];
+                const f32x4 hv = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                a = pack4(hv);
+            }
+            {
+                const f32x4 v = hp[2 * i + 1];
+                const f32x4 hv = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                b = pack4(hv);
+            }
+            mine[i] = make_uint4(a.x, a.y, b.x, b.y);
+        }
+        pair_exchange<4>(xch, wave, lane, mine, other);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 lo = h ? other[i] : mine[i], hi = h ? mine[i] : other[i];
+            hb[2 * i] = make_uint2(lo.x, lo.y);
+            hb[2 * i + 1] = make_uint2(lo.z, lo.w);
+            hb[8 + 2 * i] = make_uint2(hi.x, hi.y);
+            hb[8 + 2 * i + 1] = make_uint2(hi.z, hi.w);
+        }
+    }
+    const bool has_next = N.wqkv != nullptr;
+    WStage<128, 256> s_qk;
+    {
+        f32x4 uh[4], yh[4], other[4];
+        load_bias<64>(W.b2 + 64 * h, uh, lane);
+        gemm_staged_half<256, 128>(s_w2, smem, hb, uh, lane, h);
+        if (has_next) stage_issue<128, 256>(N.wqkv, s_qk);
+        half_of<4>(y, h, yh);
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) uh[ct] += yh[ct];
+        pair_exchange<4>(xch, wave, lane, reinterpret_cast<const uint4(&)[4]>(uh), reinterpret_cast<uint4(&)[4]>(other));
+        join_halves<4>(uh, other, h, u);
+    }
+    layer_norm_t(u, eps, &r2);
+    if (xh2_out) {
+        f32x4 mine[4];
+        half_of<4>(u, h, mine);
+        store_rows_f32_cols<64>(xh2_out, n, tok, 128, 64 * h, mine, lane, blk);
+    }
+    if (rstd_out && h == 0 && (lane >> 4) == 0)
+        __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
+                                              tok * 8, 0, 0);
+    affine_t(u, W.g2, W.be2, y, lane);
+    {
+        f32x4 mine[4];
+        half_of<4>(y, h, mine);
+        store_rows_f32_cols<64>(z, n, tok, 128, 64 * h, mine, lane, lay & kLayZBlocked);
+    }
+    if (!has_next) return;
+    // ---- F1 of the next layer on z = y (registers, both waves hold the full row)
+    const int g = lane >> 4;
+    const int p = __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(N.tok_pos, n, 4), tok * 4, 0, 0);
+    uint2 xb[8], xpb[8];
+    {
+        const __amdgpu_buffer_rsrc_t pr = table_rsrc(N.pos_table);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) {
+            const f32x4 pv = buf_load_f32x4(pr, p * 512 + 64 * ct + 16 * g);
+            xb[ct] = pack4(y[ct]);
+            xpb[ct] = pack4(y[ct] + pv);
+        }
+    }
+    if (N.x_b) {
+        uint2 m0[4], m1[4];
+        half_of<4>(xb, h, m0);
+        half_of<4>(xpb, h, m1);
+        store_rows_packed<64>(N.x_b, n, tok, 128, 64 * h, m0, lane, blk);
+        store_rows_packed<64>(N.xp_b, n, tok, 128, 64 * h, m1, lane, blk);
+    }
+    WStage<128, 128> s_v;
+    {
+        f32x4 acc[8];
+        load_bias<128>(N.bqkv + 128 * h, acc, lane);
+        gemm_staged_half<128, 256>(s_qk, smem, xpb, acc, lane, h);
+        stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
+        store_rows_bf16<128>(N.qkv, n, tok, 384, 128 * h, acc, lane, blk);
+    }
+    {
+        f32x4 acc[4];
+        load_bias<64>(N.bqkv + 256 + 64 * h, acc, lane);
+        gemm_staged_half<128, 128>(s_v, smem, xb, acc, lane, h);
+        store_rows_bf16<64>(N.qkv, n, tok, 384, 256 + 64 * h, acc, lane, blk);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // B3: backward of F3 from the saved (xhat1, xhat2, hp, rstd).  Emits
 //   dx_res [n,128] f32 (gradient reaching x through the residual = d(x + a)),  dattn [n,128] bf16,
@@ -671,6 +821,19 @@ extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc
 constexpr int kMaxLayerTokens = 2700000;
 #define GEOMAE_CHECK_TOKENS(n, who) GEOMAE_REQUIRE((n) <= kMaxLayerTokens, who ": more than 2.7 M tokens per call")
 
+// The pair kernels pay when one workgroup per CU covers the whole launch (one wave per SIMD either way, twice the CUs
+// busy); past that the single-wave form's lower total work wins.  GEOMAE_PAIR_KERNELS=0 / 1 (environment) or
+// geomae_sst_set_pair_kernels force the choice (A/B runs, the bit-identity test).
+static int g_pair_mode = [] {
+    const char* e = getenv("GEOMAE_PAIR_KERNELS");
+    return e ? atoi(e) : -1;
+}();
+static bool use_pair_kernels(int tiles) {
+    if (g_pair_mode >= 0) return g_pair_mode != 0;
+    return cdiv(tiles, 2) <= 256;
+}
+extern "C" void geomae_sst_set_pair_kernels(int32_t mode) { g_pair_mode = mode < 0 ? -1 : (mode != 0); }
+
 extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, void* qkv_bf16,
                                       void* x_bf16, void* xp_bf16, hipStream_t stream) {
@@ -708,6 +871,12 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
                     (bf16_t*)next_x_bf16, (bf16_t*)next_xp_bf16};
     }
     const int tiles = cdiv(num_tokens, 16);
+    if (use_pair_kernels(tiles)) {
+        hipLaunchKernelGGL(sst_ffn_fwd_pair_kernel, dim3(cdiv(tiles, 2)), dim3(kLayerBlk), 0, stream, x,
+                           (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
+                           (bf16_t*)hp_bf16, rstd, N, layer_layout());
+        return check_launch("sst_ffn_fwd_pair_kernel");
+    }
     hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
                        (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
                        (bf16_t*)hp_bf16, rstd, N, layer_layout());

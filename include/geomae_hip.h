@@ -245,6 +245,12 @@ typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into 
 int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
                         void* packed_bf16, float* aux_f32 /* target of transpose==2 rows: plain fp32 gather */,
                         geomaeStream_t stream);
+
+/* The layer kernels exist in two forms with bit-identical results: one wave per 16-token tile (64 tokens per workgroup),
+ * and a PAIR form (two waves share a tile, 32 tokens per workgroup: half the dependent chain per wave, twice the
+ * workgroups) that is chosen when one workgroup per CU covers the launch.  mode: -1 automatic (default), 0 never, 1 always.
+ * Process-wide; meant for A/B measurements and tests. */
+void geomae_sst_set_pair_kernels(int32_t mode);
 /* qkv [n,384] bf16 = [(x + pos_table[tok_pos]) Wqk^T + b | x Wv^T + b];  x [n,128] fp32.  For training also pass
  * x_bf16, xp_bf16 [n,128]: bf16(x) and bf16(x + pos), the operands of this layer's dW_v / dW_qk contraction
  * (geomae_sst_weight_grad); both NULL for inference. */
@@ -309,6 +315,17 @@ int geomae_heads_loss_accumulate(const float* dec_centroid, const float* dec_den
                                  const int32_t* occ_counts, const float* loss_weights /*host*/, float* losses,
                                  float* d_dec_centroid, float* d_dec_density, void* dlogits_bf16, void* cm_bf16,
                                  void* dm_bf16, geomaeStream_t stream);
+/* split form of the same launch: two workgroups per 64 masked pillars (the low-level regression outputs | everything else),
+ * each half the dependent chain.  The centroid decoder's output gradient comes back as TWO summands, d_dec_centroid and
+ * d_dec_centroid2 (both [num_keep+num_mask,128], zeroed by the caller): pass them to geomae_sst_stack_backward as dz and
+ * dz_add.  What geomae_pretrain_step uses. */
+int geomae_heads_loss_split_accumulate(const float* dec_centroid, const float* dec_density, int32_t num_keep,
+                                       int32_t num_mask, const void* head_w_packed, const float* head_bias,
+                                       const float* centroid_low, const uint8_t* mask_low, const float* centroid_med,
+                                       const uint8_t* mask_med, const float* centroid_top, const float* normal,
+                                       const int32_t* occ_counts, const float* loss_weights /*host*/, float* losses,
+                                       float* d_dec_centroid, float* d_dec_centroid2, float* d_dec_density,
+                                       void* dlogits_bf16, void* cm_bf16, void* dm_bf16, geomaeStream_t stream);
 typedef struct GeomaeHeadGrads { /* fp32 gradient buffers of the six head Linears, accumulated into */
     float *reg_low_w, *reg_low_b, *cls_low_w, *cls_low_b, *reg_med_w, *reg_med_b, *cls_med_w, *cls_med_b,
           *reg_top_w, *reg_top_b, *nor_top_w, *nor_top_b;

@@ -950,6 +950,46 @@ def test_stack_row_gather_and_gradient_scatter_equal_indexing(dev):
 
 
 
+@pytest.mark.parametrize("n_frames", [1, 3])
+def test_pair_kernels_are_bit_identical(dev, n_frames):
+    """The pair form of the layer kernels (two waves per 16-token tile, chosen for small launches) computes every value
+    with the same instruction sequence as the one-wave form: outputs, the saved activations and every gradient of a
+    training stack are identical bit for bit.  Ragged token counts (the last tile is partial, the last workgroup may
+    hold a single tile)."""
+    from geomae_amd import ops, _lib
+    lib = _lib.load()
+    model, _ = _build(dev, 2, 1, "bf16")
+    bb = model.backbone
+    frames = [synth.lidar_frame(61 + i, beams=16 + 8 * i, n_az=300 + 77 * i) for i in range(n_frames)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(n, 128, generator=gen).to(dev)
+    dz = torch.randn(n, 128, generator=gen).to(dev)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, n_frames)
+    nl = 2 * len(bb.encoder_blocks)
+    w = bb._packed.weight_array(bb._stack_base["enc"], nl)
+    res = []
+    try:
+        for mode in (0, 1):
+            lib.geomae_sst_set_pair_kernels(mode)
+            for p in bb.parameters():
+                p.grad = None
+            g = bb._packed.grad_array(bb._stack_base["enc"], nl)
+            z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0])
+            dx = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], saved)
+            torch.cuda.synchronize()
+            res.append((z.clone(), saved.clone(), dx.clone()))
+    finally:
+        lib.geomae_sst_set_pair_kernels(-1)
+    (z0, s0, d0), (z1, s1, d1) = res
+    assert torch.equal(z0, z1)
+    assert torch.equal(s0, s1)          # every saved activation (pad rows of the blocked slabs included)
+    assert torch.equal(d0, d1)
+
+
 def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
     """forward_train (fused heads+loss kernel) vs extract_feat + forward_loss on the same model / mask:
     losses and every gradient."""
