@@ -74,6 +74,19 @@ static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_
 #else
 #define GEOMAE_STAMP(i) do {} while (0)
 #endif
+// -DGEOMAE_STAMP_FWD: the stamps go to the FFN-forward kernels instead (first launch after a clear keeps its stamps)
+#if defined(GEOMAE_PHASE_TIMING) && defined(GEOMAE_STAMP_FWD)
+#undef GEOMAE_STAMP
+#define GEOMAE_STAMP(i) do {} while (0)
+#define GEOMAE_FSTAMP(i)                                                                                  \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS && gridDim.x <= GEOMAE_STAMP_MAX_GRID && \
+            gridDim.x >= GEOMAE_STAMP_MIN_GRID && geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (i)] == 0) \
+            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (i)] = clock64();                             \
+    } while (0)
+#else
+#define GEOMAE_FSTAMP(i) do {} while (0)
+#endif
 
 // The copy is split in two so that a kernel can issue the global loads of the NEXT matrix (stage_issue) before
 // the elementwise phase that precedes its GEMM: phase timing (tools/phase_timing.py) showed each GEMM waiting
@@ -94,9 +107,15 @@ __device__ __forceinline__ void stage_issue(const bf16_t* __restrict__ Wp, WStag
     }
 }
 
+template <int N>
+__device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&acc)[N / 16], int lane);
+
+// `bias`: optional [N] floats the accumulators start from, read AFTER the barriers -- the way to hand over a vector
+// that sits in LDS and was written by other threads since the last barrier (stage_params below)
 template <int K, int N>
 __device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __restrict__ smem,
-                                            const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100) {
+                                            const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100,
+                                            const float* bias = nullptr) {
     constexpr int LD = K + kPad;
     constexpr int CH = K / 8;
     constexpr int PASSES = N * CH / kLayerBlk;
@@ -111,6 +130,7 @@ __device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __re
     }
     __syncthreads();
     GEOMAE_STAMP(sb + 2);
+    if (bias) load_bias<N>(bias, acc, lane);
     const int o = lane & 15, g = lane >> 4;
     // groups of 4 output tiles advance together over K: consecutive MFMAs hit independent accumulators, so the
     // dependent-accumulator latency of a chain (kk inner loop: 38 % issue stalls in profiles/r01 PMC) is hidden
@@ -135,7 +155,8 @@ __device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __re
 // bit-identical to gemm_staged's.
 template <int K, int N>
 __device__ __forceinline__ void gemm_staged_half(const WStage<K, N>& st, bf16_t* __restrict__ smem,
-                                                 const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 32], int lane, int h) {
+                                                 const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 32], int lane, int h,
+                                                 const float* bias = nullptr /* of this half */) {
     constexpr int LD = K + kPad;
     constexpr int CH = K / 8;
     constexpr int PASSES = N * CH / kLayerBlk;
@@ -147,6 +168,7 @@ __device__ __forceinline__ void gemm_staged_half(const WStage<K, N>& st, bf16_t*
         *reinterpret_cast<u32x4*>(smem + (c / CH) * LD + 8 * (c % CH)) = st.r[p];
     }
     __syncthreads();
+    if (bias) load_bias<N / 2>(bias, acc, lane);
     const int o = lane & 15, g = lane >> 4;
     const bf16_t* base = smem + h * (N / 2) * LD + o * LD + 8 * g;
     constexpr int NH = N / 32;

@@ -135,6 +135,31 @@ struct NextQkv {
     bf16_t *x_b, *xp_b;           // bf16 copies of z and z + pos (weight-gradient operands of the next layer), or null
 };
 
+// The fp32 parameter vectors of F3 (+ the next layer's in-projection bias) go through LDS, fetched once per workgroup at
+// kernel start: [bo | g1 | be1 | b1 (256) | b2 | g2 | be2 | bqkv of the next layer (384)].  Read from global memory at
+// their point of use, each one was a round trip the wave sat through (one wave per SIMD, nothing else to run), and --
+// vmcnt retires in order -- every such wait also drained the weight-matrix prefetch issued before it: the ISA had
+// eight serial (2 loads, s_waitcnt vmcnt(0)) pairs in the LayerNorm affine alone (tools/isa_mix.py).  LDS reads wait on
+// lgkmcnt and leave the prefetches alone.
+constexpr int kPrmBo = 0, kPrmG1 = 128, kPrmBe1 = 256, kPrmB1 = 384, kPrmB2 = 640, kPrmG2 = 768, kPrmBe2 = 896, kPrmQkv = 1024;
+constexpr int kPrmFloats = 1408;
+// (clang vector types: with HIP's float4 struct this pair stayed an in-memory aggregate in the pair kernel, the compiler
+//  promoted it to LDS and the kernel ran 2x slower)
+struct PrmRegs { f32x4 a, b; };
+__device__ __forceinline__ void ffn_params_issue(const LayerW& W, const float* __restrict__ next_bqkv, PrmRegs& r) {
+    const int s = threadIdx.x;                                        // float4 slot 0..255 of the first 1024 floats
+    const float* src = s < 32 ? W.bo + 4 * s : s < 64 ? W.g1 + 4 * (s - 32) : s < 96 ? W.be1 + 4 * (s - 64)
+                     : s < 160 ? W.b1 + 4 * (s - 96) : s < 192 ? W.b2 + 4 * (s - 160) : s < 224 ? W.g2 + 4 * (s - 192)
+                     : W.be2 + 4 * (s - 224);
+    r.a = *reinterpret_cast<const f32x4*>(src);
+    r.b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (next_bqkv && s < 96) r.b = *reinterpret_cast<const f32x4*>(next_bqkv + 4 * s);
+}
+__device__ __forceinline__ void ffn_params_commit(float* __restrict__ prm, bool has_next, const PrmRegs& r) {
+    *reinterpret_cast<f32x4*>(prm + 4 * threadIdx.x) = r.a;
+    if (has_next && threadIdx.x < 96) *reinterpret_cast<f32x4*>(prm + kPrmQkv + 4 * threadIdx.x) = r.b;
+}
+
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* __restrict__ x,
                                                                 const bf16_t* __restrict__ attn, LayerW W, int n,
                                                                 float eps, float* __restrict__ z,
@@ -144,9 +169,13 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
                                                                 float* __restrict__ rstd_out, NextQkv N, int lay) {
     const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+    __shared__ __attribute__((aligned(16))) float prm[kPrmFloats];
+    PrmRegs prm_r;
+    ffn_params_issue(W, N.wqkv ? N.bqkv : nullptr, prm_r);
     const int lane = threadIdx.x & 63;
     const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
     const int tok = tile * 16 + (lane & 15);
+    GEOMAE_FSTAMP(0);
     f32x4 u[8], y[8];
     float r1, r2;
     WStage<128, 256> s_w1;
@@ -157,15 +186,16 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane, blk);
         f32x4 xr[8];
         load_rows_f32<128>(x, n, tok, xr, lane, lay & kLayXBlocked);                 // needed after the GEMM: in flight under it
-        load_bias<128>(W.bo, u, lane);
-        gemm_staged<128, 128>(s_wo, smem, ob, u, lane);
+        ffn_params_commit(prm, N.wqkv != nullptr, prm_r);
+        gemm_staged<128, 128>(s_wo, smem, ob, u, lane, -100, prm + kPrmBo);
+        GEOMAE_FSTAMP(1);
         stage_issue<128, 256>(W.w1, s_w1);                            // lands under the LayerNorm arithmetic
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
     layer_norm_t(u, eps, &r1);
     if (xh1_out) store_rows_f32<128>(xh1_out, n, tok, u, lane, blk);
-    affine_t(u, W.g1, W.be1, y, lane);
+    affine_t(u, prm + kPrmG1, prm + kPrmBe1, y, lane);
     uint2 hb[16];
     WStage<256, 128> s_w2;
     {
@@ -173,9 +203,12 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
         f32x4 hp[16];
-        load_bias<256>(W.b1, hp, lane);
+        load_bias<256>(prm + kPrmB1, hp, lane);
+        GEOMAE_FSTAMP(2);
         gemm_staged<128, 256>(s_w1, smem, yb, hp, lane);
+        GEOMAE_FSTAMP(3);
         stage_issue<256, 128>(W.w2, s_w2);                            // lands under the GELU arithmetic
+        __builtin_amdgcn_sched_barrier(0);                            // (the scheduler otherwise sinks these loads below the GELU)
         if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane, blk);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
@@ -183,8 +216,10 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
             hb[ct] = pack4(h);
         }
     }
-    load_bias<128>(W.b2, u, lane);
+    load_bias<128>(prm + kPrmB2, u, lane);
+    GEOMAE_FSTAMP(4);
     gemm_staged<256, 128>(s_w2, smem, hb, u, lane);
+    GEOMAE_FSTAMP(5);
     const bool has_next = N.wqkv != nullptr;
     WStage<128, 256> s_qk;
     if (has_next) stage_issue<128, 256>(N.wqkv, s_qk);                // lands under the LayerNorm arithmetic
@@ -195,8 +230,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     if (rstd_out && (lane >> 4) == 0)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
                                               tok * 8, 0, 0);
-    affine_t(u, W.g2, W.be2, y, lane);
+    affine_t(u, prm + kPrmG2, prm + kPrmBe2, y, lane);
     store_rows_f32<128>(z, n, tok, y, lane, lay & kLayZBlocked);
+    GEOMAE_FSTAMP(6);
     if (!has_next) return;
     // ---- F1 of the next layer on z = y (registers)
     const int g = lane >> 4;
@@ -218,16 +254,20 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     WStage<128, 128> s_v;
     {
         f32x4 acc[16];
-        load_bias<256>(N.bqkv, acc, lane);
+        load_bias<256>(prm + kPrmQkv, acc, lane);
+        GEOMAE_FSTAMP(7);
         gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
+        GEOMAE_FSTAMP(8);
         stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
         store_rows_bf16<256>(N.qkv, n, tok, 384, 0, acc, lane, blk);
     }
     {
         f32x4 acc[8];
-        load_bias<128>(N.bqkv + 256, acc, lane);
+        load_bias<128>(prm + kPrmQkv + 256, acc, lane);
         gemm_staged<128, 128>(s_v, smem, xb, acc, lane);
+        GEOMAE_FSTAMP(9);
         store_rows_bf16<128>(N.qkv, n, tok, 384, 256, acc, lane, blk);
+        GEOMAE_FSTAMP(10);
     }
 }
 
@@ -249,11 +289,15 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ uint4 xch[4 * 4 * 64];
+    __shared__ __attribute__((aligned(16))) float prm[kPrmFloats];
+    PrmRegs prm_r;
+    ffn_params_issue(W, N.wqkv ? N.bqkv : nullptr, prm_r);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = wave >> 1;                                          // which half of the output channels
     const int tile = blockIdx.x * 2 + (wave & 1);
     const int tok = tile * 16 + (lane & 15);
+    GEOMAE_FSTAMP(0);
     f32x4 u[8], y[8];
     float r1, r2;
     WStage<128, 256> s_w1;
@@ -264,8 +308,9 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
         load_rows_bf16<128>(attn, n, tok, 128, 0, ob, lane, blk);
         f32x4 xr[4], uh[4], other[4];
         load_rows_f32_cols<64>(x, n, tok, 128, 64 * h, xr, lane, lay & kLayXBlocked);
-        load_bias<64>(W.bo + 64 * h, uh, lane);
-        gemm_staged_half<128, 128>(s_wo, smem, ob, uh, lane, h);
+        ffn_params_commit(prm, N.wqkv != nullptr, prm_r);
+        gemm_staged_half<128, 128>(s_wo, smem, ob, uh, lane, h, prm + kPrmBo + 64 * h);
+        GEOMAE_FSTAMP(1);
         stage_issue<128, 256>(W.w1, s_w1);
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) uh[ct] += xr[ct];
@@ -278,7 +323,7 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
         half_of<4>(u, h, mine);
         store_rows_f32_cols<64>(xh1_out, n, tok, 128, 64 * h, mine, lane, blk);
     }
-    affine_t(u, W.g1, W.be1, y, lane);
+    affine_t(u, prm + kPrmG1, prm + kPrmBe1, y, lane);
     uint2 hb[16];
     WStage<256, 128> s_w2;
     {
@@ -286,8 +331,10 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
         f32x4 hp[8];
-        load_bias<128>(W.b1 + 128 * h, hp, lane);
+        load_bias<128>(prm + kPrmB1 + 128 * h, hp, lane);
+        GEOMAE_FSTAMP(2);
         gemm_staged_half<128, 256>(s_w1, smem, yb, hp, lane, h);
+        GEOMAE_FSTAMP(3);
         stage_issue<256, 128>(W.w2, s_w2);
         if (hp_out) store_rows_bf16<128>(hp_out, n, tok, 256, 128 * h, hp, lane, blk);
         uint4 mine[4], other[4];
@@ -320,8 +367,10 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     WStage<128, 256> s_qk;
     {
         f32x4 uh[4], yh[4], other[4];
-        load_bias<64>(W.b2 + 64 * h, uh, lane);
+        load_bias<64>(prm + kPrmB2 + 64 * h, uh, lane);
+        GEOMAE_FSTAMP(4);
         gemm_staged_half<256, 128>(s_w2, smem, hb, uh, lane, h);
+        GEOMAE_FSTAMP(5);
         if (has_next) stage_issue<128, 256>(N.wqkv, s_qk);
         half_of<4>(y, h, yh);
 #pragma unroll
@@ -338,12 +387,13 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     if (rstd_out && h == 0 && (lane >> 4) == 0)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
                                               tok * 8, 0, 0);
-    affine_t(u, W.g2, W.be2, y, lane);
+    affine_t(u, prm + kPrmG2, prm + kPrmBe2, y, lane);
     {
         f32x4 mine[4];
         half_of<4>(y, h, mine);
         store_rows_f32_cols<64>(z, n, tok, 128, 64 * h, mine, lane, lay & kLayZBlocked);
     }
+    GEOMAE_FSTAMP(6);
     if (!has_next) return;
     // ---- F1 of the next layer on z = y (registers, both waves hold the full row)
     const int g = lane >> 4;
@@ -368,16 +418,20 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     WStage<128, 128> s_v;
     {
         f32x4 acc[8];
-        load_bias<128>(N.bqkv + 128 * h, acc, lane);
+        load_bias<128>(prm + kPrmQkv + 128 * h, acc, lane);
+        GEOMAE_FSTAMP(7);
         gemm_staged_half<128, 256>(s_qk, smem, xpb, acc, lane, h);
+        GEOMAE_FSTAMP(8);
         stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
         store_rows_bf16<128>(N.qkv, n, tok, 384, 128 * h, acc, lane, blk);
     }
     {
         f32x4 acc[4];
-        load_bias<64>(N.bqkv + 256 + 64 * h, acc, lane);
+        load_bias<64>(prm + kPrmQkv + 256 + 64 * h, acc, lane);
         gemm_staged_half<128, 128>(s_v, smem, xb, acc, lane, h);
+        GEOMAE_FSTAMP(9);
         store_rows_bf16<64>(N.qkv, n, tok, 384, 256 + 64 * h, acc, lane, blk);
+        GEOMAE_FSTAMP(10);
     }
 }
 

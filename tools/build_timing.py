@@ -11,9 +11,10 @@ objs, jobs = [], []
 for src in sorted(glob.glob(os.path.join(SRC, "*.hip"))):
     o = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
     objs.append(o)
-    jobs.append(["/opt/rocm/bin/hipcc"] + flags_for(src) + ["-DGEOMAE_PHASE_TIMING"] + os.environ.get("GEOMAE_TIMING_DEFS", "").split() + ["-c", src, "-o", o])
+    stamp = [] if os.environ.get("GEOMAE_TIMING_NO_STAMPS") else ["-DGEOMAE_PHASE_TIMING"]     # (plain A/B builds of a macro)
+    jobs.append(["/opt/rocm/bin/hipcc"] + flags_for(src) + stamp + os.environ.get("GEOMAE_TIMING_DEFS", "").split() + ["-c", src, "-o", o])
 with ThreadPoolExecutor(8) as ex:
     list(ex.map(subprocess.check_call, jobs))
-out = os.path.join(ROOT, "tools", "libgeomae_timing.so")
+out = os.path.join(ROOT, "tools", os.environ.get("GEOMAE_TIMING_OUT", "libgeomae_timing.so"))
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs)
 print(out)
