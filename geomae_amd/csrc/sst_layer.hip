@@ -741,15 +741,29 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
             }
         }
     }
-    // C layout: row i = 32*wave + 16*it + 4*g + r, col j = 16*jt + o
+    // C layout: row i = 32*wave + 16*it + 4*g + r, col j = 16*jt + o.  Added to the gradient with float atomics
+    // (memory-side units): issued straight from this layout an instruction touches four 64-byte pieces of four rows.
+    // The wave first transposes in registers (ds_bpermute: target lane L pulls column 16*(L>>4) + (L&15) of one row
+    // from the 16 lanes that hold that row) so that every atomic instruction covers 256 contiguous bytes of ONE row.
+    const int sel = lane >> 4;
 #pragma unroll
     for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int jt = 0; jt < 8; ++jt)
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 32 * wave + 16 * it + 4 * g + r, j = 16 * jt + o;
-                if (i < T.rows_valid) atomicAdd(T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j, acc[it][jt][r]);
+            for (int gt = 0; gt < 4; ++gt) {
+                const int src = ((lane & 15) + 16 * gt) * 4;          // byte address of the source lane
+                const int i = 32 * wave + 16 * it + 4 * gt + r;
+                float* crow = T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + lane;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        v[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(acc[it][4 * half + q][r])));
+                    const float mine = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
+                    if (i < T.rows_valid) atomicAdd(crow + 64 * half, mine);
+                }
             }
     if (T.dbias) {
         // column sums of A: thread holds 8 channels (chunk cch) of tokens tk0 + 16k (+32 per slab)
