@@ -415,7 +415,12 @@ __device__ __forceinline__ bool attn_item(int item, int NB, int n_heads, int* b,
     return *b < NB;
 }
 
-__global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
+// H heads of one bundle per workgroup (H = 1, 2, 4; 8 / H waves per head).  H = 1 is the form for small launches (one
+// round of workgroups: the encoder); at decoder size the launch is 3-4 rounds of workgroups whose life is a chain of
+// dependent loads (bundle -> token records -> operand gather -> ... -> store), and H = 4 quarters the number of chains
+// (2 workgroups x 4 heads per CU instead of 3 x 1).
+template <int H>
+__global__ __launch_bounds__(kAttnBlk, H == 1 ? 6 : (H == 2 ? 5 : 4)) void win_attn_fwd_kernel(const unsigned short* __restrict__ qkv, int n_heads,
                                                           const int32_t* __restrict__ win_start,
                                                           const int32_t* __restrict__ win_tokens,
                                                           const int32_t* __restrict__ tok_win,
@@ -425,46 +430,57 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                                                           float* __restrict__ lse, bool blk,
                                                           const int32_t* __restrict__ bun_tok,
                                                           const int4* __restrict__ pos_info) {
-    __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) unsigned short Ks[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) unsigned short Vs[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) unsigned short Os[kMaxT * kDh];
+    constexpr int kSlice = kMaxT * kDh;                     // one head's [T, 16] tile
+    __shared__ __attribute__((aligned(16))) unsigned short Qs_all[H * kSlice];
+    __shared__ __attribute__((aligned(16))) unsigned short Ks_all[H * kSlice];
+    __shared__ __attribute__((aligned(16))) unsigned short Vs_all[H * kSlice];
+    __shared__ __attribute__((aligned(16))) unsigned short Os_all[H * kSlice];
     __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT], wlo[kMaxT], whi[kMaxT];
     const AttnPlan P = {bun_start, win_start, win_tokens, tok_win, bun_tok, pos_info};
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     const int NB = num_bundles[0];
     const int C = n_heads * kDh;
-    for (int item = blockIdx.x; item < attn_items(NB, n_heads); item += gridDim.x) {
-        int b, h;
-        if (!attn_item(item, NB, n_heads, &b, &h)) continue;
+    const int groups = n_heads / H;
+    const int hh = wave % H;                                 // this wave's head inside the group
+    const int ho = hh * kSlice;                              // (0 when H = 1)
+    for (int item = blockIdx.x; item < attn_items(NB, groups); item += gridDim.x) {
+        int b, hg;
+        if (!attn_item(item, NB, groups, &b, &hg)) continue;
+        const int h0 = hg * H, h = h0 + hh;
         const BundleCtx B = bundle_setup(b, P, toks, wid, wlo, whi);
         const int T = B.T, nt = B.nt, Tp = B.Tp;
         {
             int tk[kStageIters];
             stage_tokens(P, B, toks, tk);
-            u32x4 rq[kStageIters], rk[kStageIters], rv[kStageIters];
-            stage_load(qkv, 3 * C, h * kDh, tk, T, rq, blk);
-            stage_load(qkv, 3 * C, C + h * kDh, tk, T, rk, blk);
-            stage_load(qkv, 3 * C, 2 * C + h * kDh, tk, T, rv, blk);
-            stage_store(rq, Tp, Qs, nullptr);
-            stage_store(rk, Tp, Ks, nullptr);
-            stage_store(rv, Tp, Vs, nullptr);
+            u32x4 rq[H][kStageIters], rk[H][kStageIters], rv[H][kStageIters];
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                stage_load(qkv, 3 * C, (h0 + e) * kDh, tk, T, rq[e], blk);
+                stage_load(qkv, 3 * C, C + (h0 + e) * kDh, tk, T, rk[e], blk);
+                stage_load(qkv, 3 * C, 2 * C + (h0 + e) * kDh, tk, T, rv[e], blk);
+            }
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                stage_store(rq[e], Tp, Qs_all + e * kSlice, nullptr);
+                stage_store(rk[e], Tp, Ks_all + e * kSlice, nullptr);
+                stage_store(rv[e], Tp, Vs_all + e * kSlice, nullptr);
+            }
         }
         __syncthreads();
-        for (int it = wave; it < nt; it += kAttnBlk / 64) {
+        for (int it = wave / H; it < nt; it += kAttnBlk / 64 / H) {
             int jlo, jhi;
             tile_range(B, it, wlo, whi, &jlo, &jhi);
             // S^T tiles: A = K rows (keys), B = Q^T (queries): lane holds query i = it*16 + c,
             // keys j = jt*16 + 4*g + r
-            const bf16x4 qb = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
+            const bf16x4 qb = lds4(Qs_all + ho + (it * 16 + c) * kDh + 4 * g);
             const int wq = wid[it * 16 + c];
             f32x4 st[kMaxTiles];
             float m = -INFINITY;
 #pragma unroll
             for (int jt = 0; jt < kMaxTiles; ++jt) {
                 if (jt >= jlo && jt <= jhi) {
-                    const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
+                    const bf16x4 ka = lds4(Ks_all + ho + (jt * 16 + c) * kDh + 4 * g);
                     f32x4 z = {0, 0, 0, 0};
                     st[jt] = mfma16(ka, qb, z);
                     const int4 W4 = *reinterpret_cast<const int4*>(wid + jt * 16 + 4 * g);
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
                     bf16x4 pa;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) pa[r] = (short)f2bf(st[jt][r]);
-                    const bf16x4 vb = lds4_tr(Vs, jt * 16 + 4 * g, c);
+                    const bf16x4 vb = lds4_tr(Vs_all + ho, jt * 16 + 4 * g, c);
                     o = mfma16(pa, vb, o);
                 }
             }
@@ -508,13 +524,14 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_fwd_kernel(const unsigned s
             for (int r = 0; r < 4; ++r) {
                 const int i = it * 16 + 4 * g + r;
                 const float inv_i = __shfl(inv, 4 * g + r, 64);
-                Os[i * kDh + c] = f2bf(o[r] * inv_i);
+                Os_all[ho + i * kDh + c] = f2bf(o[r] * inv_i);
             }
             const int iq = it * 16 + c;
             if (g == 0 && iq < T) lse[(int64_t)toks[iq] * n_heads + h] = m + __logf(sum);
         }
         __syncthreads();
-        unstage_store(Os, out, C, h * kDh, toks, T, blk);
+#pragma unroll
+        for (int e = 0; e < H; ++e) unstage_store(Os_all + e * kSlice, out, C, (h0 + e) * kDh, toks, T, blk);
         __syncthreads();
     }
 }
@@ -831,6 +848,14 @@ static int attn_grid(int num_tokens, int num_heads, int max_bundles, int cap) {
     return (int)(items < 256 * 16 ? items : 256 * 16);
 }
 
+// heads per attention workgroup (see win_attn_fwd_kernel); GEOMAE_ATTN_HEADS=1/2/4 forces it (A/B runs)
+static int attn_heads_per_wg(int num_tokens, int num_heads) {
+    static const int forced = [] { const char* e = getenv("GEOMAE_ATTN_HEADS"); return e ? atoi(e) : 0; }();
+    int h = forced ? forced : (num_tokens > 8192 ? 4 : 1);      // decoder forward phase 0.342 / 0.332 / 0.327 ms at 1 / 2 / 4
+    while (h > 1 && num_heads % h) h >>= 1;
+    return h == 4 || h == 2 ? h : 1;
+}
+
 extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num_tokens, int32_t num_heads,
                                                int32_t head_dim, const int32_t* win_start,
                                                const int32_t* win_tokens, const int32_t* tok_win,
@@ -843,11 +868,17 @@ extern "C" int geomae_window_attention_forward(const void* qkv_bf16, int32_t num
                    "window_attention_forward: null argument");
     GEOMAE_REQUIRE(head_dim == kDh, "window_attention_forward: head_dim must be %d", kDh);
     GEOMAE_REQUIRE(max_window_tokens <= kMaxT, "window_attention_forward: windows hold at most %d tokens", kMaxT);
-    const int grid = attn_grid(num_tokens, num_heads, max_bundles, max_window_tokens);
-    hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
-                       num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
-                       1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse, (layer_layout() & 1) != 0,
-                       pos_info ? bun_tok : nullptr, (const int4*)(bun_tok ? pos_info : nullptr));
+    const int hpw = attn_heads_per_wg(num_tokens, num_heads);
+    const int grid = attn_grid(num_tokens, num_heads / hpw, max_bundles, max_window_tokens);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kAttnBlk), 0, stream, (const unsigned short*)qkv_bf16,
+                           num_heads, win_start, win_tokens, tok_win, bun_start, num_bundles,
+                           1.0f / sqrtf((float)head_dim), (unsigned short*)out_bf16, lse, (layer_layout() & 1) != 0,
+                           pos_info ? bun_tok : nullptr, (const int4*)(bun_tok ? pos_info : nullptr));
+    };
+    if (hpw == 4) launch(win_attn_fwd_kernel<4>);
+    else if (hpw == 2) launch(win_attn_fwd_kernel<2>);
+    else launch(win_attn_fwd_kernel<1>);
     return check_launch("win_attn_fwd_kernel");
 }
 
