@@ -49,6 +49,13 @@ const float* dz_addend();
 // sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).
 void set_tail_sum(float* sum, int from_row);
 float* tail_sum(int* from_row);
+// Input map of the NEXT geomae_sst_qkv_forward of this host thread (set by geomae_sst_stack_forward around F1 of its first
+// layer): instead of reading its tile-blocked x, the kernel gathers token t from row rows[t] (or t) of the row-major
+// `src` for t < n_src and takes `fill` for the tokens behind, and WRITES the tile-blocked x (what the stack's other
+// kernels read) -- the stack's input conversion without a launch of its own.
+struct SstInputMap { const float* src; int n_src; const float* fill; const int32_t* rows; };
+void set_input_map(const SstInputMap& m);
+SstInputMap input_map();
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

@@ -25,6 +25,9 @@ static thread_local float* g_tail_sum = nullptr;
 static thread_local int g_tail_from = 0;
 void set_tail_sum(float* sum, int from_row) { g_tail_sum = sum; g_tail_from = from_row; }
 float* tail_sum(int* from_row) { *from_row = g_tail_from; return g_tail_sum; }
+static thread_local SstInputMap g_input_map = {nullptr, 0, nullptr, nullptr};
+void set_input_map(const SstInputMap& m) { g_input_map = m; }
+SstInputMap input_map() { return g_input_map; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

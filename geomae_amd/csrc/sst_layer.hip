@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
                                                                 const float* __restrict__ pos_table, LayerW W,
                                                                 int n, bf16_t* __restrict__ qkv,
                                                                 bf16_t* __restrict__ x_b, bf16_t* __restrict__ xp_b,
-                                                                int lay) {
+                                                                int lay, SstInputMap M) {
     const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     const int lane = threadIdx.x & 63;
@@ -89,7 +89,27 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* 
     stage_issue<128, 256>(W.wqkv, s_qk);
     {
         f32x4 xv[8];
-        load_rows_f32<128>(x, n, tok, xv, lane, lay & kLayXBlocked);
+        if (M.src == nullptr) {
+            load_rows_f32<128>(x, n, tok, xv, lane, lay & kLayXBlocked);
+        } else {
+            // the stack's input conversion (common.h SstInputMap): gather / fill from the row-major source, and leave
+            // the tile-blocked copy the other kernels read.  Rows past n_src (and the pad rows of the last tile) are
+            // sent out of the descriptor's range: the hardware returns zeros.
+            int srow = tok;
+            if (M.rows) srow = __builtin_amdgcn_raw_buffer_load_b32(rows_rsrc(M.rows, M.n_src, 4), tok * 4, 0, 0);
+            const __amdgpu_buffer_rsrc_t sr =
+                __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(M.src), 0, 0x7fffffff, 0x00020000);
+            const int voff = tok < M.n_src ? srow * 512 + 16 * g : 0x7fffffff;
+            const bool take_fill = M.fill != nullptr && tok >= M.n_src && tok < n;
+            const __amdgpu_buffer_rsrc_t fr = table_rsrc(M.fill ? M.fill : M.src);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                const f32x4 a = buf_load_f32x4(sr, voff + (voff < 0x7fffff00 ? 64 * ct : 0));
+                const f32x4 f = buf_load_f32x4(fr, 64 * ct + 16 * g);
+                xv[ct] = take_fill ? f : a;
+            }
+            store_rows_f32<128>(const_cast<float*>(x), n, tok, xv, lane, true);
+        }
         const __amdgpu_buffer_rsrc_t pr = table_rsrc(pos_table);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -912,9 +932,11 @@ extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, co
     GEOMAE_REQUIRE(x && tok_pos && pos_table && qkv_bf16, "sst_qkv_forward: null argument");
     GEOMAE_REQUIRE((x_bf16 == nullptr) == (xp_bf16 == nullptr), "sst_qkv_forward: pass both operand copies or none");
     const int tiles = cdiv(num_tokens, 16);
+    const SstInputMap M = input_map();
+    GEOMAE_REQUIRE(!M.src || (layer_layout() & kLayXBlocked), "sst_qkv_forward: an input map needs the blocked layout");
     hipLaunchKernelGGL(sst_qkv_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x, tok_pos,
                        pos_table, to_layer(w), num_tokens, (bf16_t*)qkv_bf16, (bf16_t*)x_bf16, (bf16_t*)xp_bf16,
-                       layer_layout());
+                       layer_layout(), M);
     return check_launch("sst_qkv_fwd_kernel");
 }
 

@@ -99,26 +99,6 @@ struct Timed {
     }
 };
 
-// stack input: row-major [n,128] fp32 -> tile-blocked (pad rows of the last tile zero-filled).  One thread per
-// 16-byte piece, blocked address order: the writes are fully contiguous, the reads 64-byte row pieces.
-// Rows [n_src, n) (if any) are copies of `fill_row` [128]: the decoder stacks' input is the encoder output followed
-// by one learned mask token per masked pillar (bb.py:239-246 repeat + cat), which is never materialised row-major.
-__global__ __launch_bounds__(256) void rows_to_blocked_f32_kernel(const float* __restrict__ src, int n_src, int n,
-                                                                  const float* __restrict__ fill_row,
-                                                                  const int32_t* __restrict__ src_rows,
-                                                                  float* __restrict__ dst) {
-    const int64_t pieces = (int64_t)((n + 15) / 16) * 16 * 32;              // 32 float4 per row
-    for (int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x; q < pieces; q += (int64_t)gridDim.x * 256) {
-        const int c4 = (int)(q & 3), t = (int)((q >> 2) & 15), cb = (int)((q >> 6) & 7);
-        const int64_t tile = q >> 9;
-        const int64_t tok = tile * 16 + t;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (tok < n_src) v = *reinterpret_cast<const float4*>(src + (src_rows ? (int64_t)src_rows[tok] : tok) * 128 + 16 * cb + 4 * c4);
-        else if (tok < n) v = *reinterpret_cast<const float4*>(fill_row + 16 * cb + 4 * c4);
-        reinterpret_cast<float4*>(dst)[q] = v;
-    }
-}
-
 }  // namespace geomae
 
 using namespace geomae;
@@ -179,9 +159,8 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         return GEOMAE_ERR_WORKSPACE;
     }
     char* base = (char*)saved;
-    hipLaunchKernelGGL(rows_to_blocked_f32_kernel, dim3(stream_grid((int64_t)cdiv(num_tokens, 16) * 512, 256)), dim3(256), 0,
-                       stream, x_in, num_input_rows, num_tokens, fill_row, input_rows, (float*)(base + so.x));
-    if ((rc = check_launch("rows_to_blocked_f32_kernel"))) return rc;
+    // the input conversion (row-major x_in [gathered by input_rows, followed by fill_row] -> tile-blocked x of layer 0)
+    // is done by F1 of layer 0 itself (common.h SstInputMap); it used to be a 5-13 us launch in front of every stack
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
     for (int l = 0; l < num_layers; ++l) {
         char* sv = base + so.stride * l;
@@ -193,9 +172,11 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         LayerLayoutScope lay(kBlk | kXBlk | (next ? kZBlk : 0));
         if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_FWD, stream);
-            if ((rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, sv + so.xb,
-                                             sv + so.xp, stream)))
-                return rc;
+            set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
+            rc = geomae_sst_qkv_forward(x, L.tok_pos, pos_table, &layers[l], num_tokens, sv + so.qkv, sv + so.xb,
+                                        sv + so.xp, stream);
+            set_input_map(SstInputMap{nullptr, 0, nullptr, nullptr});
+            if (rc) return rc;
         }
         {
             Timed t(profiler, GEOMAE_KERNEL_ATTN_FWD, stream);
