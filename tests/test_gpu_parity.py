@@ -348,6 +348,24 @@ def test_window_attention_forward_backward(dev, shift):
         assert np.linalg.norm(a - b) / np.linalg.norm(b) < 2e-2
 
 
+def test_window_attention_at_decoder_size(dev):
+    """More than 8 k tokens: the forward kernel's four-heads-per-workgroup form (csrc/window.hip) -- same check as
+    above, forward only, against the fp64 per-window softmax."""
+    from geomae_amd import ops
+    frames = [synth.lidar_frame(40 + i) for i in range(3)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = O.unique_rows(coors)[0]
+    n = vc.shape[0]
+    assert n > 8192
+    wcfg = ops.make_window_config((12, 12), (6, 6), (400, 400))
+    L = ops.window_build(torch.as_tensor(vc, device=dev), 3, wcfg, 1)
+    win = O.window_partition(vc, (12, 12), [(0, 0), (6, 6)], LEVELS["top"], RANGE)[0][1][0]
+    qkv = (torch.randn(n, 384, generator=torch.Generator().manual_seed(4)) * 1.5).bfloat16()
+    want = _ref_window_attention(qkv.double(), win, 8)
+    got = ops.window_attention(qkv.to(dev), L, 8)
+    np.testing.assert_allclose(got.float().cpu().numpy(), want.float().numpy(), atol=2e-2, rtol=2e-2)
+
+
 # ---------------------------------------------------------------------------------- A3/A4 + A19-A24
 def _build(dev, enc, dec, compute_dtype):
     import geomae_amd
