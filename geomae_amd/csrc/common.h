@@ -49,6 +49,12 @@ const float* dz_addend();
 // sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).
 void set_tail_sum(float* sum, int from_row);
 float* tail_sum(int* from_row);
+// Split-K workspace of the geomae_sst_weight_grad calls of this host thread (set by geomae_sst_stack_backward for its own
+// layers): two buffers of kDwPartialBytes where the contraction's workgroups leave their partial sums instead of
+// atomically adding them to the gradients (sst_layer.hip dw_body); nullptr = atomics.
+constexpr long long kDwPartialBytes = 8ll * 24 * 128 * 128 * 4;       // 8 tasks x <= 24 token chunks x [128,128] fp32
+void set_dw_partial(float* ws);
+float* dw_partial();
 // Input map of the NEXT geomae_sst_qkv_forward of this host thread (set by geomae_sst_stack_forward around F1 of its first
 // layer): instead of reading its tile-blocked x, the kernel gathers token t from row rows[t] (or t) of the row-major
 // `src` for t < n_src and takes `fill` for the tokens behind, and WRITES the tile-blocked x (what the stack's other

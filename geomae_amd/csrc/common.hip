@@ -28,6 +28,9 @@ float* tail_sum(int* from_row) { *from_row = g_tail_from; return g_tail_sum; }
 static thread_local SstInputMap g_input_map = {nullptr, 0, nullptr, nullptr};
 void set_input_map(const SstInputMap& m) { g_input_map = m; }
 SstInputMap input_map() { return g_input_map; }
+static thread_local float* g_dw_partial = nullptr;
+void set_dw_partial(float* ws) { g_dw_partial = ws; }
+float* dw_partial() { return g_dw_partial; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

@@ -519,7 +519,16 @@ constexpr int kMaxDwTasks = 12;
 struct DwTasks {
     DwTask t[kMaxDwTasks];
     int blocked = 0;         // operands A, B in the tile-blocked layout (the layer stacks' slabs) instead of row-major
+    float* partial = nullptr;    // split-K through memory: [task][chunk][128 x 128] fp32 partial sums (dw_body), or atomics
 };
+// The sum of a previous launch's partials, carried by a later launch (dw_reduce_body)
+struct DwReduceTask { float* C; int ldc, c_row0, c_col0, rows_valid; };
+struct DwReduce {
+    const float* partial = nullptr;          // nullptr: nothing to reduce
+    int gx = 0, num_tasks = 0;
+    DwReduceTask t[8];
+};
+constexpr int kDwReduceBlocks = 64;          // workgroups a carrying launch adds for the reduction
 int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t stream);
 // the next geomae_sst_weight_grad call of this host thread only records its tasks; the following
 // geomae_sst_ffn_backward launches them inside its own kernel (sst_ffn_bwd_dw_kernel)

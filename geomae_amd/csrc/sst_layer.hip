@@ -681,8 +681,16 @@ __device__ __forceinline__ int64_t dw_elem(int tok, int ld, int col, bool blk) {
                : (int64_t)tok * ld + col;
 }
 
+// Split-K.  Every workgroup of a task ends with a [128,128] fp32 partial sum.  Added to the gradient with float atomics
+// (16 k per workgroup, 1.7 M per encoder-size launch, 3 M at decoder size, all through the memory-side atomic units)
+// the additions drain for ~16 us AFTER the contraction loop, past the end of the ffn-backward workgroups the
+// contraction rides with, and set the launch's duration.  With a workspace (`partial`, geomae_sst_stack_backward's
+// scratch) the workgroups STORE their partials -- accumulator order, 4 KB per instruction -- and a LATER launch of the
+// same stream sums them in chunk order and adds them to the gradient (dw_reduce_body, 64 workgroups riding in the next
+// ffn-backward launch): no atomics, and a result that no longer depends on arrival order.
 __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int bx, bf16_t* __restrict__ As,
-                                        bf16_t* __restrict__ Bs, float (*bred)[128], bool blk) {
+                                        bf16_t* __restrict__ Bs, float (*bred)[128], bool blk,
+                                        float* __restrict__ partial /* of this task: [gx][128*128], or null */) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int o = lane & 15, g = lane >> 4;
     const int t_begin = bx * chunk;
@@ -765,26 +773,35 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     // (memory-side units): issued straight from this layout an instruction touches four 64-byte pieces of four rows.
     // The wave first transposes in registers (ds_bpermute: target lane L pulls column 16*(L>>4) + (L&15) of one row
     // from the 16 lanes that hold that row) so that every atomic instruction covers 256 contiguous bytes of ONE row.
-    const int sel = lane >> 4;
+    if (partial) {
+        // accumulator order [it][jt][thread][r]: one 16-byte store per lane, 4 KB per instruction
+        f32x4* mine = reinterpret_cast<f32x4*>(partial) + (size_t)bx * 4096 + threadIdx.x;
 #pragma unroll
-    for (int it = 0; it < 2; ++it)
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+            for (int jt = 0; jt < 8; ++jt) mine[(it * 8 + jt) * 256] = acc[it][jt];
+    } else {
+        const int sel = lane >> 4;
 #pragma unroll
-            for (int gt = 0; gt < 4; ++gt) {
-                const int src = ((lane & 15) + 16 * gt) * 4;          // byte address of the source lane
-                const int i = 32 * wave + 16 * it + 4 * gt + r;
-                float* crow = T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + lane;
+        for (int it = 0; it < 2; ++it)
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float v[4];
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        v[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(acc[it][4 * half + q][r])));
-                    const float mine = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
-                    if (i < T.rows_valid) atomicAdd(crow + 64 * half, mine);
+                for (int gt = 0; gt < 4; ++gt) {
+                    const int src = ((lane & 15) + 16 * gt) * 4;          // byte address of the source lane
+                    const int i = 32 * wave + 16 * it + 4 * gt + r;
+                    float* crow = T.C + (int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + lane;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            v[q] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(acc[it][4 * half + q][r])));
+                        const float mine = sel == 0 ? v[0] : sel == 1 ? v[1] : sel == 2 ? v[2] : v[3];
+                        if (i < T.rows_valid) atomicAdd(crow + 64 * half, mine);
+                    }
                 }
-            }
+    }
     if (T.dbias) {
         // column sums of A: thread holds 8 channels (chunk cch) of tokens tk0 + 16k (+32 per slab)
         if (!blk) {
@@ -810,12 +827,48 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     }
 }
 
-__global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk) {
+// Sum of the partials an EARLIER launch left (dw_body), added to the gradients with plain loads and stores (this launch
+// is the only writer).  Block rb of nrb; one 16-byte accumulator slot (it, jt, thread) per thread and step.
+__device__ __forceinline__ void dw_reduce_body(const DwReduce& R, int rb, int nrb) {
+    const int slots = R.num_tasks * 4096;
+    for (int slot = rb * 256 + threadIdx.x; slot < slots; slot += nrb * 256) {
+        const int ti = slot >> 12, q = slot & 4095;
+        const int th = q & 255, it = q >> 11, jt = (q >> 8) & 7;
+        const f32x4* p = reinterpret_cast<const f32x4*>(R.partial) + (size_t)ti * R.gx * 4096 + q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= R.gx; k += 8) {                 // 8 loads in flight
+            f32x4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * 4096];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < R.gx; ++k) s += p[(size_t)k * 4096];
+        const DwReduceTask& T = R.t[ti];
+        const int wave = th >> 6, g = (th >> 4) & 3, o = th & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 32 * wave + 16 * it + 4 * g + r, j = 16 * jt + o;
+            if (i < T.rows_valid) T.C[(int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j] += s[r];
+        }
+    }
+}
+
+// grid (chunks, tasks [+ 1 row of reduce blocks when R carries a previous launch's partials])
+__global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk, int num_tasks, DwReduce R) {
     __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
     __shared__ float bred[4][128];
-    dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred, tasks.blocked != 0);
+    if ((int)blockIdx.y >= num_tasks) {
+        dw_reduce_body(R, blockIdx.x, gridDim.x);
+        return;
+    }
+    dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred, tasks.blocked != 0,
+            tasks.partial ? tasks.partial + (size_t)blockIdx.y * gridDim.x * 16384 : nullptr);
 }
+
+__global__ __launch_bounds__(256) void dw_reduce_kernel(DwReduce R) { dw_reduce_body(R, blockIdx.x, gridDim.x); }
 
 // Horizontal fusion for the backward of a layer stack: the data-gradient kernel of layer l and the weight-
 // gradient contraction of layer l+1 (whose operands the previous three kernels left in the other scratch
@@ -824,16 +877,19 @@ __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk
 // One launch carries both: workgroups [0, n_ffn) run ffn_bwd_body, the rest run dw_body, sharing the LDS
 // allocation of the larger body.
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs A, int n_ffn, DwTasks tasks, int dw_n,
-                                                                     int dw_chunk, int dw_gx) {
+                                                                     int dw_chunk, int dw_gx, int dw_blocks, DwReduce R) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ float red[4][4][128];
     static_assert(2 * kDwTok * kDwLd <= kWeightLds, "dw slabs must fit in the weight buffer");
     if ((int)blockIdx.x < n_ffn) {
         ffn_bwd_body(A, blockIdx.x, smem, red);
+    } else if ((int)blockIdx.x < n_ffn + dw_blocks) {
+        const int b = blockIdx.x - n_ffn, ti = b / dw_gx;
+        dw_body(tasks.t[ti], dw_n, dw_chunk, b % dw_gx, smem, smem + kDwTok * kDwLd,
+                reinterpret_cast<float (*)[128]>(&red[0][0][0]), tasks.blocked != 0,
+                tasks.partial ? tasks.partial + (size_t)ti * dw_gx * 16384 : nullptr);
     } else {
-        const int b = blockIdx.x - n_ffn;
-        dw_body(tasks.t[b / dw_gx], dw_n, dw_chunk, b % dw_gx, smem, smem + kDwTok * kDwLd,
-                reinterpret_cast<float (*)[128]>(&red[0][0][0]), tasks.blocked != 0);
+        dw_reduce_body(R, blockIdx.x - n_ffn - dw_blocks, kDwReduceBlocks);
     }
 }
 
@@ -857,6 +913,21 @@ static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out) {
 struct PendingDw { DwTasks tasks; int num_tasks, num_tokens; bool active; };
 static thread_local PendingDw g_pending_dw = {{}, 0, 0, false};
 static thread_local bool t_defer_weight_grad = false;
+// partials a launched contraction left in its workspace: the next launch of this host thread (the next ffn-backward of
+// the stack, or the flush) sums them
+static thread_local DwReduce g_pending_reduce;
+static DwReduce take_pending_reduce() {
+    const DwReduce R = g_pending_reduce;
+    g_pending_reduce = DwReduce();
+    return R;
+}
+static void note_partials(const DwTasks& T, int num_tasks, int gx) {
+    if (!T.partial) return;
+    DwReduce R;
+    R.partial = T.partial; R.gx = gx; R.num_tasks = num_tasks;
+    for (int k = 0; k < num_tasks; ++k) R.t[k] = DwReduceTask{T.t[k].C, T.t[k].ldc, T.t[k].c_row0, T.t[k].c_col0, T.t[k].rows_valid};
+    g_pending_reduce = R;
+}
 
 static LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
@@ -1013,8 +1084,11 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     g_pending_dw.active = false;
     int gx, chunk;
     dw_grid(P.num_tasks, P.num_tokens, &gx, &chunk);
-    hipLaunchKernelGGL(sst_ffn_bwd_dw_kernel, dim3(n_ffn + gx * P.num_tasks), dim3(kLayerBlk), 0, stream, A, n_ffn, P.tasks,
-                       P.num_tokens, chunk, gx);
+    const DwReduce Rd = take_pending_reduce();          // the partials of the contraction before this one
+    const int dw_blocks = gx * P.num_tasks;
+    hipLaunchKernelGGL(sst_ffn_bwd_dw_kernel, dim3(n_ffn + dw_blocks + (Rd.partial ? kDwReduceBlocks : 0)), dim3(kLayerBlk), 0,
+                       stream, A, n_ffn, P.tasks, P.num_tokens, chunk, gx, dw_blocks, Rd);
+    note_partials(P.tasks, P.num_tasks, gx);
     return check_launch("sst_ffn_bwd_dw_kernel");
 }
 
@@ -1049,6 +1123,11 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
                  *y = (const bf16_t*)y_bf16, *dv = (const bf16_t*)dv_bf16, *h = (const bf16_t*)h_bf16;
     DwTasks T;
     T.blocked = (layer_layout() & kLayBlocked) ? 1 : 0;
+    if (float* ws = dw_partial()) {                     // the stack's split-K workspace: two buffers, alternating
+        static thread_local int flip = 0;
+        flip ^= 1;
+        T.partial = ws + (size_t)flip * (kDwPartialBytes / 4);
+    }
     //          A     lda a0   B   ldb b0  C        ldc  r0   c0  dbias     rows
     T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv, 128};   // dWq
     T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv, 128};   // dWk
@@ -1073,14 +1152,26 @@ void geomae::defer_next_weight_grad() { t_defer_weight_grad = true; }
 extern "C" int geomae_flush_weight_grad(hipStream_t stream) { return geomae::flush_pending_weight_grad(stream); }
 int geomae::flush_pending_weight_grad(hipStream_t stream) {
     t_defer_weight_grad = false;
-    if (!g_pending_dw.active) return GEOMAE_OK;
-    g_pending_dw.active = false;
-    return launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
+    int rc = GEOMAE_OK;
+    if (g_pending_dw.active) {
+        g_pending_dw.active = false;
+        rc = launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
+    }
+    if (g_pending_reduce.partial) {                      // the last contraction's own partials
+        const DwReduce Rd = take_pending_reduce();
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(kDwReduceBlocks), dim3(256), 0, stream, Rd);
+        const int rc2 = check_launch("dw_reduce_kernel");
+        if (rc == GEOMAE_OK) rc = rc2;
+    }
+    return rc;
 }
 
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
     int G, chunk;
     dw_grid(num_tasks, num_tokens, &G, &chunk);
-    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks), dim3(256), 0, stream, T, num_tokens, chunk);
+    const DwReduce Rd = take_pending_reduce();
+    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? 1 : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
+                       num_tasks, Rd);
+    note_partials(T, num_tasks, G);
     return check_launch("dw_kernel");
 }

@@ -11,7 +11,8 @@
 //           x_in f32 [n,128] | qkv bf16 [n,384] | attn bf16 [n,128] | lse f32 [n,H] |
 //           xhat1 f32 [n,128] | xhat2 f32 [n,128] | hp bf16 [n,256] | rstd f32 [n,2] | xb, xp bf16 [n,128] each
 // scratch (backward only, reused by every layer): dx_res f32 [n,128] | dattn bf16 [n,128] |
-//           two sets of bf16 slabs du, dv, y [n,128] each, dhp, h [n,256] each, dqkv [n,384]
+//           two sets of bf16 slabs du, dv, y [n,128] each, dhp, h [n,256] each, dqkv [n,384] |
+//           two split-K workspaces of the weight-gradient contraction (12.6 MB each)
 //
 // Kernel chain (vertical fusion: every ~10-50 us kernel of a small stack pays a fixed launch-ramp / first-load /
 // store-drain floor, so the two projection kernels ride on their neighbours):
@@ -61,7 +62,7 @@ struct ScratchOffsets {
     int64_t dx_res, dattn;
     int64_t set0;                               // first of two identical slab sets read by the weight-gradient kernel
     int64_t du, dv, y, dhp, h, dqkv;            // offsets inside a set
-    int64_t set_bytes, total;
+    int64_t set_bytes, dw_partial, total;
 };
 static ScratchOffsets scratch_offsets(int64_t n) {
     ScratchOffsets o;
@@ -78,7 +79,8 @@ static ScratchOffsets scratch_offsets(int64_t n) {
     o.h = q;      q += al256(n * 256 * 2);
     o.dqkv = q;   q += al256(n * 384 * 2);
     o.set_bytes = q;
-    o.total = p + 2 * q;
+    o.dw_partial = p + 2 * q;                   // split-K workspace of the weight-gradient contraction: two buffers
+    o.total = o.dw_partial + 2 * kDwPartialBytes;
     return o;
 }
 
@@ -223,6 +225,10 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     // hops cost more than the overlap gained)
     const char* base = (const char*)saved;
     char* w = (char*)scratch;
+    struct DwPartialScope {                         // this stack's contractions sum through the scratch, not atomics
+        explicit DwPartialScope(float* ws) { set_dw_partial(ws); }
+        ~DwPartialScope() { set_dw_partial(nullptr); }
+    } dw_scope((float*)(w + sc.dw_partial));
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
