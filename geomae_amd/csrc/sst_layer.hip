@@ -1084,6 +1084,7 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     g_pending_dw.active = false;
     int gx, chunk;
     dw_grid(P.num_tasks, P.num_tokens, &gx, &chunk);
+    GEOMAE_REQUIRE(!P.tasks.partial || (long long)gx * P.num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();          // the partials of the contraction before this one
     const int dw_blocks = gx * P.num_tasks;
     hipLaunchKernelGGL(sst_ffn_bwd_dw_kernel, dim3(n_ffn + dw_blocks + (Rd.partial ? kDwReduceBlocks : 0)), dim3(kLayerBlk), 0,
@@ -1169,6 +1170,7 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
     int G, chunk;
     dw_grid(num_tasks, num_tokens, &G, &chunk);
+    GEOMAE_REQUIRE(!T.partial || (long long)G * num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();
     hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? 1 : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
                        num_tasks, Rd);
