@@ -167,7 +167,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes((int32_t)n));
     b += al256(nk * 512) + 4 * al256(n * 512);                                                             // z_enc, cen, den, dxa, dxb
     b += al256(M * 896 * 2) + 2 * al256(M * 128 * 2);                                                      // heads
-    b += 2 * al256(N * 128 * 2) + al256(N * 128 * 4) + al256(N * 64 * 4);                                  // VFE backward
+    b += 2 * al256(N * 128 * 2) + al256(N * 128 * 4) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);     // VFE backward
     return b + 8192;
 }
 
@@ -438,6 +438,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     char* h_dl = a.bytes(M * 896 * 2); char* h_cm = a.bytes(M * 128 * 2); char* h_dm = a.bytes(M * 128 * 2);
     char* dy1_b = a.bytes(N * 128 * 2); char* g_b = a.bytes(N * 128 * 2);
     float* dy1_f = a.take<float>(N * 128);
+    float* dw1_partial = (float*)a.bytes(2 * kDwPartialBytes);      // split-K workspace of the layer-1 weight gradient
     float* dh0 = a.take<float>(N * 64);
     if (a.overflow) {
         set_error("pretrain_step: N=%lld V=%d needs %lld bytes of step workspace, %lld available", (long long)N, V,
@@ -579,7 +580,14 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, dy1_f, dh0, dm0, use_bs0,
                                         fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main));
     ENG_CALL(order_after(e, kVfeL1, main, geo));
-    ENG_CALL(geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, geo));
+    // one [128,128] output contracted over all N points by 124 workgroups: through the split-K workspace + a reduction
+    // launch instead of 124 x 16 k float atomics on the same 64 KB (deterministic; the phase time did not change, and
+    // neither did it with this contraction on the main stream: it is not what the VFE backward waits for)
+    set_dw_partial(dw1_partial);
+    int rc_dw1 = geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, geo);
+    set_dw_partial(nullptr);
+    ENG_CALL(rc_dw1);
+    ENG_CALL(geomae_flush_weight_grad(geo));
     if (!fold) {
         ENG_CALL(geomae_bn_param_grad_add(use_bs0, 64, m.bn_dbeta[0], m.bn_dgamma[0], main));
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD0, main);

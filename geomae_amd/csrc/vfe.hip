@@ -1101,5 +1101,6 @@ extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16,
     GEOMAE_REQUIRE(dy1_bf16 && g_bf16 && dw1, "vfe_weight_grad1: null argument");
     DwTasks T;
     T.t[0] = {(const bf16_t*)dy1_bf16, 128, 0, (const bf16_t*)g_bf16, 128, 0, dw1, 128, 0, 0, nullptr, 128};
+    T.partial = dw_partial();        // a caller's split-K workspace (csrc/engine.hip), summed by its next geomae_flush_weight_grad
     return launch_dw(T, 1, (int)num_points, stream);
 }
