@@ -81,7 +81,7 @@ struct WinLayout {
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
           kPacked, kFirstMain, kNumEv };
-enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeBwd, pOpt, kNumPhase };
+enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
     GeomaePretrainConfig cfg;
@@ -571,6 +571,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         GEOMAE_HIP(hipMemsetAsync(use_bs0, 0, 128 * 8, main));
     }
     ENG_CALL(geomae_vfe_backward_stats(&va, &bn, m0, vf, d_vf, use_bs1, main));
+    mark(e, pVfeStats, main);
     float n_eff = (float)N;
     if (!fold) {
         ENG_CALL(geomae_bn_param_grad_add(use_bs1, 128, m.bn_dbeta[1], m.bn_dgamma[1], main));
@@ -579,6 +580,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     }
     ENG_CALL(geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, dy1_f, dh0, dm0, use_bs0,
                                         fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main));
+    mark(e, pVfeL1, main);
     ENG_CALL(order_after(e, kVfeL1, main, geo));
     // one [128,128] output contracted over all N points by 124 workgroups: through the split-K workspace + a reduction
     // launch instead of 124 x 16 k float atomics on the same 64 KB (deterministic; the phase time did not change, and
@@ -594,6 +596,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     }
     ENG_CALL(geomae_vfe_backward_layer0(&va, &bn, dh0, use_bs0, n_eff, N, dy1_b, g_b, m.vfe_dw0, nullptr,
                                         fold ? m.bn_dbeta[0] : nullptr, fold ? m.bn_dgamma[0] : nullptr, main));
+    mark(e, pVfeL0, main);
     ENG_CALL(order_after(e, kGeoDone, geo, main));
     mark(e, pVfeBwd, main);
 

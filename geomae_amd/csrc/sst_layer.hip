@@ -894,13 +894,17 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs
 }
 
 // enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
-static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out) {
+static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out, bool split_k = false) {
     // 512 tokens per workgroup: every workgroup ends in 16 k float atomics, and halving the chunk at encoder size (twice
     // the workgroups, twice the atomics) made the carrying ffn-backward launches 9 us slower
     int G = cdiv(num_tokens, 512);
     // (8 tasks x 24 = 192 workgroups beside the carrying launch's ffn workgroups: 12 / 16 / 20 / 24 / 32 chunks per task
     // measured 2.385 / 2.361 / 2.345 / 2.344 / 2.356 ms per step -- flat, the kernels wait, they do not queue)
-    const int cap = num_tasks >= 8 ? 24 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
+    int cap = num_tasks >= 8 ? 24 : (256 / num_tasks < 128 ? 256 / num_tasks : 128);
+    // one task over very many tokens (the VFE's layer-1 gradient: 106 k points, 54 MB of operands) is bandwidth-bound:
+    // without atomics to pay for, more workgroups pull harder (what the split-K workspace holds: 192 partials)
+    // (join wait of the VFE backward phase: 49 / 43 / 40 us at 96 / 128 / 192 workgroups)
+    if (split_k && num_tasks == 1) { cap = (int)(kDwPartialBytes / 65536); G = cdiv(num_tokens, 256); }
     if (G > cap) G = cap;
     int chunk = cdiv(num_tokens, G);
     chunk = (chunk + kDwTok - 1) / kDwTok * kDwTok;
@@ -1169,7 +1173,7 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
 
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
     int G, chunk;
-    dw_grid(num_tasks, num_tokens, &G, &chunk);
+    dw_grid(num_tasks, num_tokens, &G, &chunk, T.partial != nullptr);
     GEOMAE_REQUIRE(!T.partial || (long long)G * num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();
     hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? 1 : 0)), dim3(256), 0, stream, T, num_tokens, chunk,

@@ -16,7 +16,8 @@ from . import _lib, ops
 from ._lib import GeomaePretrainConfig, GeomaePretrainModel, check
 
 HOOK_BN_FWD0, HOOK_BN_FWD1, HOOK_BN_BWD1, HOOK_BN_BWD0, HOOK_GRADS_EARLY, HOOK_GRADS_ENCODER = range(6)
-PHASES = ("vfe_fwd", "layouts_wait", "enc_fwd", "dec_fwd", "heads_loss", "dec_bwd", "enc_bwd", "vfe_bwd", "optimizer")
+PHASES = ("vfe_fwd", "layouts_wait", "enc_fwd", "dec_fwd", "heads_loss", "dec_bwd", "enc_bwd", "vfe_bwd_stats",
+          "vfe_bwd_layer1", "vfe_bwd_layer0", "vfe_bwd_join", "optimizer")
 ERR_WORKSPACE = -3
 
 
