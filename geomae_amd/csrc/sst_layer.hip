@@ -855,13 +855,13 @@ __device__ __forceinline__ void dw_reduce_body(const DwReduce& R, int rb, int nr
     }
 }
 
-// grid (chunks, tasks [+ 1 row of reduce blocks when R carries a previous launch's partials])
+// grid (chunks, tasks [+ rows of reduce blocks when R carries a previous launch's partials])
 __global__ __launch_bounds__(256) void dw_kernel(DwTasks tasks, int n, int chunk, int num_tasks, DwReduce R) {
     __shared__ __attribute__((aligned(16))) bf16_t As[kDwTok * kDwLd];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[kDwTok * kDwLd];
     __shared__ float bred[4][128];
-    if ((int)blockIdx.y >= num_tasks) {
-        dw_reduce_body(R, blockIdx.x, gridDim.x);
+    if ((int)blockIdx.y >= num_tasks) {                  // rows of reduce blocks behind the task rows
+        dw_reduce_body(R, ((int)blockIdx.y - num_tasks) * gridDim.x + blockIdx.x, ((int)gridDim.y - num_tasks) * gridDim.x);
         return;
     }
     dw_body(tasks.t[blockIdx.y], n, chunk, blockIdx.x, As, Bs, bred, tasks.blocked != 0,
@@ -1176,7 +1176,7 @@ int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream
     dw_grid(num_tasks, num_tokens, &G, &chunk, T.partial != nullptr);
     GEOMAE_REQUIRE(!T.partial || (long long)G * num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();
-    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? 1 : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
+    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? cdiv(kDwReduceBlocks, G) : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
                        num_tasks, Rd);
     note_partials(T, num_tasks, G);
     return check_launch("dw_kernel");
