@@ -672,7 +672,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_bwd_kernel(const bf16_t*
 // DW: C[c_row0 + i][c_col0 + j] += sum_t A[t][a_col0 + i] * B[t][b_col0 + j],  i, j < 128
 //     dbias[c_row0 + i]         += sum_t A[t][a_col0 + i]                        (if dbias)
 // ------------------------------------------------------------------------------------------------
-constexpr int kDwTok = 32;             // tokens per slab (= MFMA K)
+constexpr int kDwTok = 64;             // tokens per LDS slab: two MFMA K-steps of 32 between one pair of barriers
+constexpr int kDwPieces = kDwTok * 16 / 256;   // 16-byte pieces per thread, operand and slab
 constexpr int kDwLd = 128 + 8;         // LDS row: 128 channels + 16 B pad (token-major, no transposition)
 
 // element offset of (token, column) in a [n, ld] bf16 operand: row-major or tile-blocked [n/16][ld/16][16][16]
@@ -696,12 +697,13 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     const int t_begin = bx * chunk;
     const int t_end = t_begin + chunk < n ? t_begin + chunk : n;
     if (t_begin >= n) return;
+    GEOMAE_STAMP(24);
     f32x4 acc[2][8];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 8; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging: 512 16-byte pieces per operand slab, two per thread (tokens tk0 and tk0 + 16, channel chunk cch).
+    // staging: 1024 16-byte pieces per operand slab, four per thread (tokens tk0 + 16 k, channel chunk cch).
     // Row-major operands: token = q >> 4, chunk = q & 15 (16 threads read one 256-byte row piece).  Tile-blocked
     // operands: [16-channel block][half][token]: 32 threads read one contiguous 512-byte block (with the row-major
     // mapping they gathered 8 separate 32-byte pieces per token and the contraction ran 29 % slower), and the 16
@@ -713,13 +715,14 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
     // Operand slabs travel global -> registers -> LDS.  A register ring of kDwStages slabs keeps kDwStages - 1 slabs
     // of loads in flight: with a single stage the loads issued under one slab's MFMAs (~0.3 us) were needed one
-    // slab later and each slab paid most of the memory latency (~1.9 us per slab, 16 slabs per workgroup: the
-    // contraction, not the data-gradient chain, set the duration of the encoder's backward launches).
-    constexpr int kDwStages = 4;
-    u32x4 ra[kDwStages][2], rb[kDwStages][2];
-    auto fetch = [&](int t0, u32x4 (&qa)[2], u32x4 (&qb)[2]) {
+    // slab later and each slab paid most of the memory latency.  Slabs of 64 tokens: a slab's life is a serial chain
+    // (barrier, LDS writes, barrier, transposing LDS reads, MFMAs) that cost 2.1 k cycles per 32 tokens for 512 cycles of
+    // MFMA (tools/phase_dw.py); two K-steps per chain halve the number of chains.
+    constexpr int kDwStages = 3;
+    u32x4 ra[kDwStages][kDwPieces], rb[kDwStages][kDwPieces];
+    auto fetch = [&](int t0, u32x4 (&qa)[kDwPieces], u32x4 (&qb)[kDwPieces]) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kDwPieces; ++k) {
             const int tok = t0 + tk0 + 16 * k;
             qa[k] = u32x4{0u, 0u, 0u, 0u};
             qb[k] = qa[k];
@@ -743,7 +746,7 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
                 fetch(cur + (kDwStages - 1) * kDwTok, ra[(st + kDwStages - 1) % kDwStages], rb[(st + kDwStages - 1) % kDwStages]);
                 __syncthreads();      // previous slab fully consumed
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < kDwPieces; ++k) {
                     *reinterpret_cast<u32x4*>(As + (tk0 + 16 * k) * kDwLd + 8 * cch) = ra[st][k];
                     *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = rb[st][k];
 #pragma unroll
@@ -753,22 +756,28 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
                     }
                 }
                 __syncthreads();
-                uint4 af[2];
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
-                    const uint2 lo = tr_read(arow + 32 * wave + 16 * it), hi = tr_read(arow + 4 * kDwLd + 32 * wave + 16 * it);
-                    af[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-                }
+                for (int ks = 0; ks < kDwTok / 32; ++ks) {            // MFMA K-steps of 32 tokens
+                    const bf16_t* ar = arow + 32 * ks * kDwLd;
+                    const bf16_t* br = brow + 32 * ks * kDwLd;
+                    uint4 af[2];
 #pragma unroll
-                for (int jt = 0; jt < 8; ++jt) {
-                    const uint2 lo = tr_read(brow + 16 * jt), hi = tr_read(brow + 4 * kDwLd + 16 * jt);
-                    const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    for (int it = 0; it < 2; ++it) {
+                        const uint2 lo = tr_read(ar + 32 * wave + 16 * it), hi = tr_read(ar + 4 * kDwLd + 32 * wave + 16 * it);
+                        af[it] = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                    }
 #pragma unroll
-                    for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
+                    for (int jt = 0; jt < 8; ++jt) {
+                        const uint2 lo = tr_read(br + 16 * jt), hi = tr_read(br + 4 * kDwLd + 16 * jt);
+                        const uint4 bf = make_uint4(lo.x, lo.y, hi.x, hi.y);
+#pragma unroll
+                        for (int it = 0; it < 2; ++it) acc[it][jt] = mfma32(af[it], bf, acc[it][jt]);
+                    }
                 }
             }
         }
     }
+    GEOMAE_STAMP(25);
     // C layout: row i = 32*wave + 16*it + 4*g + r, col j = 16*jt + o.  Added to the gradient with float atomics
     // (memory-side units): issued straight from this layout an instruction touches four 64-byte pieces of four rows.
     // The wave first transposes in registers (ds_bpermute: target lane L pulls column 16*(L>>4) + (L&15) of one row
@@ -802,6 +811,7 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
                     }
                 }
     }
+    GEOMAE_STAMP(26);
     if (T.dbias) {
         // column sums of A: thread holds 8 channels (chunk cch) of tokens tk0 + 16k (+32 per slab)
         if (!blk) {
