@@ -353,8 +353,8 @@ def main():
             u = json.load(open(upath))
             out["mfma_busy_stored"] = {"source": "profiles/r02_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
                                        **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
-                                                                              "sst_ffn_fwd_kernel", "sst_ffn_bwd_dw_kernel",
-                                                                              "vfe_layer1_kernel") if k in u}}
+                                                                              "sst_ffn_fwd_kernel", "sst_ffn_fwd_pair_kernel",
+                                                                              "sst_ffn_bwd_dw_kernel", "vfe_layer1_kernel") if k in u}}
         if phases is not None:
             out["main_stream_phase_ms"] = phases
             out["main_stream_phase_sum_ms"] = round(float(sum(phases.values())), 4)

@@ -1174,7 +1174,7 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
     }
     if (g_pending_reduce.partial) {                      // the last contraction's own partials
         const DwReduce Rd = take_pending_reduce();
-        hipLaunchKernelGGL(dw_reduce_kernel, dim3(kDwReduceBlocks), dim3(256), 0, stream, Rd);
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(4 * kDwReduceBlocks), dim3(256), 0, stream, Rd);      // alone on its stream: wider
         const int rc2 = check_launch("dw_reduce_kernel");
         if (rc == GEOMAE_OK) rc = rc2;
     }
@@ -1186,7 +1186,7 @@ int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream
     dw_grid(num_tasks, num_tokens, &G, &chunk, T.partial != nullptr);
     GEOMAE_REQUIRE(!T.partial || (long long)G * num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();
-    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? cdiv(kDwReduceBlocks, G) : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
+    hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? cdiv(2 * kDwReduceBlocks, G) : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
                        num_tasks, Rd);
     note_partials(T, num_tasks, G);
     return check_launch("dw_kernel");

@@ -3,12 +3,18 @@ bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: counter unit KB, gfx950
 (FETCH_SIZE reports half of a wide coalesced read stream)."""
 import csv, json, sys
 fetch, write, out = sys.argv[1], sys.argv[2], sys.argv[3]
+import re
+def kernel_name(raw):
+    """'void geomae::win_attn_fwd_kernel<4>(unsigned short const*; ...' -> 'win_attn_fwd_kernel' (template forms merged)"""
+    return re.sub(r"<.*", "", raw.split("(")[0].replace("geomae::", "").replace("void ", "")).strip()
 def load(path, col):
-    d = {}
+    acc = {}
     for r in csv.DictReader(open(path)):
-        name = r["kernel"].split("(")[0].replace("geomae::", "").replace("void ", "").strip()
-        d.setdefault(name, (float(r[col]), int(r["dispatches"])))
-    return d
+        name = kernel_name(r["kernel"])
+        v, n = float(r[col]), int(r["dispatches"])
+        s, m = acc.get(name, (0.0, 0))
+        acc[name] = (s + v * n, m + n)                     # dispatch-weighted mean over the forms of one kernel
+    return {k: (s / max(m, 1), m) for k, (s, m) in acc.items()}
 f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
 res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh, bench.py "
                    "--steps 3 --warmup 2, B=4 single-sweep frames, mean over all launches of the kernel). Counter unit KB; "
@@ -17,7 +23,7 @@ res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE
        "_raw_kb": {}}
 for k in sorted(set(f) & set(w)):
     if not (k.startswith("sst_") or k.startswith("win_") or k.startswith("vfe_") or k.startswith("voxelize") or
-            k.startswith("scan_") or k in ("dw_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
+            k.startswith("scan_") or k in ("dw_kernel", "dw_reduce_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
                                             "centroid_targets_kernel", "normal_curv_kernel", "normal_eig_kernel",
                                             "occ_count_kernel", "random_mask_kernel", "grad_sumsq_kernel",
                                             "pack_weights_kernel", "rows_to_blocked_f32_kernel", "gather_token_coors_kernel")):
