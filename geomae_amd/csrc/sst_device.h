@@ -74,6 +74,20 @@ static __device__ unsigned long long geomae_stamps[GEOMAE_STAMP_BLOCKS * GEOMAE_
 #else
 #define GEOMAE_STAMP(i) do {} while (0)
 #endif
+// wall-clock stamps (s_memrealtime, 100 MHz, one clock for the whole device): when each workgroup of a launch started and
+// ended -- clock64 differs between XCDs, so only this shows the shape of a launch (tools/launch_shape.py)
+#ifdef GEOMAE_PHASE_TIMING
+#define GEOMAE_WSTAMP(slot, kind)                                                                          \
+    do {                                                                                                  \
+        if (threadIdx.x == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS && gridDim.x <= GEOMAE_STAMP_MAX_GRID &&  \
+            gridDim.x >= GEOMAE_STAMP_MIN_GRID) {                                                          \
+            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (slot)] = wall_clock64();                      \
+            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + 30] = (kind);                                  \
+        }                                                                                                 \
+    } while (0)
+#else
+#define GEOMAE_WSTAMP(slot, kind) do {} while (0)
+#endif
 // -DGEOMAE_STAMP_FWD: the stamps go to the FFN-forward kernels instead (first launch after a clear keeps its stamps)
 #if defined(GEOMAE_PHASE_TIMING) && defined(GEOMAE_STAMP_FWD)
 #undef GEOMAE_STAMP

@@ -844,23 +844,31 @@ __device__ __forceinline__ void dw_reduce_body(const DwReduce& R, int rb, int nr
     for (int slot = rb * 256 + threadIdx.x; slot < slots; slot += nrb * 256) {
         const int ti = slot >> 12, q = slot & 4095;
         const int th = q & 255, it = q >> 11, jt = (q >> 8) & 7;
-        const f32x4* p = reinterpret_cast<const f32x4*>(R.partial) + (size_t)ti * R.gx * 4096 + q;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int k = 0;
-        for (; k + 8 <= R.gx; k += 8) {                 // 8 loads in flight
-            f32x4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * 4096];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) s += v[u];
-        }
-        for (; k < R.gx; ++k) s += p[(size_t)k * 4096];
         const DwReduceTask& T = R.t[ti];
         const int wave = th >> 6, g = (th >> 4) & 3, o = th & 15;
+        // the four gradient words first, then every partial: one memory round trip for the whole slot (the workgroup's
+        // life is latency: issued one after the other these loads made a 64-block reduction last 10-19 us)
+        float* c[4];
+        float cv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 32 * wave + 16 * it + 4 * g + r, j = 16 * jt + o;
-            if (i < T.rows_valid) T.C[(int64_t)(T.c_row0 + i) * T.ldc + T.c_col0 + j] += s[r];
+            c[r] = T.C + (int64_t)(T.c_row0 + (i < T.rows_valid ? i : 0)) * T.ldc + T.c_col0 + j;
+            cv[r] = *c[r];
+        }
+        const f32x4* p = reinterpret_cast<const f32x4*>(R.partial) + (size_t)ti * R.gx * 4096 + q;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int k0 = 0; k0 < R.gx; k0 += 12) {                          // <= 24 chunks: at most two rounds
+            f32x4 v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) v[u] = p[(size_t)(k0 + u < R.gx ? k0 + u : k0) * 4096];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) s += k0 + u < R.gx ? v[u] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 32 * wave + 16 * it + 4 * g + r;
+            if (i < T.rows_valid) *c[r] = cv[r] + s[r];
         }
     }
 }
@@ -891,6 +899,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ float red[4][4][128];
     static_assert(2 * kDwTok * kDwLd <= kWeightLds, "dw slabs must fit in the weight buffer");
+    const int wkind = (int)blockIdx.x < n_ffn ? 1 : ((int)blockIdx.x < n_ffn + dw_blocks ? 2 : 3);
+    (void)wkind;
+    GEOMAE_WSTAMP(28, wkind);
     if ((int)blockIdx.x < n_ffn) {
         ffn_bwd_body(A, blockIdx.x, smem, red);
     } else if ((int)blockIdx.x < n_ffn + dw_blocks) {
@@ -901,6 +912,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_dw_kernel(FfnBwdArgs
     } else {
         dw_reduce_body(R, blockIdx.x - n_ffn - dw_blocks, kDwReduceBlocks);
     }
+    GEOMAE_WSTAMP(29, wkind);
 }
 
 // enough workgroups to fill the chip whatever the number of tasks (the VFE's single dW1 task ran on 32)
