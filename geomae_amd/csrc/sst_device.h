@@ -57,7 +57,9 @@ constexpr int kWeightLds = 256 * (128 + kPad);   // largest staged matrix: [256]
 // a no-op in the product build)
 #ifdef GEOMAE_PHASE_TIMING
 #define GEOMAE_STAMP_SLOTS 32
+#ifndef GEOMAE_STAMP_BLOCKS
 #define GEOMAE_STAMP_BLOCKS 512
+#endif
 #ifndef GEOMAE_STAMP_MAX_GRID
 #define GEOMAE_STAMP_MAX_GRID 1000000     // -DGEOMAE_STAMP_MAX_GRID=300: only encoder-size launches leave stamps
 #endif
