@@ -1008,6 +1008,43 @@ def test_pair_kernels_are_bit_identical(dev, n_frames):
     # (the saved blob itself is not compared: it has alignment gaps nobody writes)
 
 
+def test_stack_weight_gradients_do_not_depend_on_arrival_order(dev):
+    """Inside a stack the weight-gradient contraction sums through memory (split-K partials stored, added in chunk order
+    by a later launch -- csrc/sst_layer.hip dw_body / dw_reduce_body) instead of float atomics: the matrix gradients of
+    two runs on the same inputs are identical bit for bit.  (Bias and LayerNorm-parameter gradients still go through
+    atomics and may differ in the last bits.)"""
+    from geomae_amd import ops
+    model, _ = _build(dev, 2, 1, "bf16")
+    bb = model.backbone
+    frames = [synth.lidar_frame(71 + i) for i in range(2)]
+    _, coors = O.voxelize_batch(frames, LEVELS["top"], RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(n, 128, generator=gen).to(dev)
+    dz = torch.randn(n, 128, generator=gen).to(dev)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, 2)
+    nl = 2 * len(bb.encoder_blocks)
+    w = bb._packed.weight_array(bb._stack_base["enc"], nl)
+    runs = []
+    for _ in range(2):
+        for p in bb.parameters():
+            p.grad = None
+        g = bb._packed.grad_array(bb._stack_base["enc"], nl)
+        z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0])
+        ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], saved)
+        torch.cuda.synchronize()
+        runs.append({k: p.grad.clone() for k, p in bb.encoder_blocks.named_parameters()})
+    mats = [k for k in runs[0] if k.endswith("weight") and runs[0][k].dim() == 2]
+    assert len(mats) >= 4 * nl // 2
+    for k in mats:
+        assert float(runs[0][k].abs().max()) > 0
+        assert torch.equal(runs[0][k], runs[1][k]), k
+    for k in runs[0]:
+        assert torch.allclose(runs[0][k], runs[1][k], rtol=1e-4, atol=1e-5 * float(runs[0][k].abs().max())), k
+
+
 def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
     """forward_train (fused heads+loss kernel) vs extract_feat + forward_loss on the same model / mask:
     losses and every gradient."""
