@@ -176,6 +176,43 @@ __device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, cons
         for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
     }
 }
+// The transposed product from the SAME LDS copy: dg[t][16*ot + 4g + r] = sum_o W1[o][.] dy1[t][o].  The contraction now
+// runs over W1's ROW index, so the A fragment of lane (m = lane & 15, g) -- eight o's of column k = 16 ot + m, in the
+// K order of the T-layout operand: o = 32 kk + {4g .. 4g+3, 16+4g .. 16+4g+3} -- is two groups of four consecutive
+// rows of one column: what ds_read_b64_tr_b16 returns when lane m points at row (m >> 2) and at the 4-column chunk
+// (m & 3) of the tile (chunk q of a 32-column block sits at position 8 (q & 3) + 4 (q >> 2) of the K-permuted row).
+// Same products in the same order as a GEMM against a transposed copy, without the copy (a second 69.6 KB that does not
+// fit beside the first): the backward sweep no longer parks dy1 in HBM between a W1 pass and a W1^T pass.
+template <int NG>
+__device__ __forceinline__ void layer1_group_t(const float* __restrict__ W1s, const BSplit& x, int ot0, f32x4 (&y)[NG],
+                                               int lane) {
+    const int m = lane & 15, g = lane >> 4;
+    const bf16_t* wh = reinterpret_cast<const bf16_t*>(W1s) + (4 * g + (m >> 2)) * kW1bLd + 8 * (m & 3);
+    const bf16_t* wl = wh + 128 * kW1bLd;
+#pragma unroll
+    for (int u = 0; u < NG; ++u) y[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        uint4 ah[NG], al[NG];
+#pragma unroll
+        for (int u = 0; u < NG; ++u) {
+            const int ot = ot0 + u;
+            const int col = 32 * (ot >> 1) + 4 * (ot & 1);
+            const bf16_t* ph = wh + 32 * kk * kW1bLd + col;
+            const bf16_t* pl = wl + 32 * kk * kW1bLd + col;
+            const uint2 h0 = tr_read(ph), h1 = tr_read(ph + 16 * kW1bLd);
+            const uint2 l0 = tr_read(pl), l1 = tr_read(pl + 16 * kW1bLd);
+            ah[u] = make_uint4(h0.x, h0.y, h1.x, h1.y);
+            al[u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+        }
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.h[kk], y[u]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
+#pragma unroll
+        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
+    }
+}
 __device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const BSplit& x, f32x4 (&y)[8], int lane) {
     layer1_group<4>(W1s, x, 0, reinterpret_cast<f32x4(&)[4]>(y[0]), lane);
     layer1_group<4>(W1s, x, 4, reinterpret_cast<f32x4(&)[4]>(y[4]), lane);
@@ -719,10 +756,14 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
-    // Both W1 (recompute y1) and W1^T (dg = dy1 W1) are needed.  Two fp32 copies do not fit in LDS, so the
-    // sweep is split: A1 computes dy1 with W1 and parks it in HBM (fp32); A2 re-reads it and multiplies by W1^T.
+    // Both W1 (recompute y1) and W1^T (dg = dy1 W1) are needed; the second product reads its operand from the SAME split
+    // copy with transposing LDS reads (layer1_group_t), so dy1 stays in registers between the two: one sweep.  (Until
+    // round 2 the sweep was split: A1 computed dy1 with W1 and parked it in HBM as fp32, the workgroup re-staged W1^T,
+    // A2 re-read dy1 -- 108 MB of the kernel's 234 MB.)
     stage_w1(W.w1, W1s, false);
     __syncthreads();
+    SegCarry<1> carry;
+    carry.init(false);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
@@ -731,49 +772,37 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const Bn1 bnl = shifted(bns, oz);
         const float* bs0 = bn1s[0] + oz;
         const float* bs1 = bn1s[1] + oz;
-        f32x4 y0[4], gin[8];
-        recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
-        store_rows_bf16<128>(g_b, R.j_hi, j, 128, 0, gin, lane);      // rows >= j_hi belong to the next wave: dropped
-        const BSplit gs = split_operand(gin);
-#pragma unroll
-        for (int ot0 = 0; ot0 < 8; ot0 += 2) {
-          f32x4 y4[2];
-          layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int ot = ot0 + u;
-            f32x4 dh, yh, dy;
-            routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot, lane, &dh, &yh);
-            const int c0 = 16 * ot + 4 * g;
-            const float4 sc = *reinterpret_cast<const float4*>(bnl.scale + c0);    // gamma * invstd
-            const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dy[r] = scv[r] * (dh[r] - bs0[c0 + r] - yh[r] * bs1[c0 + r]);
-            if (valid) {
-                *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy);      // operand of dW1 (dw_kernel)
-                *reinterpret_cast<float4*>(dy1_f + (int64_t)j * 128 + c0) = make_float4(dy[0], dy[1], dy[2], dy[3]);
-            }
-          }
-        }
-    }
-    __syncthreads();
-    stage_w1(W.w1, W1s, true);
-    __syncthreads();
-    SegCarry<1> carry;
-    carry.init(false);
-    for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-        const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
-        const float* W1l = W1s + opaque_zero();
         f32x4 dy1[8];
-        load_rows_f32<128>(dy1_f, R.j_hi, j, dy1, lane);
-        // W1s holds W1^T: dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
+        {
+            f32x4 y0[4], gin[8];
+            recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+            store_rows_bf16<128>(g_b, R.j_hi, j, 128, 0, gin, lane);      // rows >= j_hi belong to the next wave: dropped
+            const BSplit gs = split_operand(gin);
+#pragma unroll
+            for (int ot0 = 0; ot0 < 8; ot0 += 2) {
+                f32x4 y4[2];
+                layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ot = ot0 + u;
+                    f32x4 dh, yh;
+                    routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+                    const int c0 = 16 * ot + 4 * g;
+                    const float4 sc = *reinterpret_cast<const float4*>(bnl.scale + c0);    // gamma * invstd
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dy1[ot][r] = valid ? scv[r] * (dh[r] - bs0[c0 + r] - yh[r] * bs1[c0 + r]) : 0.f;
+                    if (valid) *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy1[ot]);   // operand of dW1
+                }
+            }
+        }
+        // dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
+        const float* W1l = W1s + opaque_zero();
         const BSplit ds = split_operand(dy1);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 d2[2];
-            layer1_group<2>(W1l, ds, ot0, d2, lane);
+            layer1_group_t<2>(W1l, ds, ot0, d2, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ct = ot0 + u;
@@ -793,6 +822,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         wave_sync();
     }
     seg_flush<1, false>(64, dm0, G.seg_start, R, carry, lane);
+    (void)dy1_f;                                   // (kept in the C ABI; no longer written)
 }
 
 // layer-0 routing sweep (needs the complete dm0): dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ;
