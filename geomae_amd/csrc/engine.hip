@@ -167,7 +167,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes((int32_t)n));
     b += al256(nk * 512) + 4 * al256(n * 512);                                                             // z_enc, cen, den, dxa, dxb
     b += al256(M * 896 * 2) + 2 * al256(M * 128 * 2);                                                      // heads
-    b += 2 * al256(N * 128 * 2) + al256(N * 128 * 4) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);     // VFE backward
+    b += 2 * al256(N * 128 * 2) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);                         // VFE backward
     return b + 8192;
 }
 
@@ -437,7 +437,6 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* dxb = a.take<float>((int64_t)n * 128);
     char* h_dl = a.bytes(M * 896 * 2); char* h_cm = a.bytes(M * 128 * 2); char* h_dm = a.bytes(M * 128 * 2);
     char* dy1_b = a.bytes(N * 128 * 2); char* g_b = a.bytes(N * 128 * 2);
-    float* dy1_f = a.take<float>(N * 128);
     float* dw1_partial = (float*)a.bytes(2 * kDwPartialBytes);      // split-K workspace of the layer-1 weight gradient
     float* dh0 = a.take<float>(N * 64);
     if (a.overflow) {
@@ -578,7 +577,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD1, main);
         n_eff = (float)((double)c.world_size * (double)N);
     }
-    ENG_CALL(geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, dy1_f, dh0, dm0, use_bs0,
+    ENG_CALL(geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, nullptr, dh0, dm0, use_bs0,
                                         fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main));
     mark(e, pVfeL1, main);
     ENG_CALL(order_after(e, kVfeL1, main, geo));

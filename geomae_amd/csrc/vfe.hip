@@ -1094,7 +1094,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     Bn1 bn; Bn0 bn0;
     if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
     if ((rc = bn_of(bnst, 0, &bn0.scale, &bn0.shift, &bn0.mean, &bn0.invstd))) return rc;
-    GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dy1_f32 && dh0 && dm0 &&
+    GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1_global && dy1_bf16 && g_bf16 && dh0 && dm0 &&
                    bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
     GEOMAE_ZERO(bsums0, 128 * sizeof(double), stream);
     GEOMAE_ZERO(dm0, (size_t)a->max_pillars * 64 * sizeof(float), stream);

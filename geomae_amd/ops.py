@@ -1101,12 +1101,11 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, sid
     n_eff = float(world * N)
     dy1_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
     g_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
-    dy1_f = torch.empty((N, 128), dtype=torch.float32, device=dev)
     dh0 = torch.empty((N, 64), dtype=torch.float32, device=dev)
     dm0 = _zeros_or_empty(zeros, (max(V, 1), 64), torch.float32, dev)
     bs0 = _zeros_or_empty(zeros, (128,), torch.float64, dev)
     check(lib.geomae_vfe_backward_layer1(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), n_eff,
-                                         _ptr(dy1_b), _ptr(g_b), _ptr(dy1_f), _ptr(dh0), _ptr(dm0), _ptr(bs0),
+                                         _ptr(dy1_b), _ptr(g_b), None, _ptr(dh0), _ptr(dm0), _ptr(bs0),
                                          _ptr(params["b1"].grad) if fold else None,
                                          _ptr(params["g1"].grad) if fold else None, _stream()), "geomae_vfe_backward_layer1")
     if side is not None:

@@ -380,7 +380,7 @@ int geomae_vfe_backward_stats(const GeomaeVfeArgs* args, const GeomaeBnState* bn
 int geomae_vfe_backward_layer1(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* m0,
                                const float* voxel_feats, const float* d_voxel_feats, const double* bsums1_global,
                                float n_eff, void* dy1_bf16 /*[N,128]*/, void* g_bf16 /*[N,128]*/,
-                               float* dy1_f32 /*[N,128] scratch*/, float* dh0 /*[N,64]*/, float* dm0 /*[V,64]*/,
+                               float* dy1_f32 /* unused since the one-sweep kernel: may be NULL */, float* dh0 /*[N,64]*/, float* dm0 /*[V,64]*/,
                                double* bsums0 /*[128]*/, float* d_beta1 /*[128] += or NULL*/,
                                float* d_gamma1 /*[128] += or NULL*/, geomaeStream_t stream);
 int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* dh0,
