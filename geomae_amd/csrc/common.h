@@ -49,6 +49,13 @@ const float* dz_addend();
 // sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).
 void set_tail_sum(float* sum, int from_row);
 float* tail_sum(int* from_row);
+// First LIVE token row of the stacks this host thread runs next (geomae_sst_stack_forward / _backward; 0 = all rows):
+// the caller promises that it never reads the stack's output rows below it and that the output GRADIENT of those rows is
+// zero.  The last layer then skips their out-projection / FFN (forward) and its backward (whose outputs for those rows are
+// zeros).  The decoders of the pre-training step: only masked pillars reach the heads (bb.py:300-335), the kept ones --
+// 30 % of the tokens -- come first.
+void set_first_live_row(int row);
+int first_live_row();
 // Split-K workspace of the geomae_sst_weight_grad calls of this host thread (set by geomae_sst_stack_backward for its own
 // layers): two buffers of kDwPartialBytes where the contraction's workgroups leave their partial sums instead of
 // atomically adding them to the gradients (sst_layer.hip dw_body); nullptr = atomics.

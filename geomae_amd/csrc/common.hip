@@ -28,6 +28,9 @@ float* tail_sum(int* from_row) { *from_row = g_tail_from; return g_tail_sum; }
 static thread_local SstInputMap g_input_map = {nullptr, 0, nullptr, nullptr};
 void set_input_map(const SstInputMap& m) { g_input_map = m; }
 SstInputMap input_map() { return g_input_map; }
+static thread_local int g_first_live_row = 0;
+void set_first_live_row(int row) { g_first_live_row = row > 0 ? row : 0; }
+int first_live_row() { return g_first_live_row; }
 static thread_local float* g_dw_partial = nullptr;
 void set_dw_partial(float* ws) { g_dw_partial = ws; }
 float* dw_partial() { return g_dw_partial; }

@@ -524,8 +524,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
                                       nullptr, b.ids_keep, e->profiler, main));
     mark(e, pEncFwd, main);
     ENG_CALL(order_after(e, kForkDec, main, aux));
+    set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_forward(z_enc, n, L_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den, sb_dec, den, nk,
                                       m.mask_token, nullptr, e->profiler, aux));
+    set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_forward(z_enc, n, L_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen, sb_dec, cen, nk,
                                       m.mask_token, nullptr, e->profiler, main));
     ENG_CALL(order_after(e, kJoinDecFwd, aux, main));
@@ -538,11 +540,13 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(geomae_heads_weight_grad(nm, h_dl, h_cm, h_dm, &m.head_grads, geo));
     mark(e, pHeads, main);
     GEOMAE_HIP(hipStreamWaitEvent(aux, e->ev[kHeads], 0));
+    set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
                                        w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
     GEOMAE_HIP(hipEventRecord(e->ev[kAuxBwd], aux));
     GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kAuxBwd], 0));
     ENG_CALL(geomae_flush_weight_grad(geo));
+    set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
                                        w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
     ENG_CALL(order_after(e, kMainDecBwd, main, geo));

@@ -186,14 +186,15 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
                                                                 float* __restrict__ xh1_out,
                                                                 float* __restrict__ xh2_out,
                                                                 bf16_t* __restrict__ hp_out,
-                                                                float* __restrict__ rstd_out, NextQkv N, int lay) {
+                                                                float* __restrict__ rstd_out, NextQkv N, int lay,
+                                                                int wg0 /* first workgroup (64 tokens each) that runs */) {
     const bool blk = lay & kLayBlocked;
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ __attribute__((aligned(16))) float prm[kPrmFloats];
     PrmRegs prm_r;
     ffn_params_issue(W, N.wqkv ? N.bqkv : nullptr, prm_r);
     const int lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * (kLayerBlk / 64) + (threadIdx.x >> 6);
+    const int tile = (blockIdx.x + wg0) * (kLayerBlk / 64) + (threadIdx.x >> 6);
     const int tok = tile * 16 + (lane & 15);
     GEOMAE_FSTAMP(0);
     f32x4 u[8], y[8];
@@ -476,6 +477,7 @@ struct FfnBwdArgs {
     const bf16_t *up_wqkT, *up_wvT;   // packed transposed in-projection of layer l+1
     int lay;                          // kLayBlocked: everything except dz (always row-major: it comes from outside)
     const float* dz_add;              // optional second summand of dz (the other decoder's input gradient), row-major
+    int wg0;                          // workgroups below it own DEAD rows (zero dz, set_first_live_row): they store zeros
 };
 
 // B1 arithmetic: acc = dx_res + dqkv[:, :256] Wqk + dqkv[:, 256:] Wv
@@ -513,6 +515,22 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     const int tok = tile * 16 + (lane & 15);
     const bool blk = A.lay & kLayBlocked, valid = tok < n;
     float* red_scratch = reinterpret_cast<float*>(smem) + wave * kRedWaveFloats;   // see ln_param_grads_t
+    if (block < A.wg0) {              // dead rows: every output of this kernel is zero for them (workgroup-uniform)
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 z8[8], z16[16];
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) z8[ct] = z4;
+#pragma unroll
+        for (int ct = 0; ct < 16; ++ct) z16[ct] = z4;
+        store_rows_f32<128>(dx_res, n, tok, z8, lane, blk);
+        store_rows_bf16<128>(dattn, n, tok, 128, 0, z8, lane, blk);
+        store_rows_bf16<128>(du_b, n, tok, 128, 0, z8, lane, blk);
+        store_rows_bf16<128>(dv_b, n, tok, 128, 0, z8, lane, blk);
+        store_rows_bf16<128>(y_b, n, tok, 128, 0, z8, lane, blk);
+        store_rows_bf16<256>(dhp_b, n, tok, 256, 0, z16, lane, blk);
+        store_rows_bf16<256>(h_b, n, tok, 256, 0, z16, lane, blk);
+        return;
+    }
     GEOMAE_STAMP(0);
     const uint2 rs = buf_load_b64(rows_rsrc(rstd_in, n, 8), tok * 8);
     const float r1 = __uint_as_float(rs.x), r2 = __uint_as_float(rs.y);
@@ -1013,6 +1031,8 @@ static int g_pair_mode = [] {
     const char* e = getenv("GEOMAE_PAIR_KERNELS");
     return e ? atoi(e) : -1;
 }();
+// rows the stack marked dead for the NEXT ffn forward / backward call of this host thread (sst_stack.hip)
+#define t_skip_rows (geomae::first_live_row())
 static bool use_pair_kernels(int tiles) {
     if (g_pair_mode >= 0) return g_pair_mode != 0;
     return cdiv(tiles, 2) <= 256;
@@ -1058,15 +1078,17 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
                     (bf16_t*)next_x_bf16, (bf16_t*)next_xp_bf16};
     }
     const int tiles = cdiv(num_tokens, 16);
-    if (use_pair_kernels(tiles)) {
+    if (use_pair_kernels(tiles) && !(t_skip_rows >= 64 && !next_w)) {
         hipLaunchKernelGGL(sst_ffn_fwd_pair_kernel, dim3(cdiv(tiles, 2)), dim3(kLayerBlk), 0, stream, x,
                            (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
                            (bf16_t*)hp_bf16, rstd, N, layer_layout());
         return check_launch("sst_ffn_fwd_pair_kernel");
     }
-    hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64)), dim3(kLayerBlk), 0, stream, x,
+    // rows the caller never reads (set_first_live_row, the last layer of a decoder stack): whole workgroups are skipped
+    const int wg0 = next_w ? 0 : t_skip_rows / 64;
+    hipLaunchKernelGGL(sst_ffn_fwd_kernel, dim3(cdiv(tiles, kLayerBlk / 64) - wg0), dim3(kLayerBlk), 0, stream, x,
                        (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
-                       (bf16_t*)hp_bf16, rstd, N, layer_layout());
+                       (bf16_t*)hp_bf16, rstd, N, layer_layout(), wg0);
     return check_launch("sst_ffn_fwd_kernel");
 }
 
@@ -1099,7 +1121,8 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
                           (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
                           (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b,
                           (const bf16_t*)up_dqkv_bf16, up_dx_res, up_w ? (const bf16_t*)up_w->wqkT_p : nullptr,
-                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout(), dz ? dz_addend() : nullptr};
+                          up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout(), dz ? dz_addend() : nullptr,
+                          dz ? t_skip_rows / 64 : 0};
     const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
     if (!g_pending_dw.active) {
         hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);

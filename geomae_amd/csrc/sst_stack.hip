@@ -149,6 +149,8 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
                                         int32_t num_heads, int32_t max_window_tokens, void* saved, int64_t saved_bytes,
                                         float* z_out, int32_t num_input_rows, const float* fill_row,
                                         const int32_t* input_rows, void* profiler, hipStream_t stream) {
+    const int live_row = first_live_row();          // caller's promise (common.h): consumed first, applied per layer below
+    set_first_live_row(0);
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_forward");
     if (rc) return rc;
@@ -161,6 +163,10 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         return GEOMAE_ERR_WORKSPACE;
     }
     char* base = (char*)saved;
+    struct LiveRowScope {
+        explicit LiveRowScope(int r) { set_first_live_row(r); }
+        ~LiveRowScope() { set_first_live_row(0); }
+    };
     // the input conversion (row-major x_in [gathered by input_rows, followed by fill_row] -> tile-blocked x of layer 0)
     // is done by F1 of layer 0 itself (common.h SstInputMap); it used to be a 5-13 us launch in front of every stack
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
@@ -190,6 +196,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         }
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
+            LiveRowScope live(next ? 0 : live_row);               // only the LAST layer's output rows can be dead
             if ((rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
                                                  (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd),
                                                  next ? &layers[l + 1] : nullptr, next ? layouts[(l + 1) & 1].tok_pos : nullptr,
@@ -209,6 +216,8 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
                                          int64_t scratch_bytes, float* dx_out, const int32_t* output_rows,
                                          int32_t num_output_rows, float* tail_sum, int32_t tail_from,
                                          int32_t defer_last_weight_grad, void* profiler, hipStream_t stream) {
+    const int live_row = first_live_row();          // as in the forward: the TOP layer's dead rows
+    set_first_live_row(0);
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -241,12 +250,14 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
             if (top) set_dz_addend(dz_add);
+            if (top) set_first_live_row(live_row);
             rc = geomae_sst_ffn_backward((const float*)(sv + so.xh1), (const float*)(sv + so.xh2), sv + so.hp,
                                          (const float*)(sv + so.rstd), top ? dz : nullptr, &layers[l], num_tokens,
                                          (float*)(w + sc.dx_res), w + sc.dattn, ws + sc.du, ws + sc.dv, ws + sc.dhp,
                                          ws + sc.y, ws + sc.h, &grads[l], top ? nullptr : ws_up + sc.dqkv,
                                          top ? nullptr : (const float*)(w + sc.dx_res), top ? nullptr : &layers[l + 1], stream);
             set_dz_addend(nullptr);
+            set_first_live_row(0);
         }
         if (rc) break;
         {
