@@ -490,6 +490,16 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     if (was_packed) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kPacked], 0));
     GEOMAE_HIP(hipEventRecord(e->ev[kLayouts], geo));
 
+    // ---------------- dec_b stream, from the start of the step: this batch's geometric targets, then the NEXT batch's stage 1
+    // (in this order: the other one measured 7 us slower).
+    // Neither depends on anything the step computes; whatever runs beside the latency-bound encoder forward is paid
+    // there almost 1:1, beside the VFE forward (8-wave workgroups, one per CU) much less: with both of them behind the
+    // VFE forward (until round 2) the encoder forward took 0.356 ms, now 0.317 (VFE forward 0.101 -> 0.107).
+    ENG_CALL(geomae_geometry_targets(b.points, c.num_features, b.order, b.seg_start, b.num_pillars, V, b.voxel_coors,
+                                     b.coors_med, b.coors_low, b.cell_table, c.batch_size, b.token_row, b.counts,
+                                     &c.targets, t_clow, t_mlow, t_cmed, t_mmed, t_ctop, t_normal, t_curv, t_top_raw,
+                                     t_med_raw, t_med_raw_mask, t_cov, t_occ, (int32_t)M, aux));
+    if (next_frames) ENG_CALL(run_stage1(e, 1 - e->pending, next_frames, next_sizes, aux));
     // ---------------- main: VFE forward
     e->phase_last = -1;
     mark(e, pStart, main);
@@ -507,15 +517,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     mark(e, pVfeFwd, main);
     ENG_CALL(order_after(e, kVfeDone, main, aux));
 
-    // ---------------- dec_b: late zero arena, the NEXT batch's stage 1, geometric targets
+    // ---------------- dec_b: late zero arena (its other work of the step started before the VFE forward, above)
     GEOMAE_HIP(hipMemsetAsync(zl0, 0, zl_bytes, aux));
     GEOMAE_HIP(hipMemsetAsync(losses, 0, 32, aux));
     const int nxt = 1 - e->pending;
-    if (next_frames) ENG_CALL(run_stage1(e, nxt, next_frames, next_sizes, aux));
-    ENG_CALL(geomae_geometry_targets(b.points, c.num_features, b.order, b.seg_start, b.num_pillars, V, b.voxel_coors,
-                                     b.coors_med, b.coors_low, b.cell_table, c.batch_size, b.token_row, b.counts,
-                                     &c.targets, t_clow, t_mlow, t_cmed, t_mmed, t_ctop, t_normal, t_curv, t_top_raw,
-                                     t_med_raw, t_med_raw_mask, t_cov, t_occ, (int32_t)M, aux));
 
     // ---------------- main: encoder, decoders
     GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kLayouts], 0));
