@@ -187,9 +187,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         with torch.cuda.stream(aux):
             # behind the VFE forward: its sweeps fill the chip, the encoder that follows leaves 150 of 256 CUs idle
             aux.wait_event(vfe_done)
-            late = [((n, C), f32), ((n, C), f32), ((V, C), f32), ((6,), f32)] + ops.vfe_backward_zero_specs(V)
+            late = [((n, C), f32), ((n, C), f32), ((n, C), f32), ((V, C), f32), ((6,), f32)] + ops.vfe_backward_zero_specs(V)
             zeros_late = ops.ZeroArena(ops.ZeroArena.nbytes(*late), dev)
-            bufs = dict(d_cen=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
+            bufs = dict(d_cen=zeros_late.take((n, C), f32), d_cen2=zeros_late.take((n, C), f32), d_den=zeros_late.take((n, C), f32),
                         d_vf=zeros_late.take((V, C), f32), losses=zeros_late.take((6,), f32), side=side)
         if next_points is not None:
             self.prefetch(next_points, stream=aux)

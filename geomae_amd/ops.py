@@ -937,30 +937,41 @@ def pack_weights(desc, num_desc, max_elems, packed, aux=None):
                                           _ptr(aux), _stream()), "geomae_pack_weights")
 
 
-def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=None, losses=None):
+def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=None, losses=None, split=False):
     """-> losses [6] f32, d_cen, d_den [n,128] f32 (gradient of sum(losses)), saved = (dlogits, cm_b, dm_b).
-    d_out: optional pair of ZEROED [n,128] f32 buffers for d_cen / d_den (the kernel writes only the masked rows).
-    losses: optional ZEROED [6] f32 buffer (then no memset is enqueued in front of the kernel)."""
+    d_out: optional ZEROED [n,128] f32 buffers for d_cen / d_den (the kernel writes only the masked rows).
+    losses: optional ZEROED [6] f32 buffer (then no memset is enqueued in front of the kernel).
+    split: the two-workgroups-per-tile form (geomae_heads_loss_split_accumulate): d(centroid decoder output) comes back as
+    TWO summands -- d_cen is then the pair (d_cen, d_cen2), to be handed to sst_stack_backward as dz and dz_add -- and
+    d_out, when given, holds three buffers (d_cen, d_cen2, d_den)."""
     dev = cen.device
     n = cen.shape[0]
-    fn = _lib.load().geomae_heads_loss if losses is None else _lib.load().geomae_heads_loss_accumulate
+    lib = _lib.load()
     if losses is None:
-        losses = torch.empty(6, dtype=torch.float32, device=dev)
-    if d_out is None:
-        d_cen, d_den = torch.zeros_like(cen), torch.zeros_like(den)
+        losses = torch.zeros(6, dtype=torch.float32, device=dev) if split else torch.empty(6, dtype=torch.float32, device=dev)
+        fn = lib.geomae_heads_loss
     else:
-        d_cen, d_den = d_out
-        if d_cen.shape != cen.shape or d_den.shape != den.shape or not (d_cen.is_contiguous() and d_den.is_contiguous()):
-            raise RuntimeError("heads_loss: d_out must be two contiguous buffers of the decoder outputs' shape")
+        fn = lib.geomae_heads_loss_accumulate
+    want = 3 if split else 2
+    if d_out is None:
+        outs = [torch.zeros_like(cen) for _ in range(want - 1)] + [torch.zeros_like(den)]
+    else:
+        outs = list(d_out)
+        if len(outs) != want or any(t.shape != cen.shape or not t.is_contiguous() for t in outs):
+            raise RuntimeError(f"heads_loss: d_out must be {want} contiguous buffers of the decoder outputs' shape")
     dl = torch.empty((n_mask, 896), dtype=torch.bfloat16, device=dev)
     cm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
     dm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
-    check(fn(
-        _ptr(cen), _ptr(den), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["centroid_low"]),
-        _ptr(tgt["mask_low_u8"]), _ptr(tgt["centroid_med"]), _ptr(tgt["mask_med_u8"]), _ptr(tgt["centroid_top"]),
-        _ptr(tgt["normal"]), _ptr(tgt["occ_counts"]), f3(weights), _ptr(losses), _ptr(d_cen), _ptr(d_den), _ptr(dl),
-        _ptr(cm_b), _ptr(dm_b), _stream()), "geomae_heads_loss")
-    return losses, d_cen, d_den, (dl, cm_b, dm_b)
+    head = (_ptr(cen), _ptr(den), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["centroid_low"]),
+            _ptr(tgt["mask_low_u8"]), _ptr(tgt["centroid_med"]), _ptr(tgt["mask_med_u8"]), _ptr(tgt["centroid_top"]),
+            _ptr(tgt["normal"]), _ptr(tgt["occ_counts"]), f3(weights), _ptr(losses))
+    tail = (_ptr(dl), _ptr(cm_b), _ptr(dm_b), _stream())
+    if split:
+        check(lib.geomae_heads_loss_split_accumulate(*head, _ptr(outs[0]), _ptr(outs[1]), _ptr(outs[2]), *tail),
+              "geomae_heads_loss_split_accumulate")
+        return losses, (outs[0], outs[1]), outs[2], (dl, cm_b, dm_b)
+    check(fn(*head, _ptr(outs[0]), _ptr(outs[1]), *tail), "geomae_heads_loss")
+    return losses, outs[0], outs[1], (dl, cm_b, dm_b)
 
 
 def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):

@@ -526,6 +526,8 @@ class MultiMAESSTSPChoose(nn.Module):
             d_out = losses_buf = None
         else:
             d_out, losses_buf = (bufs["d_cen"], bufs["d_den"]), bufs.get("losses")
+            if bufs.get("d_cen2") is not None:              # the split form of the heads kernel (two summands of d_cen)
+                d_out = (bufs["d_cen"], bufs["d_cen2"], bufs["d_den"])
             if bufs.get("ready") is not None:
                 cur.wait_event(bufs["ready"])
         ops.mark("enc_fwd_done")
@@ -542,8 +544,10 @@ class MultiMAESSTSPChoose(nn.Module):
         if tgt_ready is not None:
             cur.wait_event(tgt_ready)
         ops.mark("dec_fwd_done")
+        split = d_out is not None and len(d_out) == 3
         losses, d_cen, d_den, saved_h = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, loss_weights,
-                                                       d_out=d_out, losses=losses_buf)
+                                                       d_out=d_out, losses=losses_buf, split=split)
+        d_cen, d_cen2 = d_cen if split else (d_cen, None)
         # ---------------- backward
         side = bufs.get("side") if bufs is not None else None
         if side is None:
@@ -567,7 +571,7 @@ class MultiMAESSTSPChoose(nn.Module):
         mt = (self.mask_token.grad, n_keep)
         if side is None:
             dxb, keep_b = ops.sst_stack_backward(d_den, n, w_den, g_den, dec_layouts, pt, nh, s_den, stream=sb_, tail_sum=mt)
-            dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, tail_sum=mt)
+            dxa = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, tail_sum=mt, dz_add=d_cen2)
         else:
             # each stack's last kernel, the first layer's weight-gradient contraction (~50 us at decoder size, read
             # only by the optimizer), runs on the side stream instead of closing the decoder backward: it overlaps
@@ -578,7 +582,7 @@ class MultiMAESSTSPChoose(nn.Module):
             with torch.cuda.stream(side):
                 ops.flush_weight_grad()
             dxa, keep_a = ops.sst_stack_backward(d_cen, n, w_cen, g_cen, dec_layouts, pt, nh, s_cen, defer_last=True,
-                                                 tail_sum=mt)
+                                                 tail_sum=mt, dz_add=d_cen2)
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 ops.flush_weight_grad()

@@ -1008,6 +1008,37 @@ def test_pair_kernels_are_bit_identical(dev, n_frames):
     # (the saved blob itself is not compared: it has alignment gaps nobody writes)
 
 
+def test_split_heads_kernel_matches_single_form(dev, golden_dir):
+    """geomae_heads_loss_split_accumulate (two workgroups per 64 masked pillars, d(centroid decoder output) as two summands)
+    against geomae_heads_loss on the same inputs: losses, the logit gradients saved for the weight-gradient contraction,
+    d(density decoder output) identical; the two summands add up to the single form's gradient."""
+    from geomae_amd import ops
+    model, _ = _build(dev, 1, 1, "bf16")
+    bb = model.backbone
+    bb._packed.refresh()
+    P = bb._packed
+    n_keep, n_mask = 333, 1500 + 7                                  # a ragged last tile
+    n = n_keep + n_mask
+    gen = torch.Generator().manual_seed(12)
+    cen = torch.randn(n, 128, generator=gen).to(dev)
+    den = torch.randn(n, 128, generator=gen).to(dev)
+    tgt = dict(centroid_low=torch.rand(n_mask, 128 * 3, generator=gen).to(dev),
+               mask_low_u8=(torch.rand(n_mask, 128, generator=gen) < 0.2).to(torch.uint8).to(dev),
+               centroid_med=torch.rand(n_mask, 16 * 3, generator=gen).to(dev),
+               mask_med_u8=(torch.rand(n_mask, 16, generator=gen) < 0.4).to(torch.uint8).to(dev),
+               centroid_top=torch.rand(n_mask, 3, generator=gen).to(dev), normal=torch.randn(n_mask, 3, generator=gen).to(dev))
+    tgt["occ_counts"] = torch.stack([tgt["mask_low_u8"].sum(), tgt["mask_med_u8"].sum()]).int()
+    w = (1.0, 1.0, 1.0, 1.0, 1.0, 1.0)
+    la, dca, dda, (dla, cma, dma) = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, w)
+    lb, (dc1, dc2), ddb, (dlb, cmb, dmb) = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, w, split=True)
+    assert torch.allclose(la, lb, rtol=1e-6, atol=0)                 # (block sums combined by atomics in both)
+    assert torch.equal(dla[:, :771], dlb[:, :771]) and torch.equal(cma, cmb) and torch.equal(dma, dmb)
+    assert torch.equal(dda, ddb)
+    assert float(dc1[:n_keep].abs().max()) == 0.0 and float(dc2[:n_keep].abs().max()) == 0.0
+    assert torch.allclose(dc1 + dc2, dca, rtol=1e-5, atol=1e-6 * float(dca.abs().max()))
+    assert float(dc1.abs().max()) > 0 and float(dc2.abs().max()) > 0
+
+
 def test_stack_weight_gradients_do_not_depend_on_arrival_order(dev):
     """Inside a stack the weight-gradient contraction sums through memory (split-K partials stored, added in chunk order
     by a later launch -- csrc/sst_layer.hip dw_body / dw_reduce_body) instead of float atomics: the matrix gradients of
