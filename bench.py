@@ -146,6 +146,14 @@ def main():
         os.environ.setdefault("GEOMAE_SIDE_STREAMS", "3")      # see geomae_amd.ops.side_streams
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # GEOMAE_FORCE_EXCHANGE=1 at N = 1: the world > 1 schedule (engine hooks, SyncBN exchanges, early gradient-segment
+    # all-reduces, optimizer as a second call) over RCCL with ONE rank -- what the stream-ordered collective path costs
+    # on top of the plain N = 1 step (geomae_amd.train.exchange_mode)
+    forced = world == 1 and os.environ.get("GEOMAE_FORCE_EXCHANGE") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if share:
@@ -193,12 +201,11 @@ def main():
     DOMINANT = "sst_ffn_bwd_kernel"               # largest share in profiles/ (rocprofv3 --kernel-trace --stats)
     lib = _lib.load()
     import ctypes
-    eng = trainer.engine                          # None with --no-engine (or before the first step)
 
     def set_profiler(handle):
         ops.PROFILER = handle
-        if eng is not None:
-            eng.set_profiler(handle)
+        if trainer.engine is not None:            # (looked up at every use: None before the first step / with --no-engine)
+            trainer.engine.set_profiler(handle)
 
     def profile_on(name, launches):
         h = lib.geomae_profiler_create(ops.KERNEL_IDS[name], launches)
@@ -220,6 +227,7 @@ def main():
     prof_handle = profile_on(DOMINANT, min(4000, 20 * args.steps))
     # one timing event per step on the main stream (~4 us of queue time per step): the per-step distribution
     step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    eng = trainer.get_engine()                    # (exists before the first step too: --warmup 0)
     h0 = eng.host_times() if eng is not None else None
     if world > 1:
         dist.barrier()
@@ -331,7 +339,8 @@ def main():
             "config": {"workload": f"configs[{cfg_index}]: {workload} ({sweeps}-sweep) GeoMAE-SST pretrain (mae_sst model "
                                    f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
-                       "step_driver": "python-explicit" if eng is None else "geomae_pretrain_step (C engine)"},
+                       "step_driver": "python-explicit" if eng is None else "geomae_pretrain_step (C engine)",
+                       "exchange": "forced at world size 1 (RCCL, one rank)" if forced else ("rccl" if world > 1 else "none")},
             "loss": round(loss_val, 4),
             # GPU-side time between the ends of consecutive steps on the main stream (HIP events), rank 0
             "step_ms": {"p50": round(float(np.percentile(per_step, 50)), 4), "p90": round(float(np.percentile(per_step, 90)), 4),
@@ -365,7 +374,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 

@@ -80,7 +80,8 @@ class GeomaePretrainConfig(ctypes.Structure):
                 ("decoder_layers", c_int32), ("keep_fraction", c_double), ("mask_seed", c_uint64),
                 ("loss_weights", c_float * 6), ("vfe_voxel_size", c_float * 3), ("vfe_center_offset", c_float * 3),
                 ("bn_eps", c_float), ("bn_momentum", c_float), ("beta1", c_float), ("beta2", c_float),
-                ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32), ("sync_bn", c_int32)]
+                ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32), ("sync_bn", c_int32),
+                ("exchange_always", c_int32)]
 
 
 class GeomaePretrainModel(ctypes.Structure):
@@ -197,6 +198,8 @@ SIGNATURES = {
     "geomae_pretrain_phase_times": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
     "geomae_pretrain_invalidate_packed": (ctypes.c_int, [c_void_p]),
     "geomae_pretrain_submit": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), P]),
+    "geomae_pretrain_set_mask": (ctypes.c_int, [c_void_p, P, c_int32, P, c_int32, P]),
+    "geomae_pretrain_set_mask_draws": (ctypes.c_int, [c_void_p, ctypes.c_uint64]),
     "geomae_pretrain_step": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_float, c_float, c_int32, P]),
     "geomae_pretrain_optimizer": (ctypes.c_int, [c_void_p, c_float, c_float, P]),
     "geomae_pretrain_result_offset": (c_int64, [c_void_p, c_int32]),

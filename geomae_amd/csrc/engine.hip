@@ -34,12 +34,24 @@ __global__ void bn_param_grad_add_kernel(const double* __restrict__ bsums, int C
         d_gamma[c] += (float)bsums[C + c];
     }
 }
+// token_row / counts for a caller-supplied mask (geomae_pretrain_set_mask): what random_mask_kernel writes beside the ids
+__global__ void token_rows_from_ids_kernel(const int32_t* __restrict__ ids_keep, int n_keep,
+                                           const int32_t* __restrict__ ids_mask, int n_mask,
+                                           int32_t* __restrict__ token_row, int32_t* __restrict__ counts) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) { counts[0] = n_keep; counts[1] = n_mask; }
+    if (i < n_keep) token_row[ids_keep[i]] = i;
+    else if (i < n_keep + n_mask) token_row[ids_mask[i - n_keep]] = i;
+}
 int scale_f32(float* x, int n, float s, hipStream_t stream) {
     hipLaunchKernelGGL(scale_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, s);
     return check_launch("scale_f32_kernel");
 }
 
 inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
+// the distributed schedule (hooks, separate optimizer call): world_size > 1, or forced at world size 1 (exchange_always:
+// how the RCCL code path is exercised on a one-GPU box)
+inline bool exchanges(const GeomaePretrainConfig& c) { return c.world_size > 1 || c.exchange_always != 0; }
 
 struct Arena {
     char* base = nullptr;
@@ -80,7 +92,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNumEv };
+          kPacked, kFirstMain, kNextReady, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -97,7 +109,7 @@ struct Engine {
     int64_t persistent_bytes = 0, stage_bytes = 0;
     Batch batch[2];
     int pending = -1;                  // index of the batch submitted last, -1 = none
-    uint64_t batches_drawn = 0;
+    uint64_t mask_draws = 0;           // steps begun so far: the batch consumed by step i (0-based) drew mask i + 1
     hipStream_t geo = nullptr, aux = nullptr;
     hipEvent_t ev[kNumEv];
     hipEvent_t phase_ev[kNumPhase];
@@ -196,7 +208,7 @@ inline void mark(Engine* e, Phase p, hipStream_t s) {
 }
 
 // stage 1 of a batch on `s` (voxelize x3 -> pillar sort -> count readback -> VFE front -> random mask)
-int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* sizes, hipStream_t s) {
+int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* sizes, uint64_t draw, hipStream_t s) {
     const GeomaePretrainConfig& c = e->cfg;
     Batch& b = e->batch[which];
     b.valid = false;
@@ -256,8 +268,9 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
     ENG_CALL(geomae_segment_mean_xyz_sorted(b.points, c.num_features, b.order, b.seg_start, b.num_pillars, b.cap, b.mean, s));
     ENG_CALL(geomae_vfe_prepare(b.points, c.num_features, N, b.order, b.inv, b.mean, b.voxel_coors, c.vfe_voxel_size,
                                 c.vfe_center_offset, b.feat, b.pid, s));
-    e->batches_drawn += 1;
-    ENG_CALL(geomae_random_mask(b.sample_start, c.batch_size, c.keep_fraction, (c.mask_seed << 32) + e->batches_drawn,
+    // the mask index is a function of the step that will consume the batch (not of how many stage 1s ran: a replaced
+    // submission or a re-created engine must not shift the stream; geomae_pretrain_set_mask_draws)
+    ENG_CALL(geomae_random_mask(b.sample_start, c.batch_size, c.keep_fraction, (c.mask_seed << 32) + draw,
                                 b.ids_keep, b.ids_mask, b.token_row, b.counts, s));
     b.valid = true;
     b.counts_read = false;
@@ -319,7 +332,7 @@ int bn_forward(Engine* e, int layer, const double* sums, double count, float* sc
     const GeomaePretrainConfig& c = e->cfg;
     const GeomaePretrainModel& m = e->m;
     const int C = layer == 0 ? 64 : 128;
-    if (c.world_size <= 1 || !c.sync_bn)
+    if (!exchanges(c) || !c.sync_bn)
         return geomae_bn_finalize(sums, count, nullptr, C, m.bn_gamma[layer], m.bn_beta[layer], c.bn_eps, c.bn_momentum, 1,
                                   m.bn_running_mean[layer], m.bn_running_var[layer], scale, shift, invstd, moments,
                                   m.bn_num_batches[layer], s);
@@ -450,6 +463,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     e->off_ids_mask = (char*)b.ids_mask - e->ws;
     e->last_N = N; e->last_V = V; e->last_keep = nk; e->last_mask = nm;
     e->steps += 1;
+    e->mask_draws += 1;
 
     Prezeroed pz;
     const GeomaeSstLayerWeights* L_enc = e->layers.data();
@@ -499,7 +513,13 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
                                      b.coors_med, b.coors_low, b.cell_table, c.batch_size, b.token_row, b.counts,
                                      &c.targets, t_clow, t_mlow, t_cmed, t_mmed, t_ctop, t_normal, t_curv, t_top_raw,
                                      t_med_raw, t_med_raw_mask, t_cov, t_occ, (int32_t)M, aux));
-    if (next_frames) ENG_CALL(run_stage1(e, 1 - e->pending, next_frames, next_sizes, aux));
+    if (next_frames) {
+        // the next batch's frames were produced on the CALLER's stream (H2D copies, augmentation kernels): the decoder-B
+        // stream reads them, so it is ordered behind what `main` holds at this point (the event sits behind the previous
+        // step's optimizer, which dec_b already waited for: the wait is free unless the caller enqueued a loader)
+        ENG_CALL(order_after(e, kNextReady, main, aux));
+        ENG_CALL(run_stage1(e, 1 - e->pending, next_frames, next_sizes, e->mask_draws + 1, aux));
+    }
     // ---------------- main: VFE forward
     e->phase_last = -1;
     mark(e, pStart, main);
@@ -558,19 +578,19 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(geomae_flush_weight_grad(geo));
     GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kAuxBwd], 0));
     mark(e, pDecBwd, main);
-    if (e->hook && c.world_size > 1) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_EARLY, geo);
+    if (e->hook && exchanges(c)) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_EARLY, geo);
     ENG_CALL(geomae_sst_stack_backward(dxa, dxb, nk, L_enc, G_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, w_enc,
                                        wb_enc, d_vf, b.ids_keep, V, nullptr, 0, 1, e->profiler, main));
     ENG_CALL(order_after(e, kEncBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));
-    if (e->hook && c.world_size > 1) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_ENCODER, geo);
+    if (e->hook && exchanges(c)) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_ENCODER, geo);
     mark(e, pEncBwd, main);
 
     // ---------------- VFE backward
     GeomaeBnState bn;
     bn.scale0 = bn_scale0; bn.shift0 = bn_shift0; bn.mean0 = bn_mom0; bn.invstd0 = bn_invstd0;
     bn.scale1 = bn_scale1; bn.shift1 = bn_shift1; bn.mean1 = bn_mom1; bn.invstd1 = bn_invstd1;
-    const bool fold = c.world_size <= 1 || !c.sync_bn;
+    const bool fold = !exchanges(c) || !c.sync_bn;
     double* use_bs1 = fold ? bs1 : m.bn_sync_bsums1;
     double* use_bs0 = fold ? bs0 : m.bn_sync_bsums0;
     if (!fold) {
@@ -758,13 +778,43 @@ extern "C" int geomae_pretrain_submit(void* engine, const float* const* frame_po
     if (e->pending >= 0) e->batch[e->pending].valid = false;      // replaced
     // order behind everything of the previous step (its kernels may still read the slot's previous batch)
     if (e->have_step_end) GEOMAE_HIP(hipStreamWaitEvent(stream, e->ev[kStepEnd], 0));
-    int rc = run_stage1(e, which, frame_points, frame_sizes, stream);
+    int rc = run_stage1(e, which, frame_points, frame_sizes, e->mask_draws + 1, stream);
     if (rc != GEOMAE_OK) { e->pending = -1; return rc; }
     e->pending = which;
     // the step's side streams read the batch: order them behind this stream's stage 1
     GEOMAE_HIP(hipEventRecord(e->ev[kFirstMain], stream));
     GEOMAE_HIP(hipStreamWaitEvent(e->geo, e->ev[kFirstMain], 0));
     GEOMAE_HIP(hipStreamWaitEvent(e->aux, e->ev[kFirstMain], 0));
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_pretrain_set_mask(void* engine, const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask,
+                                        int32_t num_mask, hipStream_t stream) {
+    Engine* e = (Engine*)engine;
+    GEOMAE_REQUIRE(e, "pretrain: null engine");
+    GEOMAE_REQUIRE(e->pending >= 0 && e->batch[e->pending].valid, "pretrain_set_mask: no batch submitted");
+    GEOMAE_REQUIRE(ids_keep && ids_mask && num_keep >= 1 && num_mask >= 1, "pretrain_set_mask: bad argument");
+    Batch& b = e->batch[e->pending];
+    ENG_CALL(read_counts(e, b));
+    GEOMAE_REQUIRE(num_keep + num_mask == b.V, "pretrain_set_mask: %d kept + %d masked ids for a batch of %d pillars", num_keep,
+                   num_mask, b.V);
+    GEOMAE_HIP(hipMemcpyAsync(b.ids_keep, ids_keep, (size_t)num_keep * 4, hipMemcpyDeviceToDevice, stream));
+    GEOMAE_HIP(hipMemcpyAsync(b.ids_mask, ids_mask, (size_t)num_mask * 4, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(token_rows_from_ids_kernel, dim3(cdiv(b.V, 256)), dim3(256), 0, stream, b.ids_keep, num_keep, b.ids_mask,
+                       num_mask, b.token_row, b.counts);
+    ENG_CALL(check_launch("token_rows_from_ids_kernel"));
+    b.n_keep = num_keep;
+    b.n_mask = num_mask;
+    // the step's side streams read the mask: order them behind this stream
+    GEOMAE_HIP(hipEventRecord(e->ev[kFirstMain], stream));
+    GEOMAE_HIP(hipStreamWaitEvent(e->geo, e->ev[kFirstMain], 0));
+    GEOMAE_HIP(hipStreamWaitEvent(e->aux, e->ev[kFirstMain], 0));
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_pretrain_set_mask_draws(void* engine, uint64_t steps_begun) {
+    GEOMAE_REQUIRE(engine, "pretrain: null engine");
+    ((Engine*)engine)->mask_draws = steps_begun;
     return GEOMAE_OK;
 }
 
@@ -816,5 +866,6 @@ extern "C" int geomae_pretrain_last_sizes(void* engine, int64_t* out) {
     Engine* e = (Engine*)engine;
     GEOMAE_REQUIRE(e && out, "pretrain: null argument");
     out[0] = e->last_N; out[1] = e->last_V; out[2] = e->last_keep; out[3] = e->last_mask; out[4] = e->opt_steps;
+    out[5] = (int64_t)e->mask_draws;
     return GEOMAE_OK;
 }

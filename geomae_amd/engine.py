@@ -29,10 +29,12 @@ def supported(model):
 
 
 class PretrainEngine:
-    def __init__(self, model, flat, opt, max_norm, world=1, max_points=0, max_pillars=0):
+    def __init__(self, model, flat, opt, max_norm, world=1, max_points=0, max_pillars=0, mask_draws=0, exchange=None):
         self.lib = _lib.load()
         self.model, self.flat, self.opt, self.world = model, flat, opt, int(world)
         self.max_norm = float(max_norm or 0.0)
+        # the distributed schedule (hooks + separate optimizer call); forced at world size 1 to exercise the RCCL path
+        self.exchange = (self.world > 1) if exchange is None else bool(exchange)
         self.dev = flat.flat.device
         self.handle = None
         self.pending = None                  # the list object of the batch whose stage 1 is enqueued
@@ -52,6 +54,9 @@ class PretrainEngine:
         self._phase_timing = False
         self._opt_steps = int(opt.step_count)
         self._hook_error = None
+        # steps begun in this RUN: step i's batch draws mask i + 1 whichever engine object (workspace growth, another
+        # batch size, checkpoint resume) consumes it -- the C engine counts its own steps, this restores the total
+        self.mask_draws = int(mask_draws)
 
     # ------------------------------------------------------------------ binding
     def _config(self):
@@ -73,6 +78,7 @@ class PretrainEngine:
         c.beta1, c.beta2 = float(self.opt.betas[0]), float(self.opt.betas[1])
         c.adam_eps, c.weight_decay, c.max_grad_norm = float(self.opt.eps), float(self.opt.weight_decay), self.max_norm
         c.world_size = self.world
+        c.exchange_always = int(self.exchange)
         from .norm import NaiveSyncBatchNorm1d
         c.sync_bn = int(isinstance(n0, NaiveSyncBatchNorm1d))          # a config with plain 'BN1d' keeps local statistics
         return c
@@ -109,7 +115,7 @@ class PretrainEngine:
         assert len(nds) <= 1, "the fused AdamW pass takes a no-decay prefix and one more range"
         m.no_decay_prefix = prefix
         m.no_decay2_start, m.no_decay2_count = (nds[0][0], nds[0][1] - nds[0][0]) if nds else (0, 0)
-        if self.world > 1:                                              # (allocated even without sync_bn: 3 KB)
+        if self.exchange:                                               # (allocated even without sync_bn: 3 KB)
             z = lambda n, dt: torch.zeros(n, dtype=dt, device=self.dev)
             self.sync = dict(mom0=z(128, torch.float32), mom1=z(256, torch.float32), bs1=z(256, torch.float64),
                              bs0=z(128, torch.float64))
@@ -139,7 +145,8 @@ class PretrainEngine:
         self.handle = h
         self.pending = None
         check(self.lib.geomae_pretrain_set_optimizer_steps(ctypes.c_void_p(h), self._opt_steps), "set_optimizer_steps")
-        if self.world > 1:
+        check(self.lib.geomae_pretrain_set_mask_draws(ctypes.c_void_p(h), self.mask_draws), "set_mask_draws")
+        if self.exchange:
             check(self.lib.geomae_pretrain_set_hook(ctypes.c_void_p(h), self._hook_c, None), "geomae_pretrain_set_hook")
         if self._profiler:
             self.set_profiler(self._profiler)
@@ -156,23 +163,37 @@ class PretrainEngine:
     def _hook(self, user, what, stream):
         # an exception escaping a ctypes callback is only printed: keep it and re-raise after the C call returned
         try:
-            self._hook_body(what)
+            self._hook_body(what, stream)
         except BaseException as e:                       # noqa: BLE001
             if self._hook_error is None:
                 self._hook_error = e
 
-    def _hook_body(self, what):
+    def _stream_of(self, handle):
+        """The torch stream object for the HIP stream the engine hands to a hook.  RCCL collectives are STREAM-ordered
+        (the communicator's stream waits for torch's current stream at the call, and a blocking collective makes the
+        current stream wait for its end): the hook must make the stream it was given current, not rely on the caller's
+        current stream happening to be that one."""
+        handle = int(handle or 0)
+        for s in (self.geo, self.aux):
+            if s.cuda_stream == handle:
+                return s
+        cur = torch.cuda.current_stream(self.dev)
+        if cur.cuda_stream == handle:
+            return cur
+        return torch.cuda.ExternalStream(handle, device=self.dev)
+
+    def _hook_body(self, what, stream):
         group = self.bn_group if self.bn_group is not None else ops.BN_GROUP
-        if what == HOOK_BN_FWD0:
-            dist.all_reduce(self.sync["mom0"], group=group)
-        elif what == HOOK_BN_FWD1:
-            dist.all_reduce(self.sync["mom1"], group=group)
-        elif what == HOOK_BN_BWD1:
-            dist.all_reduce(self.sync["bs1"], group=group)
-        elif what == HOOK_BN_BWD0:
-            dist.all_reduce(self.sync["bs0"], group=group)
-        elif self.on_segment is not None:
-            with torch.cuda.stream(self.geo):               # the stream behind which the segment is complete
+        with torch.cuda.stream(self._stream_of(stream)):
+            if what == HOOK_BN_FWD0:
+                dist.all_reduce(self.sync["mom0"], group=group)
+            elif what == HOOK_BN_FWD1:
+                dist.all_reduce(self.sync["mom1"], group=group)
+            elif what == HOOK_BN_BWD1:
+                dist.all_reduce(self.sync["bs1"], group=group)
+            elif what == HOOK_BN_BWD0:
+                dist.all_reduce(self.sync["bs0"], group=group)
+            elif self.on_segment is not None:               # `stream`: the one behind which the segment is complete
                 self.on_segment(0 if what == HOOK_GRADS_EARLY else 1)
 
     # ------------------------------------------------------------------ stepping
@@ -200,11 +221,23 @@ class PretrainEngine:
               "geomae_pretrain_submit")
         self.pending, self._pending_keep = points, (ptrs, sizes)
 
-    def step(self, points, next_points, lr, run_optimizer=True):
+    def set_mask(self, ids_keep, ids_mask):
+        """Replace the random mask of the pending batch by the caller's pillar ids (the reference's
+        get_vanilla_mask_index output, ssl.py:287-304): parity tests run the ENGINE on the reference's own mask."""
+        ik = ids_keep.to(device=self.dev, dtype=torch.int32).contiguous()
+        im = ids_mask.to(device=self.dev, dtype=torch.int32).contiguous()
+        check(self.lib.geomae_pretrain_set_mask(ctypes.c_void_p(self.handle), ops._ptr(ik), ik.numel(), ops._ptr(im),
+                                                im.numel(), ops._stream()), "geomae_pretrain_set_mask")
+        self._mask_keep = (ik, im)                       # read by copies enqueued on the current stream
+
+    def step(self, points, next_points, lr, run_optimizer=True, ids_keep=None, ids_mask=None):
         """One iteration on `points` (submitted now unless it is the batch handed over as the previous step's
-        next_points).  -> (losses [6] view, gnorm 0-d view)."""
+        next_points).  ids_keep / ids_mask: an injected mask for `points` instead of the random one.
+        -> (losses [6] view, gnorm 0-d view)."""
         if self.handle is None or self.pending is not points:
             self.submit(points)
+        if ids_keep is not None:
+            self.set_mask(ids_keep, ids_mask)
         nxt = None
         if next_points is not None:
             if sum(int(p.shape[0]) for p in next_points) > self.max_points or len(next_points) != self._B:
@@ -226,7 +259,10 @@ class PretrainEngine:
             self.max_pillars = int(1.5 * self.max_pillars) + 1024
             self._create(sum(int(p.shape[0]) for p in points))
             self.submit(points)
+            if ids_keep is not None:
+                self.set_mask(ids_keep, ids_mask)
         check(rc, "geomae_pretrain_step")
+        self.mask_draws += 1
         if run_optimizer:
             self._opt_steps += 1
         self.pending, self._pending_keep = next_points, nxt
@@ -248,6 +284,13 @@ class PretrainEngine:
         if self.handle is not None:
             check(self.lib.geomae_pretrain_set_optimizer_steps(ctypes.c_void_p(self.handle), int(n)), "set_optimizer_steps")
 
+    def set_mask_draws(self, n):
+        """Steps begun in this run (Trainer.iter after a checkpoint resume): must precede the next batch's submission."""
+        self.mask_draws = int(n)
+        if self.handle is not None:
+            check(self.lib.geomae_pretrain_set_mask_draws(ctypes.c_void_p(self.handle), int(n)), "set_mask_draws")
+            self.pending = None                          # a batch drawn under the old counter is re-submitted
+
     def set_profiler(self, handle):
         self._profiler = handle
         if self.handle is not None:
@@ -268,13 +311,15 @@ class PretrainEngine:
     def host_times(self):
         """(seconds inside geomae_pretrain_step, seconds of that blocked on the count readback, steps), cumulative."""
         out = (ctypes.c_double * 3)()
+        if self.handle is None:                          # no step yet
+            return 0.0, 0.0, 0
         check(self.lib.geomae_pretrain_host_times(ctypes.c_void_p(self.handle), out), "geomae_pretrain_host_times")
         return float(out[0]), float(out[1]), int(out[2])
 
     def last_sizes(self):
-        out = (ctypes.c_int64 * 5)()
+        out = (ctypes.c_int64 * 6)()
         check(self.lib.geomae_pretrain_last_sizes(ctypes.c_void_p(self.handle), out), "geomae_pretrain_last_sizes")
-        return dict(N=out[0], V=out[1], n_keep=out[2], n_mask=out[3], optimizer_steps=out[4])
+        return dict(N=out[0], V=out[1], n_keep=out[2], n_mask=out[3], optimizer_steps=out[4], mask_draws=out[5])
 
     def last_ids(self):
         s = self.last_sizes()

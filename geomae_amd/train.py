@@ -114,6 +114,18 @@ class FlatParams:
                 p.grad = view.view_as(p.data)
 
 
+def exchange_mode():
+    """(world size, whether the step runs the distributed schedule).  The schedule of world > 1 -- SyncBN exchanges and
+    early gradient-segment all-reduces issued from the engine's hooks, the optimizer as a second call -- can be forced
+    at world size 1 with GEOMAE_FORCE_EXCHANGE=1 (and an initialised process group): the collectives then run on RCCL
+    with one rank, which is how the stream-ordered code path is exercised on a one-GPU box (tests/test_gpu_nccl.py)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, False
+    world = dist.get_world_size()
+    return world, world > 1 or os.environ.get("GEOMAE_FORCE_EXCHANGE") == "1"
+
+
 def allreduce_gradients(flat, group=None):
     """DDP semantics: gradients averaged over ranks; one collective on the single bucket."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -292,7 +304,7 @@ class Trainer:
         # only the last, small one (70 KB) is exchanged with nothing left to hide it
         late = (("backbone.encoder_blocks.",), ("voxel_encoder.",)) if hasattr(model, "train_step_explicit") else ()
         self.flat = FlatParams(model, no_decay_keys=keys or ("\0",), late_keys=late)
-        if late and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if late and exchange_mode()[1]:
             from . import ops
             if ops.BN_GROUP is None:
                 # a communicator of its own for the SyncBN statistics (every rank builds its trainer: new_group is a
@@ -340,12 +352,21 @@ class Trainer:
         self.use_engine = self.flat.flat.is_cuda
         self.engine = None
 
-    def _engine_step(self, points, next_points, world):
+    def get_engine(self):
+        """The step engine this trainer drives (created on first use), or None when the Python schedule is in charge."""
+        from . import engine as _engine
+        if not (self.use_engine and self.explicit_schedule and hasattr(self.model, "train_step_explicit")
+                and _engine.supported(self.model)):
+            return None
+        if self.engine is None:
+            world, exchange = exchange_mode()
+            self.engine = _engine.PretrainEngine(self.model, self.flat, self.opt, self.grad_clip.get("max_norm", 0.0), world,
+                                                 mask_draws=self.iter, exchange=exchange)
+        return self.engine
+
+    def _engine_step(self, points, next_points, world, exchange):
         from .detector import MultiSubVoxelDynamicVoxelNetSSL as Det
-        from .engine import PretrainEngine
-        eng = self.engine
-        if eng is None:
-            eng = self.engine = PretrainEngine(self.model, self.flat, self.opt, self.grad_clip.get("max_norm", 0.0), world)
+        eng = self.get_engine()
         if not getattr(self, "_grads_clean", False):
             self.flat.zero_grad()
         if self.lr_schedule is not None:
@@ -357,13 +378,13 @@ class Trainer:
         if getattr(self, "_engine_versions", None) not in (None, versions):
             eng.invalidate_packed()
         works = []
-        if world > 1:
+        if exchange:
             def segment_ready(i):
                 a, b, _ = self.flat.segments[i]
                 works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
             eng.on_segment = segment_ready if len(self.flat.segments) > 2 else None
-        losses, gnorm = eng.step(points, next_points, self.opt.lr, run_optimizer=(world == 1))
-        if world > 1:
+        losses, gnorm = eng.step(points, next_points, self.opt.lr, run_optimizer=not exchange)
+        if exchange:
             done = {i for i, _ in works}
             for i, (a, b, _) in enumerate(self.flat.segments):
                 if i not in done:
@@ -384,11 +405,11 @@ class Trainer:
         """next_points: the batch of the FOLLOWING step (the same list object must be passed as `points`
         then); its voxelization / pillar sort is enqueued ahead of this step so that its count readback is
         off the critical path (detector.prefetch)."""
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        world, exchange = exchange_mode()
         if self.use_engine and self.explicit_schedule and not kw and hasattr(self.model, "train_step_explicit"):
             from . import engine as _engine
             if _engine.supported(self.model):
-                return self._engine_step(points, next_points, world)
+                return self._engine_step(points, next_points, world, exchange)
         if not getattr(self, "_grads_clean", False):
             self.flat.zero_grad()
         self._grads_clean = False
@@ -491,4 +512,6 @@ class Trainer:
             self.engine.invalidate_packed()
             self.engine.set_optimizer_steps(self.opt.step_count)
         self.iter = int(ck.get("meta", {}).get("iter", 0))
+        if self.engine is not None:                      # a resumed run continues the uninterrupted run's mask stream
+            self.engine.set_mask_draws(self.iter)
         return ck.get("meta", {})

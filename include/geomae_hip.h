@@ -566,7 +566,7 @@ typedef struct GeomaePretrainConfig {
     int32_t encoder_layers;          /* 12 (= 2 x encoder_num_blocks)                                       */
     int32_t decoder_layers;          /* 4 per decoder stack                                                 */
     double keep_fraction;            /* 1 - random_mask_ratio                                               */
-    uint64_t mask_seed;              /* batch i draws its mask with seed (mask_seed << 32) + i + 1          */
+    uint64_t mask_seed;              /* step i's batch draws its mask with seed (mask_seed << 32) + i + 1   */
     float loss_weights[6];           /* curv_around, centroid_low, centroid_med, centroid_top, cls_low, cls_med */
     float vfe_voxel_size[3];         /* DynamicScatterVFE (vx, vy, vz)                                      */
     float vfe_center_offset[3];      /* v / 2 + range_min                                                   */
@@ -575,6 +575,8 @@ typedef struct GeomaePretrainConfig {
     int32_t world_size;              /* > 1: gradient-segment hooks; with sync_bn also naiveSyncBN1d's exchanges */
     int32_t sync_bn;                 /* the VFE's norm layers are naiveSyncBN1d (cross-rank statistics at world_size > 1);
                                         0 = plain BatchNorm1d statistics of the local batch whatever the world size */
+    int32_t exchange_always;         /* != 0: run the world_size > 1 schedule (hooks, SyncBN exchanges, optimizer as a
+                                        separate call) even at world_size 1 -- exercises the RCCL path on one GPU */
 } GeomaePretrainConfig;
 
 /* Device pointers of the model (parameters and gradients are views of the flat buffers; all of them must stay where
@@ -626,7 +628,23 @@ int geomae_pretrain_invalidate_packed(void* engine);
  * array of batch_size DEVICE pointers ([n_b, num_features] fp32 each), frame_sizes: HOST array of row counts. */
 int geomae_pretrain_submit(void* engine, const float* const* frame_points, const int64_t* frame_sizes,
                            geomaeStream_t stream);
-/* one training step on the batch submitted last (by geomae_pretrain_submit or as the previous step's next_*):
+/* replace the random mask of the batch submitted last by caller-supplied pillar ids (DEVICE int32 arrays, any order,
+ * together a permutation of 0..V-1; the reference's get_vanilla_mask_index output, ssl.py:287-304): what parity tests
+ * use to run the ENGINE on the reference's own mask.  Waits for the batch's pillar-count readback (host).  Call it
+ * between geomae_pretrain_submit and geomae_pretrain_step, on the stream the step will be given. */
+int geomae_pretrain_set_mask(void* engine, const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask,
+                             int32_t num_mask, geomaeStream_t stream);
+/* the batch consumed by the i-th step (0-based) of a RUN draws its mask with seed (mask_seed << 32) + i + 1, however
+ * often its stage 1 was enqueued (a replaced submission does not shift the stream).  An engine counts the steps it
+ * began itself; the counter belongs to the CALLER across engine re-creations (workspace growth, another batch size,
+ * checkpoint resume): restore it here (geomae_pretrain_last_sizes out[5] reads it) BEFORE submitting the next batch. */
+int geomae_pretrain_set_mask_draws(void* engine, uint64_t steps_begun);
+/* Ordering contract for the frames: `frame_points` of geomae_pretrain_submit are read on `stream`; `next_frame_points`
+ * of geomae_pretrain_step are read on the decoder-B side stream, which the engine orders behind everything enqueued on
+ * `stream` before the call -- so a loader that produces the next batch on the caller's stream (non-blocking H2D
+ * copies, augmentation kernels) needs no event of its own.  The frames must stay alive until the step has run.
+ *
+ * one training step on the batch submitted last (by geomae_pretrain_submit or as the previous step's next_*):
  * forward, backward and -- run_optimizer != 0 -- clip + AdamW with learning rate lr and gradients scaled by
  * grad_scale (1 / world_size).  next_frame_points / next_frame_sizes (or NULL): the following batch.
  * Byte offsets of the step's results inside the workspace: geomae_pretrain_result_offset. */
@@ -641,8 +659,8 @@ int64_t geomae_pretrain_result_offset(void* engine, int32_t what);
 int geomae_pretrain_host_times(void* engine, double* out /*host [3]*/);
 /* AdamW's step counter (bias correction): set it when optimizer state is loaded from a checkpoint */
 int geomae_pretrain_set_optimizer_steps(void* engine, int64_t steps_taken);
-/* host-side sizes of the last step: out[0..4] = N, V, n_keep, n_mask, optimizer steps taken */
-int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [5]*/);
+/* host-side sizes of the last step: out[0..5] = N, V, n_keep, n_mask, optimizer steps taken, masks drawn */
+int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [6]*/);
 
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */

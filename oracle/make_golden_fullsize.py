@@ -29,19 +29,22 @@ torch.set_num_threads(8)
 ref = ref_import.load_reference()
 
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from fullsize_cases import CASES  # noqa: E402
+from fullsize_cases import CASES, CASES_C1, make_frames  # noqa: E402
+
+ALL = dict(CASES, **CASES_C1)
 
 
 def frames_of(case):
-    return [synth.lidar_frame(**kw) for kw in CASES[case][1]]
+    return make_frames(ALL[case][1])
 
 
 def run(case):
-    geo, _ = CASES[case]
+    geo, _ = ALL[case]
     frames = frames_of(case)
     RANGE, B = geo["range"], len(frames)
     ny, nx = geo["grid"][1:]
-    params = O.make_params(7, 6, 2)
+    enc, dec = geo.get("blocks", (6, 2))
+    params = O.make_params(7, enc, dec)
     vfe = ref.vfe.DynamicScatterVFE(in_channels=5, feat_channels=[64, 128], with_distance=False, voxel_size=geo["top"],
                                     with_cluster_center=True, with_voxel_center=True, point_cloud_range=RANGE,
                                     norm_cfg=dict(type="naiveSyncBN1d", eps=1e-3, momentum=0.01))
@@ -49,7 +52,7 @@ def run(case):
     bb = ref.bb.MultiMAESSTSPChoose(cls_sub_voxel=True, window_shape=(12, 12), shifts_list=[(0, 0), (6, 6)],
                                     point_cloud_range=RANGE, voxel_size=geo["top"], shuffle_voxels=False, low=False,
                                     med=False, top=True, d_model=[128] * 6, nhead=[8] * 6, sub_voxel_ratio_low=(8, 4, 4),
-                                    sub_voxel_ratio_med=(4, 2, 2), encoder_num_blocks=6, decoder_num_blocks=2,
+                                    sub_voxel_ratio_med=(4, 2, 2), encoder_num_blocks=enc, decoder_num_blocks=dec,
                                     dim_feedforward=[256] * 6, output_shape=[ny, nx], debug=True, drop_info=drop_info,
                                     pos_temperature=10000, normalize_pos=False)
     vfe.load_state_dict({k[len("voxel_encoder."):]: v for k, v in params.items() if k.startswith("voxel_encoder.")}, strict=False)
@@ -106,16 +109,24 @@ def run(case):
            f"{case}.grad_vfe0": named["voxel_encoder.vfe_layers.0.linear.weight"].grad.numpy(),
            f"{case}.grad_mask_token": named["backbone.mask_token"].grad.numpy(),
            f"{case}.grad_pred_top_w": named["backbone.decoder_pred_top.weight"].grad.numpy(),
-           f"{case}.grad_enc5_ffn_b": named["backbone.encoder_blocks.5.encoder_list.1.linear1.bias"].grad.numpy(),
-           f"{case}.grad_dec_out_w": named["backbone.decoder_centroid_blocks.1.encoder_list.1.win_attn.self_attn.out_proj.weight"].grad.numpy()}
+           f"{case}.grad_enc5_ffn_b": named[f"backbone.encoder_blocks.{enc - 1}.encoder_list.1.linear1.bias"].grad.numpy(),
+           f"{case}.grad_dec_out_w": named[f"backbone.decoder_centroid_blocks.{dec - 1}.encoder_list.1.win_attn.self_attn.out_proj.weight"].grad.numpy(),
+           f"{case}.voxel_coors": feature_coors.numpy().astype(np.int16)}
+    if case in CASES:
+        del out[f"{case}.voxel_coors"]                    # (full-size cases keep the checksum only)
     print(case, "N", voxels.shape[0], "V", feature_coors.shape[0], "M", len(ids_mask), "losses",
           {k: round(float(v), 5) for k, v in loss.items()}, f"{time.time() - t0:.1f} s", flush=True)
     return out
 
 
 def main():
-    which = [a for a in sys.argv[1:] if a in CASES] or list(CASES)
-    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")), "g_fullsize.npz")
+    """no argument: the three full-size cases -> g_fullsize.npz; `c1`: BASELINE config 1's geometry (0.5 m pillars, grid
+    205, SST-tiny 1 + 1 blocks) on the 16 k uniform cloud, a LiDAR-ring cloud and both as a batch -> g_pipeline_c1.npz"""
+    args = sys.argv[1:]
+    c1 = "c1" in args
+    which = list(CASES_C1) if c1 else ([a for a in args if a in CASES] or list(CASES))
+    dst = os.path.join(os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden")),
+                       "g_pipeline_c1.npz" if c1 else "g_fullsize.npz")
     out = dict(np.load(dst)) if os.path.exists(dst) else {}
     for case in which:
         out.update(run(case))

@@ -1,6 +1,6 @@
 """Re-generate the round-2 fixtures from /root/reference into a scratch directory and compare them, array by array, with
 the committed tests/golden/*.npz (build container only; TEST INFRASTRUCTURE ONLY).
-    PYTHONDONTWRITEBYTECODE=1 python oracle/verify_golden.py [syncbn pipeline winops head fullsize]
+    PYTHONDONTWRITEBYTECODE=1 python oracle/verify_golden.py [syncbn pipeline winops head fullsize c1]
 Exit code 0 = every array identical bit for bit, except the float gradients of the two multi-threaded torch-CPU runs
 (syncbn: VFE layer-0 gradients, fullsize: everything float), whose summation order varies with the thread schedule:
 those must agree within 1e-6 of the array's largest magnitude (measured 1e-7)."""
@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 GEN = dict(syncbn=("make_golden_syncbn.py", "g_syncbn_w2.npz"), pipeline=("make_golden_pipeline.py", "g_input_pipeline.npz"),
            winops=("make_golden_winops.py", "g_winops.npz"), head=("make_golden_head.py", "g_head.npz"),
-           fullsize=("make_golden_fullsize.py", "g_fullsize.npz"))
+           fullsize=("make_golden_fullsize.py", "g_fullsize.npz"), c1=("make_golden_fullsize.py c1", "g_pipeline_c1.npz"))
 
 
 def main():
@@ -25,7 +25,8 @@ def main():
         for name in which:
             script, npz = GEN[name]
             env = dict(os.environ, GEOMAE_GOLDEN_OUT=tmp, PYTHONDONTWRITEBYTECODE="1")
-            subprocess.run([sys.executable, os.path.join(HERE, script)], env=env, check=True, stdout=subprocess.DEVNULL,
+            script, *extra = script.split()
+            subprocess.run([sys.executable, os.path.join(HERE, script)] + extra, env=env, check=True, stdout=subprocess.DEVNULL,
                            stderr=subprocess.DEVNULL)
             new, old = np.load(os.path.join(tmp, npz)), np.load(os.path.join(ROOT, "tests", "golden", npz))
             assert sorted(new.files) == sorted(old.files), (name, set(new.files) ^ set(old.files))
@@ -33,7 +34,7 @@ def main():
             for k in old.files:
                 a, b = old[k], new[k]
                 same = a.shape == b.shape and (np.array_equal(a, b) or (
-                    name in ("fullsize", "syncbn") and a.dtype.kind == "f" and
+                    name in ("fullsize", "syncbn", "c1") and a.dtype.kind == "f" and
                     float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) <= 1e-6 * max(float(np.abs(a).max()), 1e-30)))
                 if not same:
                     diff.append(k)
