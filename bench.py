@@ -342,6 +342,8 @@ def main():
                        "step_driver": "python-explicit" if eng is None else "geomae_pretrain_step (C engine)",
                        "exchange": "forced at world size 1 (RCCL, one rank)" if forced else ("rccl" if world > 1 else "none")},
             "loss": round(loss_val, 4),
+            # how the step's side streams were chosen (geomae_amd.ops._pick_side_streams: measured queue sharing)
+            "stream_probe": ops.STREAM_PROBE.get((dev.type, dev.index)),
             # GPU-side time between the ends of consecutive steps on the main stream (HIP events), rank 0
             "step_ms": {"p50": round(float(np.percentile(per_step, 50)), 4), "p90": round(float(np.percentile(per_step, 90)), 4),
                         "max": round(float(per_step.max()), 4), "min": round(float(per_step.min()), 4)},

@@ -238,33 +238,147 @@ def _zeros_or_empty(zeros, shape, dtype, device):
 
 
 _SIDE_STREAMS = {}
+STREAM_PROBE = {}          # device key -> what the probe saw (bench.py reports it)
+
+
+def _spin_us(dev):
+    """cycles of torch.cuda._sleep that last ~120 us on this device (calibrated once)."""
+    cyc = 200_000
+    for _ in range(2):
+        torch.cuda.synchronize(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        torch.cuda._sleep(cyc)
+        e1.record()
+        e1.synchronize()
+        us = max(e0.elapsed_time(e1) * 1e3, 1.0)
+        cyc = max(10_000, int(cyc * 120.0 / us))
+    return cyc
+
+
+def wait_blocks(victim, waiter, helper, cycles, dev):
+    """Does a cross-stream WAIT on `waiter` hold up a kernel on `victim`?  (-> blocked, seconds)
+
+    Kernels of two streams that share a hardware queue may still run side by side (their packets carry no barrier
+    bit), so a pair of spin kernels does not tell whether two streams share one.  What a shared queue cannot do is let
+    one stream wait while the other goes on: a cross-stream wait is a barrier packet, and everything behind it in the
+    hardware queue -- whichever stream it came from -- stays behind it.  (That is how a step's two decoder stacks ended
+    up running one after the other once the geometry stream, which waits for the decoder-B stream, shared the main
+    stream's queue.)  Here `helper` spins for ~120 us, `waiter` waits for it, and `victim` runs a spin of the same
+    length: alone it takes T, behind the wait 2 T.  The helper's own event record is a barrier packet too, so a
+    victim that shares the HELPER's queue is also reported -- all three streams of a schedule are meant to sit on
+    different queues anyway (_pick_side_streams tries every assignment of the roles)."""
+    import time
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(helper):
+        torch.cuda._sleep(cycles)
+        ev = helper.record_event()
+    waiter.wait_event(ev)
+    with torch.cuda.stream(waiter):
+        torch.cuda._sleep(100)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(victim):
+        torch.cuda._sleep(cycles)
+    victim.synchronize()
+    dt = time.perf_counter() - t0
+    torch.cuda.synchronize(dev)
+    return dt, t0
+
+
+def _spin_seconds(stream, cycles, dev):
+    import time
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        torch.cuda._sleep(cycles)
+    stream.synchronize()
+    return time.perf_counter() - t0
+
+
+def streams_independent(triple, cycles, dev):
+    """All three streams on different hardware queues: no assignment of (victim, waiter, helper) delays the victim."""
+    import itertools
+    alone = min(_spin_seconds(s, cycles, dev) for s in triple for _ in range(2))
+    for v, w, h in itertools.permutations(triple):
+        dt = min(wait_blocks(v, w, h, cycles, dev)[0] for _ in range(2))
+        if dt > 1.6 * alone:
+            return False
+    return True
+
+
+def _pick_side_streams(dev, names):
+    """Streams for `names` (two of them) that share a hardware queue neither with the current (main) stream nor with
+    each other.
+
+    ROCm multiplexes a process's HIP streams onto a few hardware queues per priority level (4 by default); which queue a
+    stream lands on depends on what else created streams before it -- torch's stream pool, RCCL's communicators and
+    their internal streams.  With the geometry stream on the main stream's queue the two decoder stacks of a step ran
+    one after the other (2.60 instead of 2.11 ms per step, profiles/r03_fx_timeline_before.txt: what the world > 1
+    schedule looked like once RCCL's streams existed).  Creation order cannot fix that in general, so the mapping is
+    MEASURED: pairs of candidates from torch's pool are probed together with main (streams_independent) and the first
+    pair that passes wins."""
+    import os
+    assert len(names) == 2
+    main = torch.cuda.current_stream(dev)
+    key = (dev.type, dev.index)
+    if os.environ.get("GEOMAE_STREAM_PROBE", "1") == "0":
+        STREAM_PROBE[key] = dict(probed=False)
+        return {n: torch.cuda.Stream(device=dev) for n in names}
+    cycles = _spin_us(dev)
+    cands = []
+    for _ in range(8):
+        c = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(c):
+            torch.zeros(1, device=dev)                         # first use = queue assignment
+        cands.append(c)
+    torch.cuda.synchronize(dev)
+    chosen, tried = None, 0
+    for j in range(1, len(cands)):
+        for i in range(j):
+            tried += 1
+            if streams_independent((main, cands[i], cands[j]), cycles, dev):
+                chosen = (cands[i], cands[j])
+                break
+        if chosen:
+            break
+    STREAM_PROBE[key] = dict(probed=True, pairs_tried=tried, distinct_queues=chosen is not None, spin_cycles=cycles)
+    if chosen is None:                                         # fewer queues than streams: any two
+        chosen = (cands[0], cands[1])
+    return dict(zip(names, chosen))
 
 
 def side_streams(device=None):
     """The step's side streams {"geo", "dec_b"}, one set per device (+ "dec_a" / "prefetch" on request: extra_stream).
 
-    ROCm multiplexes HIP streams onto a few hardware queues (4 by default) in the order in which the streams are
-    FIRST USED, so a fifth stream shares a queue with an earlier one -- with lazy creation the order once was prefetch,
-    geo, dec_a, dec_b, the second decoder stack shared the main stream's queue and a step took 3.83 instead of 3.31 ms.
-    The explicit training schedule therefore uses main + these TWO (created and touched here in a fixed order), which
-    leaves the fourth queue to the communication stream of torch.distributed's NCCL (= RCCL) backend whichever of them
-    is created first.  The autograd path's second decoder stream and its prefetch stream come after them."""
+    The explicit training schedule uses main + these TWO streams and needs each on a hardware queue of its own; they are
+    chosen by measurement (_pick_side_streams) at first use -- at world > 1 the trainer calls this AFTER its process
+    groups have created their communicators and streams (Trainer.__init__), so that the probe sees the final picture.
+    reset_side_streams() forgets the choice (a process group created later may have re-dealt the queues)."""
     dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     key = (dev.type, dev.index)
     if key not in _SIDE_STREAMS:
-        st = {}
         import os
-        # GEOMAE_SIDE_STREAMS=3: also create "dec_a" up front, so that a communication backend's streams wrap onto the
-        # main stream's queue.  Only for the test hook that runs several ranks on ONE GPU with gloo (bench.py
-        # GEOMAE_BENCH_SHARE_GPU, tests/test_gpu_multirank.py): two processes then own 8 queues on one device, and
-        # gloo's copy stream alone on the fourth queue of each waited ~100 ms per collective for a time slice.
-        for name in (("geo", "dec_a", "dec_b") if os.environ.get("GEOMAE_SIDE_STREAMS") == "3" else ("geo", "dec_b")):
-            st[name] = torch.cuda.Stream(device=dev)
-            with torch.cuda.stream(st[name]):
-                torch.zeros(1, device=dev)                     # first use = queue assignment
+        # GEOMAE_SIDE_STREAMS=3: also "dec_a" up front.  Only for the test hook that runs several ranks on ONE GPU with
+        # gloo (bench.py GEOMAE_BENCH_SHARE_GPU, tests/test_gpu_multirank.py): two processes then own 8 queues on one
+        # device, and gloo's copy stream alone on a queue of its own waited ~100 ms per collective for a time slice.
+        three = os.environ.get("GEOMAE_SIDE_STREAMS") == "3"
+        if three:
+            st = {}
+            for name in ("geo", "dec_a", "dec_b"):
+                st[name] = torch.cuda.Stream(device=dev)
+                with torch.cuda.stream(st[name]):
+                    torch.zeros(1, device=dev)
+            STREAM_PROBE[key] = dict(probed=False)
+        else:
+            st = _pick_side_streams(dev, ("geo", "dec_b"))
         torch.cuda.synchronize(dev)
         _SIDE_STREAMS[key] = st
     return _SIDE_STREAMS[key]
+
+
+def reset_side_streams(device=None):
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    _SIDE_STREAMS.pop((dev.type, dev.index), None)
 
 
 def extra_stream(name, device=None):
@@ -1030,6 +1144,7 @@ class VfePlan:
 # trainer installs one of its own at world > 1: on the default group's communicator the [2C]-word all-reduces of the VFE
 # backward would queue behind the encoder segment's gradient all-reduce that was started just before it.
 BN_GROUP = None
+GRAD_GROUP = None      # the gradient segments' communicator (train.Trainer creates both at world > 1)
 
 
 def _bn_finalize(plan, layer, sums, norm, world, group):

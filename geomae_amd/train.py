@@ -126,8 +126,34 @@ def exchange_mode():
     return world, world > 1 or os.environ.get("GEOMAE_FORCE_EXCHANGE") == "1"
 
 
+def _grad_group():
+    from . import ops
+    return ops.GRAD_GROUP
+
+
+def _new_comm_group(what):
+    """A process group over all ranks for `what`; on RCCL with a high-priority communication stream.  None = use the
+    default group (correct, only less overlapped)."""
+    try:
+        import os
+        if dist.get_backend() == "nccl" and os.environ.get("GEOMAE_COMM_PRIORITY", "normal") == "high":
+            try:
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+                return dist.new_group(pg_options=opts)
+            except (AttributeError, TypeError):
+                pass
+        return dist.new_group()
+    except Exception as e:
+        import warnings
+        warnings.warn(f"geomae_amd: no separate process group for the {what} exchange ({e!r}); using the default group")
+        return None
+
+
 def allreduce_gradients(flat, group=None):
     """DDP semantics: gradients averaged over ranks; one collective on the single bucket."""
+    if group is None:
+        from . import ops
+        group = ops.GRAD_GROUP
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     dist.all_reduce(flat.grad, op=dist.ReduceOp.SUM, group=group)
@@ -306,33 +332,28 @@ class Trainer:
         self.flat = FlatParams(model, no_decay_keys=keys or ("\0",), late_keys=late)
         if late and exchange_mode()[1]:
             from . import ops
+            # Communicators of the step's own: one for the gradient segments, one for the SyncBN statistics (they must not
+            # queue behind a gradient all-reduce in flight).  (Every rank builds its trainer: new_group is a collective
+            # call.)  GEOMAE_COMM_PRIORITY=high gives them high-priority communication streams -- measured on one MI355X
+            # with the forced one-rank exchange (tools/fx_envs.sh): 3.64 instead of 2.20 ms per step at the default four
+            # hardware queues (the step's side streams lose their queues to the extra priority level), so it is off.
             if ops.BN_GROUP is None:
-                # a communicator of its own for the SyncBN statistics (every rank builds its trainer: new_group is a
-                # collective call): they must not queue behind a gradient all-reduce in flight (ops.BN_GROUP)
-                try:
-                    ops.BN_GROUP = dist.new_group()
-                except Exception as e:                       # stay on the default group: correct, only less overlapped
-                    import warnings
-                    warnings.warn(f"geomae_amd: no separate process group for SyncBN ({e!r}); using the default group")
+                ops.BN_GROUP = _new_comm_group("SyncBN")
+            if ops.GRAD_GROUP is None:
+                ops.GRAD_GROUP = _new_comm_group("gradient")
             if self.flat.flat.is_cuda:
-                # ROCm maps a process's streams onto 4 hardware queues in first-use order and a 5th stream shares the
-                # first one's queue.  Fix that order here: main stream, the default group's
-                # communication stream (the gradient all-reduces must not sit in the main stream's queue: they would run
-                # in order with its kernels instead of beside them), geometry, decoder-B; the SyncBN group's stream, if
-                # the backend uses one for blocking collectives at all, comes 5th and shares the main stream's queue --
-                # harmless, the main stream waits for those collectives anyway.
-                try:
-                    t = torch.zeros(1, device=self.flat.flat.device)
-                    dist.all_reduce(t, async_op=True).wait()
-                    ops.side_streams(t.device)
+                dev = self.flat.flat.device
+                try:        # first use creates the communicators and their streams ...
+                    t = torch.zeros(1, device=dev)
+                    dist.all_reduce(t, group=ops.GRAD_GROUP, async_op=True).wait()
                     if ops.BN_GROUP is not None:
                         dist.all_reduce(t, group=ops.BN_GROUP)
-                    torch.cuda.synchronize(t.device)
-                except Exception as e:                       # only the ORDER of stream creation is lost: still correct
+                    torch.cuda.synchronize(dev)
+                except Exception as e:                       # still correct; the probe below then sees fewer streams
                     import warnings
-                    warnings.warn(f"geomae_amd: could not prime the communication streams ({e!r}); the step stays correct, "
-                                  "its side streams may share a hardware queue with the collectives")
-                    ops.side_streams(self.flat.flat.device)
+                    warnings.warn(f"geomae_amd: could not prime the communication streams ({e!r})")
+                ops.reset_side_streams(dev)                  # ... and only then are the step's side streams chosen
+                ops.side_streams(dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # what MMDistributedDataParallel does at construction: every replica starts from rank 0's parameters AND
             # buffers (BatchNorm running statistics, counters) whatever the ranks seeded or loaded; afterwards only
@@ -381,14 +402,14 @@ class Trainer:
         if exchange:
             def segment_ready(i):
                 a, b, _ = self.flat.segments[i]
-                works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+                works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
             eng.on_segment = segment_ready if len(self.flat.segments) > 2 else None
         losses, gnorm = eng.step(points, next_points, self.opt.lr, run_optimizer=not exchange)
         if exchange:
             done = {i for i, _ in works}
             for i, (a, b, _) in enumerate(self.flat.segments):
                 if i not in done:
-                    works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+                    works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
             for _, w in works:
                 w.wait()
             tap = getattr(self, "on_reduced_grad", None)
@@ -434,7 +455,7 @@ class Trainer:
             # carries its last writer): start its all-reduce now, under the rest of the backward (RCCL runs it on its own
             # stream after the kernels enqueued so far on the current one)
             a, b, _ = self.flat.segments[i]
-            works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+            works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
         nseg = len(self.flat.segments)
         early = (lambda: segment_ready(0)) if (world > 1 and nseg > 1) else None
         enc_ready = (lambda: segment_ready(1)) if (world > 1 and nseg > 2) else None
@@ -463,7 +484,7 @@ class Trainer:
                 done = {i for i, _ in works}
                 for i, (a, b, _) in enumerate(self.flat.segments):
                     if i not in done:
-                        works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, async_op=True)))
+                        works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
                 for _, w in works:
                     w.wait()
                 tap = getattr(self, "on_reduced_grad", None)

@@ -75,8 +75,11 @@ def _worker(rank, port, tmp):
             hist.append((lp, lf, float(gp), float(gf)))
             if i == 0:      # same parameters on both sides during step 0: the running statistics moved identically
                 for (k, a), (_, b) in zip(forced.named_buffers(), plain.named_buffers()):
-                    if "num_batches" not in k:    # (the cross-rank branch leaves the counter alone, ops/norm.py:58-86)
-                        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
+                    if "num_batches" in k:        # (the cross-rank branch leaves the counter alone, ops/norm.py:58-86)
+                        continue
+                    # ... and feeds the BIASED batch variance into running_var (ops/norm.py:64-76) where nn.BatchNorm1d
+                    # uses the unbiased one: a factor N / (N - 1) = 1 + 7e-5 on the increment at N = 14 k points
+                    assert torch.allclose(a.float(), b.float(), rtol=3e-4 if "running_var" in k else 1e-5, atol=1e-6), k
         assert tr_p.get_engine().exchange is False
         # per step: 4 SyncBN exchanges + 2 early segment exchanges, each handed the stream it must be ordered on
         assert len(calls) == 18, calls
