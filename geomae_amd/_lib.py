@@ -147,6 +147,7 @@ SIGNATURES = {
     "geomae_segment_max_forward": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P]),
     "geomae_segment_max_backward": (ctypes.c_int, [P, P, P, c_int64, c_int32, P, P]),
     "geomae_random_mask": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, P, P, P, P]),
+    "geomae_random_mask_windowed": (ctypes.c_int, [P, c_int32, c_double, c_uint64, P, POINTER(GeomaeWindowConfig), P, P, P, P, P]),
     "geomae_geometry_targets": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P, P, P, c_int32, P, P,
                                                POINTER(GeomaeTargetConfig), P, P, P, P, P, P, P, P, P, P, P, P, c_int32, P]),
     "geomae_window_build_workspace_bytes": (c_int64, [c_int32, c_int32, POINTER(GeomaeWindowConfig)]),

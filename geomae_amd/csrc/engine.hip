@@ -270,8 +270,9 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
                                 c.vfe_center_offset, b.feat, b.pid, s));
     // the mask index is a function of the step that will consume the batch (not of how many stage 1s ran: a replaced
     // submission or a re-created engine must not shift the stream; geomae_pretrain_set_mask_draws)
-    ENG_CALL(geomae_random_mask(b.sample_start, c.batch_size, c.keep_fraction, (c.mask_seed << 32) + draw,
-                                b.ids_keep, b.ids_mask, b.token_row, b.counts, s));
+    // window-major token lists: a 16-token tile of the stacks' activations then belongs to one or two attention windows
+    ENG_CALL(geomae_random_mask_windowed(b.sample_start, c.batch_size, c.keep_fraction, (c.mask_seed << 32) + draw,
+                                         b.voxel_coors, &c.window, b.ids_keep, b.ids_mask, b.token_row, b.counts, s));
     b.valid = true;
     b.counts_read = false;
     return GEOMAE_OK;

@@ -143,6 +143,178 @@ __global__ __launch_bounds__(kMaskBlk) void random_mask_kernel(const int32_t* __
     }
 }
 
+// ---- the same draw, tokens emitted WINDOW-MAJOR.  The subset is the one random_mask_kernel draws from the same seed;
+// only the ORDER of ids_keep / ids_mask differs: grouped by the (unshifted) SST window of the pillar, windows ascending,
+// pillars ascending inside a window.  The token order of the SST stacks is the order of these lists, and the stacks'
+// activations live in 16-token tiles: with tokens in pillar order (ascending (b, y, x)) the 16 tokens of a tile are
+// spread over the 4-5 windows a row of pillars crosses, so a (bundle, head) attention workgroup used 1-2 of the 4
+// token slices in every 128-byte line it fetched (27 MB per forward launch for 12.7 MB of operands,
+// profiles/r02_pmc_traffic.json).  Window-major, a tile belongs to one or two windows for BOTH shifts (a shifted
+// window overlaps four unshifted ones, a tile covers a row or two of one).  Nothing downstream depends on the order:
+// attention is permutation equivariant, every loss is a mean over the masked set (the reference's own order is a
+// random permutation, ssl.py:287-304).
+constexpr int kMaxWinLds = 2048;          // window slots per sample held in LDS (35^2 nuScenes, 40^2 Waymo geometry)
+constexpr int kSortCap = 256;             // tokens of one kind in one window that the in-window sort handles
+
+struct MaskWinGeom { int wx, wy, nwx, nwy; };
+
+__global__ __launch_bounds__(kMaskBlk) void random_mask_win_kernel(const int32_t* __restrict__ sample_start, int n_batch,
+                                                                   double keep_frac, uint64_t seed,
+                                                                   const int4* __restrict__ voxel_coors, MaskWinGeom g,
+                                                                   int32_t* __restrict__ ids_keep,
+                                                                   int32_t* __restrict__ ids_mask,
+                                                                   int32_t* __restrict__ token_row,
+                                                                   int32_t* __restrict__ counts) {
+    __shared__ int cur[2 * kMaxWinLds];       // radix-select histogram first, then per (kind, window) cursors
+    __shared__ int base[2 * kMaxWinLds];      // per (kind, window) first slot
+    __shared__ int scratch[kMaskBlk / 64][kSortCap];
+    __shared__ int sm[20];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_need;
+    int* hist = cur;
+    const int b = blockIdx.x;
+    const int p0 = sample_start[b];
+    const int L = sample_start[b + 1] - p0;
+    const int K = (int)((double)L * keep_frac);
+    int keep_base = 0, mask_base = 0, keep_total = 0, mask_total = 0;
+    for (int k = 0; k < n_batch; ++k) {
+        const int l = sample_start[k + 1] - sample_start[k];
+        const int kk = (int)((double)l * keep_frac);
+        if (k < b) { keep_base += kk; mask_base += l - kk; }
+        keep_total += kk;
+        mask_total += l - kk;
+    }
+    if (b == 0 && threadIdx.x == 0) { counts[0] = keep_total; counts[1] = mask_total; }
+    // ---- radix select of the K-th smallest key: identical to random_mask_kernel
+    uint32_t prefix = 0, prefix_mask = 0;
+    int need = K;
+    const int shifts[3] = {20, 8, 0};
+    const int bits[3] = {12, 12, 8};
+    if (K > 0) {
+        for (int pass = 0; pass < 3; ++pass) {
+            const int nb = 1 << bits[pass];
+            for (int t = threadIdx.x; t < nb; t += kMaskBlk) hist[t] = 0;
+            __syncthreads();
+            for (int i = threadIdx.x; i < L; i += kMaskBlk) {
+                const uint32_t key = mask_key(seed, b, i);
+                if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shifts[pass]) & (nb - 1)], 1);
+            }
+            __syncthreads();
+            {
+                int h[4], v = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int bin = threadIdx.x * 4 + k;
+                    h[k] = bin < nb ? hist[bin] : 0;
+                    v += h[k];
+                }
+                int tot;
+                int acc = block_scan_1024(v, &tot, sm);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (acc < need && acc + h[k] >= need) {
+                        s_prefix = prefix | ((uint32_t)(threadIdx.x * 4 + k) << shifts[pass]);
+                        s_need = need - acc;
+                    }
+                    acc += h[k];
+                }
+            }
+            __syncthreads();
+            prefix = s_prefix;
+            need = s_need;
+            prefix_mask |= (uint32_t)(nb - 1) << shifts[pass];
+            __syncthreads();
+        }
+    }
+    const uint32_t T = prefix;
+    const int nwin = g.nwx * g.nwy;
+    auto window_of = [&](int p) {
+        const int4 c = voxel_coors[p];
+        return (c.w / g.wx) * g.nwy + c.z / g.wy;
+    };
+    // ---- pass A: keep flag per pillar (parked in token_row), pillars per (kind, window)
+    for (int t = threadIdx.x; t < 2 * nwin; t += kMaskBlk) cur[t] = 0;
+    __syncthreads();
+    int run_eq = 0;
+    for (int i0 = 0; i0 < L; i0 += kMaskBlk) {
+        const int i = i0 + threadIdx.x;
+        int lt = 0, eq = 0;
+        if (i < L && K > 0) {
+            const uint32_t key = mask_key(seed, b, i);
+            lt = key < T;
+            eq = key == T;
+        }
+        int tot_eq;
+        const int eq_rank = run_eq + block_scan_1024(eq, &tot_eq, sm);
+        run_eq += tot_eq;
+        if (i < L) {
+            const int keep = lt | (eq & (eq_rank < need));
+            token_row[p0 + i] = keep;
+            atomicAdd(&cur[(keep ? 0 : nwin) + window_of(p0 + i)], 1);
+        }
+    }
+    __syncthreads();
+    // ---- exclusive scan over (kind, window): 2 * nwin <= 4096 entries, 4 per thread
+    {
+        int h[4], v = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = threadIdx.x * 4 + k;
+            h[k] = e < 2 * nwin ? cur[e] : 0;
+            v += h[k];
+        }
+        int tot;
+        int acc = block_scan_1024(v, &tot, sm);
+        const int kept = K;                           // entries [0, nwin) sum to K: the masked part restarts at 0
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = threadIdx.x * 4 + k;
+            if (e < 2 * nwin) {
+                const int v0 = e < nwin ? acc : acc - kept;
+                base[e] = v0;
+                cur[e] = v0;
+            }
+            acc += h[k];
+        }
+    }
+    __syncthreads();
+    // ---- pass B: place (arrival order inside a (kind, window) run; made deterministic by pass C)
+    for (int i = threadIdx.x; i < L; i += kMaskBlk) {
+        const int p = p0 + i;
+        const int keep = token_row[p];
+        const int slot = atomicAdd(&cur[(keep ? 0 : nwin) + window_of(p)], 1);
+        if (keep) ids_keep[keep_base + slot] = p;
+        else ids_mask[mask_base + slot] = p;
+    }
+    __syncthreads();
+    // ---- pass C: ascending pillar order inside every run (rank sort, one wave per run), token rows
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int* sc = scratch[wave];
+    for (int e = wave; e < 2 * nwin; e += kMaskBlk / 64) {
+        const int s0 = base[e], n = cur[e] - s0;
+        if (n <= 0) continue;
+        int32_t* ids = e < nwin ? ids_keep + keep_base : ids_mask + mask_base;
+        const int row0 = e < nwin ? keep_base : keep_total + mask_base;
+        if (n <= kSortCap) {
+            for (int t = lane; t < n; t += 64) sc[t] = ids[s0 + t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the wave's LDS writes before its reads
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int t = lane; t < n; t += 64) {
+                const int v = sc[t];
+                int r = 0;
+                for (int u = 0; u < n; ++u) r += sc[u] < v;
+                ids[s0 + r] = v;
+                token_row[v] = row0 + s0 + r;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else {
+            for (int t = lane; t < n; t += 64) token_row[ids[s0 + t]] = row0 + s0 + t;
+        }
+    }
+}
+
 // coordinates of the decoder's token list (kept pillars, then masked pillars) + the kept ids widened to int64 (the
 // index dtype torch's gather / index_copy want): one launch instead of two casts, two gathers and a concatenation
 __global__ __launch_bounds__(256) void gather_token_coors_kernel(const int32_t* __restrict__ ids_keep, int n_keep,
@@ -171,6 +343,27 @@ extern "C" int geomae_gather_token_coors(const int32_t* ids_keep, int32_t num_ke
     hipLaunchKernelGGL(gather_token_coors_kernel, dim3(stream_grid(num_keep + num_mask, 256)), dim3(256), 0, stream, ids_keep,
                        num_keep, ids_mask, num_mask, (const int4*)voxel_coors, (int4*)coors_out, (long long*)ids_keep_i64);
     return check_launch("gather_token_coors_kernel");
+}
+
+extern "C" int geomae_random_mask_windowed(const int32_t* sample_start, int32_t batch_size, double keep_fraction,
+                                           uint64_t seed, const int32_t* voxel_coors, const GeomaeWindowConfig* window,
+                                           int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row, int32_t* counts,
+                                           hipStream_t stream) {
+    GEOMAE_REQUIRE(sample_start && ids_keep && ids_mask && token_row && counts && voxel_coors && window,
+                   "random_mask_windowed: null argument");
+    GEOMAE_REQUIRE(batch_size >= 1 && keep_fraction >= 0.0 && keep_fraction <= 1.0, "random_mask_windowed: bad arguments");
+    GEOMAE_REQUIRE(window->window_shape[0] >= 1 && window->window_shape[1] >= 1 && window->bev_shape[0] >= 1 &&
+                   window->bev_shape[1] >= 1, "random_mask_windowed: bad window configuration");
+    MaskWinGeom g;
+    g.wx = window->window_shape[0];
+    g.wy = window->window_shape[1];
+    g.nwx = (window->bev_shape[0] + g.wx - 1) / g.wx;
+    g.nwy = (window->bev_shape[1] + g.wy - 1) / g.wy;
+    if ((int64_t)g.nwx * g.nwy > kMaxWinLds)           // a window table that does not fit in LDS: pillar order
+        return geomae_random_mask(sample_start, batch_size, keep_fraction, seed, ids_keep, ids_mask, token_row, counts, stream);
+    hipLaunchKernelGGL(random_mask_win_kernel, dim3(batch_size), dim3(kMaskBlk), 0, stream, sample_start, batch_size,
+                       keep_fraction, seed, (const int4*)voxel_coors, g, ids_keep, ids_mask, token_row, counts);
+    return check_launch("random_mask_win_kernel");
 }
 
 extern "C" int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double keep_fraction,

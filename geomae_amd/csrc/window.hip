@@ -249,6 +249,35 @@ __device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0);
 }
 
+// Token contractions (P V, dS K, P^T dO, dS^T Q) run over the tokens of a window: two 16-token tiles make one
+// v_mfma_f32_16x16x32_bf16.  The k slots of lane group g are [tile A tokens 4g..4g+3 | tile B tokens 4g..4g+3]: exactly
+// what the lane already holds from the two tiles' S^T accumulators (A operand) and what two transposing LDS reads
+// deliver (B operand) -- the contraction does not care about the order of its index as long as both operands agree.
+// Only Q K^T and dO V^T contract over d_head = 16 and stay 16x16x16.  An absent tile B contributes zeros on BOTH sides
+// (stale LDS rows may hold anything, and 0 * NaN is not 0).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_a;
+__device__ __forceinline__ f32x4 mfma32_pair(bf16x4 a0, bf16x4 a1, bf16x4 b0, bf16x4 b1, f32x4 c) {
+    union { struct { bf16x4 lo, hi; } p; bf16x8_a v; } fa, fb;
+    fa.p.lo = a0; fa.p.hi = a1;
+    fb.p.lo = b0; fb.p.hi = b1;
+    const f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa.v, fb.v, c, 0, 0, 0);
+    // Precaution: both operands stay alive past the instruction, so the register allocator cannot place the RESULT on
+    // top of an operand that dies here (it did, with a constant-zero accumulator: v_mfma_f32_16x16x32_bf16 v[42:45],
+    // v[42:45], v[46:49], 0).  The wrong tiles seen with that build were traced to the predicated transposing LDS read
+    // (keep_if below), not to this form; the constraint costs nothing and stays.
+    asm volatile("" ::"v"(fa.v), "v"(fb.v));
+    return d;
+}
+
+// wave-uniform select without control flow.  The transposing LDS read (ds_read_b64_tr_b16) must not sit in a
+// predicated block: compiled as "s_and_saveexec; ds_read_b64_tr_b16; s_or exec" without a branch around it, a FALSE
+// condition still left stale LDS contents in the destination (gfx950; NaN rows in windows with an odd tile count,
+// reproduced by polluting LDS, tools/dbg_attn.py) -- so absent tiles are read from a valid tile and zeroed here.
+__device__ __forceinline__ bf16x4 keep_if(bool cond, bf16x4 v) {
+    const bf16x4 z = {0, 0, 0, 0};
+    return cond ? v : z;
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 // phase timing (tools/phase_timing_attn.py; a no-op in the product build)
 #ifdef GEOMAE_PHASE_TIMING
@@ -506,16 +535,24 @@ __global__ __launch_bounds__(kAttnBlk, H == 1 ? 6 : (H == 2 ? 5 : 4)) void win_a
                 }
             }
             sum = rows4_sum(sum);
-            // O tile = P V : A = P (row i = c, k = 4g + r), B = V (k = j, col = d) read from V^T
+            // O tile = P V : A = P (row i = c, k = key), B = V (k = key, col = d); two key tiles per K = 32 MFMA
             f32x4 o = {0, 0, 0, 0};
 #pragma unroll
-            for (int jt = 0; jt < kMaxTiles; ++jt) {
-                if (jt >= jlo && jt <= jhi) {
-                    bf16x4 pa;
+            for (int jp = 0; jp < (kMaxTiles + 1) / 2; ++jp) {
+                const int j0 = 2 * jp, j1 = 2 * jp + 1;
+                const bool a0 = j0 >= jlo && j0 <= jhi;
+                const bool a1 = j1 < kMaxTiles && j1 >= jlo && j1 <= jhi;
+                if (a0 || a1) {
+                    bf16x4 pa0, pa1;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) pa[r] = (short)f2bf(st[jt][r]);
-                    const bf16x4 vb = lds4_tr(Vs_all + ho, jt * 16 + 4 * g, c);
-                    o = mfma16(pa, vb, o);
+                    for (int r = 0; r < 4; ++r) {
+                        pa0[r] = (short)f2bf(st[j0][r]);
+                        pa1[r] = (short)f2bf(st[j1 < kMaxTiles ? j1 : j0][r]);
+                    }
+                    // (an absent tile is read from the present one: always initialised rows)
+                    const bf16x4 vb0 = lds4_tr(Vs_all + ho, (a0 ? j0 : j1) * 16 + 4 * g, c);
+                    const bf16x4 vb1 = lds4_tr(Vs_all + ho, (a1 ? j1 : j0) * 16 + 4 * g, c);
+                    o = mfma32_pair(keep_if(a0, pa0), keep_if(a1, pa1), keep_if(a0, vb0), keep_if(a1, vb1), o);
                 }
             }
             // C layout: row i = 4g + r, col d = c ; the row statistics live in lane (i & 15)
@@ -603,7 +640,8 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             const float Li = Ls[it * 16 + c], Di = Ds[it * 16 + c];
             const int wq = wid[it * 16 + c];
             f32x4 dq = {0, 0, 0, 0};
-            for (int jt = jlo; jt <= jhi; ++jt) {
+            // dS^T tile of key tile jt for this wave's query tile (A operand of dQ += dS K: row i = c, k = key)
+            auto ds_tile = [&](int jt) {
                 const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
                 const bf16x4 va = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
@@ -617,9 +655,16 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                     const float p = (Wr[r] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
                     dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
                 }
-                // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
-                const bf16x4 kb = lds4_tr(Ks, jt * 16 + 4 * g, c);
-                dq = mfma16(dsa, kb, dq);
+                return dsa;
+            };
+            for (int jt = jlo; jt <= jhi; jt += 2) {
+                const bool two = jt + 1 <= jhi;
+                const int jt1 = two ? jt + 1 : jt;                            // (absent partner: recomputed from tile jt, zeroed)
+                const bf16x4 ds0 = ds_tile(jt);
+                const bf16x4 kb0 = lds4_tr(Ks, jt * 16 + 4 * g, c);        // B = K[k = key][col = d]
+                const bf16x4 ds1 = ds_tile(jt1);
+                const bf16x4 kb1 = lds4_tr(Ks, jt1 * 16 + 4 * g, c);
+                dq = mfma32_pair(ds0, keep_if(two, ds1), kb0, keep_if(two, kb1), dq);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) G1[(it * 16 + 4 * g + r) * kDh + c] = f2bf(dq[r]);
@@ -637,13 +682,13 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             const bf16x4 vb = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
             const int wk = wid[jt * 16 + c];
             f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
-            for (int it = ilo; it <= ihi; ++it) {
+            // P^T / dS^T tiles of query tile `it` for this wave's key tile (A operands: row j = c, k = query)
+            auto p_ds_tile = [&](int it, bf16x4* pa, bf16x4* dsa) {
                 const bf16x4 qa = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
                 const bf16x4 doa = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
                 const f32x4 s = mfma16(qa, kb, z);       // [i][j]
                 const f32x4 dp = mfma16(doa, vb, z);     // dP[i][j]
-                bf16x4 pa, dsa;
                 const int i0 = it * 16 + 4 * g;                       // 4 consecutive queries: one 16-byte LDS read each
                 const float4 L4 = *reinterpret_cast<const float4*>(Ls + i0), D4 = *reinterpret_cast<const float4*>(Ds + i0);
                 const int4 W4 = *reinterpret_cast<const int4*>(wid + i0);
@@ -652,15 +697,22 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = (Wr[r] == wk) ? __expf(s[r] * scale - Lr[r]) : 0.0f;
-                    pa[r] = (short)f2bf(p);
-                    dsa[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
+                    (*pa)[r] = (short)f2bf(p);
+                    (*dsa)[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
                 }
-                // dV[j][d] += sum_i P[i][j] dO[i][d] : A = P^T (row j = c, k = i), B = dO[k=i][col=d] from dO^T
-                const bf16x4 dob = lds4_tr(dOs, it * 16 + 4 * g, c);
-                dv = mfma16(pa, dob, dv);
-                // dK[j][d] += sum_i dS[i][j] Q[i][d]
-                const bf16x4 qb = lds4_tr(Qs, it * 16 + 4 * g, c);
-                dk = mfma16(dsa, qb, dk);
+            };
+            for (int it = ilo; it <= ihi; it += 2) {
+                const bool two = it + 1 <= ihi;
+                const int it1 = two ? it + 1 : it;                            // (absent partner: recomputed from tile it, zeroed)
+                bf16x4 pa0, ds0, pa1, ds1;
+                p_ds_tile(it, &pa0, &ds0);
+                const bf16x4 dob0 = lds4_tr(dOs, it * 16 + 4 * g, c);      // B = dO[k = query][col = d]
+                const bf16x4 qb0 = lds4_tr(Qs, it * 16 + 4 * g, c);        // B = Q[k = query][col = d]
+                p_ds_tile(it1, &pa1, &ds1);
+                const bf16x4 dob1 = lds4_tr(dOs, it1 * 16 + 4 * g, c);
+                const bf16x4 qb1 = lds4_tr(Qs, it1 * 16 + 4 * g, c);
+                dv = mfma32_pair(pa0, keep_if(two, pa1), dob0, keep_if(two, dob1), dv);   // dV[j][d] += sum_i P[i][j] dO[i][d]
+                dk = mfma32_pair(ds0, keep_if(two, ds1), qb0, keep_if(two, qb1), dk);     // dK[j][d] += sum_i dS[i][j] Q[i][d]
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -236,7 +236,9 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
     @torch.no_grad()
     def _launch_mask(self, seg):
         self._iter += 1
-        return ops.random_mask_launch(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter)
+        # (window-major token lists when the backbone runs the fused stacks: csrc/mask.hip)
+        return ops.random_mask_launch(seg, 1 - self.random_mask_ratio, (self.mask_seed << 32) + self._iter,
+                                      getattr(self.backbone, "_wcfg", None))
 
     @torch.no_grad()
     def get_vanilla_mask_index(self, seg):

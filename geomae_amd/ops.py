@@ -656,19 +656,26 @@ class DynamicScatter(nn.Module):
 
 
 # ------------------------------------------------------------------------------------ A6
-def random_mask_launch(seg, keep_fraction, seed):
+def random_mask_launch(seg, keep_fraction, seed, window_cfg=None):
     """Enqueue the mask kernel without needing the pillar counts on the host (buffers sized by the segment capacity):
     a training loop runs it for the NEXT batch together with that batch's voxelization.  -> raw state for
-    random_mask_finish."""
+    random_mask_finish.  window_cfg (GeomaeWindowConfig): the same subset, ids emitted window-major
+    (geomae_random_mask_windowed: the token order the SST stacks want)."""
     dev = seg.voxel_coors.device
     cap = max(int(seg.cap), 1)
     ids_keep = torch.empty(cap, dtype=torch.int32, device=dev)
     ids_mask = torch.empty(cap, dtype=torch.int32, device=dev)
     token_row = torch.empty(cap, dtype=torch.int32, device=dev)
     counts = torch.empty(2, dtype=torch.int32, device=dev)
-    check(_lib.load().geomae_random_mask(_ptr(seg.sample_start), seg.batch_size, float(keep_fraction),
-                                         int(seed) & (2 ** 64 - 1), _ptr(ids_keep), _ptr(ids_mask), _ptr(token_row),
-                                         _ptr(counts), _stream()), "geomae_random_mask")
+    if window_cfg is not None:
+        check(_lib.load().geomae_random_mask_windowed(_ptr(seg.sample_start), seg.batch_size, float(keep_fraction),
+                                                      int(seed) & (2 ** 64 - 1), _ptr(seg.voxel_coors), ctypes.byref(window_cfg),
+                                                      _ptr(ids_keep), _ptr(ids_mask), _ptr(token_row), _ptr(counts), _stream()),
+              "geomae_random_mask_windowed")
+    else:
+        check(_lib.load().geomae_random_mask(_ptr(seg.sample_start), seg.batch_size, float(keep_fraction),
+                                             int(seed) & (2 ** 64 - 1), _ptr(ids_keep), _ptr(ids_mask), _ptr(token_row),
+                                             _ptr(counts), _stream()), "geomae_random_mask")
     return ids_keep, ids_mask, token_row, counts, float(keep_fraction)
 
 
@@ -681,9 +688,10 @@ def random_mask_finish(raw, seg):
     return ids_keep[:n_keep], ids_mask[:V - n_keep], token_row[:V], counts
 
 
-def random_mask(seg, keep_fraction, seed):
-    """-> ids_keep [n_keep], ids_mask [n_mask] (int32, ascending), token_row [V] int32, counts [2] int32."""
-    return random_mask_finish(random_mask_launch(seg, keep_fraction, seed), seg)
+def random_mask(seg, keep_fraction, seed, window_cfg=None):
+    """-> ids_keep [n_keep], ids_mask [n_mask] (int32; ascending, or window-major with window_cfg), token_row [V] int32,
+    counts [2] int32."""
+    return random_mask_finish(random_mask_launch(seg, keep_fraction, seed, window_cfg), seg)
 
 
 def gather_token_coors(ids_keep, ids_mask, voxel_coors):

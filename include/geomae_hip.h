@@ -105,6 +105,7 @@ int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double k
                        uint64_t seed, int32_t* ids_keep, int32_t* ids_mask, int32_t* token_row,
                        int32_t* counts, geomaeStream_t stream);
 
+
 /* coors_out [num_keep + num_mask, 4] = voxel_coors rows of the kept pillars followed by the masked pillars (the
  * decoder's token order; its head is the encoder's token list, bb.py:227-246 torch.cat of the two gathers), and
  * optionally ids_keep widened to int64. */
@@ -153,6 +154,15 @@ typedef struct GeomaeWindowConfig {
     int32_t shift[2];           /* second layout's shift, e.g. 6, 6 (shift_index 1)                   */
     int32_t bev_shape[2];       /* pillars along (x, y), e.g. 400, 400                                */
 } GeomaeWindowConfig;
+
+/* The same subset as geomae_random_mask draws from the same seed, with ids_keep / ids_mask emitted WINDOW-MAJOR: grouped
+ * by the unshifted SST window of the pillar (windows ascending, pillars ascending inside a window) instead of ascending
+ * pillar index.  The lists' order is the token order of the SST stacks, whose activations live in 16-token tiles: this
+ * order keeps a tile inside one or two attention windows for both shifts (csrc/mask.hip).  voxel_coors [V,4] int32
+ * (b,z,y,x) of the pillars.  Falls back to geomae_random_mask when a sample has more than 2048 window slots. */
+int geomae_random_mask_windowed(const int32_t* sample_start, int32_t batch_size, double keep_fraction, uint64_t seed,
+                                const int32_t* voxel_coors, const GeomaeWindowConfig* window, int32_t* ids_keep,
+                                int32_t* ids_mask, int32_t* token_row, int32_t* counts, geomaeStream_t stream);
 
 /* replaces window_partition + get_voxel_keep_inds + get_flat2win_inds (bb.py:413-681): tokens
  * grouped by window as CSR.  coors [n, 4] int32.  Outputs: win_start [min(n, slots) + 1],

@@ -178,6 +178,38 @@ def test_random_mask_properties(dev):
     assert torch.equal(k2, ops.random_mask(seg, 0.3, 3)[0]) and not torch.equal(k2, ops.random_mask(seg, 0.3, 4)[0])
 
 
+@pytest.mark.parametrize("grid,vs", [((1, 400, 400), LEVELS["top"]), ((1, 205, 205), LEVELS["c1_top"])])
+def test_windowed_random_mask_is_the_same_draw_in_window_major_order(dev, grid, vs):
+    """geomae_random_mask_windowed: the SAME subset as geomae_random_mask for the same seed; ids grouped by the unshifted
+    12 x 12 window of the pillar (per sample, windows ascending, pillars ascending inside a window); token rows
+    consistent; deterministic.  Grid 205 (config 1) has a cut last window."""
+    from geomae_amd import ops
+    frames = _frames() + [synth.lidar_frame(13, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, vs, RANGE)
+    seg = ops.pillar_segment(torch.as_tensor(coors, device=dev), 3, grid)
+    starts = seg.sync_counts()
+    V = starts[-1]
+    vc = seg.voxel_coors[:V].cpu().numpy()
+    wcfg = ops.make_window_config((12, 12), (6, 6), grid[1:])
+    for seed in (0, 1, 7):
+        k0, m0, _, _ = ops.random_mask(seg, 0.3, seed)
+        k1, m1, row, counts = ops.random_mask(seg, 0.3, seed, wcfg)
+        assert counts.cpu().tolist() == [k1.numel(), m1.numel()]
+        assert torch.equal(torch.sort(k1).values, k0) and torch.equal(torch.sort(m1).values, m0)
+        for ids in (k1.cpu().numpy(), m1.cpu().numpy()):
+            c = vc[ids]
+            key = (c[:, 0].astype(np.int64) << 40) | ((c[:, 3] // 12).astype(np.int64) << 28) | \
+                ((c[:, 2] // 12).astype(np.int64) << 16)
+            full = (key << 0) + 0
+            assert (np.diff(full) >= 0).all()                                   # samples, then windows, ascending
+            same = np.diff(full) == 0
+            assert (np.diff(ids)[same] > 0).all()                               # pillars ascending inside a window
+        r = row.cpu().numpy()
+        assert np.array_equal(r[k1.cpu().numpy()], np.arange(k1.numel()))
+        assert np.array_equal(r[m1.cpu().numpy()], k1.numel() + np.arange(m1.numel()))
+        assert torch.equal(k1, ops.random_mask(seg, 0.3, seed, wcfg)[0])
+
+
 # ---------------------------------------------------------------------------------- A5, A7-A11
 def test_geometry_targets(dev, golden_dir):
     from geomae_amd import ops
