@@ -255,6 +255,10 @@ __device__ __forceinline__ f32x4 mfma16(bf16x4 a, bf16x4 b, f32x4 c) {
 // deliver (B operand) -- the contraction does not care about the order of its index as long as both operands agree.
 // Only Q K^T and dO V^T contract over d_head = 16 and stay 16x16x16.  An absent tile B contributes zeros on BOTH sides
 // (stale LDS rows may hold anything, and 0 * NaN is not 0).
+// Used by the FORWARD kernel (P V: decoder-size launches 28.1 -> 25.3 us, encoder-size 8.3 -> 8.0).  The backward
+// kernel's three token contractions (dS K, P^T dO, dS^T Q) were built the same way and measured: 24.1 instead of
+// 21.5 us per launch -- holding two tiles' P / dS fragments costs 22 registers (70 -> 92 VGPRs, 7 -> 5 waves per SIMD)
+// in a kernel that waits on loads 70 % of its time and issues MFMAs 5 % of it; it keeps one K = 16 MFMA per tile.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_a;
 __device__ __forceinline__ f32x4 mfma32_pair(bf16x4 a0, bf16x4 a1, bf16x4 b0, bf16x4 b1, f32x4 c) {
     union { struct { bf16x4 lo, hi; } p; bf16x8_a v; } fa, fb;
@@ -269,10 +273,12 @@ __device__ __forceinline__ f32x4 mfma32_pair(bf16x4 a0, bf16x4 a1, bf16x4 b0, bf
     return d;
 }
 
-// wave-uniform select without control flow.  The transposing LDS read (ds_read_b64_tr_b16) must not sit in a
-// predicated block: compiled as "s_and_saveexec; ds_read_b64_tr_b16; s_or exec" without a branch around it, a FALSE
-// condition still left stale LDS contents in the destination (gfx950; NaN rows in windows with an odd tile count,
-// reproduced by polluting LDS, tools/dbg_attn.py) -- so absent tiles are read from a valid tile and zeroed here.
+// The transposing LDS read (ds_read_b64_tr_b16) must not sit in a PREDICATED block: compiled as "s_and_saveexec;
+// ds_read_b64_tr_b16; s_or exec" without a branch around it, a false condition still left stale LDS contents in the
+// destination (gfx950; NaN rows in windows with an odd tile count, reproduced by polluting LDS with NaNs,
+// tools/dbg_attn.py): 0 * NaN in the absent half of a tile pair.  Two guards: the tile ranges live in SGPRs
+// (tile_range), so the conditions around these reads are scalar branches that skip the block; and the operand of an
+// absent tile passes through this select, whatever the read left behind.
 __device__ __forceinline__ bf16x4 keep_if(bool cond, bf16x4 v) {
     const bf16x4 z = {0, 0, 0, 0};
     return cond ? v : z;
@@ -413,8 +419,10 @@ __device__ __forceinline__ BundleCtx bundle_setup(int b, const AttnPlan& P, int*
 __device__ __forceinline__ void tile_range(const BundleCtx& c, int it, const int* wlo, const int* whi, int* lo, int* hi) {
     const int first = it * 16;
     const int last = (first + 15 < c.T ? first + 15 : c.T - 1);
-    *lo = (wlo[first] - c.s0) >> 4;
-    *hi = (whi[last] - 1 - c.s0) >> 4;
+    // wave-uniform by construction; pinned to SGPRs so that every branch on them is a scalar branch (a block the wave
+    // does not take is then SKIPPED, not run under an empty EXEC mask: see keep_if)
+    *lo = __builtin_amdgcn_readfirstlane((wlo[first] - c.s0) >> 4);
+    *hi = __builtin_amdgcn_readfirstlane((whi[last] - 1 - c.s0) >> 4);
 }
 
 // this thread's staging rows -> their token ids.  With the build's attention plan they come straight from global
@@ -543,16 +551,19 @@ __global__ __launch_bounds__(kAttnBlk, H == 1 ? 6 : (H == 2 ? 5 : 4)) void win_a
                 const bool a0 = j0 >= jlo && j0 <= jhi;
                 const bool a1 = j1 < kMaxTiles && j1 >= jlo && j1 <= jhi;
                 if (a0 || a1) {
-                    bf16x4 pa0, pa1;
+                    const bf16x4 zero4 = {0, 0, 0, 0};
+                    bf16x4 pa0 = zero4, pa1 = zero4, vb0 = zero4, vb1 = zero4;
+                    if (a0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        pa0[r] = (short)f2bf(st[j0][r]);
-                        pa1[r] = (short)f2bf(st[j1 < kMaxTiles ? j1 : j0][r]);
+                        for (int r = 0; r < 4; ++r) pa0[r] = (short)f2bf(st[j0][r]);
+                        vb0 = lds4_tr(Vs_all + ho, j0 * 16 + 4 * g, c);
                     }
-                    // (an absent tile is read from the present one: always initialised rows)
-                    const bf16x4 vb0 = lds4_tr(Vs_all + ho, (a0 ? j0 : j1) * 16 + 4 * g, c);
-                    const bf16x4 vb1 = lds4_tr(Vs_all + ho, (a1 ? j1 : j0) * 16 + 4 * g, c);
-                    o = mfma32_pair(keep_if(a0, pa0), keep_if(a1, pa1), keep_if(a0, vb0), keep_if(a1, vb1), o);
+                    if (a1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) pa1[r] = (short)f2bf(st[j1 < kMaxTiles ? j1 : j0][r]);
+                        vb1 = lds4_tr(Vs_all + ho, j1 * 16 + 4 * g, c);
+                    }
+                    o = mfma32_pair(pa0, pa1, keep_if(a0, vb0), keep_if(a1, vb1), o);
                 }
             }
             // C layout: row i = 4g + r, col d = c ; the row statistics live in lane (i & 15)
@@ -640,8 +651,7 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             const float Li = Ls[it * 16 + c], Di = Ds[it * 16 + c];
             const int wq = wid[it * 16 + c];
             f32x4 dq = {0, 0, 0, 0};
-            // dS^T tile of key tile jt for this wave's query tile (A operand of dQ += dS K: row i = c, k = key)
-            auto ds_tile = [&](int jt) {
+            for (int jt = jlo; jt <= jhi; ++jt) {
                 const bf16x4 ka = lds4(Ks + (jt * 16 + c) * kDh + 4 * g);
                 const bf16x4 va = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
@@ -655,16 +665,9 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                     const float p = (Wr[r] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
                     dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
                 }
-                return dsa;
-            };
-            for (int jt = jlo; jt <= jhi; jt += 2) {
-                const bool two = jt + 1 <= jhi;
-                const int jt1 = two ? jt + 1 : jt;                            // (absent partner: recomputed from tile jt, zeroed)
-                const bf16x4 ds0 = ds_tile(jt);
-                const bf16x4 kb0 = lds4_tr(Ks, jt * 16 + 4 * g, c);        // B = K[k = key][col = d]
-                const bf16x4 ds1 = ds_tile(jt1);
-                const bf16x4 kb1 = lds4_tr(Ks, jt1 * 16 + 4 * g, c);
-                dq = mfma32_pair(ds0, keep_if(two, ds1), kb0, keep_if(two, kb1), dq);
+                // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
+                const bf16x4 kb = lds4_tr(Ks, jt * 16 + 4 * g, c);
+                dq = mfma16(dsa, kb, dq);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) G1[(it * 16 + 4 * g + r) * kDh + c] = f2bf(dq[r]);
@@ -682,13 +685,13 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
             const bf16x4 vb = lds4(Vs + (jt * 16 + c) * kDh + 4 * g);
             const int wk = wid[jt * 16 + c];
             f32x4 dk = {0, 0, 0, 0}, dv = {0, 0, 0, 0};
-            // P^T / dS^T tiles of query tile `it` for this wave's key tile (A operands: row j = c, k = query)
-            auto p_ds_tile = [&](int it, bf16x4* pa, bf16x4* dsa) {
+            for (int it = ilo; it <= ihi; ++it) {
                 const bf16x4 qa = lds4(Qs + (it * 16 + c) * kDh + 4 * g);
                 const bf16x4 doa = lds4(dOs + (it * 16 + c) * kDh + 4 * g);
                 f32x4 z = {0, 0, 0, 0};
                 const f32x4 s = mfma16(qa, kb, z);       // [i][j]
                 const f32x4 dp = mfma16(doa, vb, z);     // dP[i][j]
+                bf16x4 pa, dsa;
                 const int i0 = it * 16 + 4 * g;                       // 4 consecutive queries: one 16-byte LDS read each
                 const float4 L4 = *reinterpret_cast<const float4*>(Ls + i0), D4 = *reinterpret_cast<const float4*>(Ds + i0);
                 const int4 W4 = *reinterpret_cast<const int4*>(wid + i0);
@@ -697,22 +700,15 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = (Wr[r] == wk) ? __expf(s[r] * scale - Lr[r]) : 0.0f;
-                    (*pa)[r] = (short)f2bf(p);
-                    (*dsa)[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
+                    pa[r] = (short)f2bf(p);
+                    dsa[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
                 }
-            };
-            for (int it = ilo; it <= ihi; it += 2) {
-                const bool two = it + 1 <= ihi;
-                const int it1 = two ? it + 1 : it;                            // (absent partner: recomputed from tile it, zeroed)
-                bf16x4 pa0, ds0, pa1, ds1;
-                p_ds_tile(it, &pa0, &ds0);
-                const bf16x4 dob0 = lds4_tr(dOs, it * 16 + 4 * g, c);      // B = dO[k = query][col = d]
-                const bf16x4 qb0 = lds4_tr(Qs, it * 16 + 4 * g, c);        // B = Q[k = query][col = d]
-                p_ds_tile(it1, &pa1, &ds1);
-                const bf16x4 dob1 = lds4_tr(dOs, it1 * 16 + 4 * g, c);
-                const bf16x4 qb1 = lds4_tr(Qs, it1 * 16 + 4 * g, c);
-                dv = mfma32_pair(pa0, keep_if(two, pa1), dob0, keep_if(two, dob1), dv);   // dV[j][d] += sum_i P[i][j] dO[i][d]
-                dk = mfma32_pair(ds0, keep_if(two, ds1), qb0, keep_if(two, qb1), dk);     // dK[j][d] += sum_i dS[i][j] Q[i][d]
+                // dV[j][d] += sum_i P[i][j] dO[i][d] : A = P^T (row j = c, k = i), B = dO[k=i][col=d] from dO^T
+                const bf16x4 dob = lds4_tr(dOs, it * 16 + 4 * g, c);
+                dv = mfma16(pa, dob, dv);
+                // dK[j][d] += sum_i dS[i][j] Q[i][d]
+                const bf16x4 qb = lds4_tr(Qs, it * 16 + 4 * g, c);
+                dk = mfma16(dsa, qb, dk);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
