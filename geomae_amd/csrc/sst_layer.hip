@@ -61,6 +61,9 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
 constexpr int kLayBlocked = 1;    // tensors only these kernels exchange: qkv, attn, the saved activations, the backward slabs
 constexpr int kLayXBlocked = 2;   // the layer input x (residual stream)
 constexpr int kLayZBlocked = 4;   // the layer output z
+constexpr int kLaySavedBf16 = 8;  // the saved normalised activations xhat1 / xhat2 are bf16 [n,128] (the stacks; the per-op
+                                  // C ABI documents fp32): 1 KB less per token and layer each way, the backward reads them as
+                                  // the LayerNorm's x-hat and re-derives y = xhat1 * g1 + be1 -- a bf16 GEMM operand anyway
 
 struct LayerW {
     const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
@@ -70,6 +73,27 @@ struct LayerW {
 // ------------------------------------------------------------------------------------------------
 // F1: qkv = [(x + pos) Wqk^T + bqk | x Wv^T + bv]  ->  bf16 [n, 384]
 // ------------------------------------------------------------------------------------------------
+// saved x-hat rows: fp32 (C ABI) or bf16 (kLaySavedBf16); `half_cols`: the pair form's 64-column halves
+__device__ __forceinline__ void store_xhat(float* dst, int n, int tok, const f32x4 (&u)[8], int lane, bool blk, bool as_bf16) {
+    if (as_bf16) store_rows_bf16<128>(reinterpret_cast<bf16_t*>(dst), n, tok, 128, 0, u, lane, blk);
+    else store_rows_f32<128>(dst, n, tok, u, lane, blk);
+}
+__device__ __forceinline__ void store_xhat_half(float* dst, int n, int tok, int h, const f32x4 (&u)[4], int lane, bool blk,
+                                                bool as_bf16) {
+    if (as_bf16) store_rows_bf16<64>(reinterpret_cast<bf16_t*>(dst), n, tok, 128, 64 * h, u, lane, blk);
+    else store_rows_f32_cols<64>(dst, n, tok, 128, 64 * h, u, lane, blk);
+}
+__device__ __forceinline__ void load_xhat(const float* src, int n, int tok, f32x4 (&u)[8], int lane, bool blk, bool as_bf16) {
+    if (as_bf16) {
+        uint2 p[8];
+        load_rows_bf16<128>(reinterpret_cast<const bf16_t*>(src), n, tok, 128, 0, p, lane, blk);
+#pragma unroll
+        for (int ct = 0; ct < 8; ++ct) u[ct] = unpack4(p[ct]);
+    } else {
+        load_rows_f32<128>(src, n, tok, u, lane, blk);
+    }
+}
+
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_qkv_fwd_kernel(const float* __restrict__ x,
                                                                 const int32_t* __restrict__ tok_pos,
                                                                 const float* __restrict__ pos_table, LayerW W,
@@ -215,7 +239,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
     layer_norm_t(u, eps, &r1);
-    if (xh1_out) store_rows_f32<128>(xh1_out, n, tok, u, lane, blk);
+    if (xh1_out) store_xhat(xh1_out, n, tok, u, lane, blk, lay & kLaySavedBf16);
     affine_t(u, prm + kPrmG1, prm + kPrmBe1, y, lane);
     uint2 hb[16];
     WStage<256, 128> s_w2;
@@ -247,7 +271,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
     layer_norm_t(u, eps, &r2);
-    if (xh2_out) store_rows_f32<128>(xh2_out, n, tok, u, lane, blk);
+    if (xh2_out) store_xhat(xh2_out, n, tok, u, lane, blk, lay & kLaySavedBf16);
     if (rstd_out && (lane >> 4) == 0)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
                                               tok * 8, 0, 0);
@@ -342,7 +366,7 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     if (xh1_out) {
         f32x4 mine[4];
         half_of<4>(u, h, mine);
-        store_rows_f32_cols<64>(xh1_out, n, tok, 128, 64 * h, mine, lane, blk);
+        store_xhat_half(xh1_out, n, tok, h, mine, lane, blk, lay & kLaySavedBf16);
     }
     affine_t(u, prm + kPrmG1, prm + kPrmBe1, y, lane);
     uint2 hb[16];
@@ -403,7 +427,7 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
     if (xh2_out) {
         f32x4 mine[4];
         half_of<4>(u, h, mine);
-        store_rows_f32_cols<64>(xh2_out, n, tok, 128, 64 * h, mine, lane, blk);
+        store_xhat_half(xh2_out, n, tok, h, mine, lane, blk, lay & kLaySavedBf16);
     }
     if (rstd_out && h == 0 && (lane >> 4) == 0)
         __builtin_amdgcn_raw_buffer_store_b64(u32x2{__float_as_uint(r1), __float_as_uint(r2)}, rows_rsrc(rstd_out, n, 8),
@@ -550,7 +574,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     // ---- LN2 backward
     {
         f32x4 xh2[8];
-        load_rows_f32<128>(xh2_in, n, tok, xh2, lane, blk);
+        load_xhat(xh2_in, n, tok, xh2, lane, blk, A.lay & kLaySavedBf16);
         stage_issue<128, 256>(W.w2T, s_w2T);                          // lands under the LayerNorm arithmetic
         if (A.up_dqkv) __syncthreads();                               // B1's last matrix consumed by every wave
         ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane, valid);   // d gamma2, d beta2
@@ -593,7 +617,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     }
     GEOMAE_STAMP(6);
     f32x4 xh1[8];
-    load_rows_f32<128>(xh1_in, n, tok, xh1, lane, blk);               // in flight under the GEMM
+    load_xhat(xh1_in, n, tok, xh1, lane, blk, A.lay & kLaySavedBf16);  // in flight under the GEMM
     gemm_staged<256, 128>(s_w1T, smem, dhpb, dv, lane, 7);            // dv now holds dy
     GEOMAE_STAMP(10);
     WStage<128, 128> s_woT;

@@ -37,7 +37,12 @@ struct SavedOffsets {
     int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
 };
 // layout flags of sst_layer.hip (kLayBlocked / kLayXBlocked / kLayZBlocked)
-constexpr int kBlk = 1, kXBlk = 2, kZBlk = 4;
+constexpr int kBlk = 1, kXBlk = 2, kZBlk = 4, kSavedBf16 = 8;
+// bf16 saved x-hat rows (sst_layer.hip kLaySavedBf16); GEOMAE_SAVED_F32=1 keeps them fp32 (A/B runs, parity checks)
+static int saved_flag() {
+    static const int f = [] { const char* e = getenv("GEOMAE_SAVED_F32"); return (e && e[0] == '1') ? 0 : kSavedBf16; }();
+    return f;
+}
 
 // The stack's own buffers are tile-blocked ([n/16][C/16][16][16], sst_device.h "Row layouts"): sized for ceil16(n) rows
 static SavedOffsets saved_offsets(int64_t n, int heads) {
@@ -177,7 +182,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         float* z = (l + 1 < num_layers) ? (float*)(sv + so.stride + so.x) : z_out;
         const bool next = l + 1 < num_layers;
         // everything between the stack's input copy and its output is tile-blocked; z of the last layer is the output
-        LayerLayoutScope lay(kBlk | kXBlk | (next ? kZBlk : 0));
+        LayerLayoutScope lay(kBlk | kXBlk | (next ? kZBlk : 0) | saved_flag());
         if (l == 0) {
             Timed t(profiler, GEOMAE_KERNEL_QKV_FWD, stream);
             set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
@@ -244,7 +249,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         const int set = l & 1;
         char* ws = w + sc.set0 + set * sc.set_bytes;
         const bool top = l + 1 == num_layers;
-        LayerLayoutScope lay(kBlk);                 // dz (top layer) and dx_out are the row-major boundary tensors
+        LayerLayoutScope lay(kBlk | saved_flag());  // dz (top layer) and dx_out are the row-major boundary tensors
         const char* ws_up = w + sc.set0 + ((l + 1) & 1) * sc.set_bytes;       // slabs of the layer above
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
