@@ -110,6 +110,11 @@ SIGNATURES = {
     "geomae_grid_size": (ctypes.c_int, [F3, F3, POINTER(c_int32)]),
     "geomae_dynamic_voxelize": (ctypes.c_int, [P, c_int64, c_int32, F3, F3, P, P]),
     "geomae_voxelize_batch3": (ctypes.c_int, [P, c_int64, c_int32, P, c_int32, F3, F3, F3, F3, P, P, P, P]),
+    "geomae_voxelize_frames3": (ctypes.c_int, [POINTER(c_void_p), POINTER(c_int64), c_int32, c_int32, F3, F3, F3, F3, P, P, P, P, P,
+                                               P, c_int64, P, c_int64, P]),
+    "geomae_pillar_segment_ex": (ctypes.c_int, [P, c_int32, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P,
+                                                P, P, P, c_int64, P, c_int32, P]),
+    "geomae_pillar_segment_scan_state_bytes": (c_int64, [c_int32, c_int32, c_int32, c_int32]),
     "geomae_pillar_segment_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32]),
     "geomae_pillar_segment": (ctypes.c_int, [P, c_int64, c_int32, c_int32, c_int32, c_int32, P, P, P, P, P, P, P,
                                              P, c_int64, P]),
@@ -164,6 +169,8 @@ SIGNATURES = {
     "geomae_pack_weights": (ctypes.c_int, [P, P, c_int32, c_int64, P, P, P]),
     "geomae_heads_loss": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_gather_token_coors": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, P, P]),
+    "geomae_gather_token_coors_zero": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, P, P, c_int64, P]),
+    "geomae_window_build_batch_table_bytes": (c_int64, [POINTER(c_int32), c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_set_accumulators_prezeroed": (ctypes.c_int, [c_int32]),
     "geomae_heads_loss_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_sst_set_pair_kernels": (None, [c_int32]),

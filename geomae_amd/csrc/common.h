@@ -69,6 +69,10 @@ float* dw_partial();
 struct SstInputMap { const float* src; int n_src; const float* fill; const int32_t* rows; };
 void set_input_map(const SstInputMap& m);
 SstInputMap input_map();
+// geomae_window_build_batch of this host thread finds its window tables (the first table bytes of its workspace) already
+// zero: the step engine clears them with the token-coordinate gather that precedes the build (no memset kernel).
+void set_window_tables_prezeroed(bool on);
+bool window_tables_prezeroed();
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

@@ -34,6 +34,9 @@ int first_live_row() { return g_first_live_row; }
 static thread_local float* g_dw_partial = nullptr;
 void set_dw_partial(float* ws) { g_dw_partial = ws; }
 float* dw_partial() { return g_dw_partial; }
+static thread_local bool g_win_prezeroed = false;
+void set_window_tables_prezeroed(bool on) { g_win_prezeroed = on; }
+bool window_tables_prezeroed() { return g_win_prezeroed; }
 static thread_local bool g_prezeroed = false;
 bool accumulators_prezeroed() { return g_prezeroed; }
 }  // namespace geomae

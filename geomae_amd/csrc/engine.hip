@@ -43,6 +43,18 @@ __global__ void token_rows_from_ids_kernel(const int32_t* __restrict__ ids_keep,
     if (i < n_keep) token_row[ids_keep[i]] = i;
     else if (i < n_keep + n_mask) token_row[ids_mask[i - n_keep]] = i;
 }
+// arena clears: one launch of our own per arena (hipMemsetAsync is a runtime kernel of the same cost; this one can be
+// seen and accounted for in the profile like every other kernel of the step)
+__global__ __launch_bounds__(256) void zero_arena_kernel(uint4* __restrict__ p, int64_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (int64_t i = blockIdx.x * (int64_t)256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = z;
+}
+int zero_arena(void* p, int64_t bytes, hipStream_t stream) {
+    if (bytes <= 0) return GEOMAE_OK;
+    if ((bytes & 15) || ((uintptr_t)p & 15)) { GEOMAE_HIP(hipMemsetAsync(p, 0, (size_t)bytes, stream)); return GEOMAE_OK; }
+    hipLaunchKernelGGL(zero_arena_kernel, dim3(stream_grid(bytes / 16, 256)), dim3(256), 0, stream, (uint4*)p, bytes / 16);
+    return check_launch("zero_arena_kernel");
+}
 int scale_f32(float* x, int n, float s, hipStream_t stream) {
     hipLaunchKernelGGL(scale_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, s);
     return check_launch("scale_f32_kernel");
@@ -252,18 +264,33 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
                   (long long)e->stage_bytes);
         return GEOMAE_ERR_WORKSPACE;
     }
-    // the reference concatenates the per-sample tensors (ssl.py:320-329 torch.cat); so does this
-    for (int i = 0; i < c.batch_size; ++i)
-        if (sizes[i] > 0)
-            GEOMAE_HIP(hipMemcpyAsync(b.points + (int64_t)b.host_offs[i] * c.num_features, frames[i],
-                                      (size_t)sizes[i] * c.num_features * 4, hipMemcpyDeviceToDevice, s));
-    GEOMAE_HIP(hipMemcpyAsync(b.boffs, b.host_offs, (size_t)(c.batch_size + 1) * 4, hipMemcpyHostToDevice, s));
-    ENG_CALL(geomae_voxelize_batch3(b.points, N, c.num_features, b.boffs, c.batch_size, c.targets.voxel_size_top,
-                                    c.targets.voxel_size_med, c.targets.voxel_size_low, c.targets.coors_range,
-                                    b.coors_top, b.coors_med, b.coors_low, s));
-    ENG_CALL(geomae_pillar_segment(b.coors_top, N, c.batch_size, e->gz, e->gy, e->gx, b.cell_table, b.voxel_coors, b.inv,
-                                   b.order, b.seg_start, b.sample_start, b.num_pillars, seg_ws, wsb, s));
-    GEOMAE_HIP(hipMemcpyAsync(b.host_counts, b.sample_start, (size_t)(c.batch_size + 1) * 4, hipMemcpyDeviceToHost, s));
+    // the reference concatenates the per-sample tensors (ssl.py:320-329 torch.cat) and voxelizes three times; here ONE
+    // launch reads the frames where they lie, writes the concatenated rows + the three coordinate arrays and clears the
+    // pillar table and the scan state on the side; the pillar sort is three more launches, and the per-sample pillar
+    // counts land in pinned host memory from the scan kernel itself (no copy command).  Round 2: B + 1 copies, a
+    // memset, voxelize, five segment kernels, a device-to-host copy.
+    const int64_t scan_state = geomae_pillar_segment_scan_state_bytes(c.batch_size, e->gz, e->gy, e->gx);
+    if (c.batch_size <= 32) {
+        ENG_CALL(geomae_voxelize_frames3(frames, sizes, c.batch_size, c.num_features, c.targets.voxel_size_top,
+                                         c.targets.voxel_size_med, c.targets.voxel_size_low, c.targets.coors_range, b.points,
+                                         b.boffs, b.coors_top, b.coors_med, b.coors_low, b.cell_table,
+                                         al256((int64_t)e->cells * 4), seg_ws, scan_state, s));
+        ENG_CALL(geomae_pillar_segment_ex(b.coors_top, 4, N, c.batch_size, e->gz, e->gy, e->gx, b.cell_table, b.voxel_coors,
+                                          b.inv, b.order, b.seg_start, b.sample_start, b.num_pillars, seg_ws, wsb,
+                                          b.host_counts, 1, s));
+    } else {
+        for (int i = 0; i < c.batch_size; ++i)
+            if (sizes[i] > 0)
+                GEOMAE_HIP(hipMemcpyAsync(b.points + (int64_t)b.host_offs[i] * c.num_features, frames[i],
+                                          (size_t)sizes[i] * c.num_features * 4, hipMemcpyDeviceToDevice, s));
+        GEOMAE_HIP(hipMemcpyAsync(b.boffs, b.host_offs, (size_t)(c.batch_size + 1) * 4, hipMemcpyHostToDevice, s));
+        ENG_CALL(geomae_voxelize_batch3(b.points, N, c.num_features, b.boffs, c.batch_size, c.targets.voxel_size_top,
+                                        c.targets.voxel_size_med, c.targets.voxel_size_low, c.targets.coors_range,
+                                        b.coors_top, b.coors_med, b.coors_low, s));
+        ENG_CALL(geomae_pillar_segment(b.coors_top, N, c.batch_size, e->gz, e->gy, e->gx, b.cell_table, b.voxel_coors, b.inv,
+                                       b.order, b.seg_start, b.sample_start, b.num_pillars, seg_ws, wsb, s));
+        GEOMAE_HIP(hipMemcpyAsync(b.host_counts, b.sample_start, (size_t)(c.batch_size + 1) * 4, hipMemcpyDeviceToHost, s));
+    }
     GEOMAE_HIP(hipEventRecord(b.readback, s));
     ENG_CALL(geomae_segment_mean_xyz_sorted(b.points, c.num_features, b.order, b.seg_start, b.num_pillars, b.cap, b.mean, s));
     ENG_CALL(geomae_vfe_prepare(b.points, c.num_features, N, b.order, b.inv, b.mean, b.voxel_coors, c.vfe_voxel_size,
@@ -491,7 +518,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     const bool was_packed = e->packed_fresh;
     if (!was_packed) ENG_CALL(pack_weights(e, geo));
     e->packed_fresh = false;
-    ENG_CALL(geomae_gather_token_coors(b.ids_keep, nk, b.ids_mask, nm, b.voxel_coors, coors_all, nullptr, geo));
+    const int64_t win_tables = geomae_window_build_batch_table_bytes(ns, 4, c.batch_size, &c.window);
+    GEOMAE_REQUIRE(win_tables >= 0 && win_tables <= win_wsb, "pretrain_step: bad window table size");
+    ENG_CALL(geomae_gather_token_coors_zero(b.ids_keep, nk, b.ids_mask, nm, b.voxel_coors, coors_all, nullptr, win_ws,
+                                            win_tables, geo));
     {
         GeomaeWindowBuildJob jobs[4];
         for (int k = 0; k < 4; ++k) {
@@ -500,7 +530,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
             jobs[k].tok_pos = lay[k].tok_pos; jobs[k].num_windows = lay[k].num_windows; jobs[k].bun_start = lay[k].bun_start;
             jobs[k].num_bundles = lay[k].num_bundles; jobs[k].bun_tok = lay[k].bun_tok; jobs[k].pos_info = lay[k].pos_info;
         }
-        ENG_CALL(geomae_window_build_batch(jobs, 4, c.batch_size, &c.window, win_ws, win_wsb, geo));
+        set_window_tables_prezeroed(true);         // (cleared by the gather above)
+        const int rc_win = geomae_window_build_batch(jobs, 4, c.batch_size, &c.window, win_ws, win_wsb, geo);
+        set_window_tables_prezeroed(false);
+        ENG_CALL(rc_win);
     }
     if (was_packed) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kPacked], 0));
     GEOMAE_HIP(hipEventRecord(e->ev[kLayouts], geo));
@@ -524,7 +557,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // ---------------- main: VFE forward
     e->phase_last = -1;
     mark(e, pStart, main);
-    GEOMAE_HIP(hipMemsetAsync(zf0, 0, zf_bytes, main));
+    ENG_CALL(zero_arena(zf0, zf_bytes, main));
     GeomaeVfeArgs va;
     va.feat_sorted = b.feat; va.pid_sorted = b.pid; va.seg_start = b.seg_start;
     va.num_points = N; va.max_pillars = V;
@@ -539,8 +572,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(order_after(e, kVfeDone, main, aux));
 
     // ---------------- dec_b: late zero arena (its other work of the step started before the VFE forward, above)
-    GEOMAE_HIP(hipMemsetAsync(zl0, 0, zl_bytes, aux));
-    GEOMAE_HIP(hipMemsetAsync(losses, 0, 32, aux));
+    ENG_CALL(zero_arena(zl0, zl_bytes, aux));
+    ENG_CALL(zero_arena(losses, 32, aux));
     const int nxt = 1 - e->pending;
 
     // ---------------- main: encoder, decoders
@@ -596,8 +629,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     double* use_bs0 = fold ? bs0 : m.bn_sync_bsums0;
     if (!fold) {
         GEOMAE_REQUIRE(use_bs1 && use_bs0, "pretrain: world_size > 1 needs bn_sync_bsums buffers");
-        GEOMAE_HIP(hipMemsetAsync(use_bs1, 0, 256 * 8, main));
-        GEOMAE_HIP(hipMemsetAsync(use_bs0, 0, 128 * 8, main));
+        ENG_CALL(zero_arena(use_bs1, 256 * 8, main));
+        ENG_CALL(zero_arena(use_bs0, 128 * 8, main));
     }
     ENG_CALL(geomae_vfe_backward_stats(&va, &bn, m0, vf, d_vf, use_bs1, main));
     mark(e, pVfeStats, main);

@@ -321,7 +321,10 @@ __global__ __launch_bounds__(256) void gather_token_coors_kernel(const int32_t* 
                                                                  const int32_t* __restrict__ ids_mask, int n_mask,
                                                                  const int4* __restrict__ voxel_coors,
                                                                  int4* __restrict__ coors_out,
-                                                                 long long* __restrict__ ids_keep_i64) {
+                                                                 long long* __restrict__ ids_keep_i64,
+                                                                 uint4* __restrict__ zero, long long zero_n16) {
+    for (long long e = blockIdx.x * 256 + threadIdx.x; e < zero_n16; e += (long long)gridDim.x * 256)
+        zero[e] = make_uint4(0u, 0u, 0u, 0u);          // (the window tables of the build that follows)
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n_keep + n_mask; i += gridDim.x * 256) {
         const int id = i < n_keep ? ids_keep[i] : ids_mask[i - n_keep];
         coors_out[i] = voxel_coors[id];
@@ -336,12 +339,23 @@ using namespace geomae;
 extern "C" int geomae_gather_token_coors(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask,
                                          int32_t num_mask, const int32_t* voxel_coors, int32_t* coors_out,
                                          int64_t* ids_keep_i64, hipStream_t stream) {
+    return geomae_gather_token_coors_zero(ids_keep, num_keep, ids_mask, num_mask, voxel_coors, coors_out, ids_keep_i64,
+                                          nullptr, 0, stream);
+}
+
+extern "C" int geomae_gather_token_coors_zero(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask,
+                                              int32_t num_mask, const int32_t* voxel_coors, int32_t* coors_out,
+                                              int64_t* ids_keep_i64, void* zero, int64_t zero_bytes, hipStream_t stream) {
     GEOMAE_REQUIRE(num_keep >= 0 && num_mask >= 0, "gather_token_coors: bad sizes");
-    if (num_keep + num_mask == 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE((ids_keep || num_keep == 0) && (ids_mask || num_mask == 0) && voxel_coors && coors_out,
-                   "gather_token_coors: null argument");
-    hipLaunchKernelGGL(gather_token_coors_kernel, dim3(stream_grid(num_keep + num_mask, 256)), dim3(256), 0, stream, ids_keep,
-                       num_keep, ids_mask, num_mask, (const int4*)voxel_coors, (int4*)coors_out, (long long*)ids_keep_i64);
+    GEOMAE_REQUIRE(zero_bytes >= 0 && zero_bytes % 16 == 0 && (zero || zero_bytes == 0) && ((uintptr_t)zero % 16) == 0,
+                   "gather_token_coors: the zero range must be a 16-byte aligned multiple of 16 bytes");
+    if (num_keep + num_mask == 0 && zero_bytes == 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(num_keep + num_mask == 0 || ((ids_keep || num_keep == 0) && (ids_mask || num_mask == 0) && voxel_coors &&
+                   coors_out), "gather_token_coors: null argument");
+    const int64_t work = num_keep + num_mask > zero_bytes / 16 ? num_keep + num_mask : zero_bytes / 16;
+    hipLaunchKernelGGL(gather_token_coors_kernel, dim3(stream_grid(work, 256)), dim3(256), 0, stream, ids_keep,
+                       num_keep, ids_mask, num_mask, (const int4*)voxel_coors, (int4*)coors_out, (long long*)ids_keep_i64,
+                       (uint4*)zero, (long long)(zero_bytes / 16));
     return check_launch("gather_token_coors_kernel");
 }
 

@@ -6,11 +6,12 @@
 // and torch_scatter's mean/max by ONE counting sort per batch over the dense cell table
 // (B*gz*gy*gx int32, 2.5 MB for the nuScenes config):
 //   1. hist   : rank_in_cell[i] = atomicAdd(table[key_i], 1)          (1 atomic / point)
-//   2. scan   : exclusive scans of (occupied, count) over cells -> pillar id, segment start;
-//               pillar ids increase with the cell key, i.e. exactly the lexicographic
+//   2. scan   : ONE pass over the cells (decoupled look-back): exclusive scans of (occupied, count) -> pillar id,
+//               segment start; pillar ids increase with the cell key, i.e. exactly the lexicographic
 //               (b, z, y, x) order torch.unique(dim=0) returns; table[cell] <- pillar id | -1
 //               (kept: it is the neighbour / parent lookup table of the target kernels)
 //   3. place  : inv[i] = table[key_i];  order[start[inv[i]] + rank_in_cell[i]] = i
+// Three launches (round 2: five -- tile totals, a single-workgroup scan of them, emit -- plus a memset kernel).
 // Segmented reductions then walk contiguous point ranges (no float atomics):
 //   mean  -> 2^-32 fixed-point int64 sums: order-independent, deterministic
 //   max   -> exact in any order; arg-max kept for the backward pass
@@ -71,100 +72,123 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* smem /*>=
     return woff + incl - v;
 }
 
-// pass 1: per-tile totals of (occupied cells, points)
-__global__ __launch_bounds__(kBlk) void scan_reduce_kernel(const int32_t* __restrict__ table, int64_t cells,
-                                                           int2* __restrict__ tile_sums) {
-    __shared__ int sm[2 * (kBlk / 64)];
-    const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
-    int occ = 0, cnt = 0;
-#pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int64_t c = base + k;
-        const int v = c < cells ? table[c] : 0;
-        occ += v > 0;
-        cnt += v;
-    }
-    occ = wave_sum(occ);
-    cnt = wave_sum(cnt);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) { sm[w] = occ; sm[kBlk / 64 + w] = cnt; }
+// ---- single-pass scan of (occupied, count) over the cell table with decoupled look-back.
+// Tile t publishes one 64-bit status word: [flag:2 | occupied:31 | points:31], flag 1 = the tile's own totals
+// (published as soon as they are known), flag 2 = the inclusive prefix up to and including the tile.  A tile finds its
+// exclusive prefix by walking back over the status words: inclusive prefixes end the walk, aggregates are added and the
+// walk goes on, zero (= not yet published) is polled.  The value travels INSIDE the word that carries the flag, so no
+// fence is needed (an agent-scope fence is an L2 write-back on this 8-XCD part, ~20 us per launch: DESIGN section 4);
+// the words are written and read with agent-scope atomics, which bypass the non-coherent per-XCD L2.  Tiles are handed
+// out by a ticket counter, so a tile's predecessors have always started (no dependence on the dispatch order).
+// status [tiles] + ticket live in the caller's workspace and must be ZERO at launch.
+constexpr unsigned long long kFlagAgg = 1ull << 62, kFlagIncl = 2ull << 62, kValMask = (1ull << 31) - 1;
+__device__ __forceinline__ unsigned long long pack_status(unsigned long long flag, int occ, int cnt) {
+    return flag | ((unsigned long long)(unsigned)occ << 31) | (unsigned long long)(unsigned)cnt;
+}
+
+__global__ __launch_bounds__(kBlk) void scan_lookback_kernel(int32_t* __restrict__ table, int64_t cells, int n_tiles,
+                                                             unsigned long long* __restrict__ status,
+                                                             unsigned int* __restrict__ ticket, int gz, int gy, int gx,
+                                                             int n_batch, int32_t* __restrict__ voxel_coors,
+                                                             int32_t* __restrict__ seg_start,
+                                                             int32_t* __restrict__ sample_start,
+                                                             int32_t* __restrict__ sample_start_mirror,
+                                                             int32_t* __restrict__ num_pillars) {
+    __shared__ int sm[8];
+    __shared__ int s_tile, s_off_occ, s_off_cnt;
+    if (threadIdx.x == 0) s_tile = (int)atomicAdd(ticket, 1u);
     __syncthreads();
-    if (threadIdx.x == 0) {
-        int o = 0, c = 0;
-        for (int k = 0; k < kBlk / 64; ++k) { o += sm[k]; c += sm[kBlk / 64 + k]; }
-        tile_sums[blockIdx.x] = make_int2(o, c);
-    }
-}
-
-// pass 2: one workgroup scans the tile totals in place (exclusive) and publishes V
-__global__ __launch_bounds__(kBlk) void scan_tiles_kernel(int2* __restrict__ tile_sums, int n_tiles,
-                                                          int32_t* __restrict__ num_pillars) {
-    __shared__ int sm[8];
-    int run_o = 0, run_c = 0;
-    for (int base = 0; base < n_tiles; base += kBlk) {
-        const int t = base + threadIdx.x;
-        int2 v = t < n_tiles ? tile_sums[t] : make_int2(0, 0);
-        int tot_o, tot_c;
-        const int eo = block_excl_scan(v.x, &tot_o, sm);
-        const int ec = block_excl_scan(v.y, &tot_c, sm);
-        if (t < n_tiles) tile_sums[t] = make_int2(run_o + eo, run_c + ec);
-        run_o += tot_o;
-        run_c += tot_c;
-    }
-    if (threadIdx.x == 0) {
-        num_pillars[0] = run_o;
-        tile_sums[n_tiles] = make_int2(run_o, run_c);      // totals: pillars, valid points
-    }
-}
-
-// pass 3: per-cell pillar id / segment start; emit pillar coordinates; table <- pillar id | -1
-__global__ __launch_bounds__(kBlk) void scan_emit_kernel(int32_t* __restrict__ table, int64_t cells,
-                                                         const int2* __restrict__ tile_sums, int gz, int gy,
-                                                         int gx, int n_batch, int32_t* __restrict__ voxel_coors,
-                                                         int32_t* __restrict__ seg_start,
-                                                         int32_t* __restrict__ sample_start, int64_t n_points,
-                                                         const int32_t* __restrict__ num_pillars) {
-    __shared__ int sm[8];
-    const int64_t base = (int64_t)blockIdx.x * kTile + (int64_t)threadIdx.x * kItems;
+    const int tile = s_tile;
+    const int64_t base = (int64_t)tile * kTile + (int64_t)threadIdx.x * kItems;
     int v[kItems];
+    if (base + kItems <= cells) {
+        const int4 q = *reinterpret_cast<const int4*>(table + base);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k) v[k] = base + k < cells ? table[base + k] : 0;
+    }
     int occ = 0, cnt = 0;
 #pragma unroll
-    for (int k = 0; k < kItems; ++k) {
-        const int64_t c = base + k;
-        v[k] = c < cells ? table[c] : 0;
-        occ += v[k] > 0;
-        cnt += v[k];
+    for (int k = 0; k < kItems; ++k) { occ += v[k] > 0; cnt += v[k]; }
+    int tot_occ, tot_cnt;
+    int eo = block_excl_scan(occ, &tot_occ, sm);
+    int ec = block_excl_scan(cnt, &tot_cnt, sm);
+    if (threadIdx.x < 64) {                      // wave 0: publish, then look back 64 tiles at a time
+        const int lane = threadIdx.x;
+        if (lane == 0)
+            __hip_atomic_store(status + tile, pack_status(tile == 0 ? kFlagIncl : kFlagAgg, tot_occ, tot_cnt), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        int run_occ = 0, run_cnt = 0;
+        int hi = tile;                           // tiles [hi - 64, hi) are inspected next
+        while (hi > 0) {
+            const int t = hi - 1 - lane;         // lane 0 = nearest predecessor
+            unsigned long long w = kFlagIncl;    // (lanes before tile 0 count as a zero inclusive prefix)
+            if (t >= 0) {
+                do {
+                    w = __hip_atomic_load(status + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } while ((w >> 62) == 0);
+            }
+            // nearest lane holding an inclusive prefix ends the walk: sum the aggregates in front of it and add it
+            const unsigned long long incl_mask = __ballot((w >> 62) == 2);
+            const int stop = incl_mask ? __ffsll((long long)incl_mask) - 1 : 64;      // first such lane
+            const bool use = lane <= stop && lane < 64;
+            int o = use ? (int)((w >> 31) & kValMask) : 0, c = use ? (int)(w & kValMask) : 0;
+            o = wave_sum(o);
+            c = wave_sum(c);
+            run_occ += o;
+            run_cnt += c;
+            if (incl_mask) break;
+            hi -= 64;
+        }
+        if (lane == 0) {
+            s_off_occ = run_occ;
+            s_off_cnt = run_cnt;
+            if (tile > 0)
+                __hip_atomic_store(status + tile, pack_status(kFlagIncl, run_occ + tot_occ, run_cnt + tot_cnt), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    int tot;
-    int eo = block_excl_scan(occ, &tot, sm);
-    int ec = block_excl_scan(cnt, &tot, sm);
-    const int2 off = tile_sums[blockIdx.x];
-    eo += off.x;
-    ec += off.y;
+    __syncthreads();
+    eo += s_off_occ;
+    ec += s_off_cnt;
     const int64_t cells_per_sample = (int64_t)gz * gy * gx;
 #pragma unroll
     for (int k = 0; k < kItems; ++k) {
         const int64_t c = base + k;
         if (c >= cells) break;
-        if (c % cells_per_sample == 0) sample_start[c / cells_per_sample] = eo;
-        if (v[k] > 0) {
+        if (c % cells_per_sample == 0) {
+            sample_start[c / cells_per_sample] = eo;
+            if (sample_start_mirror) sample_start_mirror[c / cells_per_sample] = eo;
+        }
+        const int pts = v[k];
+        if (pts > 0) {
             int64_t r = c;
             const int x = (int)(r % gx); r /= gx;
             const int y = (int)(r % gy); r /= gy;
             const int z = (int)(r % gz); r /= gz;
             reinterpret_cast<int4*>(voxel_coors)[eo] = make_int4((int)r, z, y, x);
             seg_start[eo] = ec;
-            table[c] = eo;
+            v[k] = eo;                            // table[cell] <- pillar id
             ++eo;
-            ec += v[k];
+            ec += pts;
         } else {
-            table[c] = -1;
+            v[k] = -1;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const int V = num_pillars[0];
+    if (base + kItems <= cells) {
+        *reinterpret_cast<int4*>(table + base) = make_int4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kItems; ++k)
+            if (base + k < cells) table[base + k] = v[k];
+    }
+    if (tile == n_tiles - 1 && threadIdx.x == 0) {
+        const int V = s_off_occ + tot_occ;
+        num_pillars[0] = V;
         sample_start[n_batch] = V;
-        seg_start[V] = tile_sums[gridDim.x].y;             // number of valid points (= n_points when none is dropped)
+        if (sample_start_mirror) sample_start_mirror[n_batch] = V;
+        seg_start[V] = s_off_cnt + tot_cnt;                 // number of valid points (= n_points when none is dropped)
     }
 }
 
@@ -224,13 +248,18 @@ __global__ void seg_max_bwd_kernel(const float* __restrict__ grad_out, const int
 
 using namespace geomae;
 
+// workspace layout: [status (tiles x 8 B) | ticket (8 B) | pad to 256 B][rank_in_cell (N x 4 B)]
+static int64_t scan_state_bytes(int64_t cells) {
+    const int64_t tiles = (cells + kTile - 1) / kTile;
+    return (tiles * 8 + 8 + 255) / 256 * 256;
+}
+
 extern "C" int64_t geomae_pillar_segment_workspace_bytes(int64_t num_points, int32_t batch_size, int32_t gz,
                                                          int32_t gy, int32_t gx) {
     const int64_t cells = (int64_t)batch_size * gz * gy * gx;
-    const int64_t tiles = (cells + kTile - 1) / kTile;
-    // rank_in_cell [n] int32 + tile sums [tiles + 1] int2, 256-byte aligned pieces
+    // scan state (tile status words + ticket) first, then rank_in_cell [n] int32; 256-byte aligned pieces
     auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    return al(num_points * 4) + al((tiles + 1) * 8);
+    return scan_state_bytes(cells) + al(num_points * 4);
 }
 
 extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, int32_t batch_size, int32_t gz,
@@ -242,11 +271,24 @@ extern "C" int geomae_pillar_segment(const int32_t* coors, int64_t num_points, i
                                     seg_start, sample_start, num_pillars, workspace, workspace_bytes, stream);
 }
 
+extern "C" int64_t geomae_pillar_segment_scan_state_bytes(int32_t batch_size, int32_t gz, int32_t gy, int32_t gx) {
+    return scan_state_bytes((int64_t)batch_size * gz * gy * gx);
+}
+
 extern "C" int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int64_t num_points, int32_t batch_size,
                                         int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors,
                                         int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
                                         int32_t* num_pillars, void* workspace, int64_t workspace_bytes,
                                         hipStream_t stream) {
+    return geomae_pillar_segment_ex(coors, ndim, num_points, batch_size, gz, gy, gx, cell_table, voxel_coors, inv, order,
+                                    seg_start, sample_start, num_pillars, workspace, workspace_bytes, nullptr, 0, stream);
+}
+
+extern "C" int geomae_pillar_segment_ex(const int32_t* coors, int32_t ndim, int64_t num_points, int32_t batch_size,
+                                        int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors,
+                                        int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
+                                        int32_t* num_pillars, void* workspace, int64_t workspace_bytes,
+                                        int32_t* sample_start_mirror, int32_t prezeroed, hipStream_t stream) {
     GEOMAE_REQUIRE(ndim == 4 || (ndim == 3 && batch_size == 1), "pillar_segment: coors are [N,4] (b,z,y,x) or [N,3] (z,y,x)");
     GEOMAE_REQUIRE(num_points >= 0 && batch_size >= 1 && gz >= 1 && gy >= 1 && gx >= 1, "pillar_segment: bad sizes");
     GEOMAE_REQUIRE(cell_table && voxel_coors && seg_start && sample_start && num_pillars,
@@ -258,20 +300,22 @@ extern "C" int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int6
         set_error("pillar_segment: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
         return GEOMAE_ERR_WORKSPACE;
     }
-    auto al = [](int64_t b) { return (b + 255) / 256 * 256; };
-    int32_t* rank_in_cell = (int32_t*)workspace;
-    int2* tile_sums = (int2*)((char*)workspace + al(num_points * 4));
+    const int64_t state = scan_state_bytes(cells);
     const int tiles = (int)((cells + kTile - 1) / kTile);
-    GEOMAE_HIP(hipMemsetAsync(cell_table, 0, cells * sizeof(int32_t), stream));
+    unsigned long long* status = (unsigned long long*)workspace;
+    unsigned int* ticket = (unsigned int*)(status + tiles);
+    int32_t* rank_in_cell = (int32_t*)((char*)workspace + state);
+    if (!prezeroed) {
+        GEOMAE_HIP(hipMemsetAsync(cell_table, 0, cells * sizeof(int32_t), stream));
+        GEOMAE_HIP(hipMemsetAsync(workspace, 0, (size_t)state, stream));
+    }
     if (num_points > 0) {
         GEOMAE_REQUIRE(coors && inv && order, "pillar_segment: null argument");
         hipLaunchKernelGGL(hist_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream, coors, num_points,
                            ndim, batch_size, gz, gy, gx, cell_table, rank_in_cell);
     }
-    hipLaunchKernelGGL(scan_reduce_kernel, dim3(tiles), dim3(kBlk), 0, stream, cell_table, cells, tile_sums);
-    hipLaunchKernelGGL(scan_tiles_kernel, dim3(1), dim3(kBlk), 0, stream, tile_sums, tiles, num_pillars);
-    hipLaunchKernelGGL(scan_emit_kernel, dim3(tiles), dim3(kBlk), 0, stream, cell_table, cells, tile_sums, gz, gy,
-                       gx, batch_size, voxel_coors, seg_start, sample_start, num_points, num_pillars);
+    hipLaunchKernelGGL(scan_lookback_kernel, dim3(tiles), dim3(kBlk), 0, stream, cell_table, cells, tiles, status, ticket,
+                       gz, gy, gx, batch_size, voxel_coors, seg_start, sample_start, sample_start_mirror, num_pillars);
     if (num_points > 0) {
         hipLaunchKernelGGL(place_kernel, dim3(stream_grid(num_points, kBlk)), dim3(kBlk), 0, stream, coors, num_points,
                            ndim, batch_size, gz, gy, gx, cell_table, rank_in_cell, seg_start, inv, order);

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(64) void centroid_targets_kernel(
     const int32_t* __restrict__ mask_counts, TargetCfg cfg, float* __restrict__ centroid_low,
     uint8_t* __restrict__ mask_low, float* __restrict__ centroid_med, uint8_t* __restrict__ mask_med,
     float* __restrict__ centroid_top, float* __restrict__ top_raw, float* __restrict__ med_raw,
-    uint8_t* __restrict__ med_raw_mask) {
+    uint8_t* __restrict__ med_raw_mask, int32_t* __restrict__ occ_clear) {
+    if (occ_clear && blockIdx.x == 0 && threadIdx.x < 2) occ_clear[threadIdx.x] = 0;      // accumulators of the later occ_count_kernel
     __shared__ unsigned long long s_low[kLowMax * 3];
     __shared__ unsigned long long s_med[kMedMax * 3];
     __shared__ int c_low[kLowMax];
@@ -348,11 +349,10 @@ extern "C" int geomae_geometry_targets(const float* points, int32_t num_features
     int rc = fill_cfg(c, config);
     if (rc) return rc;
     const int grid = max_pillars < 256 * 64 ? max_pillars : 256 * 64;
-    if (occ_counts) GEOMAE_HIP(hipMemsetAsync(occ_counts, 0, 2 * sizeof(int32_t), stream));
     hipLaunchKernelGGL(centroid_targets_kernel, dim3(grid), dim3(64), 0, stream, points, num_features, order,
                        seg_start, num_pillars, (const int4*)voxel_coors, (const int4*)coors_med,
                        (const int4*)coors_low, token_row, mask_counts, c, centroid_low, mask_low, centroid_med,
-                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask);
+                       mask_med, centroid_top, top_raw, med_raw, med_raw_mask, occ_counts);
     // with a scatter-matrix buffer from the caller the eigen-decompositions run one per thread in a second launch
     hipLaunchKernelGGL(normal_curv_kernel, dim3(grid), dim3(64), 0, stream, num_pillars, (const int4*)voxel_coors,
                        cell_table, token_row, mask_counts, c, batch_size, top_raw, med_raw, med_raw_mask, normal, curv,

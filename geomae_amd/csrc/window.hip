@@ -821,6 +821,15 @@ extern "C" int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_
     return total;
 }
 
+extern "C" int64_t geomae_window_build_batch_table_bytes(const int32_t* num_tokens, int32_t num_jobs, int32_t batch_size,
+                                                         const GeomaeWindowConfig* cfg) {
+    if (!num_tokens || num_jobs < 1 || num_jobs > kMaxWinJobs) return -1;
+    WinGeom g;
+    int sps;
+    if (win_geom(cfg, 0, &g, &sps)) return -1;
+    return (int64_t)num_jobs * (((int64_t)batch_size * sps * 4 + 255) / 256 * 256);
+}
+
 extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32_t num_jobs, int32_t batch_size,
                                          const GeomaeWindowConfig* cfg, void* workspace, int64_t workspace_bytes,
                                          hipStream_t stream) {
@@ -863,7 +872,7 @@ extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32
         J.j[k].rank = (int32_t*)rp;  rp += al((int64_t)J.j[k].n * 4);
     }
     for (int k = num_jobs; k < kMaxWinJobs; ++k) J.j[k] = J.j[0];
-    GEOMAE_HIP(hipMemsetAsync(workspace, 0, (size_t)table_bytes, stream));
+    if (!window_tables_prezeroed()) GEOMAE_HIP(hipMemsetAsync(workspace, 0, (size_t)table_bytes, stream));
     const dim3 tok_grid(stream_grid(max_n > 0 ? max_n : 1, kWBlk), num_jobs);
     if (max_n > 0) hipLaunchKernelGGL(win_hist_jobs_kernel, tok_grid, dim3(kWBlk), 0, stream, J);
     hipLaunchKernelGGL(win_scan_jobs_kernel, dim3(1, num_jobs), dim3(1024), 0, stream, J);

@@ -54,6 +54,16 @@ int geomae_voxelize_batch3(const float* points, int64_t num_points, int32_t num_
                            const float* voxel_size_low, const float* coors_range /*all host*/,
                            int32_t* coors_top, int32_t* coors_med, int32_t* coors_low,
                            geomaeStream_t stream);
+/* The step's entry point: B frames -> the concatenated point rows (the reference's torch.cat, ssl.py:320-329) and the
+ * three coordinate arrays of geomae_voxelize_batch3, in ONE launch.  frame_points / frame_sizes: HOST arrays (device
+ * pointers, row counts; at most 32 frames).  points_out [N, num_features], batch_offsets_out [B + 1] int32 (or NULL).
+ * zero_a / zero_b: up to two device ranges (16-byte aligned, multiples of 16 bytes, or NULL / 0) cleared by the same
+ * launch -- the pillar table and the scan state of geomae_pillar_segment_ex (prezeroed = 1). */
+int geomae_voxelize_frames3(const float* const* frame_points, const int64_t* frame_sizes, int32_t batch_size,
+                            int32_t num_features, const float* voxel_size_top, const float* voxel_size_med,
+                            const float* voxel_size_low, const float* coors_range, float* points_out,
+                            int32_t* batch_offsets_out, int32_t* coors_top, int32_t* coors_med, int32_t* coors_low,
+                            void* zero_a, int64_t zero_a_bytes, void* zero_b, int64_t zero_b_bytes, geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A2 pillar segments
  * replaces torch.unique(coors, dim=0, return_inverse=True) of scatter_v2 (sst_ops.py:8-39) and of
@@ -77,6 +87,16 @@ int geomae_pillar_segment_nd(const int32_t* coors, int32_t ndim, int64_t num_poi
                              int32_t gz, int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors,
                              int32_t* inv, int32_t* order, int32_t* seg_start, int32_t* sample_start,
                              int32_t* num_pillars, void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
+/* geomae_pillar_segment_nd plus: sample_start_mirror (or NULL) -- a second copy of sample_start written by the same
+ * kernel, e.g. pinned host memory the device can address (the step's one count readback without a copy command);
+ * prezeroed != 0 -- the caller hands in cell_table and the first geomae_pillar_segment_scan_state_bytes(...) bytes of
+ * the workspace already ZERO (geomae_voxelize_frames3 clears them on the side), so no memset is enqueued. */
+int geomae_pillar_segment_ex(const int32_t* coors, int32_t ndim, int64_t num_points, int32_t batch_size, int32_t gz,
+                             int32_t gy, int32_t gx, int32_t* cell_table, int32_t* voxel_coors, int32_t* inv,
+                             int32_t* order, int32_t* seg_start, int32_t* sample_start, int32_t* num_pillars,
+                             void* workspace, int64_t workspace_bytes, int32_t* sample_start_mirror, int32_t prezeroed,
+                             geomaeStream_t stream);
+int64_t geomae_pillar_segment_scan_state_bytes(int32_t batch_size, int32_t gz, int32_t gy, int32_t gx);
 
 /* torch_scatter.scatter(reduce='mean') of the xyz columns (voxel_encoder.py:375): mean [cap, 3].
  * 2^-32 fixed-point int64 atomics per point (order independent); sum_workspace: cap * 3 * 8 bytes. */
@@ -112,6 +132,12 @@ int geomae_random_mask(const int32_t* sample_start, int32_t batch_size, double k
 int geomae_gather_token_coors(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask, int32_t num_mask,
                               const int32_t* voxel_coors /*[V,4]*/, int32_t* coors_out, int64_t* ids_keep_i64 /*or NULL*/,
                               geomaeStream_t stream);
+/* the same, and clears `zero_bytes` bytes at `zero` (16-byte aligned, a multiple of 16; or NULL / 0) on the side: the step
+ * engine hands it the window tables of the geomae_window_build_batch that follows (geomae_window_build_batch_table_bytes
+ * bytes at the start of that call's workspace), which then enqueues no memset */
+int geomae_gather_token_coors_zero(const int32_t* ids_keep, int32_t num_keep, const int32_t* ids_mask, int32_t num_mask,
+                                   const int32_t* voxel_coors, int32_t* coors_out, int64_t* ids_keep_i64, void* zero,
+                                   int64_t zero_bytes, geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ A5,A7-A11 geometric targets */
 typedef struct GeomaeTargetConfig {
@@ -195,6 +221,9 @@ int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens /*ho
 int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs /*host [num_jobs]*/, int32_t num_jobs,
                               int32_t batch_size, const GeomaeWindowConfig* cfg /*host*/, void* workspace,
                               int64_t workspace_bytes, geomaeStream_t stream);
+/* bytes of window tables at the start of geomae_window_build_batch's workspace (what the call clears first) */
+int64_t geomae_window_build_batch_table_bytes(const int32_t* num_tokens, int32_t num_jobs, int32_t batch_size,
+                                              const GeomaeWindowConfig* cfg);
 
 /* Operator-level window plumbing (mmdet3d/ops/__init__.py:22-26; ops/sst/sst_ops.py:57-135, 225-251, 271-319, 371-388):
  * the hot path works on the CSR layout above and never calls these; they back the reference's function names

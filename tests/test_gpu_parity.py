@@ -76,6 +76,63 @@ def test_voxelize_batch3_matches_per_level(dev):
         assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_voxelize_frames3_equals_cat_plus_batch3(dev):
+    """geomae_voxelize_frames3 (the step's entry: frames read where they lie, concatenated rows + three coordinate arrays +
+    two side clears in ONE launch) against torch.cat + geomae_voxelize_batch3; ragged frames whose boundaries fall inside
+    a 256-row tile, an empty frame, and the pillar sort fed by it with prezeroed tables (geomae_pillar_segment_ex)."""
+    from geomae_amd import _lib, ops
+    lib = _lib.load()
+    frames = [synth.lidar_frame(51, beams=16, n_az=333), np.zeros((0, 5), np.float32), synth.lidar_frame(52, beams=8, n_az=100),
+              synth.lidar_frame(53, beams=16, n_az=777)[:1001]]
+    pts = [torch.as_tensor(f, device=dev) for f in frames]
+    B, N = len(pts), sum(p.shape[0] for p in pts)
+    cat = torch.cat(pts)
+    boffs = torch.tensor([0] + list(np.cumsum([p.shape[0] for p in pts])), dtype=torch.int32, device=dev)
+    want = ops.voxelize_batch3(cat, boffs, B, LEVELS["top"], LEVELS["med"], LEVELS["low"], RANGE)
+    ptrs, sizes = (ctypes.c_void_p * B)(), (ctypes.c_int64 * B)()
+    for i, p in enumerate(pts):
+        ptrs[i], sizes[i] = p.data_ptr() if p.numel() else None, p.shape[0]
+    out_pts = torch.empty(N, 5, device=dev)
+    offs = torch.empty(B + 1, dtype=torch.int32, device=dev)
+    co = [torch.empty(N, 4, dtype=torch.int32, device=dev) for _ in range(3)]
+    gz, gy, gx = 1, 400, 400
+    cells = B * gz * gy * gx
+    table = torch.full(((cells * 4 + 255) // 256 * 64,), 7, dtype=torch.int32, device=dev)
+    state = lib.geomae_pillar_segment_scan_state_bytes(B, gz, gy, gx)
+    wsb = lib.geomae_pillar_segment_workspace_bytes(N, B, gz, gy, gx)
+    ws = torch.full((wsb,), 0x5a, dtype=torch.uint8, device=dev)
+    f3 = lambda v: (ctypes.c_float * len(v))(*[float(x) for x in v])
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = lib.geomae_voxelize_frames3(ptrs, sizes, B, 5, f3(LEVELS["top"]), f3(LEVELS["med"]), f3(LEVELS["low"]), f3(RANGE), P(out_pts),
+                                     P(offs), P(co[0]), P(co[1]), P(co[2]), P(table), table.numel() * 4, P(ws), state, ops._stream())
+    assert rc == 0, lib.geomae_last_error()
+    assert torch.equal(out_pts, cat) and torch.equal(offs, boffs)
+    for a, b in zip(co, want):
+        assert torch.equal(a, b)
+    assert int(table.abs().sum()) == 0 and int(ws[:state].sum()) == 0 and int(ws[state]) == 0x5a
+    # the pillar sort on the prezeroed tables, counts mirrored into a second buffer
+    ref = ops.pillar_segment(want[0], B, (gz, gy, gx))
+    cap = min(N, cells)
+    vc = torch.empty(cap, 4, dtype=torch.int32, device=dev)
+    inv, order = torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, dtype=torch.int32, device=dev)
+    seg_start = torch.empty(cap + 1, dtype=torch.int32, device=dev)
+    ss, mirror = torch.empty(B + 1, dtype=torch.int32, device=dev), torch.empty(B + 1, dtype=torch.int32, device=dev)
+    nump = torch.empty(1, dtype=torch.int32, device=dev)
+    rc = lib.geomae_pillar_segment_ex(P(co[0]), 4, N, B, gz, gy, gx, P(table), P(vc), P(inv), P(order), P(seg_start), P(ss), P(nump),
+                                      P(ws), wsb, P(mirror), 1, ops._stream())
+    assert rc == 0, lib.geomae_last_error()
+    V = ref.V
+    assert int(nump) == V and torch.equal(ss, mirror) and torch.equal(ss, ref.sample_start)
+    assert torch.equal(vc[:V], ref.voxel_coors[:V]) and torch.equal(inv, ref.inv) and torch.equal(seg_start[:V + 1], ref.seg_start[:V + 1])
+    assert torch.equal(table[:cells], ref.cell_table[:cells])
+    # the order inside a pillar is the atomic arrival order: compare as sets per pillar
+    o1, o2 = order.cpu().numpy(), ref.order.cpu().numpy()
+    st = seg_start[:V + 1].cpu().numpy()
+    assert np.array_equal(np.sort(o1), np.sort(o2))
+    for p in (0, V // 2, V - 1):
+        assert set(o1[st[p]:st[p + 1]]) == set(o2[st[p]:st[p + 1]])
+
+
 def test_voxelize_large_property(dev):
     """Full-size (10-sweep, B=4) property check: nesting of the three resolutions and clamping."""
     from geomae_amd import ops
