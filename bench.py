@@ -309,9 +309,9 @@ def main():
         # HBM bytes per launch are NOT measured in this run: they come from the stored PMC passes of tools/pmc.sh
         # (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs) and only apply to the workload they were taken on
         traffic, traffic_src = {}, None
-        for cand in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for cand in (f"r03_{workload}_pmc_traffic.json",) + (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if workload == "nuscenes1" else ()):
             tpath = os.path.join(ROOT, "profiles", cand)
-            if workload == "nuscenes1" and B == 4 and os.path.exists(tpath):
+            if B == 4 and os.path.exists(tpath):
                 traffic, traffic_src = json.load(open(tpath)), "profiles/" + cand
                 break
         kern = {}
@@ -361,13 +361,15 @@ def main():
                                            engine_busy=round(1e3 * busy / args.steps, 4))
         # north_star: "MFMA utilisation on the bucketed attention".  Not measurable from inside this process (PMC needs
         # rocprofv3): the stored pass of tools/r2_profile.sh for this workload, labelled as such
-        upath = os.path.join(ROOT, "profiles", "r02_mfma_util.json")
-        if workload == "nuscenes1" and B == 4 and os.path.exists(upath):
-            u = json.load(open(upath))
-            out["mfma_busy_stored"] = {"source": "profiles/r02_mfma_util.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
-                                       **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
-                                                                              "sst_ffn_fwd_kernel", "sst_ffn_fwd_pair_kernel",
-                                                                              "sst_ffn_bwd_dw_kernel", "vfe_layer1_kernel") if k in u}}
+        for cand in (f"r03_{workload}_mfma_util.json",) + (("r02_mfma_util.json",) if workload == "nuscenes1" else ()):
+            upath = os.path.join(ROOT, "profiles", cand)
+            if B == 4 and os.path.exists(upath):
+                u = json.load(open(upath))
+                out["mfma_busy_stored"] = {"source": f"profiles/{cand} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
+                                           **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
+                                                                                  "sst_ffn_fwd_kernel", "sst_ffn_fwd_pair_kernel",
+                                                                                  "sst_ffn_bwd_dw_kernel", "vfe_layer1_kernel") if k in u}}
+                break
         if phases is not None:
             out["main_stream_phase_ms"] = phases
             out["main_stream_phase_sum_ms"] = round(float(sum(phases.values())), 4)

@@ -46,7 +46,7 @@ class GeomaeSstStackLayout(ctypes.Structure):
 class GeomaeVfeArgs(ctypes.Structure):
     _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("num_points", c_int64),
                 ("max_pillars", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
-                ("scale1", c_void_p), ("shift1", c_void_p)]
+                ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p)]
 
 
 class GeomaeSweepInfo(ctypes.Structure):
@@ -123,6 +123,8 @@ SIGNATURES = {
     "geomae_segment_mean_xyz": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, c_int32, P, P, P]),
     "geomae_segment_mean_xyz_sorted": (ctypes.c_int, [P, c_int32, P, P, P, c_int32, P, P]),
     "geomae_vfe_prepare": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, P, F3, F3, P, P, P]),
+    "geomae_vfe_moments_workspace_bytes": (c_int64, []),
+    "geomae_vfe_prepare_moments": (ctypes.c_int, [P, c_int32, c_int64, P, P, P, P, F3, F3, P, P, P, P, P]),
     "geomae_dynamic_point_to_voxel_workspace_bytes": (c_int64, [c_int64, c_int32, c_int32, c_int32, c_int32, c_int32]),
     "geomae_dynamic_point_to_voxel_forward": (ctypes.c_int, [P, P, c_int64, c_int32, c_int32, c_int32, c_int32, c_int32,
                                                              c_int32, c_int32, c_int32, P, P, P, P, P, P, c_int64, P]),

@@ -90,6 +90,7 @@ struct Batch {
     int32_t *cell_table = nullptr, *voxel_coors = nullptr, *inv = nullptr, *order = nullptr, *seg_start = nullptr;
     int32_t *sample_start = nullptr, *num_pillars = nullptr;
     float *mean = nullptr, *feat = nullptr;
+    double* moments = nullptr;         // feature moments of the batch (geomae_vfe_prepare_moments)
     int32_t* pid = nullptr;
     int32_t *ids_keep = nullptr, *ids_mask = nullptr, *token_row = nullptr, *counts = nullptr;
     int32_t* host_offs = nullptr;      // pinned [B + 1]
@@ -159,6 +160,7 @@ int64_t stage_region_bytes(const GeomaePretrainConfig& c, int64_t N) {
     b += al256(geomae_pillar_segment_workspace_bytes(N, c.batch_size, c.targets.grid_size[0], c.targets.grid_size[1],
                                                      c.targets.grid_size[2]));
     b += al256(cap * 12) + al256(N * 64) + al256(N * 4);   // mean, feat, pid
+    b += al256(144 * 8) + al256(geomae_vfe_moments_workspace_bytes());   // feature moments + their partial sums
     b += 3 * al256(cap * 4) + 256;                      // mask
     return b + 4096;
 }
@@ -178,7 +180,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     const int64_t s_med = (int64_t)c.targets.ratio_med[0] * c.targets.ratio_med[1] * c.targets.ratio_med[2];
     const int64_t n = V < 1 ? 1 : V, M = n, nk = n;
     int64_t b = 0;
-    b += al256(256 * 8) + al256(128 * 8) + 3 * al256(n * 512) + al256(n * 512) + al256(n * 256);          // zeros_late
+    b += al256(256 * 8) + al256(128 * 8) + 3 * al256(n * 512) + al256(n * 512) + al256(n * 256) + al256(4096);   // zeros_late
     b += 6 * al256(128 * 4) + al256(256 * 4) * 2 + al256(128 * 8) + al256(n * 256) + al256(256 * 8) + al256(n * 512);  // zeros_fwd
     b += al256(n * 16);                                                                                    // coors_all
     b += 2 * window_layout_bytes(c, nk) + 2 * window_layout_bytes(c, n);
@@ -255,6 +257,8 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
     b.mean = a.take<float>(cap * 3);
     b.feat = a.take<float>(N * 16);
     b.pid = a.take<int32_t>(N);
+    b.moments = a.take<double>(144);
+    char* mom_ws = a.bytes(geomae_vfe_moments_workspace_bytes());
     b.ids_keep = a.take<int32_t>(cap);
     b.ids_mask = a.take<int32_t>(cap);
     b.token_row = a.take<int32_t>(cap);
@@ -293,8 +297,8 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
     }
     GEOMAE_HIP(hipEventRecord(b.readback, s));
     ENG_CALL(geomae_segment_mean_xyz_sorted(b.points, c.num_features, b.order, b.seg_start, b.num_pillars, b.cap, b.mean, s));
-    ENG_CALL(geomae_vfe_prepare(b.points, c.num_features, N, b.order, b.inv, b.mean, b.voxel_coors, c.vfe_voxel_size,
-                                c.vfe_center_offset, b.feat, b.pid, s));
+    ENG_CALL(geomae_vfe_prepare_moments(b.points, c.num_features, N, b.order, b.inv, b.mean, b.voxel_coors, c.vfe_voxel_size,
+                                        c.vfe_center_offset, b.feat, b.pid, mom_ws, b.moments, s));
     // the mask index is a function of the step that will consume the batch (not of how many stage 1s ran: a replaced
     // submission or a re-created engine must not shift the stream; geomae_pretrain_set_mask_draws)
     // window-major token lists: a 16-token tile of the stacks' activations then belongs to one or two attention windows
@@ -432,6 +436,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* d_den = a.take<float>((int64_t)n * 128);
     float* d_vf = a.take<float>((int64_t)V * 128);
     float* dm0 = a.take<float>((int64_t)V * 64);
+    float* dw0_acc = a.take<float>(64 * 16);               // layer-0 weight-gradient contraction of the VFE backward
     const int64_t zl_bytes = (a.base + a.off) - zl0;
     // zero arena of the VFE forward (one fill on the main stream)
     char* zf0 = a.base + a.off;
@@ -563,6 +568,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     va.num_points = N; va.max_pillars = V;
     va.w0 = m.vfe_w0; va.w1 = m.vfe_w1;
     va.scale0 = bn_scale0; va.shift0 = bn_shift0; va.scale1 = bn_scale1; va.shift1 = bn_shift1;
+    va.moments = b.moments; va.dw0_acc = dw0_acc;
     ENG_CALL(geomae_vfe_stats0(&va, sums0, main));
     ENG_CALL(bn_forward(e, 0, sums0, (double)N, bn_scale0, bn_shift0, bn_invstd0, bn_mom0, main));
     ENG_CALL(geomae_vfe_layer0(&va, m0, sums1, main));

@@ -79,14 +79,30 @@ __device__ __forceinline__ void build_features(const VfeGeo& G, int j, bool vali
     f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
 }
 
+// Moments of the 11 decorated features over all points: S1[k] = sum f_k, S2[k][l] = sum f_k f_l  (fp64, [16] + [11][11]).
+// Layer 0 is linear without bias (y0 = W0 f), so everything its BatchNorm needs from the batch follows from them:
+//   sum y0_c = W0[c] . S1,  sum y0_c^2 = W0[c] S2 W0[c]^T        (the forward statistics: no sweep over the points)
+//   sum yhat0_c f = invstd_c (W0[c] S2 - mean_c S1)               (the BatchNorm backward term of dW0: no second sweep)
+// They depend on the points only, so they are computed with the features, in stage 1 of the batch (a step earlier).
+constexpr int kMomS2 = 16, kMomCount = 16 + 121;        // S1 padded to 16, then S2 row-major [11][11]
+constexpr int kMomPad = 144;                            // doubles per partial row
+constexpr int kMomBlocks = 256;                         // grid cap of the prepare kernel when it accumulates moments
+
 // features of every point, written in pillar order: [x y z i | dt x-mx y-my z-mz | x-cx y-cy z-cz 0 | 0 0 0 0]
+// partials (or null): [gridDim.x][kMomPad] doubles, this workgroup's sums of the 11 features and their 66 products
 __global__ __launch_bounds__(256) void vfe_prepare_kernel(const float* __restrict__ pts, int stride, int64_t n,
                                                           const int32_t* __restrict__ order,
                                                           const int32_t* __restrict__ inv,
                                                           const float* __restrict__ mean,
                                                           const int4* __restrict__ voxel_coors, float vx, float vy,
                                                           float vz, float xo, float yo, float zo,
-                                                          float* __restrict__ feat, int32_t* __restrict__ pid_out) {
+                                                          float* __restrict__ feat, int32_t* __restrict__ pid_out,
+                                                          double* __restrict__ partials) {
+    float s1[11], s2[66];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) s1[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 66; ++k) s2[k] = 0.f;
     for (int64_t j = blockIdx.x * 256 + threadIdx.x; j < n; j += (int64_t)gridDim.x * 256) {
         const int i = order[j];
         const int p = inv[i];
@@ -94,16 +110,95 @@ __global__ __launch_bounds__(256) void vfe_prepare_kernel(const float* __restric
         const float x = q[0], y = q[1], z = q[2];
         const float* m = mean + (int64_t)p * 3;
         const int4 c = voxel_coors[p];
-        float4* o = reinterpret_cast<float4*>(feat + j * 16);
-        o[0] = make_float4(x, y, z, q[3]);
-        o[1] = make_float4(q[4], x - m[0], y - m[1], z - m[2]);
+        float f[11];
+        f[0] = x; f[1] = y; f[2] = z; f[3] = q[3]; f[4] = q[4];
+        f[5] = x - m[0]; f[6] = y - m[1]; f[7] = z - m[2];
         // x - (coor * v + offset): every operation rounded separately, as the reference's tensor ops
-        o[2] = make_float4(__fsub_rn(x, __fadd_rn(__fmul_rn((float)c.w, vx), xo)),
-                           __fsub_rn(y, __fadd_rn(__fmul_rn((float)c.z, vy), yo)),
-                           __fsub_rn(z, __fadd_rn(__fmul_rn((float)c.y, vz), zo)), 0.f);
+        f[8] = __fsub_rn(x, __fadd_rn(__fmul_rn((float)c.w, vx), xo));
+        f[9] = __fsub_rn(y, __fadd_rn(__fmul_rn((float)c.z, vy), yo));
+        f[10] = __fsub_rn(z, __fadd_rn(__fmul_rn((float)c.y, vz), zo));
+        float4* o = reinterpret_cast<float4*>(feat + j * 16);
+        o[0] = make_float4(f[0], f[1], f[2], f[3]);
+        o[1] = make_float4(f[4], f[5], f[6], f[7]);
+        o[2] = make_float4(f[8], f[9], f[10], 0.f);
         o[3] = make_float4(0.f, 0.f, 0.f, 0.f);
         pid_out[j] = p;
+        if (partials) {
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                s1[k] += f[k];
+#pragma unroll
+                for (int l = k; l < 11; ++l) s2[e++] += f[k] * f[l];
+            }
+        }
     }
+    if (!partials) return;
+    __shared__ double red[4][80];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float v = wave_sum(s1[k]);
+        if (lane == 0) red[wave][k] = (double)v;
+    }
+#pragma unroll
+    for (int k = 0; k < 66; ++k) {
+        const float v = wave_sum(s2[k]);
+        if (lane == 0) red[wave][11 + k] = (double)v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 77)
+        partials[(int64_t)blockIdx.x * kMomPad + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] +
+                                                                red[3][threadIdx.x];
+}
+
+// partial rows -> moments [kMomCount]: one workgroup, sums in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void vfe_moments_reduce_kernel(const double* __restrict__ partials, int rows,
+                                                                  double* __restrict__ moments) {
+    __shared__ double acc[12][80];
+    const int e = threadIdx.x % 80, slice = threadIdx.x / 80;            // 12 slices x 80 entries = 960 threads
+    if (slice < 12) {
+        double s = 0.0;
+        if (e < 77)
+            for (int r = slice; r < rows; r += 12) s += partials[(int64_t)r * kMomPad + e];
+        acc[slice][e] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 77) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) s += acc[k][threadIdx.x];
+        acc[0][threadIdx.x] = s;
+    }
+    __syncthreads();
+    // unpack: S1 [16] (5 zeros), S2 [11][11] symmetric from the 66 upper-triangle sums
+    if (threadIdx.x < 16) moments[threadIdx.x] = threadIdx.x < 11 ? acc[0][threadIdx.x] : 0.0;
+    if (threadIdx.x < 121) {
+        const int k = threadIdx.x / 11, l = threadIdx.x % 11;
+        const int a = k < l ? k : l, b = k < l ? l : k;
+        const int idx = a * 11 - a * (a - 1) / 2 + (b - a);             // position of (a, b), a <= b, in the row-wise triangle
+        moments[kMomS2 + threadIdx.x] = acc[0][11 + idx];
+    }
+}
+
+// sums0 [128] (sum y0, sum y0^2 per channel) from the moments: what vfe_stats0_kernel measures with a sweep
+__global__ __launch_bounds__(64) void vfe_stats0_from_moments_kernel(const double* __restrict__ moments,
+                                                                     const float* __restrict__ w0, double* __restrict__ sums0) {
+    const int c = threadIdx.x;
+    double w[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) w[k] = (double)w0[c * 11 + k];
+    double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        m1 += w[k] * moments[k];
+        double r = 0.0;
+#pragma unroll
+        for (int l = 0; l < 11; ++l) r += w[l] * moments[kMomS2 + k * 11 + l];
+        m2 += w[k] * r;
+    }
+    sums0[c] = m1;
+    sums0[64 + c] = m2;
 }
 
 // y0[t][16*ot + 4g + r] = sum_k W0[.][k] f[t][k]; W0s: LDS [64][16] fp32 (columns >= 11 are zero)
@@ -827,19 +922,34 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
 
 // layer-0 routing sweep (needs the complete dm0): dh0 = dh0_direct + dm0[pid] where h0 == m0[pid] > 0 ;
 // sums of dh0 and dh0 * yhat0 for the BN0 backward
+// ACC: also contract A[o][k] = sum_t dh0[t][o] * ft[t][k] over the points, ft = [f - S1/N (11 centred features) | 0 0 0 0 | 1]
+// (column 15 = the plain sum of dh0), into dw0_acc [64][16] (zero-filled by the caller) -- with the moments of the features
+// that is all the layer-0 weight gradient needs (vfe_dw0_finalize_kernel), so dh0 is not written back and no further
+// sweep reads it.  Centred features keep the accumulated magnitudes near those of the gradient itself.
+template <bool ACC>
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                                  Bn0 bn0, const float* __restrict__ dm0,
-                                                                 float* __restrict__ dh0, double* __restrict__ bsums0) {
+                                                                 float* __restrict__ dh0, double* __restrict__ bsums0,
+                                                                 const double* __restrict__ moments, float inv_n,
+                                                                 float* __restrict__ dw0_acc) {
     __shared__ float W0s[64 * 16];
     __shared__ float red[kVfeWaves * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float tiles[ACC ? kVfeWaves : 1][ACC ? 16 * kTile0Ld : 4];   // [t][0..63] dh0, [t][64..79] ft
+    __shared__ float acc_s[ACC ? 64 * 16 : 4];
+    __shared__ float mu_s[16];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0(bn0, bn0l)
+    if (ACC) {
+        for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) acc_s[e] = 0.f;
+        if (threadIdx.x < 16) mu_s[threadIdx.x] = threadIdx.x < 11 ? (float)(moments[threadIdx.x] * (double)inv_n) : 0.f;
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
-    f32x4 s1[4], s2[4];
+    float* tile = tiles[ACC ? wave : 0];
+    f32x4 s1[4], s2[4], dw[4];
 #pragma unroll
-    for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; dw[ot] = f32x4{0, 0, 0, 0}; }
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
@@ -850,6 +960,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
         build_features(G, j, valid, g, f);
         f32x4 y0[4];
         layer0_linear(W0s + oz, f, y0, lane);
+        f32x4 dhv[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
             const int c0 = 16 * ot + 4 * g;
@@ -866,21 +977,90 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
             const float sc[4] = {s.x, s.y, s.z, s.w}, sh[4] = {b.x, b.y, b.z, b.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w},
                         iv[4] = {is.x, is.y, is.z, is.w}, mx[4] = {m.x, m.y, m.z, m.w}, dmv[4] = {dm.x, dm.y, dm.z, dm.w},
                         ddv[4] = {dd.x, dd.y, dd.z, dd.w};
-            float outv[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float h = fmaxf(y0[ot][r] * sc[r] + sh[r], 0.f);
                 float dh = 0.f;
                 if (valid && h > 0.f) dh = ddv[r] + (h == mx[r] ? dmv[r] : 0.f);
                 const float yh = (y0[ot][r] - mn[r]) * iv[r];
-                outv[r] = dh;
+                dhv[ot][r] = dh;
                 s1[ot][r] += dh;
                 s2[ot][r] += dh * yh;
             }
-            if (valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + c0) = make_float4(outv[0], outv[1], outv[2], outv[3]);
+            if (!ACC && valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + c0) = make_float4(dhv[ot][0], dhv[ot][1], dhv[ot][2], dhv[ot][3]);
+        }
+        if (ACC) {
+            // A[o][k] += sum_t dh0[t][o] ft[t][k]: token contraction -> tile through LDS, MFMA with k = t
+            tile_store<4, kTile0Ld>(tile, dhv, lane);
+            float4 ft = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) {
+                const float4 mu4 = *reinterpret_cast<const float4*>(mu_s + 4 * g);
+                ft = make_float4(f[0] - mu4.x, f[1] - mu4.y, f[2] - mu4.z, f[3] - mu4.w);
+                if (g == 2) ft.w = 0.f;                       // feature 11 is padding (mu 0, f 0): keep it exactly 0
+                if (g == 3) ft = make_float4(0.f, 0.f, 0.f, 1.f);     // columns 12-14 unused, column 15 = 1
+            }
+            *reinterpret_cast<float4*>(tile + (lane & 15) * kTile0Ld + 64 + 4 * g) = ft;
+            wave_sync();
+            const int o = lane & 15;
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int sgrp = 0; sgrp < 4; ++sgrp) {
+                    const float a = tile[(4 * sgrp + g) * kTile0Ld + 16 * ot + o];      // A[row = o][k = t = 4s + g]
+                    const float b = tile[(4 * sgrp + g) * kTile0Ld + 64 + o];           // B[k = t][col = feature o]
+                    dw[ot] = mfma_f32(a, b, dw[ot]);
+                }
+            wave_sync();
         }
     }
-    flush_channel_sums<4>(s1, s2, bsums0, 64, red, lane, wave);
+    if (ACC) {
+        // dw[ot][r] = A[16*ot + 4g + r][feature = lane & 15]
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) atomicAdd(&acc_s[(16 * ot + 4 * g + r) * 16 + (lane & 15)], dw[ot][r]);
+    }
+    flush_channel_sums<4>(s1, s2, bsums0, 64, red, lane, wave);      // (contains the workgroup barrier the flush below needs)
+    if (ACC)
+        for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) atomicAdd(dw0_acc + e, acc_s[e]);
+}
+
+// dW0 from the accumulated contraction and the feature moments (one workgroup; fp64 arithmetic):
+//   dW0[o][k] += sc_o * ( A'[o][k] - (T2_o / n) * invstd_o * (W0[o] Cov)[k] + sdy_o * mu[k] )
+//   Cov = S2 - S1 S1^T / N,  mu = S1 / N,  A' = sum dh0 (f - mu)^T,
+//   sdy_o = sum_t dy0[t][o] / sc_o = A[o][15] - N T1_o / n - (T2_o / n) invstd_o (W0[o] . S1 - N mean_o)
+// (N: local points, n: points of all ranks; T1, T2: the -- at world > 1 all-reduced -- sums of dh0 and dh0 * yhat0.  With
+// one process sdy vanishes up to rounding.)  Derivation: dy0 = sc (dh0 - T1/n - yhat0 T2/n), yhat0 = invstd (W0 f - mean).
+__global__ __launch_bounds__(1024) void vfe_dw0_finalize_kernel(const float* __restrict__ acc, const double* __restrict__ moments,
+                                                                const double* __restrict__ bsums0, double n_local, double n_eff,
+                                                                const float* __restrict__ w0, Bn0 bn0, float* __restrict__ dw0,
+                                                                float* __restrict__ d_beta0, float* __restrict__ d_gamma0) {
+    __shared__ double cov[11][11], mu[11];
+    const int o = threadIdx.x >> 4, k = threadIdx.x & 15;
+    if (threadIdx.x < 11) mu[threadIdx.x] = moments[threadIdx.x] / n_local;
+    if (threadIdx.x < 121) {
+        const int a = threadIdx.x / 11, b = threadIdx.x % 11;
+        cov[a][b] = moments[kMomS2 + threadIdx.x] - moments[a] * moments[b] / n_local;
+    }
+    __syncthreads();
+    const double t1 = bsums0[o], t2 = bsums0[64 + o];
+    const double invstd = (double)bn0.invstd[o], mean = (double)bn0.mean[o], sc = (double)bn0.scale[o];
+    if (k < 11) {
+        double wc = 0.0, ws1 = 0.0;
+#pragma unroll
+        for (int j = 0; j < 11; ++j) {
+            const double w = (double)w0[o * 11 + j];
+            wc += w * cov[j][k];
+            ws1 += w * moments[j];
+        }
+        const double sdy = (double)acc[o * 16 + 15] - n_local * t1 / n_eff - (t2 / n_eff) * invstd * (ws1 - n_local * mean);
+        const double v = (double)acc[o * 16 + k] - (t2 / n_eff) * invstd * wc + sdy * mu[k];
+        dw0[o * 11 + k] += (float)(sc * v);
+    }
+    if (k == 15 && d_beta0) {                 // single process: the sums ARE d beta / d gamma
+        d_beta0[o] += (float)t1;
+        d_gamma0[o] += (float)t2;
+    }
 }
 
 // layer-0 backward: dy0 = invstd0 * (dyh0 - T1/n - yhat0 * T2/n) ; dW0 += dy0^T f   (64 x 11)
@@ -984,8 +1164,28 @@ extern "C" int geomae_vfe_prepare(const float* points, int32_t num_features, int
     GEOMAE_REQUIRE(num_features >= 5, "vfe_prepare: points need 5 features (x, y, z, intensity, dt)");
     hipLaunchKernelGGL(vfe_prepare_kernel, dim3(stream_grid(num_points, 256)), dim3(256), 0, stream, points, num_features,
                        num_points, order, inv, pillar_mean, (const int4*)voxel_coors, voxel_size[0], voxel_size[1],
-                       voxel_size[2], center_offset[0], center_offset[1], center_offset[2], feat_sorted, pid_sorted);
+                       voxel_size[2], center_offset[0], center_offset[1], center_offset[2], feat_sorted, pid_sorted,
+                       (double*)nullptr);
     return check_launch("vfe_prepare_kernel");
+}
+
+extern "C" int64_t geomae_vfe_moments_workspace_bytes(void) { return (int64_t)kMomBlocks * kMomPad * sizeof(double); }
+
+extern "C" int geomae_vfe_prepare_moments(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
+                                          const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
+                                          const float* voxel_size, const float* center_offset, float* feat_sorted,
+                                          int32_t* pid_sorted, void* workspace, double* moments, hipStream_t stream) {
+    if (num_points <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(points && order && inv && pillar_mean && voxel_coors && voxel_size && center_offset && feat_sorted &&
+                   pid_sorted && workspace && moments, "vfe_prepare_moments: null argument");
+    GEOMAE_REQUIRE(num_features >= 5, "vfe_prepare_moments: points need 5 features (x, y, z, intensity, dt)");
+    int grid = stream_grid(num_points, 256);
+    if (grid > kMomBlocks) grid = kMomBlocks;
+    hipLaunchKernelGGL(vfe_prepare_kernel, dim3(grid), dim3(256), 0, stream, points, num_features, num_points, order, inv,
+                       pillar_mean, (const int4*)voxel_coors, voxel_size[0], voxel_size[1], voxel_size[2], center_offset[0],
+                       center_offset[1], center_offset[2], feat_sorted, pid_sorted, (double*)workspace);
+    hipLaunchKernelGGL(vfe_moments_reduce_kernel, dim3(1), dim3(1024), 0, stream, (const double*)workspace, grid, moments);
+    return check_launch("vfe_prepare_moments");
 }
 
 extern "C" int geomae_segment_mean_xyz(const float* points, int32_t num_features, int64_t num_points,
@@ -1031,6 +1231,10 @@ extern "C" int geomae_vfe_stats0(const GeomaeVfeArgs* a, double* sums0, hipStrea
     int rc = vfe_common(a, &G, &W, "vfe_stats0");
     if (rc) return rc;
     GEOMAE_REQUIRE(sums0, "vfe_stats0: null output");
+    if (a->moments) {          // y0 = W0 f is linear: its batch statistics follow from the feature moments (no sweep)
+        hipLaunchKernelGGL(vfe_stats0_from_moments_kernel, dim3(1), dim3(64), 0, stream, a->moments, a->w0, sums0);
+        return check_launch("vfe_stats0_from_moments_kernel");
+    }
     GEOMAE_ZERO(sums0, 128 * sizeof(double), stream);
     hipLaunchKernelGGL(vfe_stats0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, sums0);
     return check_launch("vfe_stats0_kernel");
@@ -1101,8 +1305,14 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
                        bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0, d_beta1, d_gamma1);
     if ((rc = check_launch("vfe_bwd_layer1_kernel"))) return rc;
-    hipLaunchKernelGGL(vfe_bwd_route0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0, dh0,
-                       bsums0);
+    if (a->moments && a->dw0_acc) {
+        GEOMAE_ZERO(a->dw0_acc, 64 * 16 * sizeof(float), stream);
+        hipLaunchKernelGGL(vfe_bwd_route0_kernel<true>, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0,
+                           dh0, bsums0, a->moments, 1.0f / (float)a->num_points, a->dw0_acc);
+    } else {
+        hipLaunchKernelGGL(vfe_bwd_route0_kernel<false>, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0,
+                           dh0, bsums0, (const double*)nullptr, 0.f, (float*)nullptr);
+    }
     return check_launch("vfe_bwd_route0_kernel");
 }
 
@@ -1118,8 +1328,13 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     GEOMAE_REQUIRE(dh0 && bsums0_global && dw0 && n_eff > 0 && (!dw1 || (dy1_bf16 && g_bf16)),
                    "vfe_backward_layer0: null argument");
     GEOMAE_REQUIRE((d_beta0 == nullptr) == (d_gamma0 == nullptr), "vfe_backward_layer0: pass both BN gradients or none");
-    hipLaunchKernelGGL(vfe_bwd_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, dh0, bn0, bsums0_global, n_eff,
-                       dw0, d_beta0, d_gamma0);
+    if (a->moments && a->dw0_acc) {
+        hipLaunchKernelGGL(vfe_dw0_finalize_kernel, dim3(1), dim3(1024), 0, stream, (const float*)a->dw0_acc, a->moments,
+                           bsums0_global, (double)a->num_points, (double)n_eff, a->w0, bn0, dw0, d_beta0, d_gamma0);
+    } else {
+        hipLaunchKernelGGL(vfe_bwd_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, dh0, bn0, bsums0_global, n_eff,
+                           dw0, d_beta0, d_gamma0);
+    }
     rc = check_launch("vfe_bwd_layer0_kernel");
     if (rc || !dw1) return rc;                       // dw1 == NULL: the caller runs geomae_vfe_weight_grad1 itself
     return geomae_vfe_weight_grad1(dy1_bf16, g_bf16, num_points, dw1, stream);

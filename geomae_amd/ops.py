@@ -1102,6 +1102,9 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 
 
 # ------------------------------------------------------------------------------------ fused VFE
+VFE_MOMENTS = True       # False: the sweep forms of the layer-0 statistics / weight gradient (A/B, tests)
+
+
 def vfe_prepare_points(points, seg, voxel_size, center_offset, zeros=None):
     """The weight-independent front of the fused VFE: pillar means and the decorated point features in pillar order
     (-> (mean [cap,3], feat [N,16], pid [N])).  It needs only the points and their segments, not the pillar count on
@@ -1111,10 +1114,14 @@ def vfe_prepare_points(points, seg, voxel_size, center_offset, zeros=None):
     mean = segment_mean_xyz(points, seg, zeros)
     feat = torch.empty((max(N, 1), 16), dtype=torch.float32, device=dev)
     pid = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-    check(lib.geomae_vfe_prepare(_ptr(points), points.shape[1], N, _ptr(seg.order), _ptr(seg.inv), _ptr(mean),
-                                 _ptr(seg.voxel_coors), f3(voxel_size), f3(center_offset), _ptr(feat), _ptr(pid),
-                                 _stream()), "geomae_vfe_prepare")
-    return mean, feat, pid
+    # ... and the moments of the decorated features (fp64 [16 + 121]): layer 0 is linear, so its BatchNorm statistics and
+    # the BatchNorm term of its weight gradient follow from them without a sweep over the points (csrc/vfe.hip)
+    moments = torch.zeros(144, dtype=torch.float64, device=dev)
+    ws = torch.empty(lib.geomae_vfe_moments_workspace_bytes(), dtype=torch.uint8, device=dev)
+    check(lib.geomae_vfe_prepare_moments(_ptr(points), points.shape[1], N, _ptr(seg.order), _ptr(seg.inv), _ptr(mean),
+                                         _ptr(seg.voxel_coors), f3(voxel_size), f3(center_offset), _ptr(feat), _ptr(pid),
+                                         _ptr(ws), _ptr(moments), _stream()), "geomae_vfe_prepare_moments")
+    return mean, feat, pid, moments
 
 
 class VfePlan:
@@ -1126,7 +1133,9 @@ class VfePlan:
         self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
         if prepared is None:
             prepared = vfe_prepare_points(points, seg, voxel_size, center_offset, zeros)
-        self.mean, self.feat, self.pid = prepared
+        self.mean, self.feat, self.pid = prepared[:3]
+        self.moments = prepared[3] if len(prepared) > 3 and VFE_MOMENTS else None
+        self.dw0_acc = None
         # [layer][scale, shift, mean, invstd]
         self.bn = zeros.take((2, 4, 128), torch.float32) if zeros is not None else \
             torch.zeros((2, 4, 128), dtype=torch.float32, device=dev)
@@ -1136,6 +1145,8 @@ class VfePlan:
         a.w0, a.w1 = w0.data_ptr(), w1.data_ptr()
         a.scale0, a.shift0 = self.bn[0, 0].data_ptr(), self.bn[0, 1].data_ptr()
         a.scale1, a.shift1 = self.bn[1, 0].data_ptr(), self.bn[1, 1].data_ptr()
+        if self.moments is not None:
+            a.moments = self.moments.data_ptr()
         self.args = a
         self._keep = (w0, w1)
 
@@ -1238,6 +1249,9 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, sid
     dh0 = torch.empty((N, 64), dtype=torch.float32, device=dev)
     dm0 = _zeros_or_empty(zeros, (max(V, 1), 64), torch.float32, dev)
     bs0 = _zeros_or_empty(zeros, (128,), torch.float64, dev)
+    if plan.moments is not None:          # layer-0 weight gradient from one contraction + the moments: no sweep of its own
+        plan.dw0_acc = torch.zeros(64 * 16, dtype=torch.float32, device=dev)
+        plan.args.dw0_acc = plan.dw0_acc.data_ptr()
     check(lib.geomae_vfe_backward_layer1(a, ctypes.byref(bn), _ptr(m0), _ptr(vf), _ptr(dvf), _ptr(bs1), n_eff,
                                          _ptr(dy1_b), _ptr(g_b), None, _ptr(dh0), _ptr(dm0), _ptr(bs0),
                                          _ptr(params["b1"].grad) if fold else None,

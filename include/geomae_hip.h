@@ -387,6 +387,10 @@ typedef struct GeomaeVfeArgs {
     const float *w0, *w1;                            /* vfe_layers.0.linear.weight [64,11], .1 [128,128] */
     const float *scale0, *shift0, *scale1, *shift1;  /* folded BatchNorm (geomae_bn_finalize); may be NULL
                                                         for the sweeps that do not need them            */
+    const double* moments;                           /* [16 + 121] feature moments of geomae_vfe_prepare_moments, or NULL.
+                                                        With them geomae_vfe_stats0 needs no sweep over the points, and
+                                                        together with dw0_acc the layer-0 backward needs none either */
+    float* dw0_acc;                                  /* [64,16] scratch of the layer-0 weight gradient, or NULL        */
 } GeomaeVfeArgs;
 /* decorated point features [x y z i dt | xyz - pillar mean | xyz - pillar centre | 0...] in pillar order
  * (voxel_encoder.py:372-397); voxel_size (vx,vy,vz) and center_offset = v/2 + range_min are host arrays */
@@ -394,6 +398,14 @@ int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_po
                        const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
                        const float* voxel_size, const float* center_offset, float* feat_sorted,
                        int32_t* pid_sorted, geomaeStream_t stream);
+/* the same + the moments of the 11 decorated features over all points (fp64: S1 [16], S2 [11][11]): layer 0 is linear
+ * without bias, so its BatchNorm statistics (forward) and the BatchNorm term of its weight gradient (backward) follow
+ * from them -- GeomaeVfeArgs.moments.  workspace: geomae_vfe_moments_workspace_bytes() bytes. */
+int64_t geomae_vfe_moments_workspace_bytes(void);
+int geomae_vfe_prepare_moments(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
+                               const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,
+                               const float* voxel_size, const float* center_offset, float* feat_sorted,
+                               int32_t* pid_sorted, void* workspace, double* moments /*[137]*/, geomaeStream_t stream);
 /* sums [2C] fp64 (sum, sum of squares) and count -> (mean, mean of squares) in moments_out [2C] and/or, when
  * scale != NULL, the folded affine scale/shift, invstd and the running-stat update.  Pass moments_in [2C]
  * instead of sums to finalize from externally averaged moments (naiveSyncBN1d). */

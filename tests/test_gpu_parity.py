@@ -503,6 +503,37 @@ def test_vfe_forward_backward(dev, golden_dir, fused):
         assert off.mean() < 0.05, (k, off.mean())
 
 
+def test_vfe_moment_form_equals_sweep_form(dev):
+    """Layer 0 of the VFE is linear without bias, so its BatchNorm statistics and the BatchNorm term of its weight
+    gradient follow from the 11 x 11 moment matrix of the decorated features (csrc/vfe.hip: geomae_vfe_prepare_moments,
+    vfe_stats0_from_moments_kernel, vfe_dw0_finalize_kernel).  Against the sweep forms they replace (ops.VFE_MOMENTS =
+    False): same voxel features and the same six parameter gradients, to the rounding of two different summation orders."""
+    from geomae_amd import ops
+    frames = [synth.lidar_frame(61, sweeps=3), synth.lidar_frame(62, beams=16, n_az=500)]
+    res = {}
+    for mode in (True, False):
+        ops.VFE_MOMENTS = mode
+        try:
+            model, _ = _build(dev, 1, 1, "fp32")
+            pts = [torch.as_tensor(f, device=dev) for f in frames]
+            voxels, coors, _, _ = model.voxelize_all(pts)
+            seg = ops.pillar_segment(coors, 2, (1, 400, 400))
+            vf, _ = model.voxel_encoder(voxels, coors, seg=seg)
+            w = torch.randn(vf.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            (vf * w).sum().backward()
+            res[mode] = (vf.detach().clone(), {k: p.grad.clone() for k, p in model.voxel_encoder.named_parameters()},
+                         {k: b.clone() for k, b in model.voxel_encoder.named_buffers() if "running" in k})
+        finally:
+            ops.VFE_MOMENTS = True
+    (vf_m, g_m, b_m), (vf_s, g_s, b_s) = res[True], res[False]
+    assert torch.allclose(vf_m, vf_s, rtol=1e-4, atol=1e-4), float((vf_m - vf_s).abs().max())     # measured 2.9e-5
+    for k in g_s:
+        rel = float((g_m[k] - g_s[k]).norm() / g_s[k].norm().clamp(min=1e-12))
+        assert rel < 2e-3, (k, rel)              # an arg-max tie may route one pooled gradient to another point
+    for k in b_s:
+        assert torch.allclose(b_m[k], b_s[k], rtol=1e-5, atol=1e-6), k
+
+
 # (loss, gradient-norm, full-gradient Frobenius) tolerances ~2x the measured maxima this test prints with
 # GEOMAE_TEST_VERBOSE=1; the full-size versions of the same comparison are tests/test_gpu_fullsize.py
 # measured: fp32 composed path (attention core in bf16) 8.0e-4 / 9.1e-4 / 1.9e-3, bf16 fused path 2.5e-3 / 4.7e-3 / 1.4e-2

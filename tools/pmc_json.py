@@ -3,6 +3,7 @@ bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: counter unit KB, gfx950
 (FETCH_SIZE reports half of a wide coalesced read stream)."""
 import csv, json, sys
 fetch, write, out = sys.argv[1], sys.argv[2], sys.argv[3]
+workload = sys.argv[4] if len(sys.argv) > 4 else "nuscenes1"
 import re
 def kernel_name(raw):
     """'void geomae::win_attn_fwd_kernel<4>(unsigned short const*; ...' -> 'win_attn_fwd_kernel' (template forms merged)"""
@@ -17,7 +18,7 @@ def load(path, col):
     return {k: (s / max(m, 1), m) for k, (s, m) in acc.items()}
 f, w = load(fetch, "FETCH_SIZE"), load(write, "WRITE_SIZE")
 res = {"_comment": "HBM bytes per launch from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/pmc.sh, bench.py "
-                   "--steps 3 --warmup 2, B=4 single-sweep frames, mean over all launches of the kernel). Counter unit KB; "
+                   f"--workload {workload} --steps 3 --warmup 2, 4 frames per GPU, mean over all launches of the kernel). Counter unit KB; "
                    "corrected as MI355X_MICROARCH.md prescribes for gfx950: bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024. "
                    "Regenerate: tools/pmc.sh fetch2 FETCH_SIZE ...; tools/pmc.sh write2 WRITE_SIZE ...; tools/pmc_json.py",
        "_raw_kb": {}}
@@ -25,7 +26,7 @@ for k in sorted(set(f) & set(w)):
     if not (k.startswith("sst_") or k.startswith("win_") or k.startswith("vfe_") or k.startswith("voxelize") or
             k.startswith("scan_") or k in ("dw_kernel", "dw_reduce_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
                                             "centroid_targets_kernel", "normal_curv_kernel", "normal_eig_kernel",
-                                            "occ_count_kernel", "random_mask_kernel", "grad_sumsq_kernel",
+                                            "occ_count_kernel", "random_mask_kernel", "random_mask_win_kernel", "zero_arena_kernel", "grad_sumsq_kernel",
                                             "pack_weights_kernel", "rows_to_blocked_f32_kernel", "gather_token_coors_kernel")):
         continue
     res[k] = int((2 * f[k][0] + w[k][0]) * 1024)
