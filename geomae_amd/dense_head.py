@@ -133,13 +133,18 @@ def max_iou_assign(overlaps, pos_iou_thr, neg_iou_thr, min_pos_iou, match_low_qu
     pos = max_ov >= pos_iou_thr
     assigned[pos] = argmax_ov[pos] + 1
     if match_low_quality:
-        gt_max = overlaps.max(dim=1).values
-        for i in range(G):                       # sequential: a later gt overrides an earlier one on ties
-            if gt_max[i] >= min_pos_iou:
-                if gt_max_assign_all:
-                    assigned[overlaps[i] == gt_max[i]] = i + 1
-                else:
-                    assigned[overlaps[i].argmax()] = i + 1
+        # mmdet loops over the gts in order ("a later gt overrides an earlier one on ties"): the same result without a
+        # host round trip per gt is, per anchor, the LARGEST gt index among the gts that claim it
+        gt_max, gt_arg = overlaps.max(dim=1)
+        ok = gt_max >= min_pos_iou                                            # [G]
+        if gt_max_assign_all:
+            claim = (overlaps == gt_max[:, None]) & ok[:, None]               # [G, A]
+        else:
+            claim = torch.zeros_like(overlaps, dtype=torch.bool)
+            claim[torch.arange(G, device=overlaps.device), gt_arg] = ok
+        idx = torch.arange(1, G + 1, device=overlaps.device)[:, None] * claim  # 0 where not claimed
+        last = idx.max(dim=0).values
+        assigned = torch.where(last > 0, last, assigned)
     return assigned
 
 

@@ -69,7 +69,11 @@ class FlatParams:
             self.segments.append((start, off, n_nd))
         total = off
         where = {n: j for j, n in enumerate(self.names)}
-        self.model_order = [where[n] for n in model_names]      # flat index of the i-th parameter of the model
+        self.model_order = [where[n] for n in model_names]      # flat index of the i-th TRAINABLE parameter of the model
+        # ... and of the i-th parameter counting the frozen ones too (None): the index space of an mmcv / torch optimizer
+        # checkpoint, whose DefaultOptimizerConstructor lists every parameter of the model
+        self.all_order = [where.get(n) for n, _ in model.named_parameters()]
+        self.all_params = [p for _, p in model.named_parameters()]
         self.n_no_decay = self.segments[0][2] if len(self.segments) == 1 else None
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -254,10 +258,20 @@ class FlatAdamW:
         f = self.flat
         return [(f.params[j], f.offsets[j]) for j in f.model_order]
 
+    def _checkpoint_order(self):
+        """[(parameter, flat offset or None)] over ALL parameters of the model in named_parameters() order: frozen ones
+        (requires_grad=False, e.g. in the fine-tune configs) keep their slot in the index space, with no state."""
+        f = self.flat
+        return [(p, None if j is None else f.offsets[j]) for p, j in zip(f.all_params, f.all_order)]
+
     def state_dict(self):
         f, state, groups = self.flat, {}, []
         decayed = f.decay_ranges()
-        for i, (p, off) in enumerate(self._model_order()):
+        for i, (p, off) in enumerate(self._checkpoint_order()):
+            if off is None:                      # frozen: a parameter group without state, as torch.optim writes it
+                groups.append(dict(params=[i], lr=self.lr, initial_lr=self.base_lr, betas=tuple(self.betas), eps=self.eps,
+                                   weight_decay=self.weight_decay, amsgrad=False))
+                continue
             n = p.numel()
             wd = self.weight_decay if any(a <= off < b for a, b in decayed) else 0.0
             state[i] = dict(step=torch.tensor(float(self.step_count)),
@@ -268,13 +282,15 @@ class FlatAdamW:
         return dict(state=state, param_groups=groups)
 
     def load_state_dict(self, sd):
-        order = self._model_order()
+        order = self._checkpoint_order()
         extra = [k for k in sd["state"] if not (isinstance(k, int) and 0 <= k < len(order))]
         if extra:
             raise ValueError(f"optimizer state has entries for parameters this model does not have: {extra[:4]}")
         for i, (p, off) in enumerate(order):
             n = p.numel()
             st = sd["state"].get(i)
+            if st is not None and off is None:
+                continue                         # state of a parameter that is frozen here: nothing to restore
             if st is not None:
                 for key in ("exp_avg", "exp_avg_sq"):
                     if tuple(st[key].shape) != tuple(p.shape):

@@ -1,6 +1,11 @@
 """Anchor3DHead (fine-tune config) in plain torch vs the reference's own head run under stubs
 (tests/golden/g_head.npz, oracle/make_golden_head.py): anchors, target assignment, the three losses and every gradient.
-The head is torch-only by design (SURVEY: "leave to MIOpen/PyTorch"), so this runs on CPU."""
+The head is torch-only by design (SURVEY: "leave to MIOpen/PyTorch"), so this runs on CPU.
+
+What the fixture pins: the reference's own Anchor3DHead / train_mixins / anchor generator / box coder code.  What it
+cannot pin: mmdet 2.20's MaxIoUAssigner, FocalLoss, SmoothL1Loss and bbox_overlaps, which are absent from the tree and
+the image -- the generator ran the reference head with the SAME restatements of them standing in (make_golden_head.py), so
+for target assignment and the loss formulas this is a self-consistency check ("parity unpinned")."""
 import os
 import sys
 
@@ -65,3 +70,31 @@ def test_max_iou_assigner_semantics():
     assert a.tolist() == [1, 0, 2, 0, -1]         # anchor 2: best anchor of gt 1 (0.5 >= min_pos_iou); anchor 4: 0.35 is neither
     a = max_iou_assign(ov, 0.6, 0.3, 0.55)
     assert a.tolist() == [1, 0, -1, 0, -1]
+
+
+def test_vectorised_low_quality_match_equals_the_sequential_loop():
+    """max_iou_assign's match_low_quality step without a Python loop over the gts (one host sync per gt before): per anchor
+    the LARGEST claiming gt index, which is what mmdet's in-order loop leaves behind ("a later gt overrides")."""
+    from geomae_amd.dense_head import max_iou_assign
+
+    def loop(overlaps, pos, neg, minp, assign_all):
+        G, A = overlaps.shape
+        assigned = overlaps.new_full((A,), -1, dtype=torch.long)
+        max_ov, argmax_ov = overlaps.max(0)
+        assigned[(max_ov >= 0) & (max_ov < neg)] = 0
+        p = max_ov >= pos
+        assigned[p] = argmax_ov[p] + 1
+        gt_max = overlaps.max(1).values
+        for i in range(G):
+            if gt_max[i] >= minp:
+                if assign_all:
+                    assigned[overlaps[i] == gt_max[i]] = i + 1
+                else:
+                    assigned[overlaps[i].argmax()] = i + 1
+        return assigned
+    g = torch.Generator().manual_seed(0)
+    for _ in range(100):
+        G, A = int(torch.randint(1, 9, (1,), generator=g)), int(torch.randint(5, 60, (1,), generator=g))
+        ov = (torch.rand(G, A, generator=g) * 10).round() / 10            # coarse values: many ties
+        for assign_all in (True, False):
+            assert torch.equal(max_iou_assign(ov, 0.6, 0.45, 0.45, True, assign_all), loop(ov, 0.6, 0.45, 0.45, assign_all))

@@ -269,3 +269,43 @@ def test_zero_arena_carves_aligned_zero_views():
     assert not views[1].any() and not views[2].any() and not views[3].any()
     with pytest.raises(RuntimeError):
         arena.take((1024,), torch.float32)
+
+
+def test_checkpoint_indices_count_frozen_parameters(tmp_path):
+    """A frozen parameter (the fine-tune configs freeze parts of the model) keeps its slot in the optimizer
+    checkpoint's index space -- mmcv's DefaultOptimizerConstructor / torch.optim list every parameter of the model, so
+    skipping the frozen ones would shift every later index."""
+    import torch.nn as nn
+    from geomae_amd.train import Trainer
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Linear(4, 3)
+            self.frozen = nn.Linear(3, 3)
+            self.b = nn.Linear(3, 2)
+            for p in self.frozen.parameters():
+                p.requires_grad_(False)
+
+        def forward_train(self, points, metas, **kw):
+            return dict(loss=self.b(self.frozen(self.a(points))).pow(2).mean())
+
+    torch.manual_seed(0)
+    tr = Trainer(Tiny())
+    x = torch.randn(5, 4)
+    for _ in range(2):
+        tr.train_step(x)
+    sd = tr.opt.state_dict()
+    names = [n for n, _ in tr.model.named_parameters()]
+    assert names == ["a.weight", "a.bias", "frozen.weight", "frozen.bias", "b.weight", "b.bias"]
+    assert len(sd["param_groups"]) == 6 and sorted(sd["state"]) == [0, 1, 4, 5]
+    assert tuple(sd["state"][4]["exp_avg"].shape) == (2, 3) and tuple(sd["state"][5]["exp_avg"].shape) == (2,)
+    path = str(tmp_path / "ck.pth")
+    tr.save_checkpoint(path)
+    torch.manual_seed(1)
+    tr2 = Trainer(Tiny())
+    tr2.load_checkpoint(path)
+    assert torch.equal(tr2.opt.exp_avg, tr.opt.exp_avg) and torch.equal(tr2.opt.exp_avg_sq, tr.opt.exp_avg_sq)
+    l1, _ = tr.train_step(x)
+    l2, _ = tr2.train_step(x)
+    assert torch.equal(l1["loss"], l2["loss"])
