@@ -280,6 +280,36 @@ class _FusedDecoderPair(torch.autograd.Function):
         return dx, None, None, None, None, None, None, None, None
 
 
+EXACT_ATTENTION_FP32 = True      # compute_dtype='fp32' (the parity mode): attention core in fp32 ATen ops, not the bf16 kernel
+
+
+def window_attention_fp32(qkv, layout, nhead):
+    """softmax(q k^T / sqrt(d)) v inside every window in fp32 ATen ops, differentiable (qkv [n, 3C] fp32 -> [n, C]).
+    The parity mode's attention core: with it the composed fp32 path has NO bf16 step left, so the tight-tolerance tests
+    separate the error of the hand-written bf16 MFMA kernel (ops.window_attention) from everything else.  Windows are
+    padded to the longest one (what the reference does per bucket, sst_basic_block.py:36-59); never on the product path."""
+    n, C3 = qkv.shape
+    C = C3 // 3
+    d = C // nhead
+    W = int(layout.num_windows)                                   # (host sync: test path only)
+    ws = layout.win_start[:W + 1].long()
+    cnt = ws[1:] - ws[:-1]
+    T = int(cnt.max())
+    w_of_pos = torch.repeat_interleave(torch.arange(W, device=qkv.device), cnt)
+    slot = torch.arange(n, device=qkv.device) - ws[w_of_pos]
+    tok = layout.win_tokens[:n].long()
+    pad = qkv.new_zeros((W, T, C3))
+    pad[w_of_pos, slot] = qkv[tok]
+    q, k, v = (pad[..., i * C:(i + 1) * C].reshape(W, T, nhead, d).permute(0, 2, 1, 3) for i in range(3))
+    valid = torch.arange(T, device=qkv.device)[None, :] < cnt[:, None]                     # [W, T]
+    s = (q @ k.transpose(-1, -2)) / math.sqrt(d)
+    s = s.masked_fill(~valid[:, None, None, :], float("-inf"))
+    o = (torch.softmax(s, dim=-1) @ v).permute(0, 2, 1, 3).reshape(W, T, C)
+    out = qkv.new_zeros((n, C))
+    out[tok] = o[w_of_pos, slot]
+    return out
+
+
 class WindowAttention(nn.Module):
     def __init__(self, d_model, nhead, dropout, batch_first=False, layer_id=None):
         super().__init__()
@@ -298,8 +328,11 @@ class WindowAttention(nn.Module):
         qk_in = (x + pos).to(dt)
         qk = F.linear(qk_in, w[:2 * C], b[:2 * C])
         v = F.linear(x.to(dt), w[2 * C:], b[2 * C:])
-        qkv = torch.cat([qk, v], dim=1).to(torch.bfloat16)
-        o = ops.window_attention(qkv, layout, self.nhead).to(dt)
+        qkv = torch.cat([qk, v], dim=1)
+        if dt == torch.float32 and EXACT_ATTENTION_FP32:
+            o = window_attention_fp32(qkv, layout, self.nhead)
+        else:
+            o = ops.window_attention(qkv.to(torch.bfloat16), layout, self.nhead).to(dt)
         return F.linear(o, a.out_proj.weight.to(dt), a.out_proj.bias.to(dt)).float()
 
 

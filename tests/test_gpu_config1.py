@@ -19,14 +19,15 @@ FULL = (("grad_vfe0", "voxel_encoder.vfe_layers.0.linear.weight"), ("grad_mask_t
         ("grad_enc5_ffn_b", "backbone.encoder_blocks.0.encoder_list.1.linear1.bias"),
         ("grad_dec_out_w", "backbone.decoder_centroid_blocks.0.encoder_list.1.win_attn.self_attn.out_proj.weight"))
 # (loss, gradient norm, full-gradient Frobenius); the fp32 composed path / the bf16 fused path and engine
-TOL = {"fp32": (2e-3, 2e-3, 5e-3), "bf16": (1e-2, 3.5e-2, 5.5e-2)}
+TOL = {"fp32": (1e-3, 1e-3, 1.5e-3), "bf16": (1e-2, 3.5e-2, 5.5e-2)}      # fp32 measured (LiDAR cloud): 4.4e-4 / 2.9e-4 / 4.9e-4
 # The 16 k UNIFORM cloud at 0.5 m leaves 17.8 % of the masked pillars (c1u; 16.4 % in the batch c1b, 3.4 % in the LiDAR
 # cloud) with <= 2 occupied med cells in their 3 x 3 neighbourhood: the scatter matrix has rank <= 1, its two smallest
 # eigenvalues coincide, and the "normal" is whatever vector of that null space the solver returns (LAPACK gesdd in the
 # reference, ssl.py:598-602; a Jacobi sweep here).  The normal target, hence loss_curv_around and the gradients of the
 # density decoder that regresses it, are defined only up to that choice on those rows: bounds for them on the fp32
-# path are set from the measured 5.6e-3 / 5.6e-3 (the five other losses and the centroid decoder keep the tight ones).
-ILL = {"c1u": (1.5e-2, 1.2e-2, 8e-3), "c1b": (1.5e-2, 1.2e-2, 8e-3)}
+# path are set from the measured 5.6e-3 (loss) / 6.9e-3 (gradient norm) / 3.6e-3 (the five other losses and the centroid
+# decoder keep the tight ones).
+ILL = {"c1u": (1.5e-2, 1.5e-2, 8e-3), "c1b": (1.5e-2, 1.5e-2, 8e-3)}
 
 
 def _model(compute_dtype):

@@ -21,9 +21,10 @@ FULL = ("grad_vfe0", "voxel_encoder.vfe_layers.0.linear.weight"), ("grad_mask_to
     ("grad_enc5_ffn_b", "backbone.encoder_blocks.5.encoder_list.1.linear1.bias"), \
     ("grad_dec_out_w", "backbone.decoder_centroid_blocks.1.encoder_list.1.win_attn.self_attn.out_proj.weight")
 # (loss tolerance, gradient-norm tolerance, full-gradient relative Frobenius tolerance) per compute dtype
-# measured maxima over c2 / c3 / c4 (GEOMAE_TEST_VERBOSE=1): fp32 composed path 5.0e-4 / 6.8e-4 / 2.4e-3; bf16 fused path
-# 4.2e-3 / 1.7e-2 / 2.7e-2 (the VFE layer-0 weight at 10 sweeps: 260 k points reduced through bf16x3 products)
-TOL = {"fp32": (1e-3, 1.5e-3, 5e-3), "bf16": (1e-2, 3.5e-2, 5.5e-2)}
+# measured maxima over c2 / c3 / c4 (GEOMAE_TEST_VERBOSE=1): fp32 composed path 5.2e-5 / 1.9e-4 / 3.5e-4 (round 3: fp32
+# attention core in it; with the bf16 attention kernel 5.0e-4 / 6.8e-4 / 2.4e-3); bf16 fused path 4.2e-3 / 1.7e-2 / 2.7e-2
+# (the VFE layer-0 weight at 10 sweeps: 260 k points reduced through bf16x3 products)
+TOL = {"fp32": (1.5e-4, 5e-4, 1e-3), "bf16": (1e-2, 3.5e-2, 5.5e-2)}
 
 
 def _frames(case):
