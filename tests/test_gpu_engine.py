@@ -59,7 +59,7 @@ def test_engine_gradients_match_python_explicit_schedule():
         a, b = g_c[off:off + p.numel()], g_py[off:off + p.numel()]
         worst = max(worst, (_rel(a, b), name))
     print(f"largest engine-vs-python gradient difference: {worst[0]:.2e} ({worst[1]})")
-    assert worst[0] < 5e-3, worst
+    assert worst[0] < 2.5e-3, worst                # measured 6.6e-4 ... 8.1e-4 (three runs); bound = 3x
     # BatchNorm running statistics moved identically
     for (k, a), (_, b) in zip(m_c.voxel_encoder.named_buffers(), m_py.voxel_encoder.named_buffers()):
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k

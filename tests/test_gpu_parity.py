@@ -596,6 +596,9 @@ def test_forward_train_random_mask_runs_and_is_finite(dev):
     assert torch.isfinite(total) and all(torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+EXPLICIT_VS_AUTOGRAD_TOL = 2.5e-3      # measured 7.4e-4 ... 8.4e-4 (three runs): the run-to-run noise of either path; bound = 3x
+
+
 def test_explicit_schedule_matches_autograd_path(dev):
     """detector.train_step_explicit (no autograd tape / engine) vs forward_train + backward through the autograd
     Functions: the same kernels in the same order.  Two runs of EITHER path differ by ~1e-4 on the losses (the order
@@ -612,10 +615,13 @@ def test_explicit_schedule_matches_autograd_path(dev):
     for k in la:
         assert torch.allclose(la[k], lb[k].detach(), rtol=2e-3, atol=1e-5), (k, float(la[k]), float(lb[k]))
     ga, gb = dict(a.named_parameters()), dict(b.named_parameters())
+    worst = (0.0, "")
     for k in ga:
         assert ga[k].grad is not None and gb[k].grad is not None, k
         d = float((ga[k].grad - gb[k].grad).norm() / gb[k].grad.norm().clamp(min=1e-12))
-        assert d < 3e-2, (k, d)
+        worst = max(worst, (d, k))
+    print(f"largest explicit-vs-autograd gradient difference: {worst[0]:.2e} ({worst[1]})")
+    assert worst[0] < EXPLICIT_VS_AUTOGRAD_TOL, worst
     for (k, x), (_, y) in zip(a.named_buffers(), b.named_buffers()):
         assert torch.allclose(x.float(), y.float(), rtol=1e-4, atol=1e-6), k      # BatchNorm running statistics
 
