@@ -22,10 +22,6 @@
 namespace geomae {
 namespace {
 
-__global__ void scale_f32_kernel(float* x, int n, float s) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) x[i] *= s;
-}
 __global__ void bn_param_grad_add_kernel(const double* __restrict__ bsums, int C, float* __restrict__ d_beta,
                                          float* __restrict__ d_gamma) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -54,10 +50,6 @@ int zero_arena(void* p, int64_t bytes, hipStream_t stream) {
     if ((bytes & 15) || ((uintptr_t)p & 15)) { GEOMAE_HIP(hipMemsetAsync(p, 0, (size_t)bytes, stream)); return GEOMAE_OK; }
     hipLaunchKernelGGL(zero_arena_kernel, dim3(stream_grid(bytes / 16, 256)), dim3(256), 0, stream, (uint4*)p, bytes / 16);
     return check_launch("zero_arena_kernel");
-}
-int scale_f32(float* x, int n, float s, hipStream_t stream) {
-    hipLaunchKernelGGL(scale_f32_kernel, dim3(cdiv(n, 256)), dim3(256), 0, stream, x, n, s);
-    return check_launch("scale_f32_kernel");
 }
 
 inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
@@ -370,10 +362,11 @@ int bn_forward(Engine* e, int layer, const double* sums, double count, float* sc
                                   m.bn_num_batches[layer], s);
     float* mom = layer == 0 ? m.bn_sync_moments0 : m.bn_sync_moments1;
     GEOMAE_REQUIRE(mom && e->hook, "pretrain: world_size > 1 needs bn_sync buffers and a hook");
-    ENG_CALL(geomae_bn_finalize(sums, count, nullptr, C, nullptr, nullptr, 0.f, 0.f, 0, nullptr, nullptr, nullptr, nullptr,
-                                nullptr, mom, nullptr, s));
+    // local (mean, mean of squares) already divided by the world size (count * world as the divisor), so that the SUM
+    // all-reduce delivers naiveSyncBN1d's equal-weight average and no scaling kernel sits behind the collective
+    ENG_CALL(geomae_bn_finalize(sums, count * (double)c.world_size, nullptr, C, nullptr, nullptr, 0.f, 0.f, 0, nullptr, nullptr,
+                                nullptr, nullptr, nullptr, mom, nullptr, s));
     e->hook(e->hook_user, layer == 0 ? GEOMAE_HOOK_BN_FWD0 : GEOMAE_HOOK_BN_FWD1, s);
-    ENG_CALL(scale_f32(mom, 2 * C, 1.0f / (float)c.world_size, s));
     return geomae_bn_finalize(nullptr, count, mom, C, m.bn_gamma[layer], m.bn_beta[layer], c.bn_eps, c.bn_momentum, 0,
                               m.bn_running_mean[layer], m.bn_running_var[layer], scale, shift, invstd, moments, nullptr, s);
 }

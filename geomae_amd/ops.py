@@ -1181,10 +1181,10 @@ def _bn_finalize(plan, layer, sums, norm, world, group):
                                      _ptr(norm.num_batches_tracked), _stream()), "geomae_bn_finalize")
     else:
         mom = torch.empty(2 * C, dtype=torch.float32, device=sums.device)
-        check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N), None, C, None, None, 0.0, 0.0, 0, None, None, None, None,
+        # (divisor N * world: the SUM all-reduce then delivers the equal-weight average of the ranks' moments directly)
+        check(lib.geomae_bn_finalize(_ptr(sums), float(plan.N) * world, None, C, None, None, 0.0, 0.0, 0, None, None, None, None,
                                      None, _ptr(mom), None, _stream()), "geomae_bn_finalize")
         dist.all_reduce(mom, group=group)
-        mom.mul_(1.0 / world)
         # (no batch counter here: the reference's cross-rank branch never touches num_batches_tracked, ops/norm.py:58-86)
         check(lib.geomae_bn_finalize(None, float(plan.N), _ptr(mom), *common, 0, _ptr(norm.running_mean),
                                      _ptr(norm.running_var), _ptr(bn[0]), _ptr(bn[1]), _ptr(bn[3]), _ptr(bn[2]),

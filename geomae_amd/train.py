@@ -135,6 +135,20 @@ def _grad_group():
     return ops.GRAD_GROUP
 
 
+def _wait_all(works):
+    """Make the current stream wait for the gradient-segment all-reduces.  On RCCL every collective of one process group
+    runs on that group's communication stream, in issue order: waiting for the LAST one orders the current stream behind
+    all of them with one cross-queue wait instead of one per segment (each costs ~10 us of queue time on the waiting
+    stream).  Other backends (gloo: host threads) are waited for one by one."""
+    if not works:
+        return
+    if dist.get_backend(_grad_group()) == "nccl":
+        works[-1][1].wait()
+    else:
+        for _, w in works:
+            w.wait()
+
+
 def _new_comm_group(what):
     """A process group over all ranks for `what`; on RCCL with a high-priority communication stream.  None = use the
     default group (correct, only less overlapped)."""
@@ -426,8 +440,7 @@ class Trainer:
             for i, (a, b, _) in enumerate(self.flat.segments):
                 if i not in done:
                     works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
-            for _, w in works:
-                w.wait()
+            _wait_all(works)
             tap = getattr(self, "on_reduced_grad", None)
             if tap is not None:
                 tap(self.flat.grad)
@@ -501,8 +514,7 @@ class Trainer:
                 for i, (a, b, _) in enumerate(self.flat.segments):
                     if i not in done:
                         works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
-                for _, w in works:
-                    w.wait()
+                _wait_all(works)
                 tap = getattr(self, "on_reduced_grad", None)
                 if tap is not None:                  # test tap: the summed gradient buffer the optimizer is about to read
                     tap(self.flat.grad)
