@@ -188,6 +188,7 @@ SIGNATURES = {
     "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
     "geomae_sst_stack_saved_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "geomae_sst_stack_scratch_bytes": (c_int64, [c_int32]),
+    "geomae_sst_stack_scratch_bytes_layers": (c_int64, [c_int32, c_int32]),
     "geomae_sst_stack_forward": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, c_int32, c_int32, P, c_int64, P, c_int32, P,
                                                 P, P, P]),
     "geomae_sst_stack_backward": (ctypes.c_int, [P, P, c_int32, P, P, c_int32, P, P, c_int32, c_int32, P, P, c_int64, P,

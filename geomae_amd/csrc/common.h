@@ -73,6 +73,11 @@ SstInputMap input_map();
 // zero: the step engine clears them with the token-coordinate gather that precedes the build (no memset kernel).
 void set_window_tables_prezeroed(bool on);
 bool window_tables_prezeroed();
+// "Defer all" mode of the weight-gradient contractions of geomae_sst_stack_backward on this host thread (sst_layer.hip):
+// they are queued and launched by the next geomae_flush_weight_grad on ITS stream.  The stack then needs one set of
+// operand slabs per layer (geomae_sst_stack_scratch_bytes_layers).
+void set_defer_all_weight_grads(bool on);
+bool defer_all_weight_grads();
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

@@ -182,7 +182,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
          al256(M * 24) + al256(n * 12) + al256(n * s_med * 12) + al256(n * s_med) + al256(M * 24) + 256;   // targets
     b += al256(geomae_sst_stack_saved_bytes((int32_t)nk, c.encoder_layers, c.num_heads)) +
          2 * al256(geomae_sst_stack_saved_bytes((int32_t)n, c.decoder_layers, c.num_heads));
-    b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes((int32_t)n));
+    b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes_layers((int32_t)n, c.decoder_layers));
     b += al256(nk * 512) + 4 * al256(n * 512);                                                             // z_enc, cen, den, dxa, dxb
     b += al256(M * 896 * 2) + 2 * al256(M * 128 * 2);                                                      // heads
     b += 2 * al256(N * 128 * 2) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);                         // VFE backward
@@ -466,7 +466,18 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* t_cov = a.take<float>(M * 6);
     int32_t* t_occ = a.take<int32_t>(2);
     const int64_t sb_enc = geomae_sst_stack_saved_bytes(nk, ne, nh), sb_dec = geomae_sst_stack_saved_bytes(n, nd, nh);
-    const int64_t wb_enc = geomae_sst_stack_scratch_bytes(nk), wb_dec = geomae_sst_stack_scratch_bytes(n);
+    const int64_t wb_enc = geomae_sst_stack_scratch_bytes(nk), wb_dec = geomae_sst_stack_scratch_bytes_layers(n, nd);
+    // The weight-gradient contractions of the two DECODER stacks run on the geometry stream after their stack's backward,
+    // beside the encoder backward (GEOMAE_DW_DEFER_ALL=0: riding in the stacks' ffn-backward launches, round 2's form).
+    // The decoder backward is at the memory system's roof (two stacks, 7 TB/s between L2 and fabric): without the
+    // contractions' 4 KB per token and layer its phase is 0.49 -> 0.41 ms, while the encoder backward -- one workgroup
+    // chain per CU, half the chip idle -- takes them in for +0.02 ms.  The ENCODER's own contractions keep riding: queued
+    // behind its backward they are twelve launches of one round each, 0.11 ms that nothing is left to hide.
+    static const bool defer_dec_dw = [] { const char* v = getenv("GEOMAE_DW_DEFER_ALL"); return !v || v[0] != '0'; }();
+    struct DeferAllScope {
+        explicit DeferAllScope(bool on) { set_defer_all_weight_grads(on); }
+        ~DeferAllScope() { set_defer_all_weight_grads(false); }
+    };
     char* s_enc = a.bytes(sb_enc); char* s_cen = a.bytes(sb_dec); char* s_den = a.bytes(sb_dec);
     char* w_enc = a.bytes(wb_enc); char* w_cen = a.bytes(wb_dec); char* w_den = a.bytes(wb_dec);
     float* z_enc = a.take<float>((int64_t)nk * 128);
@@ -599,14 +610,20 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     mark(e, pHeads, main);
     GEOMAE_HIP(hipStreamWaitEvent(aux, e->ev[kHeads], 0));
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
-    ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
-                                       w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
+    {
+        DeferAllScope defer(defer_dec_dw);
+        ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
+                                           w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
+    }
     GEOMAE_HIP(hipEventRecord(e->ev[kAuxBwd], aux));
     GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kAuxBwd], 0));
     ENG_CALL(geomae_flush_weight_grad(geo));
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
-    ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
-                                       w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
+    {
+        DeferAllScope defer(defer_dec_dw);
+        ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
+                                           w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
+    }
     ENG_CALL(order_after(e, kMainDecBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));
     GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kAuxBwd], 0));

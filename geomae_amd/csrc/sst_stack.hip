@@ -69,7 +69,7 @@ struct ScratchOffsets {
     int64_t du, dv, y, dhp, h, dqkv;            // offsets inside a set
     int64_t set_bytes, dw_partial, total;
 };
-static ScratchOffsets scratch_offsets(int64_t n) {
+static ScratchOffsets scratch_offsets(int64_t n, int sets = 2) {
     ScratchOffsets o;
     n = (n + 15) / 16 * 16;
     int64_t p = 0;
@@ -84,7 +84,7 @@ static ScratchOffsets scratch_offsets(int64_t n) {
     o.h = q;      q += al256(n * 256 * 2);
     o.dqkv = q;   q += al256(n * 384 * 2);
     o.set_bytes = q;
-    o.dw_partial = p + 2 * q;                   // split-K workspace of the weight-gradient contraction: two buffers
+    o.dw_partial = p + (int64_t)sets * q;       // split-K workspace of the weight-gradient contraction: two buffers
     o.total = o.dw_partial + 2 * kDwPartialBytes;
     return o;
 }
@@ -140,6 +140,9 @@ extern "C" int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_
     return saved_offsets(num_tokens, num_heads).stride * num_layers;
 }
 extern "C" int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens) { return scratch_offsets(num_tokens).total; }
+extern "C" int64_t geomae_sst_stack_scratch_bytes_layers(int32_t num_tokens, int32_t num_layers) {
+    return scratch_offsets(num_tokens, num_layers < 2 ? 2 : num_layers).total;
+}
 
 static int check_stack(const GeomaeSstLayerWeights* layers, int n_layers, const GeomaeSstStackLayout* lay, const char* who) {
     GEOMAE_REQUIRE(layers && n_layers >= 1 && lay, "%s: null layers / layouts", who);
@@ -228,7 +231,10 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     if (rc) return rc;
     GEOMAE_REQUIRE(dz && grads && pos_table && saved && scratch && dx_out, "sst_stack_backward: null argument");
     const SavedOffsets so = saved_offsets(num_tokens, num_heads);
-    const ScratchOffsets sc = scratch_offsets(num_tokens);
+    // "defer all": the contractions run after the whole stack, so every layer keeps its own operand slabs
+    const bool defer_all = defer_all_weight_grads();
+    const int n_sets = defer_all ? (num_layers < 2 ? 2 : num_layers) : 2;
+    const ScratchOffsets sc = scratch_offsets(num_tokens, n_sets);
     if (scratch_bytes < sc.total) {
         set_error("sst_stack_backward: scratch %lld < %lld bytes", (long long)scratch_bytes, (long long)sc.total);
         return GEOMAE_ERR_WORKSPACE;
@@ -246,11 +252,11 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
-        const int set = l & 1;
+        const int set = defer_all ? l : (l & 1);
         char* ws = w + sc.set0 + set * sc.set_bytes;
         const bool top = l + 1 == num_layers;
         LayerLayoutScope lay(kBlk | saved_flag());  // dz (top layer) and dx_out are the row-major boundary tensors
-        const char* ws_up = w + sc.set0 + ((l + 1) & 1) * sc.set_bytes;       // slabs of the layer above
+        const char* ws_up = w + sc.set0 + (defer_all ? (l + 1 < num_layers ? l + 1 : l) : ((l + 1) & 1)) * sc.set_bytes;   // slabs of the layer above
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
@@ -289,13 +295,13 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         } else {
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
             // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
-            if (defer_last_weight_grad) defer_next_weight_grad();
+            if (defer_last_weight_grad || defer_all) defer_next_weight_grad();
             Timed t(profiler, GEOMAE_KERNEL_DW, stream);
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
-    if (!(defer_last_weight_grad && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
+    if (!((defer_last_weight_grad || defer_all) && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
         rc = GEOMAE_ERR_HIP;                                                                         // error paths only
     return rc;
 }

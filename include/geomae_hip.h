@@ -460,6 +460,9 @@ typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_b
 } GeomaeSstStackLayout;
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
+/* scratch for a backward whose weight-gradient contractions are all deferred to geomae_flush_weight_grad (the step
+ * engine's schedule): one set of operand slabs per layer instead of two alternating ones */
+int64_t geomae_sst_stack_scratch_bytes_layers(int32_t num_tokens, int32_t num_layers);
 /* x_in holds num_input_rows rows; the remaining num_tokens - num_input_rows input rows are copies of fill_row [128]
  * (the decoders' mask token, bb.py:239-246).  fill_row == NULL: x_in holds all num_tokens rows.
  * input_rows != NULL: token t (t < num_input_rows) reads row input_rows[t] of x_in (the gather of the kept voxels,
