@@ -196,8 +196,11 @@ def main():
     # (the stand-alone dw_kernel launches are not in the list: the schedule defers them to the geometry stream,
     # geomae_flush_weight_grad, so the stack's event pair would bracket their recording, not their execution;
     # profiles/*kernel_stats.csv has their durations)
-    TIMED = ("sst_ffn_bwd_kernel", "win_attn_bwd_kernel", "sst_ffn_fwd_kernel", "sst_qkv_bwd_kernel",
-             "win_attn_fwd_kernel", "sst_qkv_fwd_kernel")
+    # (the ffn launches come in two kernels each -- sst_ffn_bwd_kernel / sst_ffn_bwd_dw_kernel: without / with a
+    # weight-gradient contraction riding along; sst_ffn_fwd_kernel / sst_ffn_fwd_pair_kernel -- and are timed per
+    # kernel, under the names of the rocprofv3 table)
+    TIMED = ("sst_ffn_bwd_kernel", "sst_ffn_bwd_dw_kernel", "win_attn_bwd_kernel", "sst_ffn_fwd_kernel",
+             "sst_ffn_fwd_pair_kernel", "sst_qkv_bwd_kernel", "win_attn_fwd_kernel", "sst_qkv_fwd_kernel")
     DOMINANT = "sst_ffn_bwd_kernel"               # largest share in profiles/ (rocprofv3 --kernel-trace --stats)
     lib = _lib.load()
     import ctypes
@@ -251,6 +254,8 @@ def main():
     elapsed = float(t.item())
     per_step = np.array([step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)])
     durations = {DOMINANT: profile_off(prof_handle)}
+    steps_timed = {k: 3 for k in TIMED}
+    steps_timed[DOMINANT] = len(range(0, args.steps, max(1, args.profile_every)))
     for k in TIMED:                               # the other kernels: 3 extra (untimed) steps each
         if k != DOMINANT:
             h = profile_on(k, 64)
@@ -258,6 +263,15 @@ def main():
             for i in range(3):
                 step(i)
             durations[k] = profile_off(h)
+    # what an event pair with NOTHING between its records measures on this stream (the two records' own queue time): the
+    # per-launch durations above contain it, rocprofv3's kernel durations do not
+    torch.cuda.synchronize()
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    for a_, b_ in pairs:
+        a_.record()
+        b_.record()
+    torch.cuda.synchronize()
+    event_pair_ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in pairs]))
     phases = None
     if eng is not None:                           # where the main stream's time goes: 3 instrumented (untimed) steps
         eng.set_phase_timing(True)
@@ -291,20 +305,28 @@ def main():
                     n_tok += [int(toks.shape[0])] * (layers // 2)
         n_sum, sq_sum = float(np.sum(n_tok)), float(np.sum(sq))          # over the 20 layers of one step
         # Fusion structure of a stack of L layers (12-layer encoder, two 4-layer decoders; csrc/sst_stack.hip):
-        #   forward : F1(0) | attn | F3(l)+F1(l+1) ... | F3(L-1)             -> 17 of 20 ffn-forward launches carry an F1
+        #   forward : F1(0) | attn | F3(l)+F1(l+1) ... | F3(L-1)      -> L-1 of a stack's L ffn-forward launches carry an F1
         #   backward: B3(L-1) | battn | B1(l+1)+B3(l) [+ dW(l+1)] ... | B1(0) | dW(0)
-        #                                                                     -> 17 of 20 ffn-backward launches carry B1 + dW
-        # 3 stand-alone F1 / B1 / dW launches remain per step (one per stack).
+        # The encoder's launches carry the contraction dW(l+1) (sst_ffn_bwd_dw_kernel, 11 per step; its top layer's
+        # launch is a plain sst_ffn_bwd_kernel); the decoders' contractions are queued for the geometry stream
+        # (csrc/engine.hip, GEOMAE_DW_DEFER_ALL), so their 8 launches are plain ones (B3, 6 of them with a B1 head).
+        # With the python step driver / GEOMAE_DW_DEFER_ALL=0 the decoders' 6 non-top launches carry a dW too.
+        # 3 stand-alone F1 / B1 launches per step (one per stack); the stand-alone dw_kernel launches are not timed here.
         n_e, n_d = float(n_tok[0]), float(n_tok[-1])
-        carried, alone = 11 * n_e + 6 * n_d, n_e + 2 * n_d
-        flops_step = {"sst_ffn_bwd_kernel": 2 * 81920 * n_sum + 2 * (49152 + 131072) * carried,
-                      "sst_ffn_fwd_kernel": 2 * 81920 * n_sum + 2 * 49152 * carried,
-                      "sst_qkv_fwd_kernel": 2 * 49152 * alone, "sst_qkv_bwd_kernel": 2 * 49152 * alone,
-                      "dw_kernel": 2 * 131072 * alone, "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum,
-                      "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum}
-        launches_step = {k: 20.0 for k in flops_step}
-        launches_step.update({"dw_kernel": 3.0, "sst_qkv_fwd_kernel": 3.0, "sst_qkv_bwd_kernel": 3.0})
-        report_name = {"sst_ffn_bwd_kernel": "sst_ffn_bwd_dw_kernel"}
+        F3, F1, DW = 2 * 81920.0, 2 * 49152.0, 2 * 131072.0           # FLOPs per token: ffn (3 GEMMs) / qkv / contractions
+        lps = lambda k: (len(durations.get(k) or []) / steps_timed[k]) if durations.get(k) else 0.0     # launches per step
+        dec_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 11
+        flops_step = {"sst_ffn_bwd_kernel": F3 * (n_e + 8 * n_d) + F1 * 6 * n_d if dec_deferred else F3 * (n_e + 2 * n_d),
+                      "sst_ffn_bwd_dw_kernel": (F3 + F1 + DW) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
+                      "sst_ffn_fwd_kernel": F3 * 8 * n_d + F1 * 6 * n_d,
+                      "sst_ffn_fwd_pair_kernel": F3 * 12 * n_e + F1 * 11 * n_e,
+                      "sst_qkv_fwd_kernel": F1 * (n_e + 2 * n_d), "sst_qkv_bwd_kernel": F1 * (n_e + 2 * n_d),
+                      "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum, "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum}
+        expect = {"sst_ffn_bwd_kernel": 9.0 if dec_deferred else 3.0, "sst_ffn_bwd_dw_kernel": 11.0 if dec_deferred else 17.0,
+                  "sst_ffn_fwd_kernel": 8.0, "sst_ffn_fwd_pair_kernel": 12.0, "sst_qkv_fwd_kernel": 3.0,
+                  "sst_qkv_bwd_kernel": 3.0, "win_attn_fwd_kernel": 20.0, "win_attn_bwd_kernel": 20.0}
+        launches_step = {k: lps(k) for k in flops_step}
+        report_name = {}
         peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         # HBM bytes per launch are NOT measured in this run: they come from the stored PMC passes of tools/pmc.sh
         # (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs) and only apply to the workload they were taken on
@@ -317,19 +339,22 @@ def main():
         kern = {}
         for k in TIMED:
             d = durations.get(k) or []
-            if d:
+            if d and abs(launches_step[k] - expect[k]) < 0.01:      # (another launch structure: no FLOP model here)
                 ms_step = float(np.sum(d)) / (len(d) / launches_step[k])
                 ach = flops_step[k] / (ms_step * 1e-3) / 1e12
                 tr_b = traffic.get(report_name.get(k, k))
                 kern[k] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
                            "frac": round(ach / peak, 5), "traffic": tr_b, "traffic_source": traffic_src if tr_b else None,
                            "avg_launch_ms": round(float(np.mean(d)), 5), "launches_timed": len(d),
-                           "ms_per_step": round(ms_step, 4)}
+                           "launches_per_step": round(launches_step[k], 2), "ms_per_step": round(ms_step, 4),
+                           # the same average less the empty event pair: comparable with rocprofv3's AverageNs
+                           "avg_launch_ms_less_event_pair": round(float(np.mean(d)) - event_pair_ms, 5),
+                           "empty_event_pair_ms": round(event_pair_ms, 5)}
                 if tr_b:        # the same launch against the HBM roof (8 TB/s): stored PMC bytes / measured duration
                     gbs = tr_b / (float(np.mean(d)) * 1e-3) / 1e9
                     kern[k]["hbm_view"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(gbs / 8000.0, 4)}
-        dominant = DOMINANT
+        dominant = DOMINANT if DOMINANT in kern else (max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None)
         out = {
             "metric": "pretrain frames/sec (nuScenes SST-GeoMAE)",
             "value": round(world * B * args.steps / elapsed, 3), "unit": "frames/s",
@@ -350,7 +375,7 @@ def main():
             # host wall time to ENQUEUE the timed steps (everything but the final synchronize), per step; with the
             # engine also the share of it spent blocked on the pillar-count readback (= how far the host runs ahead)
             "host_ms_per_step": {"enqueue_loop": round(1e3 * t_enq / args.steps, 4)},
-            "roofline": dict(kernel=report_name.get(dominant, dominant), **kern[dominant]),
+            "roofline": dict(kernel=report_name.get(dominant, dominant), **kern[dominant]) if dominant else None,
             "roofline_other_kernels": {report_name.get(k, k): v for k, v in kern.items() if k != dominant},
         }
         if h0 is not None:
@@ -368,7 +393,8 @@ def main():
                 out["mfma_busy_stored"] = {"source": f"profiles/{cand} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
                                            **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
                                                                                   "sst_ffn_fwd_kernel", "sst_ffn_fwd_pair_kernel",
-                                                                                  "sst_ffn_bwd_dw_kernel", "vfe_layer1_kernel") if k in u}}
+                                                                                  "sst_ffn_bwd_kernel", "sst_ffn_bwd_dw_kernel",
+                                                                                  "vfe_layer1_kernel") if k in u}}
                 break
         if phases is not None:
             out["main_stream_phase_ms"] = phases

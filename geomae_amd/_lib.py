@@ -95,7 +95,8 @@ class GeomaePretrainModel(ctypes.Structure):
                  ("bn_num_batches", c_void_p * 2), ("params", c_void_p), ("grads", c_void_p), ("exp_avg", c_void_p),
                  ("exp_avg_sq", c_void_p), ("num_params", c_int64), ("no_decay_prefix", c_int64),
                  ("no_decay2_start", c_int64), ("no_decay2_count", c_int64), ("bn_sync_moments0", c_void_p),
-                 ("bn_sync_moments1", c_void_p), ("bn_sync_bsums1", c_void_p), ("bn_sync_bsums0", c_void_p)])
+                 ("bn_sync_moments1", c_void_p), ("bn_sync_bsums1", c_void_p), ("bn_sync_bsums0", c_void_p),
+                 ("bn_sync_feat_moments", c_void_p)])
 
 
 PRETRAIN_HOOK = ctypes.CFUNCTYPE(None, c_void_p, c_int32, c_void_p)

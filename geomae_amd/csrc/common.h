@@ -56,6 +56,11 @@ float* tail_sum(int* from_row);
 // 30 % of the tokens -- come first.
 void set_first_live_row(int row);
 int first_live_row();
+// which variant of a layer kernel the last launch on this thread used (0 = plain; 1 = sst_ffn_fwd_pair_kernel /
+// sst_ffn_bwd_dw_kernel): the stack's per-kernel timer (bench.py's roofline) keeps a launch's events only if it was the
+// kernel asked for, so that its averages are those of ONE kernel of the rocprofv3 table
+void set_last_kernel_variant(int v);
+int last_kernel_variant();
 // Split-K workspace of the geomae_sst_weight_grad calls of this host thread (set by geomae_sst_stack_backward for its own
 // layers): two buffers of kDwPartialBytes where the contraction's workgroups leave their partial sums instead of
 // atomically adding them to the gradients (sst_layer.hip dw_body); nullptr = atomics.

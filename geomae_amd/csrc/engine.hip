@@ -89,6 +89,7 @@ struct Batch {
     int32_t* host_counts = nullptr;    // pinned [B + 1]
     hipEvent_t readback = nullptr;
     int32_t V = 0, n_keep = 0, n_mask = 0;
+    bool moments_exchanged = false;    // the rank-averaged feature moments of this batch are in bn_sync_feat_moments[slot]
 };
 
 struct WinLayout {
@@ -97,7 +98,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNextReady, kNumEv };
+          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -298,6 +299,35 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
                                          b.voxel_coors, &c.window, b.ids_keep, b.ids_mask, b.token_row, b.counts, s));
     b.valid = true;
     b.counts_read = false;
+    return GEOMAE_OK;
+}
+
+// naiveSyncBN1d of the first VFE layer, exchanged AHEAD: y0 = W0 f is linear in the point features, so the equal-weight
+// rank average of (mean y0, mean y0^2) is W0 applied to the rank average of the per-rank NORMALISED feature moments
+// (S1 / N_r, S2 / N_r).  Those depend on the batch only -- not on the weights -- and are complete with its stage 1, one
+// step before the VFE forward that needs them: the all-reduce leaves the main stream's critical path (the in-line form,
+// BN_FWD0, stops the VFE forward for a collective round trip).  Raised behind every other hook of the step, so the
+// process group sees the same order of collectives on every rank.
+__global__ void scale_moments_kernel(const double* __restrict__ in, double* __restrict__ out, double inv, int count) {
+    const int i = threadIdx.x;
+    out[i] = i < count ? in[i] * inv : 0.0;
+}
+
+constexpr int kFeatMoments = 144;      // doubles per slot (csrc/vfe.hip: S1 padded to 16, S2 [11][11], padding)
+
+int exchange_moments(Engine* e, int which, hipStream_t s) {
+    const GeomaePretrainConfig& c = e->cfg;
+    Batch& b = e->batch[which];
+    b.moments_exchanged = false;
+    if (!exchanges(c) || !c.sync_bn || !e->m.bn_sync_feat_moments) return GEOMAE_OK;
+    GEOMAE_REQUIRE(e->hook, "pretrain: world_size > 1 needs a hook");
+    double* buf = e->m.bn_sync_feat_moments + (int64_t)kFeatMoments * which;
+    hipLaunchKernelGGL(scale_moments_kernel, dim3(1), dim3(kFeatMoments), 0, s, (const double*)b.moments, buf,
+                       1.0 / ((double)b.N * (double)c.world_size), 16 + 121);
+    GEOMAE_HIP(hipGetLastError());
+    e->hook(e->hook_user, which == 0 ? GEOMAE_HOOK_FEAT_MOMENTS0 : GEOMAE_HOOK_FEAT_MOMENTS1, s);
+    GEOMAE_HIP(hipEventRecord(e->ev[which == 0 ? kMoments0 : kMoments1], s));
+    b.moments_exchanged = true;
     return GEOMAE_OK;
 }
 
@@ -573,8 +603,19 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     va.w0 = m.vfe_w0; va.w1 = m.vfe_w1;
     va.scale0 = bn_scale0; va.shift0 = bn_shift0; va.scale1 = bn_scale1; va.shift1 = bn_shift1;
     va.moments = b.moments; va.dw0_acc = dw0_acc;
-    ENG_CALL(geomae_vfe_stats0(&va, sums0, main));
-    ENG_CALL(bn_forward(e, 0, sums0, (double)N, bn_scale0, bn_shift0, bn_invstd0, bn_mom0, main));
+    if (b.moments_exchanged) {
+        // (mean, mean of squares) of all ranks straight from the averaged moments: no collective in the VFE forward
+        GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[e->pending == 0 ? kMoments0 : kMoments1], 0));
+        GeomaeVfeArgs vs = va;
+        vs.moments = m.bn_sync_feat_moments + (int64_t)kFeatMoments * e->pending;
+        ENG_CALL(geomae_vfe_stats0(&vs, sums0, main));
+        ENG_CALL(geomae_bn_finalize(sums0, 1.0, nullptr, 64, m.bn_gamma[0], m.bn_beta[0], c.bn_eps, c.bn_momentum, 0,
+                                    m.bn_running_mean[0], m.bn_running_var[0], bn_scale0, bn_shift0, bn_invstd0, bn_mom0,
+                                    nullptr, main));
+    } else {
+        ENG_CALL(geomae_vfe_stats0(&va, sums0, main));
+        ENG_CALL(bn_forward(e, 0, sums0, (double)N, bn_scale0, bn_shift0, bn_invstd0, bn_mom0, main));
+    }
     ENG_CALL(geomae_vfe_layer0(&va, m0, sums1, main));
     ENG_CALL(bn_forward(e, 1, sums1, (double)N, bn_scale1, bn_shift1, bn_invstd1, bn_mom1, main));
     ENG_CALL(geomae_vfe_layer1(&va, m0, vf, main));
@@ -678,6 +719,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(order_after(e, kGeoDone, geo, main));
     mark(e, pVfeBwd, main);
 
+    // the next batch's feature moments -> all ranks (behind every other collective of this step)
+    if (next_frames) ENG_CALL(exchange_moments(e, nxt, aux));
     // the consumed batch's slot is free again; the next batch (if any) is pending
     b.valid = false;
     e->pending = next_frames ? nxt : -1;
@@ -829,6 +872,7 @@ extern "C" int geomae_pretrain_submit(void* engine, const float* const* frame_po
     // order behind everything of the previous step (its kernels may still read the slot's previous batch)
     if (e->have_step_end) GEOMAE_HIP(hipStreamWaitEvent(stream, e->ev[kStepEnd], 0));
     int rc = run_stage1(e, which, frame_points, frame_sizes, e->mask_draws + 1, stream);
+    if (rc == GEOMAE_OK) rc = exchange_moments(e, which, stream);
     if (rc != GEOMAE_OK) { e->pending = -1; return rc; }
     e->pending = which;
     // the step's side streams read the batch: order them behind this stream's stage 1

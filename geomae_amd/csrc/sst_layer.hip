@@ -1113,6 +1113,7 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
         hipLaunchKernelGGL(sst_ffn_fwd_pair_kernel, dim3(cdiv(tiles, 2)), dim3(kLayerBlk), 0, stream, x,
                            (const bf16_t*)attn_bf16, to_layer(w), num_tokens, w->ln_eps, z, xhat1, xhat2,
                            (bf16_t*)hp_bf16, rstd, N, layer_layout());
+        set_last_kernel_variant(1);
         return check_launch("sst_ffn_fwd_pair_kernel");
     }
     // rows the caller never reads (set_first_live_row, the last layer of a decoder stack): whole workgroups are skipped
@@ -1170,6 +1171,7 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     hipLaunchKernelGGL(sst_ffn_bwd_dw_kernel, dim3(n_ffn + dw_blocks + (Rd.partial ? kDwReduceBlocks : 0)), dim3(kLayerBlk), 0,
                        stream, A, n_ffn, P.tasks, P.num_tokens, chunk, gx, dw_blocks, Rd);
     note_partials(P.tasks, P.num_tasks, gx);
+    set_last_kernel_variant(1);
     return check_launch("sst_ffn_bwd_dw_kernel");
 }
 

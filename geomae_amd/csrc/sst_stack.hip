@@ -95,14 +95,20 @@ struct Profiler {
     std::vector<hipEvent_t> ev;     // pairs
     int used = 0;
 };
+// ids 8 / 9 are the second variants of the ffn launches (include/geomae_hip.h): which one a launch turned out to be is
+// known after it (last_kernel_variant), so the pair is kept or dropped in the destructor
 struct Timed {
-    Profiler* p; hipStream_t s; bool on;
-    Timed(void* prof, int id, hipStream_t st) : p((Profiler*)prof), s(st) {
-        on = p && p->kernel_id == id && p->used + 2 <= (int)p->ev.size();
+    Profiler* p; hipStream_t s; bool on; int want;
+    Timed(void* prof, int id, hipStream_t st) : p((Profiler*)prof), s(st), want(0) {
+        int base = p ? p->kernel_id : 0;
+        if (base == GEOMAE_KERNEL_FFN_BWD_DW) { base = GEOMAE_KERNEL_FFN_BWD; want = 1; }
+        if (base == GEOMAE_KERNEL_FFN_FWD_PAIR) { base = GEOMAE_KERNEL_FFN_FWD; want = 1; }
+        on = p && base == id && p->used + 2 <= (int)p->ev.size();
+        set_last_kernel_variant(0);
         if (on) (void)hipEventRecord(p->ev[p->used], s);
     }
     ~Timed() {
-        if (on) { (void)hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
+        if (on && last_kernel_variant() == want) { (void)hipEventRecord(p->ev[p->used + 1], s); p->used += 2; }
     }
 };
 

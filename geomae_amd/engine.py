@@ -15,7 +15,8 @@ from torch import distributed as dist
 from . import _lib, ops
 from ._lib import GeomaePretrainConfig, GeomaePretrainModel, check
 
-HOOK_BN_FWD0, HOOK_BN_FWD1, HOOK_BN_BWD1, HOOK_BN_BWD0, HOOK_GRADS_EARLY, HOOK_GRADS_ENCODER = range(6)
+HOOK_BN_FWD0, HOOK_BN_FWD1, HOOK_BN_BWD1, HOOK_BN_BWD0, HOOK_GRADS_EARLY, HOOK_GRADS_ENCODER, HOOK_FEAT_MOMENTS0, \
+    HOOK_FEAT_MOMENTS1 = range(8)
 PHASES = ("vfe_fwd", "layouts_wait", "enc_fwd", "dec_fwd", "heads_loss", "dec_bwd", "enc_bwd", "vfe_bwd_stats",
           "vfe_bwd_layer1", "vfe_bwd_layer0", "vfe_bwd_join", "optimizer")
 ERR_WORKSPACE = -3
@@ -121,6 +122,12 @@ class PretrainEngine:
                              bs0=z(128, torch.float64))
             m.bn_sync_moments0, m.bn_sync_moments1 = self.sync["mom0"].data_ptr(), self.sync["mom1"].data_ptr()
             m.bn_sync_bsums1, m.bn_sync_bsums0 = self.sync["bs1"].data_ptr(), self.sync["bs0"].data_ptr()
+            # layer-0 statistics exchanged one step ahead, as rank-averaged feature moments (include/geomae_hip.h
+            # FEAT_MOMENTS; GEOMAE_BN0_AHEAD=0: in line, inside the VFE forward)
+            import os
+            if os.environ.get("GEOMAE_BN0_AHEAD", "1") != "0":
+                self.sync["featmom"] = z(2 * 144, torch.float64)
+                m.bn_sync_feat_moments = self.sync["featmom"].data_ptr()
         return m
 
     def _create(self, n_points):
@@ -193,6 +200,9 @@ class PretrainEngine:
                 dist.all_reduce(self.sync["bs1"], group=group)
             elif what == HOOK_BN_BWD0:
                 dist.all_reduce(self.sync["bs0"], group=group)
+            elif what in (HOOK_FEAT_MOMENTS0, HOOK_FEAT_MOMENTS1):
+                slot = what - HOOK_FEAT_MOMENTS0
+                dist.all_reduce(self.sync["featmom"][144 * slot:144 * (slot + 1)], group=group)
             elif self.on_segment is not None:               # `stream`: the one behind which the segment is complete
                 self.on_segment(0 if what == HOOK_GRADS_EARLY else 1)
 

@@ -651,14 +651,21 @@ typedef struct GeomaePretrainModel {
     int64_t no_decay_prefix, no_decay2_start, no_decay2_count;
     float *bn_sync_moments0 /*[128]*/, *bn_sync_moments1 /*[256]*/;
     double *bn_sync_bsums1 /*[256]*/, *bn_sync_bsums0 /*[128]*/;
+    double *bn_sync_feat_moments /*[2][144]*/;   /* or NULL: layer-0 statistics exchanged in line (BN_FWD0) */
 } GeomaePretrainModel;
 
 /* hook(user, what, stream): called from inside geomae_pretrain_step at world_size > 1, with the stream behind which
  * the named data is complete.  BN_*: all-reduce (sum) the matching bn_sync_* buffer on `stream` before returning (the
  * engine divides by world_size itself); GRADS_*: the gradient segment is complete in `stream`'s order -- start its
- * exchange (the engine does not wait for it; the caller does, before geomae_pretrain_optimizer). */
+ * exchange (the engine does not wait for it; the caller does, before geomae_pretrain_optimizer).
+ * FEAT_MOMENTS0 / 1 (only with bn_sync_feat_moments): all-reduce (sum) the 144 doubles of slot 0 / 1 of that buffer.  The
+ * first VFE layer is linear, so the cross-rank statistics of its BatchNorm follow from the rank-averaged moments of the
+ * point features, which depend on the BATCH only: they are exchanged when the batch's stage 1 is done -- at the end of the
+ * previous step, or inside geomae_pretrain_submit -- instead of in the middle of the VFE forward (BN_FWD0 is then never
+ * raised).  Every rank raises the hooks of one process group in the same order as long as all ranks step together. */
 enum { GEOMAE_HOOK_BN_FWD0 = 0, GEOMAE_HOOK_BN_FWD1 = 1, GEOMAE_HOOK_BN_BWD1 = 2, GEOMAE_HOOK_BN_BWD0 = 3,
-       GEOMAE_HOOK_GRADS_EARLY = 4, GEOMAE_HOOK_GRADS_ENCODER = 5 };
+       GEOMAE_HOOK_GRADS_EARLY = 4, GEOMAE_HOOK_GRADS_ENCODER = 5, GEOMAE_HOOK_FEAT_MOMENTS0 = 6,
+       GEOMAE_HOOK_FEAT_MOMENTS1 = 7 };
 typedef void (*GeomaePretrainHook)(void* user, int32_t what, geomaeStream_t stream);
 
 int64_t geomae_pretrain_workspace_bytes(const GeomaePretrainConfig* cfg, int64_t max_points, int32_t max_pillars);
@@ -719,7 +726,10 @@ int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [6]*/);
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */
 enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_FWD = 3, GEOMAE_KERNEL_FFN_BWD = 4,
-       GEOMAE_KERNEL_ATTN_BWD = 5, GEOMAE_KERNEL_QKV_BWD = 6, GEOMAE_KERNEL_DW = 7 };
+       GEOMAE_KERNEL_ATTN_BWD = 5, GEOMAE_KERNEL_QKV_BWD = 6, GEOMAE_KERNEL_DW = 7,
+       GEOMAE_KERNEL_FFN_BWD_DW = 8 /* the ffn-backward launches that carry a weight-gradient contraction
+                                       (sst_ffn_bwd_dw_kernel); 4 = those that do not (sst_ffn_bwd_kernel) */,
+       GEOMAE_KERNEL_FFN_FWD_PAIR = 9 /* sst_ffn_fwd_pair_kernel launches; 3 = sst_ffn_fwd_kernel launches */ };
 void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches);
 int32_t geomae_profiler_read(void* profiler, float* ms_out, int32_t capacity);
 void geomae_profiler_destroy(void* profiler);

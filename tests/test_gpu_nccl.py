@@ -81,14 +81,20 @@ def _worker(rank, port, tmp):
                     # uses the unbiased one: a factor N / (N - 1) = 1 + 7e-5 on the increment at N = 14 k points
                     assert torch.allclose(a.float(), b.float(), rtol=3e-4 if "running_var" in k else 1e-5, atol=1e-6), k
         assert tr_p.get_engine().exchange is False
-        # per step: 4 SyncBN exchanges + 2 early segment exchanges, each handed the stream it must be ordered on
-        assert len(calls) == 18, calls
-        per_step = [w for w, _ in calls[:6]]
-        assert sorted(per_step) == [E.HOOK_BN_FWD0, E.HOOK_BN_FWD1, E.HOOK_BN_BWD1, E.HOOK_BN_BWD0, E.HOOK_GRADS_EARLY,
-                                    E.HOOK_GRADS_ENCODER], per_step
+        # per step: 3 SyncBN exchanges in line + 2 early segment exchanges + the NEXT batch's feature moments (layer-0
+        # statistics, exchanged a step ahead) behind them; the first batch's moments inside its submission.  Each hook
+        # is handed the stream it must be ordered on.
+        assert len(calls) == 1 + 3 * 6, calls
+        assert calls[0][0] == E.HOOK_FEAT_MOMENTS0
+        for i in range(3):
+            per_step = [w for w, _ in calls[1 + 6 * i:7 + 6 * i]]
+            assert per_step == [E.HOOK_BN_FWD1, E.HOOK_GRADS_EARLY, E.HOOK_GRADS_ENCODER, E.HOOK_BN_BWD1, E.HOOK_BN_BWD0,
+                                E.HOOK_FEAT_MOMENTS1 if i % 2 == 0 else E.HOOK_FEAT_MOMENTS0], (i, per_step)
         main = torch.cuda.current_stream(dev).cuda_stream
-        for w, s in calls:
+        for j, (w, s) in enumerate(calls):
             want = eng_f.geo.cuda_stream if w in (E.HOOK_GRADS_EARLY, E.HOOK_GRADS_ENCODER) else main
+            if w in (E.HOOK_FEAT_MOMENTS0, E.HOOK_FEAT_MOMENTS1) and j > 0:
+                want = eng_f.aux.cuda_stream               # (stage 1 of the next batch runs on the decoder-B stream)
             assert s == want, (w, s, want)
         for i, (lp, lf, gp, gf) in enumerate(hist):
             # the run-to-run noise of either path: 2e-4 on the losses (tools/engine_noise.py); bound = 6x
