@@ -45,6 +45,7 @@ def _worker(rank, world, port, tmp):
         fused.load_state_dict(O.make_params(7, 1, 1), strict=False)       # the weights of tests/golden/g_syncbn_w2.npz
         composed = copy.deepcopy(fused)
         composed.voxel_encoder.use_fused = False               # torch ops + the NaiveSyncBatchNorm1d module
+        fresh = copy.deepcopy(fused)                           # untouched running statistics, for section 3
         pts = _frames(rank)
 
         # ---- 1. fused VFE with cross-rank BatchNorm statistics vs the composed module path (fp32 both)
@@ -146,6 +147,19 @@ def _worker(rank, world, port, tmp):
             ob.step()
             assert abs(float(na) - float(nb)) <= 2e-6 * float(nb)
             assert torch.allclose(fa.flat, fb.flat, rtol=2e-6, atol=1e-8), float((fa.flat - fb.flat).abs().max())
+        # ---- 3. the C step ENGINE's cross-rank BatchNorm against the REFERENCE: one engine step at world size 2 (ranks
+        #         with different point counts; the first layer's statistics travel a step ahead as rank-averaged feature
+        #         moments, the second layer's in line) must leave the running statistics the reference's
+        #         NaiveSyncBatchNorm1d left on these frames and weights (the VFE forward does not depend on the mask)
+        tr_fresh = Trainer(fresh)
+        tr_fresh.train_step(pts)
+        torch.cuda.synchronize()
+        assert tr_fresh.engine is not None and tr_fresh.engine.world == 2 and "featmom" in tr_fresh.engine.sync
+        for k, b in fresh.voxel_encoder.named_buffers():
+            if "running" in k:
+                assert torch.allclose(b, G("v_buf." + k), rtol=1e-5, atol=1e-6), (k, float((b - G("v_buf." + k)).abs().max()))
+            if k.endswith("num_batches_tracked"):
+                assert int(b) == 0, k
         torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
         faulthandler.cancel_dump_traceback_later()
     except BaseException:
