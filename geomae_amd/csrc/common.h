@@ -56,6 +56,11 @@ float* tail_sum(int* from_row);
 // 30 % of the tokens -- come first.
 void set_first_live_row(int row);
 int first_live_row();
+// an event that the next multi-kernel entry point of this thread records BETWEEN its launches (geomae_vfe_backward_layer1:
+// behind its layer-1 sweep, before the routing sweep), so that a caller can start work on another stream that needs only
+// the first kernel's outputs.  One-shot: taken (and cleared) by the callee.
+void set_mid_launch_event(hipEvent_t ev);
+hipEvent_t take_mid_launch_event();
 // which variant of a layer kernel the last launch on this thread used (0 = plain; 1 = sst_ffn_fwd_pair_kernel /
 // sst_ffn_bwd_dw_kernel): the stack's per-kernel timer (bench.py's roofline) keeps a launch's events only if it was the
 // kernel asked for, so that its averages are those of ONE kernel of the rocprofv3 table

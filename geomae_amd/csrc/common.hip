@@ -31,6 +31,9 @@ SstInputMap input_map() { return g_input_map; }
 static thread_local int g_first_live_row = 0;
 void set_first_live_row(int row) { g_first_live_row = row > 0 ? row : 0; }
 int first_live_row() { return g_first_live_row; }
+static thread_local hipEvent_t g_mid_launch_event = nullptr;
+void set_mid_launch_event(hipEvent_t ev) { g_mid_launch_event = ev; }
+hipEvent_t take_mid_launch_event() { hipEvent_t ev = g_mid_launch_event; g_mid_launch_event = nullptr; return ev; }
 static thread_local int g_last_kernel_variant = 0;
 void set_last_kernel_variant(int v) { g_last_kernel_variant = v; }
 int last_kernel_variant() { return g_last_kernel_variant; }

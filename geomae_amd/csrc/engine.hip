@@ -697,10 +697,16 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD1, main);
         n_eff = (float)((double)c.world_size * (double)N);
     }
-    ENG_CALL(geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, nullptr, dh0, dm0, use_bs0,
-                                        fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main));
+    // (the event sits between the layer-1 sweep and the routing sweep: the layer-1 weight-gradient contraction needs
+    //  only dy1 / g and runs on the geometry stream BESIDE the routing sweep -- recorded behind both, its 30 us were what
+    //  the main stream waited for at the end of the backward)
+    set_mid_launch_event(e->ev[kVfeL1]);
+    const int rc_l1 = geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, nullptr, dh0, dm0, use_bs0,
+                                                 fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main);
+    (void)take_mid_launch_event();                       // (an early error return leaves it set)
+    ENG_CALL(rc_l1);
     mark(e, pVfeL1, main);
-    ENG_CALL(order_after(e, kVfeL1, main, geo));
+    GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
     // one [128,128] output contracted over all N points by 124 workgroups: through the split-K workspace + a reduction
     // launch instead of 124 x 16 k float atomics on the same 64 KB (deterministic; the phase time did not change, and
     // neither did it with this contraction on the main stream: it is not what the VFE backward waits for)
