@@ -241,10 +241,15 @@ _SIDE_STREAMS = {}
 STREAM_PROBE = {}          # device key -> what the probe saw (bench.py reports it)
 
 
-def _spin_us(dev):
-    """cycles of torch.cuda._sleep that last ~120 us on this device (calibrated once)."""
-    cyc = 200_000
-    for _ in range(2):
+def _spin_us(dev, target_us=500.0):
+    """cycles of torch.cuda._sleep that last ~target_us on this device.  Calibrated after a warm-up (at idle clocks the
+    same cycle count lasts twice as long as a moment later) and long against the ~40 us of launch + synchronise that the
+    host-side timing of wait_blocks contains: with 120 us spins calibrated cold, a blocked victim (2 T + o) measured
+    1.6 x the free one (T + o) -- exactly the threshold -- and a run picked side streams on the main stream's queue."""
+    cyc = 400_000
+    for _ in range(8):                                         # ~ms of work: clocks up
+        torch.cuda._sleep(cyc)
+    for _ in range(3):
         torch.cuda.synchronize(dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -252,7 +257,7 @@ def _spin_us(dev):
         e1.record()
         e1.synchronize()
         us = max(e0.elapsed_time(e1) * 1e3, 1.0)
-        cyc = max(10_000, int(cyc * 120.0 / us))
+        cyc = max(10_000, int(cyc * target_us / us))
     return cyc
 
 
@@ -264,7 +269,7 @@ def wait_blocks(victim, waiter, helper, cycles, dev):
     one stream wait while the other goes on: a cross-stream wait is a barrier packet, and everything behind it in the
     hardware queue -- whichever stream it came from -- stays behind it.  (That is how a step's two decoder stacks ended
     up running one after the other once the geometry stream, which waits for the decoder-B stream, shared the main
-    stream's queue.)  Here `helper` spins for ~120 us, `waiter` waits for it, and `victim` runs a spin of the same
+    stream's queue.)  Here `helper` spins for ~500 us, `waiter` waits for it, and `victim` runs a spin of the same
     length: alone it takes T, behind the wait 2 T.  The helper's own event record is a barrier packet too, so a
     victim that shares the HELPER's queue is also reported -- all three streams of a schedule are meant to sit on
     different queues anyway (_pick_side_streams tries every assignment of the roles)."""
@@ -285,6 +290,32 @@ def wait_blocks(victim, waiter, helper, cycles, dev):
     return dt, t0
 
 
+def comm_blocks(victim, issuer, helper, group, cycles, dev):
+    """Does a collective of `group` issued from `issuer` hold up a kernel on `victim`?  A stream-ordered collective makes
+    the communicator's own stream WAIT for the issuing stream; if that stream shares the victim's hardware queue the
+    victim stays behind the wait (wait_blocks with the communicator's stream as the waiter: the step's hooks issue
+    collectives from the side streams, and the main stream must not stand behind them).  -> seconds of the victim's spin"""
+    import time
+    from torch import distributed as dist
+    t = torch.zeros(8, device=dev)
+    torch.cuda.synchronize(dev)
+    with torch.cuda.stream(helper):
+        torch.cuda._sleep(cycles)
+        ev = helper.record_event()
+    issuer.wait_event(ev)
+    with torch.cuda.stream(issuer):
+        work = dist.all_reduce(t, group=group, async_op=True)
+    t0 = time.perf_counter()
+    with torch.cuda.stream(victim):
+        torch.cuda._sleep(cycles)
+    victim.synchronize()
+    dt = time.perf_counter() - t0
+    with torch.cuda.stream(issuer):
+        work.wait()
+    torch.cuda.synchronize(dev)
+    return dt
+
+
 def _spin_seconds(stream, cycles, dev):
     import time
     torch.cuda.synchronize(dev)
@@ -301,7 +332,7 @@ def streams_independent(triple, cycles, dev):
     alone = min(_spin_seconds(s, cycles, dev) for s in triple for _ in range(2))
     for v, w, h in itertools.permutations(triple):
         dt = min(wait_blocks(v, w, h, cycles, dev)[0] for _ in range(2))
-        if dt > 1.6 * alone:
+        if dt > 1.5 * alone:                                   # (blocked: ~1.9 x with 500 us spins)
             return False
     return True
 

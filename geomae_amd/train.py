@@ -15,6 +15,7 @@ clipping is one norm over one buffer, and the optimizer is one fused update over
 """
 import ctypes
 
+import os
 import torch
 from torch import distributed as dist
 
@@ -165,6 +166,48 @@ def _new_comm_group(what):
         import warnings
         warnings.warn(f"geomae_amd: no separate process group for the {what} exchange ({e!r}); using the default group")
         return None
+
+
+def _move_comm_streams_off_main(dev, attempts=4):
+    """The step's hooks issue collectives from its SIDE streams (gradient segments: geometry stream; the next batch's
+    feature moments: decoder-B stream).  A stream-ordered collective makes the communicator's internal stream wait for the
+    issuing stream, and a wait is a barrier packet for everything behind it in the hardware queue: a communicator whose
+    stream shares the MAIN stream's queue makes the main stream wait for the side streams -- the two decoder stacks then
+    run one after the other (seen once in ~20 forced one-rank runs: 2.61 instead of 2.10 ms).  More streams than queues
+    exist, so sharing as such cannot be avoided, only moved: measured here (ops.comm_blocks), and a group found on the
+    main stream's queue is re-created after taking one more stream from torch's pool (the communicator's stream is the
+    pool's next one, and pool stream k sits on queue k mod 4).  Every rank takes part in new_group: the decision is
+    all-reduced.  Recorded in ops.STREAM_PROBE."""
+    from . import ops
+    key = (dev.type, dev.index)
+    info = ops.STREAM_PROBE.setdefault(key, {})
+    if dist.get_backend() != "nccl" or os.environ.get("GEOMAE_STREAM_PROBE", "1") == "0":
+        return
+    st = ops.side_streams(dev)
+    main = torch.cuda.current_stream(dev)
+    cycles = ops._spin_us(dev)
+    alone = min(ops._spin_seconds(main, cycles, dev) for _ in range(2))
+    moved = {}
+    for name, issuer, helper in (("GRAD_GROUP", st["geo"], st["dec_b"]), ("BN_GROUP", st["dec_b"], st["geo"])):
+        for attempt in range(attempts + 1):
+            group = getattr(ops, name)
+            if group is None:
+                break
+            dt = min(ops.comm_blocks(main, issuer, helper, group, cycles, dev) for _ in range(2))
+            flag = torch.tensor([1.0 if dt > 1.5 * alone else 0.0], device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if float(flag.item()) == 0.0 or attempt == attempts:
+                moved[name] = dict(recreated=attempt, blocks_main=bool(float(flag.item())))
+                break
+            keep = torch.cuda.Stream(device=dev)              # one pool slot further
+            with torch.cuda.stream(keep):
+                torch.zeros(1, device=dev)
+            new = dist.new_group()
+            t = torch.zeros(1, device=dev)
+            dist.all_reduce(t, group=new)
+            torch.cuda.synchronize(dev)
+            setattr(ops, name, new)                           # (the old communicator stays alive, idle)
+    info["comm_streams"] = moved
 
 
 def allreduce_gradients(flat, group=None):
@@ -384,6 +427,7 @@ class Trainer:
                     warnings.warn(f"geomae_amd: could not prime the communication streams ({e!r})")
                 ops.reset_side_streams(dev)                  # ... and only then are the step's side streams chosen
                 ops.side_streams(dev)
+                _move_comm_streams_off_main(dev)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             # what MMDistributedDataParallel does at construction: every replica starts from rank 0's parameters AND
             # buffers (BatchNorm running statistics, counters) whatever the ranks seeded or loaded; afterwards only
