@@ -178,6 +178,8 @@ SIGNATURES = {
     "geomae_heads_loss_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_sst_set_pair_kernels": (None, [c_int32]),
     "geomae_heads_loss_split_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P, P]),
+    "geomae_heads_loss_centroid_accumulate": (ctypes.c_int, [P, c_int32, c_int32, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P]),
+    "geomae_heads_loss_density_accumulate": (ctypes.c_int, [P, c_int32, c_int32, P, P, P, F3, P, P, P, P, P]),
     "geomae_heads_weight_grad": (ctypes.c_int, [c_int32, P, P, P, POINTER(GeomaeHeadGrads), P]),
     "geomae_sst_qkv_forward": (ctypes.c_int, [P, P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P]),
     "geomae_sst_ffn_forward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P, P, P, P, P]),

@@ -98,7 +98,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kNumEv };
+          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -625,6 +625,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // ---------------- dec_b: late zero arena (its other work of the step started before the VFE forward, above)
     ENG_CALL(zero_arena(zl0, zl_bytes, aux));
     ENG_CALL(zero_arena(losses, 32, aux));
+    GEOMAE_HIP(hipEventRecord(e->ev[kZeroLate], aux));
     const int nxt = 1 - e->pending;
 
     // ---------------- main: encoder, decoders
@@ -640,16 +641,33 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_forward(z_enc, n, L_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen, sb_dec, cen, nk,
                                       m.mask_token, nullptr, e->profiler, main));
-    ENG_CALL(order_after(e, kJoinDecFwd, aux, main));
     mark(e, pDecFwd, main);
-    ENG_CALL(geomae_heads_loss_split_accumulate(cen, den, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed,
-                                                t_mmed, t_ctop, t_normal, t_occ, c.loss_weights, losses, d_cen, d_cen2, d_den,
-                                                h_dl, h_cm, h_dm, main));
+    // ---------------- heads + losses BY DECODER: each decoder's stream runs the heads that read its stack and goes straight
+    // on into that stack's backward -- neither waits for the other stack's forward (one launch for all heads needed the
+    // decoder-B stream to join the main stream in front of it and to fork again behind it: two cross-queue hand-overs of
+    // ~13 us on the critical path).  The density decoder feeds ONE head (nor_top -> loss_curv_around), the centroid
+    // decoder the other five.  GEOMAE_HEADS_JOINT=1: the joint launch.
+    static const bool heads_joint = [] { const char* v = getenv("GEOMAE_HEADS_JOINT"); return v && v[0] == '1'; }();
+    if (heads_joint) {
+        ENG_CALL(order_after(e, kJoinDecFwd, aux, main));
+        ENG_CALL(geomae_heads_loss_split_accumulate(cen, den, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed,
+                                                    t_mmed, t_ctop, t_normal, t_occ, c.loss_weights, losses, d_cen, d_cen2,
+                                                    d_den, h_dl, h_cm, h_dm, main));
+        ENG_CALL(order_after(e, kHeads, main, geo));
+        GEOMAE_HIP(hipStreamWaitEvent(aux, e->ev[kHeads], 0));
+    } else {
+        // (d_cen / d_cen2 / losses were zeroed on the decoder-B stream, long ago: one already-complete event to wait for)
+        GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kZeroLate], 0));
+        ENG_CALL(geomae_heads_loss_centroid_accumulate(cen, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed, t_mmed,
+                                                       t_ctop, t_occ, c.loss_weights, losses, d_cen, d_cen2, h_dl, h_cm, main));
+        ENG_CALL(geomae_heads_loss_density_accumulate(den, nk, nm, m.head_w_packed, m.head_bias, t_normal, c.loss_weights,
+                                                      losses, d_den, h_dl, h_dm, aux));
+        ENG_CALL(order_after(e, kHeads, main, geo));
+        ENG_CALL(order_after(e, kJoinDecFwd, aux, geo));            // (the geometry stream needs both halves of dl)
+    }
     // ---------------- backward.  Contractions that only the optimizer reads go to the geometry stream.
-    ENG_CALL(order_after(e, kHeads, main, geo));
     ENG_CALL(geomae_heads_weight_grad(nm, h_dl, h_cm, h_dm, &m.head_grads, geo));
     mark(e, pHeads, main);
-    GEOMAE_HIP(hipStreamWaitEvent(aux, e->ev[kHeads], 0));
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     {
         DeferAllScope defer(defer_dec_dw);

@@ -37,6 +37,9 @@ struct HeadArgs {
     float* d_cen; float* d_den;               // [n,128], rows >= n_keep written (others pre-zeroed by caller)
     float* d_cen2;                            // split mode (see heads_loss_kernel): second summand of d_cen, or nullptr
     bf16_t* dl; bf16_t* cm_b; bf16_t* dm_b;   // [M,896], [M,128], [M,128]
+    int part = 0;                             // 0: every head; 1: the centroid decoder's heads (chunks 0-5, split in two
+                                              //    workgroup kinds); 2: the density decoder's head (chunk 6) -- see
+                                              //    geomae_heads_loss_centroid_accumulate / _density_accumulate
 };
 
 
@@ -79,29 +82,40 @@ __device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, c
 // 72 us chain of 7 x (GEMM -> loss arithmetic -> dX GEMM); the split form is 482 workgroups, two per CU, each half as
 // long.  Both halves contribute to d(centroid decoder output): they write SEPARATE zero-initialised buffers (d_cen,
 // d_cen2) that the decoder's backward sums while loading (geomae_sst_stack_backward dz + dz_add) -- no atomics.
+// MODE 3: chunk 6 alone (the only head that reads the density decoder); MODE 4: chunks 3-5 (MODE 2 without chunk 6): with
+// MODE 1 + 4 in one launch and MODE 3 in another, each decoder stream runs its own heads and goes straight on into its
+// backward -- no stream waits for the other decoder's forward.
 template <int MODE>
 __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __restrict__ smem, float (*red)[6]) {
-    constexpr int kFirst = MODE == 2 ? 3 : 0, kLast = MODE == 1 ? 3 : 7;
-    float* const d_cen_out = MODE == 2 ? A.d_cen2 : A.d_cen;
+    constexpr int kFirst = MODE == 3 ? 6 : ((MODE == 2 || MODE == 4) ? 3 : 0), kLast = MODE == 1 ? 3 : (MODE == 4 ? 6 : 7);
+    float* const d_cen_out = (MODE == 2 || MODE == 4) ? A.d_cen2 : A.d_cen;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
     const int64_t row = (int64_t)tile * 16 + (lane & 15);     // masked-row index
     const bool valid = row < A.M;
     const int64_t tok = A.n_keep + row;
-    const float inv_low = A.w_low / fmaxf(1.f, (float)A.occ[0]);
-    const float inv_med = A.w_med / fmaxf(1.f, (float)A.occ[1]);
+    const float inv_low = MODE == 3 ? 0.f : A.w_low / fmaxf(1.f, (float)A.occ[0]);      // (MODE 3: no occupancy counts passed)
+    const float inv_med = MODE == 3 ? 0.f : A.w_med / fmaxf(1.f, (float)A.occ[1]);
     const float inv_top = A.w_top / (float)A.M, inv_nor = A.w_nor / (float)A.M;
     const float inv_cl = A.w_cls_low / ((float)A.M * 256.f), inv_cm = A.w_cls_med / ((float)A.M * 32.f);
     float l_nor = 0.f, l_low = 0.f, l_med = 0.f, l_top = 0.f, l_cl = 0.f, l_cm = 0.f;
 
+    if (MODE == 3) {
+        // chunk 6 stages 32 weight rows; its dX GEMM reads all 128 rows of the tile against dl = 0 for the other 96.  Behind
+        // chunk 5 those are stale (finite) weights; with nothing before it they are whatever the last kernel left in LDS,
+        // and 0 x NaN is NaN: clear them (gemm_staged's barriers order these writes before the reads)
+        constexpr int LD = 128 + kPad;
+        for (int e = threadIdx.x; e < 96 * LD / 8; e += kLayerBlk)
+            *reinterpret_cast<uint4*>(smem + 32 * LD + 8 * e) = make_uint4(0u, 0u, 0u, 0u);
+    }
     uint2 xb[8];
-    {
+    if (MODE != 3) {
         f32x4 x[8];
         load_rows_f32<128>(A.cen, A.n_keep + A.M, (int)tok, x, lane);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) xb[ct] = pack4(x[ct]);
-        if (MODE != 2) store_rows_bf16<128>(A.cm_b, A.M, (int)row, 128, 0, x, lane);
+        if (MODE != 2 && MODE != 4) store_rows_bf16<128>(A.cm_b, A.M, (int)row, 128, 0, x, lane);
     }
     f32x4 dx[8];
 #pragma unroll
@@ -113,13 +127,15 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
     for (int chunk = kFirst; chunk < kLast; ++chunk) {
         if (chunk == 6) {
             // flush d_cen, switch the input to the density decoder
+            if (MODE != 3) {
 #pragma unroll
-            for (int ct = 0; ct < 8; ++ct)
+                for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-                    if (rr < A.M) d_cen_out[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
-                }
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
+                        if (rr < A.M) d_cen_out[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
+                    }
+            }
             f32x4 x[8];
             load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
 #pragma unroll
@@ -226,7 +242,7 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
         }
         accumulate_dx(smem, dlb, dx, lane);
     }
-    float* const d_last = MODE == 1 ? A.d_cen : A.d_den;       // MODE 1 ends on the centroid decoder's chunks
+    float* const d_last = MODE == 1 ? A.d_cen : (MODE == 4 ? A.d_cen2 : A.d_den);   // MODE 1 / 4 end on the centroid decoder's chunks
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
@@ -235,7 +251,7 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
             if (rr < A.M) d_last[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
         }
     // zero the padding columns of dl that dw_kernel will read: [771,896)
-    if (valid && MODE != 1)
+    if (valid && MODE != 1 && MODE != 4)
         for (int cidx = 800 + 4 * g; cidx < kDlLd; cidx += 16)
             *reinterpret_cast<uint2*>(A.dl + row * kDlLd + cidx) = make_uint2(0u, 0u);
     // ---- losses: wave reduce, block reduce, one atomic per loss
@@ -253,7 +269,9 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
 __global__ __launch_bounds__(kLayerBlk, 2) void heads_loss_kernel(HeadArgs A) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ float red[4][6];
-    if (A.d_cen2 == nullptr) heads_loss_body<0>(A, smem, red);
+    if (A.part == 2) heads_loss_body<3>(A, smem, red);
+    else if (A.part == 1) { if (blockIdx.y == 0) heads_loss_body<1>(A, smem, red); else heads_loss_body<4>(A, smem, red); }
+    else if (A.d_cen2 == nullptr) heads_loss_body<0>(A, smem, red);
     else if (blockIdx.y == 0) heads_loss_body<1>(A, smem, red);
     else heads_loss_body<2>(A, smem, red);
 }
@@ -268,12 +286,15 @@ static int heads_loss_launch(const float* dec_centroid, const float* dec_density
                              const uint8_t* mask_med, const float* centroid_top, const float* normal,
                              const int32_t* occ_counts, const float* loss_weights, float* losses,
                              float* d_dec_centroid, float* d_dec_centroid2, float* d_dec_density, void* dlogits_bf16,
-                             void* cm_bf16, void* dm_bf16, hipStream_t stream) {
+                             void* cm_bf16, void* dm_bf16, hipStream_t stream, int part = 0) {
     if (num_mask <= 0) return GEOMAE_OK;
-    GEOMAE_REQUIRE(dec_centroid && dec_density && head_w_packed && head_bias && centroid_low && mask_low &&
-                   centroid_med && mask_med && centroid_top && normal && occ_counts && loss_weights && losses &&
-                   d_dec_centroid && d_dec_density && dlogits_bf16 && cm_bf16 && dm_bf16, "heads_loss: null argument");
+    GEOMAE_REQUIRE(head_w_packed && head_bias && loss_weights && losses && dlogits_bf16, "heads_loss: null argument");
+    GEOMAE_REQUIRE(part == 2 || (dec_centroid && centroid_low && mask_low && centroid_med && mask_med && centroid_top &&
+                                 occ_counts && d_dec_centroid && cm_bf16), "heads_loss: null argument (centroid heads)");
+    GEOMAE_REQUIRE(part == 1 || (dec_density && normal && d_dec_density && dm_bf16), "heads_loss: null argument (density head)");
+    GEOMAE_REQUIRE(part != 1 || d_dec_centroid2, "heads_loss: the centroid part needs both summand buffers");
     HeadArgs A;
+    A.part = part;
     A.cen = dec_centroid; A.den = dec_density; A.n_keep = num_keep; A.M = num_mask;
     A.wp = (const bf16_t*)head_w_packed; A.bias = head_bias;
     A.t_low = centroid_low; A.m_low = mask_low; A.t_med = centroid_med; A.m_med = mask_med;
@@ -283,8 +304,8 @@ static int heads_loss_launch(const float* dec_centroid, const float* dec_density
     A.loss = losses; A.d_cen = d_dec_centroid; A.d_den = d_dec_density; A.d_cen2 = d_dec_centroid2;
     A.dl = (bf16_t*)dlogits_bf16; A.cm_b = (bf16_t*)cm_bf16; A.dm_b = (bf16_t*)dm_bf16;
     const int tiles = cdiv(num_mask, 16);
-    hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64), d_dec_centroid2 ? 2 : 1), dim3(kLayerBlk), 0,
-                       stream, A);
+    hipLaunchKernelGGL(heads_loss_kernel, dim3(cdiv(tiles, kLayerBlk / 64), part == 2 ? 1 : (d_dec_centroid2 ? 2 : 1)),
+                       dim3(kLayerBlk), 0, stream, A);
     return check_launch("heads_loss_kernel");
 }
 
@@ -315,6 +336,30 @@ extern "C" int geomae_heads_loss_split_accumulate(const float* dec_centroid, con
     return heads_loss_launch(dec_centroid, dec_density, num_keep, num_mask, head_w_packed, head_bias, centroid_low, mask_low,
                              centroid_med, mask_med, centroid_top, normal, occ_counts, loss_weights, losses, d_dec_centroid,
                              d_dec_centroid2, d_dec_density, dlogits_bf16, cm_bf16, dm_bf16, stream);
+}
+
+// The heads by decoder: everything that reads the centroid decoder (reg_low, cls_low, reg_med, cls_med, reg_top: five of
+// the six losses) and the one head of the density decoder (nor_top: loss_curv_around), as launches of their own -- each on
+// its decoder's stream, so that neither stack's backward waits for the other stack's forward.  Disjoint outputs (columns
+// [0,768) / [768,896) of dlogits, cm / dm, d_dec_centroid(2) / d_dec_density); `losses` accumulated with atomics.
+extern "C" int geomae_heads_loss_centroid_accumulate(const float* dec_centroid, int32_t num_keep, int32_t num_mask,
+                                 const void* head_w_packed, const float* head_bias, const float* centroid_low,
+                                 const uint8_t* mask_low, const float* centroid_med, const uint8_t* mask_med,
+                                 const float* centroid_top, const int32_t* occ_counts, const float* loss_weights,
+                                 float* losses, float* d_dec_centroid, float* d_dec_centroid2, void* dlogits_bf16,
+                                 void* cm_bf16, hipStream_t stream) {
+    return heads_loss_launch(dec_centroid, nullptr, num_keep, num_mask, head_w_packed, head_bias, centroid_low, mask_low,
+                             centroid_med, mask_med, centroid_top, nullptr, occ_counts, loss_weights, losses, d_dec_centroid,
+                             d_dec_centroid2, nullptr, dlogits_bf16, cm_bf16, nullptr, stream, 1);
+}
+
+extern "C" int geomae_heads_loss_density_accumulate(const float* dec_density, int32_t num_keep, int32_t num_mask,
+                                 const void* head_w_packed, const float* head_bias, const float* normal,
+                                 const float* loss_weights, float* losses, float* d_dec_density, void* dlogits_bf16,
+                                 void* dm_bf16, hipStream_t stream) {
+    return heads_loss_launch(nullptr, dec_density, num_keep, num_mask, head_w_packed, head_bias, nullptr, nullptr, nullptr,
+                             nullptr, nullptr, normal, nullptr, loss_weights, losses, nullptr, nullptr, d_dec_density,
+                             dlogits_bf16, nullptr, dm_bf16, stream, 2);
 }
 
 extern "C" int geomae_heads_loss(const float* dec_centroid, const float* dec_density, int32_t num_keep,

@@ -1127,6 +1127,33 @@ def heads_loss(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, d_out=
     return losses, outs[0], outs[1], (dl, cm_b, dm_b)
 
 
+def heads_loss_by_decoder(cen, den, n_keep, n_mask, head_w, head_bias, tgt, weights, side_stream=None):
+    """The heads as TWO launches with disjoint outputs (geomae_heads_loss_centroid_accumulate: the five heads that read
+    the centroid decoder; geomae_heads_loss_density_accumulate: the density decoder's normal head) -- what the step
+    engine runs, each on its decoder's stream.  side_stream: where to launch the density part (default: current).
+    -> losses [6], (d_cen, d_cen2), d_den, (dlogits, cm_b, dm_b): as heads_loss(split=True)."""
+    dev = cen.device
+    lib = _lib.load()
+    losses = torch.zeros(6, dtype=torch.float32, device=dev)
+    d_cen, d_cen2, d_den = torch.zeros_like(cen), torch.zeros_like(cen), torch.zeros_like(den)
+    dl = torch.empty((n_mask, 896), dtype=torch.bfloat16, device=dev)
+    cm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
+    dm_b = torch.empty((n_mask, 128), dtype=torch.bfloat16, device=dev)
+    check(lib.geomae_heads_loss_centroid_accumulate(
+        _ptr(cen), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["centroid_low"]), _ptr(tgt["mask_low_u8"]),
+        _ptr(tgt["centroid_med"]), _ptr(tgt["mask_med_u8"]), _ptr(tgt["centroid_top"]), _ptr(tgt["occ_counts"]), f3(weights),
+        _ptr(losses), _ptr(d_cen), _ptr(d_cen2), _ptr(dl), _ptr(cm_b), _stream()), "geomae_heads_loss_centroid_accumulate")
+    cur = torch.cuda.current_stream(dev)
+    side = side_stream if side_stream is not None else cur
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        check(lib.geomae_heads_loss_density_accumulate(
+            _ptr(den), n_keep, n_mask, _ptr(head_w), _ptr(head_bias), _ptr(tgt["normal"]), f3(weights), _ptr(losses),
+            _ptr(d_den), _ptr(dl), _ptr(dm_b), _stream()), "geomae_heads_loss_density_accumulate")
+    cur.wait_stream(side)
+    return losses, (d_cen, d_cen2), d_den, (dl, cm_b, dm_b)
+
+
 def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
     check(_lib.load().geomae_heads_weight_grad(n_mask, _ptr(dl), _ptr(cm_b), _ptr(dm_b), ctypes.byref(grads),
                                                _stream()), "geomae_heads_weight_grad")

@@ -365,6 +365,20 @@ int geomae_heads_loss_split_accumulate(const float* dec_centroid, const float* d
                                        const int32_t* occ_counts, const float* loss_weights /*host*/, float* losses,
                                        float* d_dec_centroid, float* d_dec_centroid2, float* d_dec_density,
                                        void* dlogits_bf16, void* cm_bf16, void* dm_bf16, geomaeStream_t stream);
+/* the heads BY DECODER, as two launches with disjoint outputs (dlogits columns [0,768) | [768,896), cm | dm, the two
+ * summands of d_dec_centroid | d_dec_density; `losses` accumulated with atomics): the five heads that read the centroid
+ * decoder, and the density decoder's normal head.  Each can run on its decoder's stream right behind that decoder's
+ * forward, and that stream goes straight on into the decoder's backward.  What geomae_pretrain_step uses. */
+int geomae_heads_loss_centroid_accumulate(const float* dec_centroid, int32_t num_keep, int32_t num_mask,
+                                          const void* head_w_packed, const float* head_bias, const float* centroid_low,
+                                          const uint8_t* mask_low, const float* centroid_med, const uint8_t* mask_med,
+                                          const float* centroid_top, const int32_t* occ_counts,
+                                          const float* loss_weights /*host*/, float* losses, float* d_dec_centroid,
+                                          float* d_dec_centroid2, void* dlogits_bf16, void* cm_bf16, geomaeStream_t stream);
+int geomae_heads_loss_density_accumulate(const float* dec_density, int32_t num_keep, int32_t num_mask,
+                                         const void* head_w_packed, const float* head_bias, const float* normal,
+                                         const float* loss_weights /*host*/, float* losses, float* d_dec_density,
+                                         void* dlogits_bf16, void* dm_bf16, geomaeStream_t stream);
 typedef struct GeomaeHeadGrads { /* fp32 gradient buffers of the six head Linears, accumulated into */
     float *reg_low_w, *reg_low_b, *cls_low_w, *cls_low_b, *reg_med_w, *reg_med_b, *cls_med_w, *cls_med_b,
           *reg_top_w, *reg_top_b, *nor_top_w, *nor_top_b;

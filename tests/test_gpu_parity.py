@@ -1179,6 +1179,44 @@ def test_split_heads_kernel_matches_single_form(dev, golden_dir):
     assert float(dc1.abs().max()) > 0 and float(dc2.abs().max()) > 0
 
 
+def test_heads_by_decoder_match_split_form(dev, golden_dir):
+    """geomae_heads_loss_centroid_accumulate + geomae_heads_loss_density_accumulate (what the step engine launches, one per
+    decoder stream) against the joint split launch: same logit gradients, operand copies and output gradients bit for bit,
+    same losses.  The density part runs on a second stream, after a kernel that leaves NaN bit patterns in LDS: the part
+    stages 32 weight rows and its dX GEMM reads 128 (the rest against zero logit gradients) -- they must have been cleared."""
+    from geomae_amd import ops
+    model, _ = _build(dev, 1, 1, "bf16")
+    bb = model.backbone
+    bb._packed.refresh()
+    P = bb._packed
+    n_keep, n_mask = 210, 1900 + 5
+    n = n_keep + n_mask
+    gen = torch.Generator().manual_seed(21)
+    cen = torch.randn(n, 128, generator=gen).to(dev)
+    den = torch.randn(n, 128, generator=gen).to(dev)
+    tgt = dict(centroid_low=torch.rand(n_mask, 128 * 3, generator=gen).to(dev),
+               mask_low_u8=(torch.rand(n_mask, 128, generator=gen) < 0.2).to(torch.uint8).to(dev),
+               centroid_med=torch.rand(n_mask, 16 * 3, generator=gen).to(dev),
+               mask_med_u8=(torch.rand(n_mask, 16, generator=gen) < 0.4).to(torch.uint8).to(dev),
+               centroid_top=torch.rand(n_mask, 3, generator=gen).to(dev), normal=torch.randn(n_mask, 3, generator=gen).to(dev))
+    tgt["occ_counts"] = torch.stack([tgt["mask_low_u8"].sum(), tgt["mask_med_u8"].sum()]).int()
+    w = (0.7, 1.0, 1.3, 1.0, 0.5, 2.0)
+    la, (a1, a2), da, (dla, cma, dma) = ops.heads_loss(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, w, split=True)
+    # pollute LDS: a layer kernel on NaN inputs leaves NaN weights / activations behind in every CU's LDS
+    bad = torch.full((4096, 128), float("nan"), device=dev)
+    for _ in range(3):
+        torch.nn.functional.softmax(bad, dim=1)
+    side = torch.cuda.Stream(device=dev)
+    lb, (b1, b2), db, (dlb, cmb, dmb) = ops.heads_loss_by_decoder(cen, den, n_keep, n_mask, P.head_w, P.head_bias, tgt, w,
+                                                                  side_stream=side)
+    torch.cuda.synchronize()
+    assert torch.allclose(la, lb, rtol=1e-6, atol=0), (la, lb)
+    assert torch.equal(dla[:, :771], dlb[:, :771]) and torch.equal(cma, cmb) and torch.equal(dma, dmb)
+    assert float(dlb[:, 771:].float().abs().max()) == 0.0           # the padding columns the contraction reads
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)
+    assert torch.isfinite(db).all() and torch.equal(da, db)
+
+
 def test_stack_weight_gradients_do_not_depend_on_arrival_order(dev):
     """Inside a stack the weight-gradient contraction sums through memory (split-K partials stored, added in chunk order
     by a later launch -- csrc/sst_layer.hip dw_body / dw_reduce_body) instead of float atomics: the matrix gradients of
