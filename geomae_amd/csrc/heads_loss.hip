@@ -58,6 +58,7 @@ __device__ __forceinline__ void bce(float x, float y, float* l, float* d) {
 // ds_read_b64_tr_b16 (two per MFMA; it was eight 2-byte LDS reads plus their repacking).  LDS column j holds
 // channel kperm(j) (the chunk is staged K-permuted for the forward GEMM), so column c of accumulator tile ct is
 // channel kperm(16 ct + c): the caller un-permutes in its store index.
+template <int KK = 4>                     // 32-row groups of the staged chunk that hold weights (the normal head's chunk: 1)
 __device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, const uint2 (&dlb)[8],
                                               f32x4 (&acc)[8], int lane) {
     constexpr int LD = 128 + kPad;
@@ -66,7 +67,7 @@ __device__ __forceinline__ void accumulate_dx(const bf16_t* __restrict__ smem, c
     // receives column m of it: rows = this lane group's output rows 32 kk + 4 g + 0..3 (lo) and + 16 (hi)
     const bf16_t* base = smem + (4 * g + (m >> 2)) * LD + 4 * (m & 3);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < KK; ++kk) {
         const uint4 a = make_uint4(dlb[2 * kk].x, dlb[2 * kk].y, dlb[2 * kk + 1].x, dlb[2 * kk + 1].y);
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) {
@@ -101,14 +102,6 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
     const float inv_cl = A.w_cls_low / ((float)A.M * 256.f), inv_cm = A.w_cls_med / ((float)A.M * 32.f);
     float l_nor = 0.f, l_low = 0.f, l_med = 0.f, l_top = 0.f, l_cl = 0.f, l_cm = 0.f;
 
-    if (MODE == 3) {
-        // chunk 6 stages 32 weight rows; its dX GEMM reads all 128 rows of the tile against dl = 0 for the other 96.  Behind
-        // chunk 5 those are stale (finite) weights; with nothing before it they are whatever the last kernel left in LDS,
-        // and 0 x NaN is NaN: clear them (gemm_staged's barriers order these writes before the reads)
-        constexpr int LD = 128 + kPad;
-        for (int e = threadIdx.x; e < 96 * LD / 8; e += kLayerBlk)
-            *reinterpret_cast<uint4*>(smem + 32 * LD + 8 * e) = make_uint4(0u, 0u, 0u, 0u);
-    }
     uint2 xb[8];
     if (MODE != 3) {
         f32x4 x[8];
@@ -240,7 +233,11 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
             if (valid && (chunk < 6 || ct < 2))
                 *reinterpret_cast<uint2*>(A.dl + row * kDlLd + row0 + 16 * ct + 4 * g) = dlb[ct];
         }
-        accumulate_dx(smem, dlb, dx, lane);
+        // (chunk 6 stages 32 rows; in a launch of its own -- MODE 3 -- the other 96 rows of the LDS tile are whatever the last
+        //  kernel left there, and 0 x NaN is NaN: only the 32 rows are read.  Behind chunk 5 they are stale finite weights
+        //  against dl = 0, as before.)
+        if (MODE == 3) accumulate_dx<1>(smem, dlb, dx, lane);
+        else accumulate_dx(smem, dlb, dx, lane);
     }
     float* const d_last = MODE == 1 ? A.d_cen : (MODE == 4 ? A.d_cen2 : A.d_den);   // MODE 1 / 4 end on the centroid decoder's chunks
 #pragma unroll
