@@ -41,7 +41,10 @@ def run(K, reps=30):
     # split points: sample boundaries
     per = [int((bidx < b).sum()) for b in range(B + 1)]
     cuts = [per[(B * k) // K] for k in range(K + 1)]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(K - 1)]
+    # side streams on hardware queues of their own (ops.side_streams: measured), not just any new streams
+    st = ops.side_streams(dev)
+    side = [st["geo"], st["dec_b"]] + [torch.cuda.Stream() for _ in range(max(0, K - 3))]
+    streams = [torch.cuda.current_stream()] + side[:K - 1]
     parts = []
     for k in range(K):
         a, b = cuts[k], cuts[k + 1]
@@ -93,5 +96,5 @@ def run(K, reps=30):
     return res
 
 
-for K in (1, 2, 4):
+for K in (1, 2, 3, 4):
     print(K, "chains:", {k: round(v, 4) for k, v in run(K).items()}, "ms", flush=True)
