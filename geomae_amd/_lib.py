@@ -29,18 +29,19 @@ class GeomaeWindowConfig(ctypes.Structure):
 class GeomaeWindowBuildJob(ctypes.Structure):
     _fields_ = ([("coors", c_void_p), ("num_tokens", c_int32), ("shift_index", c_int32)]
                 + [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "bun_start",
-                                           "num_bundles", "bun_tok", "pos_info")])
+                                           "num_bundles", "bun_tok", "pos_info", "fbun_tok", "num_fbundles")])
 
 
 class GeomaeSstLayerWeights(ctypes.Structure):
     _fields_ = ([(n, c_void_p) for n in ("wqkv_p", "wqkT_p", "wvT_p", "wo_p", "woT_p", "w1_p", "w1T_p", "w2_p",
                                          "w2T_p", "bqkv", "bo", "b1", "b2", "ln1_w", "ln1_b", "ln2_w", "ln2_b")]
-                + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float)])
+                + [("d_model", c_int32), ("d_ffn", c_int32), ("ln_eps", c_float), ("frag_p", c_void_p)])
 
 
 class GeomaeSstStackLayout(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "bun_start", "num_bundles")] + \
-               [("max_bundles", c_int32), ("bun_tok", c_void_p), ("pos_info", c_void_p)]
+               [("max_bundles", c_int32), ("bun_tok", c_void_p), ("pos_info", c_void_p), ("fbun_tok", c_void_p),
+                ("num_fbundles", c_void_p)]
 
 
 class GeomaeVfeArgs(ctypes.Structure):
@@ -189,6 +190,10 @@ SIGNATURES = {
                                                P, P, P, POINTER(GeomaeSstLayerGrads), P, P, POINTER(GeomaeSstLayerWeights), P]),
     "geomae_sst_qkv_backward": (ctypes.c_int, [P, P, POINTER(GeomaeSstLayerWeights), c_int32, P, P]),
     "geomae_sst_weight_grad": (ctypes.c_int, [c_int32, P, P, P, P, P, P, P, P, P, POINTER(GeomaeSstLayerGrads), P]),
+    "geomae_window_bundle_cap": (c_int32, [c_int32, c_int32]),
+    "geomae_sst_layer_forward": (ctypes.c_int, [P, c_int32, POINTER(GeomaeSstLayerWeights), POINTER(GeomaeSstStackLayout),
+                                                c_int32, P, P, c_int32, P, P, P, P, P, P, P, P, P, P]),
+    "geomae_sst_set_fused_layers": (None, [c_int32]),
     "geomae_sst_stack_saved_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "geomae_sst_stack_scratch_bytes": (c_int64, [c_int32]),
     "geomae_sst_stack_scratch_bytes_layers": (c_int64, [c_int32, c_int32]),

@@ -95,6 +95,7 @@ struct Batch {
 struct WinLayout {
     int32_t n = 0, max_windows = 1;
     int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles, *bun_tok, *pos_info;
+    int32_t *fbun_tok, *num_fbundles;
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
@@ -165,7 +166,7 @@ int64_t window_layout_bytes(const GeomaePretrainConfig& c, int64_t n) {
     int64_t mw = n < slots ? n : slots;
     if (mw < 1) mw = 1;
     const int64_t n1 = n < 1 ? 1 : n;
-    return 3 * al256((mw + 1) * 4) + 3 * al256(n1 * 4) + 2 * 256 + al256(n1 * 16);
+    return 4 * al256((mw + 1) * 4) + 3 * al256(n1 * 4) + 3 * 256 + al256(n1 * 16);
 }
 
 int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
@@ -364,6 +365,8 @@ void carve_layout(Arena& a, const GeomaePretrainConfig& c, int32_t n, WinLayout*
     L->num_windows = a.take<int32_t>(1);
     L->num_bundles = a.take<int32_t>(1);
     L->pos_info = a.take<int32_t>(n1 * 4);
+    L->fbun_tok = a.take<int32_t>(mw + 1);
+    L->num_fbundles = a.take<int32_t>(1);
 }
 
 void stack_layouts(const WinLayout* L, GeomaeSstStackLayout* out) {
@@ -371,6 +374,7 @@ void stack_layouts(const WinLayout* L, GeomaeSstStackLayout* out) {
         out[i].win_start = L[i].win_start; out[i].win_tokens = L[i].win_tokens; out[i].tok_win = L[i].tok_win;
         out[i].tok_pos = L[i].tok_pos; out[i].bun_start = L[i].bun_start; out[i].num_bundles = L[i].num_bundles;
         out[i].max_bundles = L[i].max_windows; out[i].bun_tok = L[i].bun_tok; out[i].pos_info = L[i].pos_info;
+        out[i].fbun_tok = L[i].fbun_tok; out[i].num_fbundles = L[i].num_fbundles;
     }
 }
 
@@ -568,6 +572,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
             jobs[k].win_start = lay[k].win_start; jobs[k].win_tokens = lay[k].win_tokens; jobs[k].tok_win = lay[k].tok_win;
             jobs[k].tok_pos = lay[k].tok_pos; jobs[k].num_windows = lay[k].num_windows; jobs[k].bun_start = lay[k].bun_start;
             jobs[k].num_bundles = lay[k].num_bundles; jobs[k].bun_tok = lay[k].bun_tok; jobs[k].pos_info = lay[k].pos_info;
+            jobs[k].fbun_tok = lay[k].fbun_tok; jobs[k].num_fbundles = lay[k].num_fbundles;
         }
         set_window_tables_prezeroed(true);         // (cleared by the gather above)
         const int rc_win = geomae_window_build_batch(jobs, 4, c.batch_size, &c.window, win_ws, win_wsb, geo);

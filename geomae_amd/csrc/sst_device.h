@@ -551,4 +551,34 @@ int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t s
 void defer_next_weight_grad();
 int flush_pending_weight_grad(hipStream_t stream);      // launches a recorded-but-unlaunched contraction, if any
 
+// the packed weights / fp32 parameter vectors of one layer as the kernels take them (GeomaeSstLayerWeights, host side)
+struct LayerW {
+    const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
+    const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
+    const bf16_t* frag;      // the nine matrices again, fragment-major, at the element offsets below (or null)
+};
+// element offsets of the matrices inside a layer's packed block (row-major block and fragment-major block alike)
+constexpr int kOffWqkv = 0, kOffWqkT = 49152, kOffWvT = 81920, kOffWo = 98304, kOffWoT = 114688, kOffW1 = 131072,
+              kOffW1T = 163840, kOffW2 = 196608, kOffW2T = 229376, kPackedPerLayer = 262144;
+#ifdef GEOMAE_HIP_H
+inline LayerW to_layer(const GeomaeSstLayerWeights* w) {
+    LayerW L;
+    L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;
+    L.wo = (const bf16_t*)w->wo_p; L.woT = (const bf16_t*)w->woT_p; L.w1 = (const bf16_t*)w->w1_p;
+    L.w1T = (const bf16_t*)w->w1T_p; L.w2 = (const bf16_t*)w->w2_p; L.w2T = (const bf16_t*)w->w2T_p;
+    L.bqkv = w->bqkv; L.bo = w->bo; L.b1 = w->b1; L.b2 = w->b2;
+    L.g1 = w->ln1_w; L.be1 = w->ln1_b; L.g2 = w->ln2_w; L.be2 = w->ln2_b;
+    L.frag = (const bf16_t*)w->frag_p;
+    return L;
+}
+inline int check_weights(const GeomaeSstLayerWeights* w, const char* who) {
+    GEOMAE_REQUIRE(w, "%s: null weights", who);
+    GEOMAE_REQUIRE(w->wqkv_p && w->wqkT_p && w->wvT_p && w->wo_p && w->woT_p && w->w1_p && w->w1T_p && w->w2_p &&
+                   w->w2T_p && w->bqkv && w->bo && w->b1 && w->b2 && w->ln1_w && w->ln1_b && w->ln2_w && w->ln2_b,
+                   "%s: null weight pointer", who);
+    GEOMAE_REQUIRE(w->d_model == 128 && w->d_ffn == 256, "%s: kernels are built for d_model=128, d_ffn=256", who);
+    return GEOMAE_OK;
+}
+#endif
+
 }  // namespace geomae

@@ -1,0 +1,509 @@
+// One launch per SST encoder layer (forward): in-projection with the positional term -> window attention -> out-projection
+// + residual + LayerNorm + FFN(GELU) + residual + LayerNorm, for one BUNDLE of windows per workgroup.
+//
+// Reference: EncoderLayer.forward / WindowAttention.forward (mmdet3d/models/sst/sst_basic_block.py:26-61, 85-102), which
+// pads every window to a bucket size and runs nn.MultiheadAttention + ~25 ATen kernels per layer.  The unfused build of this
+// repository (sst_layer.hip + window.hip) ran a layer as three launches -- q/k/v, the attention output and the residual
+// stream making a round trip through HBM between them -- and the attention launch, with d_head = 16, was a chain of
+// dependent gathers around a handful of tiny MFMAs (1 % of the MFMA roof for three rounds).
+//
+// Design (gfx950; 512 threads = 8 waves = 8 heads per workgroup, one workgroup per bundle of <= 144 tokens):
+//  * WEIGHT-STATIONARY, N-SPLIT GEMMs.  Wave w owns a slice of every GEMM's OUTPUT channels for ALL token tiles of the
+//    bundle: head w's 16 q / k / v channels, channel tile w of the out-projection and of FFN2, channel tiles 2w, 2w+1 of
+//    FFN1.  Its weight fragments (A operands of the transposed product Y^T = W X^T) are read from L2 ONCE into registers;
+//    the activations (B operands) come from an LDS copy of the bundle's rows that all waves share.  Per-wave work is
+//    (32 + attention) MFMAs per 16-token tile whatever the bundle size: the dependent chain of a wave scales with the
+//    bundle, not with a fixed 16-token x 256-MFMA tile as in the one-wave-per-tile kernels.
+//  * ATTENTION IN REGISTERS.  With the transposed product the q / k accumulators of head w (lane = token, 4 channels per
+//    lane group) ARE the B / A operands of S^T = K Q^T (v_mfma_f32_16x16x16_bf16); V is projected a second time in the
+//    untransposed orientation (4 MFMAs per tile), whose accumulator is the A operand of O^T = V^T P^T; and O^T comes out
+//    in the T-layout again.  q, k, v and P never touch LDS; the softmax row of a query lives in one lane (x 4 lane groups).
+//  * the only exchanges between waves: the bf16 rows x / x + pos (in), the attention output, y = LN1(..), gelu(..) -- each
+//    one LDS write + barrier + fragment reads -- and the two LayerNorm statistics (per-wave (mean, M2) of its 16 channels,
+//    merged Welford-style: one barrier each).  Six barriers per layer.
+//  * token rows are addressed through the build's plan records (window.hip pos_info: token, in-window position, window
+//    start, window end per bundle position); every tensor keeps the TOKEN-ORDER tile-blocked layout of the stacks, so the
+//    saved activations are exactly what the (unfused) backward kernels read.
+#include "common.h"
+#include "../../include/geomae_hip.h"
+
+#include "sst_device.h"
+
+namespace geomae {
+
+typedef __attribute__((ext_vector_type(4))) short bf16x4_s;
+
+__device__ __forceinline__ bf16x4_s as_bf4(uint2 v) { return __builtin_bit_cast(bf16x4_s, v); }
+__device__ __forceinline__ f32x4 mfma16(uint2 a, uint2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as_bf4(a), as_bf4(b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma32_2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, f32x4 c) {
+    return mfma32(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), c);
+}
+
+// phase stamps (tools/fused_layer_time.py builds a second library with -DGEOMAE_PHASE_TIMING; a no-op in the product build)
+#ifdef GEOMAE_PHASE_TIMING
+#define FUSED_STAMP(i)                                                                                          \
+    do {                                                                                                        \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS)                                        \
+            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (threadIdx.x >> 8) * 16 + (i)] = clock64();           \
+    } while (0)
+#else
+#define FUSED_STAMP(i) do {} while (0)
+#endif
+
+constexpr int kFusedThreads = 512;
+constexpr int kFMaxT = 144;              // tokens per bundle (a 12 x 12 window)
+constexpr int kFRow = 2 * (128 + 8);     // bytes of one bf16 row of 128 channels in LDS (+16 B: conflict-free b128 reads)
+constexpr int kFRowH = 2 * (256 + 8);    // ... of 256 channels
+constexpr int kFOor = 0x7fff0000;        // a byte offset past every buffer: loads return 0, stores are dropped
+// LDS: [X / Y | XP | O] (H aliases XP + O) | LayerNorm statistics [token][wave][2] | window start / end per position
+constexpr int kFLdsX = 0, kFLdsXP = kFMaxT * kFRow, kFLdsO = 2 * kFMaxT * kFRow, kFLdsRed = 3 * kFMaxT * kFRow;
+constexpr int kFLdsWl = kFLdsRed + kFMaxT * 64, kFLdsWh = kFLdsWl + kFMaxT * 4, kFLdsPrm = kFLdsWh + kFMaxT * 4;
+constexpr int kFLdsBytes = kFLdsPrm + 1408 * 4;
+static_assert(kFMaxT * kFRowH <= 2 * kFMaxT * kFRow, "H must fit in XP + O");
+
+struct FusedFwd {
+    const float* x;              // layer input, token order: tile-blocked [ceil16(n)][128] fp32 -- unless M.src is set
+    SstInputMap M;               // first layer of a stack: row-major source rows (+ row map, + fill row), common.h
+    const int32_t* bun_tok;      // [NB + 1] bundle b covers plan positions [bun_tok[b], bun_tok[b + 1])
+    const int4* plan;            // per position: (token, in-window position, window start, window end)
+    const int32_t* num_bundles;
+    const float* pos_table;      // [wx * wy][128]
+    LayerW W;
+    int n;
+    float eps;
+    float* z;                    // layer output [n][128] fp32: tile-blocked (z_blocked) or row-major
+    int z_blocked;
+    // saved for the backward (token order, tile-blocked; all or none)
+    bf16_t *qkv, *attn, *xh1, *xh2, *hp, *xb, *xp;
+    float *lse, *rstd;
+};
+
+// byte offset of lane (token, g)'s 4 channels of channel tile ct in a tile-blocked [.][ld] tensor of E-byte elements
+template <int E>
+__device__ __forceinline__ int blk_off(int tok, int ld, int ct, int g) {
+    return (tok >> 4) * (16 * ld * E) + ct * (256 * E) + (tok & 15) * (16 * E) + g * (4 * E);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p), 0, kFOor, 0x00020000);   // (offsets >= kFOor are out of range)
+}
+__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
+}
+__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
+}
+__device__ __forceinline__ uint4 lds_b128(const char* p) { return *reinterpret_cast<const uint4*>(p); }
+
+// A fragments of output tile `ot` of a FRAGMENT-MAJOR packed [N][K] matrix (pack_weights_kernel, tr & 4): one contiguous
+// 1-KB piece per (tile, k step).  (Read as 16 rows x 64 B from the row-major copy the same fetch took 8 k cycles longer
+// per workgroup: every 128-byte line was requested twice, by two different instructions.)
+template <int K>
+__device__ __forceinline__ void load_wfrag(const bf16_t* __restrict__ Wf, int ot, int lane, uint4 (&f)[K / 32]) {
+#ifdef FUSED_ABL_NO_WEIGHTS          // (timing ablation: what the weight fetch costs the chain)
+#pragma unroll
+    for (int kk = 0; kk < K / 32; ++kk) f[kk] = make_uint4(lane, ot, kk, 0x3c003c00u);
+    return;
+#endif
+    const bf16_t* p = Wf + (size_t)ot * (16 * K) + 8 * lane;
+#pragma unroll
+    for (int kk = 0; kk < K / 32; ++kk) f[kk] = *reinterpret_cast<const uint4*>(p + 512 * kk);
+}
+__device__ __forceinline__ f32x4 load_f4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+// LayerNorm over the 128 channels of a token that 8 waves hold 16 channels each of: every wave leaves (sum, sum of squares)
+// of its 16 channels -- two INDEPENDENT cross-lane reductions (the Welford form, mean first and then the centred squares,
+// was one dependent chain twice as long on the critical path of two phases) -- and every wave merges the eight pairs.
+// The inputs are residual sums of LayerNorm outputs (|mean| of the order of sigma), far from the cancellation regime of
+// E[x^2] - E[x]^2 in fp32.
+__device__ __forceinline__ void ln_merge(const float* red_tok, float eps, float* mean_out, float* rstd_out) {
+    f32x4 a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(red_tok + 4 * i);
+    const f32x4 s = (a[0] + a[1]) + (a[2] + a[3]);
+    const float mean = (s[0] + s[2]) * (1.0f / 128.0f);
+    const float var = fmaxf((s[1] + s[3]) * (1.0f / 128.0f) - mean * mean, 0.0f);
+    *mean_out = mean;
+    *rstd_out = rsqrtf(var + eps);
+}
+// this wave's (sum, sum of squares) of the 16 channels it holds of token (lane & 15): u = 4 channels per lane group
+__device__ __forceinline__ void ln_partial(const f32x4 u, float* red_tok_wave, int g) {
+    const float s = rows4_sum((u[0] + u[1]) + (u[2] + u[3]));
+    const float q = rows4_sum((u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]));
+    if (g == 0) *reinterpret_cast<float2*>(red_tok_wave) = make_float2(s, q);
+}
+
+// fp32 parameter vectors of the layer, fetched once per workgroup into LDS (read back with ds_read: a global load at the
+// point of use waits behind every store the wave issued before it -- vmcnt retires in order on gfx9)
+constexpr int kPBq = 0, kPBo = 384, kPG1 = 512, kPBe1 = 640, kPB1 = 768, kPB2 = 1024, kPG2 = 1152, kPBe2 = 1280, kPFloats = 1408;
+__device__ __forceinline__ f32x4 params_issue(const LayerW& W) {
+    const int s = threadIdx.x;                                        // float4 slot 0..351
+    const float* src = s < 96 ? W.bqkv + 4 * s : s < 128 ? W.bo + 4 * (s - 96) : s < 160 ? W.g1 + 4 * (s - 128)
+                     : s < 192 ? W.be1 + 4 * (s - 160) : s < 256 ? W.b1 + 4 * (s - 192) : s < 288 ? W.b2 + 4 * (s - 256)
+                     : s < 320 ? W.g2 + 4 * (s - 288) : W.be2 + 4 * (s - 320);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (s < kPFloats / 4) v = *reinterpret_cast<const f32x4*>(src);
+    return v;
+}
+
+// NT: tiles the body is unrolled for.  EXACT: the bundle has exactly NT tiles -- straight-line code (the scheduler overlaps
+// the tiles' chains), all tile pairs of the attention computed (the mask does the block-diagonal).  !EXACT: nt <= NT tiles
+// behind scalar branches, key-tile ranges.  Weight fragments are fetched two phases ahead of their first use.
+template <int NT, bool EXACT>
+__device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, const int T, const int nt_in, char* lds) {
+    const int nt = EXACT ? NT : nt_in;
+#define FOR_TILES(it) _Pragma("unroll") for (int it = 0; it < NT; ++it) if (EXACT || it < nt)
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // head = channel tile of this wave
+    const int t = lane & 15, g = lane >> 4;
+    char* X = lds + kFLdsX;
+    char* XP = lds + kFLdsXP;
+    char* O = lds + kFLdsO;
+    char* H = lds + kFLdsXP;
+    float* red = reinterpret_cast<float*>(lds + kFLdsRed);
+    int* wl = reinterpret_cast<int*>(lds + kFLdsWl);
+    int* wh = reinterpret_cast<int*>(lds + kFLdsWh);
+    const float* prm = reinterpret_cast<const float*>(lds + kFLdsPrm);
+    const bool save = A.qkv != nullptr;
+    const LayerW& W = A.W;
+    // where this wave's 16 channels sit in a K-permuted bf16 row (sst_device.h kperm): 8 bytes per lane group
+    const int perm_b = 2 * (32 * (w >> 1) + 8 * g + 4 * (w & 1));
+    FUSED_STAMP(0);
+
+    // ---- the plan records first (the head of the longest dependent chain), then the weights
+    int4 rec[NT];
+    FOR_TILES(it) {
+        const int idx = 16 * it + t;
+        rec[it] = make_int4(-1, 0, -1 - idx, 0);
+        if (idx < T) rec[it] = A.plan[s0 + idx];
+    }
+    const f32x4 prm_r = params_issue(W);
+    uint4 wq[4], wk[4], wv[4], wo[4], w1a[4], w1b[4], w2[8];
+
+    // ---- phase A: this wave's channel tile of every row: fp32 (kept for the residual), bf16 x and x + pos into LDS
+    int tok[NT];
+    f32x4 xr[NT];
+    {
+        const __amdgpu_buffer_rsrc_t xres = whole_rsrc(A.M.src ? A.M.src : A.x);
+        const __amdgpu_buffer_rsrc_t pres = whole_rsrc(A.pos_table);
+        const __amdgpu_buffer_rsrc_t xb_r = whole_rsrc(A.xb), xp_r = whole_rsrc(A.xp);
+        f32x4 pv[NT];
+        FOR_TILES(it) {
+            const int tk = rec[it].x;
+            tok[it] = tk;
+            int off;
+            if (A.M.src) {                    // the stack's input conversion: row-major rows, gathered / filled
+                int srow = tk;
+                if (A.M.rows && tk >= 0 && tk < A.M.n_src) srow = A.M.rows[tk];
+                off = (tk >= 0 && tk < A.M.n_src) ? srow * 512 + 64 * w + 16 * g : kFOor;
+            } else {
+                off = tk >= 0 ? blk_off<4>(tk, 128, w, g) : kFOor;
+            }
+            xr[it] = buf_load_f32x4(xres, off);
+            pv[it] = buf_load_f32x4(pres, tk >= 0 ? rec[it].y * 512 + 64 * w + 16 * g : kFOor);
+        }
+        // the in-projection's weights BEHIND the row loads: the rows (the longer dependent chain: plan -> row) are not
+        // queued behind 96 KB of fragments, and the fragments land under the LDS writes and the barrier
+        __builtin_amdgcn_sched_barrier(0);                          // (the scheduler otherwise hoists them above the plan wait)
+        load_wfrag<128>(W.frag + kOffWqkv, w, lane, wq);
+        load_wfrag<128>(W.frag + kOffWqkv, 8 + w, lane, wk);
+        load_wfrag<128>(W.frag + kOffWqkv, 16 + w, lane, wv);
+        if (A.M.src && A.M.fill) {
+            const f32x4 fill = load_f4(A.M.fill + 16 * w + 4 * g);
+            FOR_TILES(it) if (tok[it] >= A.M.n_src) xr[it] = fill;
+        }
+        if (threadIdx.x < kPFloats / 4) *reinterpret_cast<f32x4*>(lds + kFLdsPrm + 16 * threadIdx.x) = prm_r;
+        FOR_TILES(it) {
+            const int idx = 16 * it + t;
+            const uint2 xb = pack4(xr[it]), xpb = pack4(xr[it] + pv[it]);
+            *reinterpret_cast<uint2*>(X + idx * kFRow + perm_b) = xb;
+            *reinterpret_cast<uint2*>(XP + idx * kFRow + perm_b) = xpb;
+            if (save) {
+                const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor;
+                buf_store_b64(xb_r, o2, xb);
+                buf_store_b64(xp_r, o2, xpb);
+            }
+            if (w == 0 && g == 0) { wl[idx] = rec[it].z; wh[idx] = rec[it].w; }
+        }
+    }
+    FUSED_STAMP(1);
+    __syncthreads();                                                                           // (1) rows in LDS
+    FUSED_STAMP(2);
+    load_wfrag<128>(W.frag + kOffWo, w, lane, wo);                   // first use: phase D
+
+    // ---- phase B: q, k (T-layout), v (T-layout for the backward, untransposed for P V) of head w
+    uint2 qf[NT], kf[NT], vtf[NT];
+    {
+        const __amdgpu_buffer_rsrc_t qkv_r = whole_rsrc(A.qkv);
+        const f32x4 bq = load_f4(prm + kPBq + 16 * w + 4 * g), bk = load_f4(prm + kPBq + 128 + 16 * w + 4 * g);
+        const f32x4 bv = load_f4(prm + kPBq + 256 + 16 * w + 4 * g);
+        const float bvn = prm[kPBq + 256 + 16 * w + t];
+        FOR_TILES(it) {
+            const char* xrow = X + (16 * it + t) * kFRow + 16 * g;
+            const char* xprow = XP + (16 * it + t) * kFRow + 16 * g;
+            uint4 bx[4], bxp[4];
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) { bxp[kk] = lds_b128(xprow + 64 * kk); bx[kk] = lds_b128(xrow + 64 * kk); }
+            f32x4 aq = bq, ak = bk, av = bv, avt = {bvn, bvn, bvn, bvn};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                aq = mfma32(wq[kk], bxp[kk], aq);
+                ak = mfma32(wk[kk], bxp[kk], ak);
+                avt = mfma32(bx[kk], wv[kk], avt);
+                av = mfma32(wv[kk], bx[kk], av);
+            }
+            qf[it] = pack4(aq);
+            kf[it] = pack4(ak);
+            vtf[it] = pack4(avt);
+            if (save) {
+                const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 384, w, g) : kFOor;
+                buf_store_b64(qkv_r, o2, qf[it]);
+                buf_store_b64(qkv_r, o2 + 8 * 512, kf[it]);
+                buf_store_b64(qkv_r, o2 + 16 * 512, pack4(av));
+            }
+        }
+    }
+    FUSED_STAMP(3);
+    load_wfrag<128>(W.frag + kOffW1, 2 * w, lane, w1a);                         // in flight under the attention (first use: phase E)
+    load_wfrag<128>(W.frag + kOffW1, 2 * w + 1, lane, w1b);
+
+    // ---- phase C: attention of head w over the bundle, block-diagonal by window
+    {
+        const __amdgpu_buffer_rsrc_t attn_r = whole_rsrc(A.attn), lse_r = whole_rsrc(A.lse);
+        const float scale = 0.25f;                                   // 1 / sqrt(16)
+        FOR_TILES(it) {
+            const int first = 16 * it;
+            int jlo = 0, jhi = NT - 1;
+            if (!EXACT) {
+                const int last = first + 15 < T ? first + 15 : T - 1;
+                jlo = __builtin_amdgcn_readfirstlane((wl[first] - s0) >> 4);
+                jhi = __builtin_amdgcn_readfirstlane((wh[last] - 1 - s0) >> 4);
+            }
+            const int wq_key = wl[first + t];
+            f32x4 st[NT];
+            float m = -INFINITY;
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+                if (EXACT || (jt >= jlo && jt <= jhi)) {
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    st[jt] = mfma16(kf[jt], qf[it], z4);          // S^T: rows = keys 4g + r, column = query t
+                    const int4 W4 = *reinterpret_cast<const int4*>(wl + 16 * jt + 4 * g);
+                    const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[jt][r] = (Wr[r] == wq_key) ? st[jt][r] * scale : -INFINITY;
+                        m = fmaxf(m, st[jt][r]);
+                    }
+                }
+            m = rows4_max(m);
+            float sum = 0.f;
+            uint2 pb[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt)
+                if (EXACT || (jt >= jlo && jt <= jhi)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float p = __expf(st[jt][r] - m);
+                        st[jt][r] = p;
+                        sum += p;
+                    }
+                    pb[jt] = pack4(st[jt]);
+                }
+            sum = rows4_sum(sum);
+            // O^T = V^T P^T: rows = channels 4g + r of head w, column = query t; two key tiles per K = 32 MFMA
+            f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jp = 0; jp < (NT + 1) / 2; ++jp) {
+                const int j0 = 2 * jp, j1 = 2 * jp + 1;
+                const bool a0 = EXACT || (j0 >= jlo && j0 <= jhi);
+                const bool a1 = j1 < NT && (EXACT || (j1 >= jlo && j1 <= jhi));
+                if (a0 || a1) {
+                    const uint2 zz = make_uint2(0u, 0u);
+                    const int j1c = j1 < NT ? j1 : j0;
+                    o = mfma32_2(a0 ? vtf[j0] : zz, a1 ? vtf[j1c] : zz, a0 ? pb[j0] : zz, a1 ? pb[j1c] : zz, o);
+                }
+            }
+            const float inv = 1.0f / sum;
+            o *= inv;
+            const uint2 ob = pack4(o);
+            *reinterpret_cast<uint2*>(O + (first + t) * kFRow + perm_b) = ob;
+            if (save) {
+                buf_store_b64(attn_r, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, ob);
+                if (g == 0) buf_store_f32(lse_r, tok[it] >= 0 ? (tok[it] * 8 + w) * 4 : kFOor, m + __logf(sum));
+            }
+        }
+    }
+    load_wfrag<256>(W.frag + kOffW2, w, lane, w2);                              // first use: phase F
+    FUSED_STAMP(4);
+    __syncthreads();                                                                           // (2) attention output in LDS
+    FUSED_STAMP(5);
+
+    // ---- phase D: u = x + attn Wo^T + bo (channel tile w), LayerNorm 1
+    {
+        const f32x4 bo = load_f4(prm + kPBo + 16 * w + 4 * g);
+        FOR_TILES(it) {
+            const char* orow = O + (16 * it + t) * kFRow + 16 * g;
+            f32x4 au = bo;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) au = mfma32(wo[kk], lds_b128(orow + 64 * kk), au);
+            xr[it] += au;
+            ln_partial(xr[it], red + (16 * it + t) * 16 + 2 * w, g);
+        }
+    }
+    FUSED_STAMP(6);
+    __syncthreads();                                                                           // (3) LayerNorm-1 statistics
+    FUSED_STAMP(7);
+    {
+        const __amdgpu_buffer_rsrc_t xh1_r = whole_rsrc(A.xh1), rstd_r = whole_rsrc(A.rstd);
+        const f32x4 g1 = load_f4(prm + kPG1 + 16 * w + 4 * g), be1 = load_f4(prm + kPBe1 + 16 * w + 4 * g);
+        FOR_TILES(it) {
+            float mean, rstd;
+            ln_merge(red + (16 * it + t) * 16, A.eps, &mean, &rstd);
+            f32x4 xh = (xr[it] - mean) * rstd;
+            if (save) {
+                buf_store_b64(xh1_r, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(xh));
+                if (w == 0 && g == 0) buf_store_f32(rstd_r, tok[it] >= 0 ? tok[it] * 8 : kFOor, rstd);
+            }
+            xr[it] = xh * g1 + be1;                                // y: the FFN's input and its residual
+            *reinterpret_cast<uint2*>(X + (16 * it + t) * kFRow + perm_b) = pack4(xr[it]);
+        }
+    }
+    FUSED_STAMP(8);
+    __syncthreads();                                                                           // (4) y in LDS
+    FUSED_STAMP(9);
+
+    // ---- phase E: h = gelu(y W1^T + b1), channel tiles 2w, 2w + 1
+    {
+        const __amdgpu_buffer_rsrc_t hp_r = whole_rsrc(A.hp);
+        const f32x4 b1a = load_f4(prm + kPB1 + 32 * w + 4 * g), b1b = load_f4(prm + kPB1 + 32 * w + 16 + 4 * g);
+        FOR_TILES(it) {
+            const char* yrow = X + (16 * it + t) * kFRow + 16 * g;
+            f32x4 ha = b1a, hb = b1b;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint4 by = lds_b128(yrow + 64 * kk);
+                ha = mfma32(w1a[kk], by, ha);
+                hb = mfma32(w1b[kk], by, hb);
+            }
+            if (save) {
+                const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 256, 2 * w, g) : kFOor;
+                buf_store_b64(hp_r, o2, pack4(ha));
+                buf_store_b64(hp_r, o2 + 512, pack4(hb));
+            }
+            const f32x4 ga = {gelu_f(ha[0]), gelu_f(ha[1]), gelu_f(ha[2]), gelu_f(ha[3])};
+            const f32x4 gb = {gelu_f(hb[0]), gelu_f(hb[1]), gelu_f(hb[2]), gelu_f(hb[3])};
+            const uint2 pa = pack4(ga), pb = pack4(gb);
+            *reinterpret_cast<uint4*>(H + (16 * it + t) * kFRowH + 2 * (32 * w + 8 * g)) = make_uint4(pa.x, pa.y, pb.x, pb.y);
+        }
+    }
+    FUSED_STAMP(10);
+    __syncthreads();                                                                           // (5) gelu output in LDS
+    FUSED_STAMP(11);
+
+    // ---- phase F: v = y + h W2^T + b2, LayerNorm 2
+    {
+        const f32x4 b2 = load_f4(prm + kPB2 + 16 * w + 4 * g);
+        FOR_TILES(it) {
+            const char* hrow = H + (16 * it + t) * kFRowH + 16 * g;
+            f32x4 a = b2;
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a = mfma32(w2[kk], lds_b128(hrow + 64 * kk), a);
+            xr[it] += a;
+            ln_partial(xr[it], red + (16 * it + t) * 16 + 2 * w, g);
+        }
+    }
+    FUSED_STAMP(12);
+    __syncthreads();                                                                           // (6) LayerNorm-2 statistics
+    FUSED_STAMP(13);
+    {
+        const __amdgpu_buffer_rsrc_t xh2_r = whole_rsrc(A.xh2), rstd_r = whole_rsrc(A.rstd), z_r = whole_rsrc(A.z);
+        const f32x4 g2 = load_f4(prm + kPG2 + 16 * w + 4 * g), be2 = load_f4(prm + kPBe2 + 16 * w + 4 * g);
+        FOR_TILES(it) {
+            float mean, rstd;
+            ln_merge(red + (16 * it + t) * 16, A.eps, &mean, &rstd);
+            const f32x4 xh = (xr[it] - mean) * rstd;
+            const int tk = tok[it];
+            if (save) {
+                buf_store_b64(xh2_r, tk >= 0 ? blk_off<2>(tk, 128, w, g) : kFOor, pack4(xh));
+                if (w == 0 && g == 0) buf_store_f32(rstd_r, tk >= 0 ? tk * 8 + 4 : kFOor, rstd);
+            }
+            const f32x4 zz = xh * g2 + be2;
+            const int zo = tk < 0 ? kFOor : (A.z_blocked ? blk_off<4>(tk, 128, w, g) : tk * 512 + 64 * w + 16 * g);
+            buf_store_f32x4(z_r, zo, zz);
+        }
+    }
+    FUSED_STAMP(14);
+#undef FOR_TILES
+}
+
+__global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFwd A) {
+    __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
+    // (bun_tok holds max_bundles + 1 >= gridDim.x + 1 words: read before the bundle count is known, one round trip less)
+    const int NB = A.num_bundles[0];
+    for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+        const int s0 = A.bun_tok[b];
+        const int T = A.bun_tok[b + 1] - s0;
+        const int nt = (T + 15) >> 4;
+        switch (nt) {
+            case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
+            case 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
+            case 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
+            case 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
+            default: fused_fwd_body<9, false>(A, s0, T, nt, lds); break;
+        }
+        if (b + (int)gridDim.x < NB) __syncthreads();
+    }
+}
+
+// one workgroup per bundle; the bundle count lives on the device, its bound from the greedy packing is 2 n / cap + 1
+static int fused_grid(int num_tokens, int max_bundles, int cap) {
+    int64_t nb = 2 * (int64_t)num_tokens / (cap > 0 ? cap : 1) + 2;
+    if (nb > max_bundles) nb = max_bundles;
+    if (nb > 4096) nb = 4096;
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+}  // namespace geomae
+
+using namespace geomae;
+
+#ifdef GEOMAE_PHASE_TIMING
+extern "C" int geomae_debug_read_fused_stamps(unsigned long long* host, int clear) {
+    hipDeviceSynchronize();
+    if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(geomae_stamps), sizeof(unsigned long long) * GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS);
+    if (clear) {
+        static unsigned long long zeros[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
+        hipMemcpyToSymbol(HIP_SYMBOL(geomae_stamps), zeros, sizeof(zeros));
+    }
+    return 0;
+}
+#endif
+
+extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, const GeomaeSstLayerWeights* w,
+                                        const GeomaeSstStackLayout* layout, int32_t bundle_cap, const float* pos_table,
+                                        float* z, int32_t z_blocked, void* qkv_bf16, void* attn_bf16, float* lse,
+                                        void* xhat1_bf16, void* xhat2_bf16, void* hp_bf16, float* rstd, void* x_bf16,
+                                        void* xp_bf16, hipStream_t stream) {
+    if (num_tokens <= 0) return GEOMAE_OK;
+    int rc = check_weights(w, "sst_layer_forward");
+    if (rc) return rc;
+    GEOMAE_REQUIRE(num_tokens <= 2700000, "sst_layer_forward: more than 2.7 M tokens per call");
+    GEOMAE_REQUIRE(layout && layout->fbun_tok && layout->pos_info && layout->num_fbundles && layout->max_bundles >= 1,
+                   "sst_layer_forward: the layout needs the build's plan and second packing (pos_info, fbun_tok, num_fbundles)");
+    GEOMAE_REQUIRE(pos_table && z, "sst_layer_forward: null argument");
+    GEOMAE_REQUIRE(w->frag_p, "sst_layer_forward: the layer has no fragment-major packed weights (frag_p)");
+    const SstInputMap M = input_map();
+    GEOMAE_REQUIRE(x || M.src, "sst_layer_forward: null input");
+    const bool save = qkv_bf16 || attn_bf16 || lse || xhat1_bf16 || xhat2_bf16 || hp_bf16 || rstd || x_bf16 || xp_bf16;
+    GEOMAE_REQUIRE(!save || (qkv_bf16 && attn_bf16 && lse && xhat1_bf16 && xhat2_bf16 && hp_bf16 && rstd && x_bf16 && xp_bf16),
+                   "sst_layer_forward: pass all nine save buffers or none");
+    FusedFwd A;
+    A.x = x; A.M = M; A.bun_tok = layout->fbun_tok; A.plan = (const int4*)layout->pos_info; A.num_bundles = layout->num_fbundles;
+    A.pos_table = pos_table; A.W = to_layer(w); A.n = num_tokens; A.eps = w->ln_eps; A.z = z; A.z_blocked = z_blocked;
+    A.qkv = (bf16_t*)qkv_bf16; A.attn = (bf16_t*)attn_bf16; A.xh1 = (bf16_t*)xhat1_bf16; A.xh2 = (bf16_t*)xhat2_bf16;
+    A.hp = (bf16_t*)hp_bf16; A.xb = (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
+    const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
+    hipLaunchKernelGGL(sst_layer_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
+    return check_launch("sst_layer_fwd_kernel");
+}

@@ -33,7 +33,8 @@ namespace geomae {
 
 // ------------------------------------------------------------------------------------------------
 // weight packing: desc[d] = {src_off, rows, cols, transpose, dst_off}; dst [R][K] bf16 with
-// dst[r][p] = W[r][kperm(p)] (K = cols) or, transposed, dst[j][p] = W[kperm(p)][j] (R = cols, K = rows)
+// dst[r][p] = W[r][kperm(p)] (K = cols) or, transposed (tr & 1), dst[j][p] = W[kperm(p)][j] (R = cols, K = rows);
+// tr & 4: the same matrix stored fragment-major (below); tr == 2: plain fp32 gather into aux
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ flat,
                                                            const int64_t* __restrict__ desc,
@@ -47,14 +48,19 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
     // 32-bit index arithmetic (a matrix has at most 384 x 256 elements): the 64-bit division per element was most of
     // this kernel's 20 us, which it spends beside the next step's first (latency-bound) kernels
-    const int K = (int)(tr ? rows : cols), C = (int)cols, T = (int)total;
+    const bool tp = tr & 1, frag = tr & 4;
+    const int K = (int)(tp ? rows : cols), C = (int)cols, T = (int)total;
     const float* __restrict__ w = flat + src;
     bf16_t* __restrict__ out = packed + dst;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < T; e += gridDim.x * 256) {
         const int r = e / K;
-        const int k = kperm(e - r * K);
-        const float v = tr ? w[k * C + r] : w[r * C + k];
-        out[e] = (bf16_t)f2bf_bits(v);
+        const int p = e - r * K;
+        const int k = kperm(p);
+        const float v = tp ? w[k * C + r] : w[r * C + k];
+        // fragment-major (tr & 4; the one-launch layer kernels, sst_fused.hip): the 16 rows x 32 positions that one MFMA A
+        // fragment of 64 lanes covers are one contiguous 1-KB piece [out tile][k step][lane = 16 g + row][8 positions]
+        const int d = frag ? ((r >> 4) * (K >> 5) + (p >> 5)) * 512 + ((((p >> 3) & 3) << 4) + (r & 15)) * 8 + (p & 7) : e;
+        out[d] = (bf16_t)f2bf_bits(v);
     }
 }
 
@@ -66,10 +72,6 @@ constexpr int kLaySavedBf16 = 8;  // the saved normalised activations xhat1 / xh
                                   // C ABI documents fp32): 1 KB less per token and layer each way, the backward reads them as
                                   // the LayerNorm's x-hat and re-derives y = xhat1 * g1 + be1 -- a bf16 GEMM operand anyway
 
-struct LayerW {
-    const bf16_t *wqkv, *wqkT, *wvT, *wo, *woT, *w1, *w1T, *w2, *w2T;
-    const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
-};
 
 // ------------------------------------------------------------------------------------------------
 // F1: qkv = [(x + pos) Wqk^T + bqk | x Wv^T + bv]  ->  bf16 [n, 384]
@@ -1004,24 +1006,6 @@ static void note_partials(const DwTasks& T, int num_tasks, int gx) {
     g_pending_reduce = R;
 }
 
-static LayerW to_layer(const GeomaeSstLayerWeights* w) {
-    LayerW L;
-    L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;
-    L.wo = (const bf16_t*)w->wo_p; L.woT = (const bf16_t*)w->woT_p; L.w1 = (const bf16_t*)w->w1_p;
-    L.w1T = (const bf16_t*)w->w1T_p; L.w2 = (const bf16_t*)w->w2_p; L.w2T = (const bf16_t*)w->w2T_p;
-    L.bqkv = w->bqkv; L.bo = w->bo; L.b1 = w->b1; L.b2 = w->b2;
-    L.g1 = w->ln1_w; L.be1 = w->ln1_b; L.g2 = w->ln2_w; L.be2 = w->ln2_b;
-    return L;
-}
-
-static int check_weights(const GeomaeSstLayerWeights* w, const char* who) {
-    GEOMAE_REQUIRE(w, "%s: null weights", who);
-    GEOMAE_REQUIRE(w->wqkv_p && w->wqkT_p && w->wvT_p && w->wo_p && w->woT_p && w->w1_p && w->w1T_p && w->w2_p &&
-                   w->w2T_p && w->bqkv && w->bo && w->b1 && w->b2 && w->ln1_w && w->ln1_b && w->ln2_w && w->ln2_b,
-                   "%s: null weight pointer", who);
-    GEOMAE_REQUIRE(w->d_model == 128 && w->d_ffn == 256, "%s: kernels are built for d_model=128, d_ffn=256", who);
-    return GEOMAE_OK;
-}
 
 }  // namespace geomae
 

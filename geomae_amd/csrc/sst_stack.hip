@@ -33,6 +33,16 @@ namespace geomae {
 
 static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 
+// geomae_sst_set_fused_layers / GEOMAE_FUSED_LAYERS = 0 (never) | 1 (automatic) | 2 (always)
+// The one-launch layer kernel is a LATENCY design: one workgroup of 8 waves per bundle and CU (134 KB of LDS), every
+// wave walking the whole layer for its channel slice.  It wins where a layer's launches do not fill the chip anyway (the
+// encoder's kept pillars at BASELINE configs 1 / 2: 26.1 vs 27.7 us per layer); at 28 k tokens (config 3's encoder) the
+// three-launch form, with two workgroups per CU, moves more tokens per us (52 vs 72 us per layer), and so it does at the
+// decoders' sizes (tools/fused_layer_time.py).  Automatic = token sets of at most kFusedMaxTokens.
+static int g_fused_mode = [] { const char* e = getenv("GEOMAE_FUSED_LAYERS"); return e ? atoi(e) : 1; }();
+constexpr int kFusedMaxTokens = 12288;
+static bool fused_layers_enabled(int num_tokens) { return g_fused_mode == 2 || (g_fused_mode == 1 && num_tokens <= kFusedMaxTokens); }
+
 struct SavedOffsets {
     int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
 };
@@ -116,6 +126,8 @@ struct Timed {
 
 using namespace geomae;
 
+extern "C" void geomae_sst_set_fused_layers(int32_t mode) { g_fused_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+
 extern "C" void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches) {
     Profiler* p = new Profiler();
     p->kernel_id = kernel_id;
@@ -181,6 +193,25 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         explicit LiveRowScope(int r) { set_first_live_row(r); }
         ~LiveRowScope() { set_first_live_row(0); }
     };
+    // ---- one launch per layer (sst_fused.hip) when the layouts carry the build's plan.  Same saved tensors, same layouts
+    // as the three-launch form below (which stays for layouts without a plan, GEOMAE_SAVED_F32=1 and A/B runs).
+    if (fused_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
+        saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
+        const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
+        for (int l = 0; l < num_layers; ++l) {
+            char* sv = base + so.stride * l;
+            const bool next = l + 1 < num_layers;
+            float* z = next ? (float*)(sv + so.stride + so.x) : z_out;
+            Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
+            if (l == 0) set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
+            rc = geomae_sst_layer_forward((const float*)(sv + so.x), num_tokens, &layers[l], &layouts[l & 1], cap, pos_table, z,
+                                          next ? 1 : 0, sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1,
+                                          sv + so.xh2, sv + so.hp, (float*)(sv + so.rstd), sv + so.xb, sv + so.xp, stream);
+            if (l == 0) set_input_map(SstInputMap{nullptr, 0, nullptr, nullptr});
+            if (rc) return rc;
+        }
+        return GEOMAE_OK;
+    }
     // the input conversion (row-major x_in [gathered by input_rows, followed by fill_row] -> tile-blocked x of layer 0)
     // is done by F1 of layer 0 itself (common.h SstInputMap); it used to be a 5-13 us launch in front of every stack
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer

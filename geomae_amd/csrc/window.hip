@@ -59,8 +59,10 @@ struct WinJob {
     int n, slots, cap;
     WinGeom g;
     int32_t *table, *rank, *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
+    int fcap;                // second packing (the one-launch layer kernel's bundles): cap, starts, count; or fbun_tok null
+    int32_t *fbun_tok, *num_fbundles;
     int32_t* bun_tok;        // optional attention plan (see bundle_setup): token position where each bundle starts
-    int4* pos_info;          // ... and per position of win_tokens: (token, window, window start, window end)
+    int4* pos_info;          // ... and per position of win_tokens: (token, in-window position = pos-embed row, window start, window end)
 };
 struct WinJobs { WinJob j[kMaxWinJobs]; };
 
@@ -134,96 +136,107 @@ __global__ __launch_bounds__(64) void win_sort_jobs_kernel(WinJobs J) {
                 int r = 0;
                 for (int u = 0; u < n; ++u) r += a[u] < v;
                 win_tokens[s + r] = v;
-                if (j.pos_info) j.pos_info[s + r] = make_int4(v, w, s, s + n);
+                if (j.pos_info) j.pos_info[s + r] = make_int4(v, j.tok_pos[v], s, s + n);
             }
             __syncthreads();
         } else if (j.pos_info) {
-            for (int t = threadIdx.x; t < n; t += 64) j.pos_info[s + t] = make_int4(win_tokens[s + t], w, s, s + n);
+            for (int t = threadIdx.x; t < n; t += 64) {
+                const int v = win_tokens[s + t];
+                j.pos_info[s + t] = make_int4(v, j.tok_pos[v], s, s + n);
+            }
         }
     }
 }
 
-// greedy packing of consecutive windows into bundles of at most `cap` tokens (cap >= the largest window):
-// most windows hold a handful of pillars, and one wavefront per (window, head) drowned in fixed
-// per-wave latency (profiles/r01d: 16k waves per launch).  One thread, sizes pipelined from LDS.
-__global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
-    const WinJob& j = J.j[blockIdx.y];
-    const int32_t* __restrict__ win_start = j.win_start; const int32_t* __restrict__ num_windows = j.num_windows;
-    const int cap = j.cap; int32_t* __restrict__ bun_start = j.bun_start; int32_t* __restrict__ num_bundles = j.num_bundles;
+// greedy packing of consecutive windows into bundles of at most `cap` tokens (a window larger than the cap is a bundle of
+// its own): most windows hold a handful of pillars, and one wavefront per (window, head) drowned in fixed per-wave latency
+// (profiles/r01d: 16k waves per launch).  Two packings per layout: the attention kernels' (cap = a whole window, bun_start /
+// bun_tok / num_bundles) and, optionally, the one-launch layer kernel's (sst_fused.hip: fcap, fbun_tok / num_fbundles).
+struct BundleLds { int ws[8192]; int nx[8192]; int ja[8192 + 1]; int jb[8192 + 1]; int n_anchors; };
+
+__device__ __forceinline__ void bundle_pack(const WinJob& j, int cap, int32_t* __restrict__ bun_start /*or null*/,
+                                            int32_t* __restrict__ bun_tok /*or null*/, int32_t* __restrict__ num_bundles,
+                                            BundleLds& L, int W, bool in_lds) {
+    const int32_t* __restrict__ win_start = j.win_start;
     int32_t* __restrict__ nxt_ws = j.rank;      // reused: the window counting sort is done with it
     // nxt[w] = end (exclusive) of the greedy bundle that starts at window w: the largest e with
     // win_start[e] - win_start[w] <= cap (binary search, all threads); then one thread follows the chain
     // 0 -> nxt[0] -> ... (one dependent read per BUNDLE instead of per window).
-    __shared__ int ws[8192];
-    __shared__ int nx[8192];
-    const int W = num_windows[0];
-    const bool in_lds = W < 8192;
-    if (in_lds)
-        for (int t = threadIdx.x; t <= W; t += 1024) ws[t] = win_start[t];
-    __syncthreads();
     for (int w = threadIdx.x; w < W; w += 1024) {
-        const int limit = (in_lds ? ws[w] : win_start[w]) + cap;
-        int lo = w + 1, hi = W;                          // answer in [w+1, W]: a window never exceeds cap
+        const int limit = (in_lds ? L.ws[w] : win_start[w]) + cap;
+        int lo = w + 1, hi = W;                          // answer in [w+1, W] (w+1: a window larger than the cap)
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            const int v = in_lds ? ws[mid] : win_start[mid];
+            const int v = in_lds ? L.ws[mid] : win_start[mid];
             if (v <= limit) lo = mid; else hi = mid - 1;
         }
-        if (in_lds) nx[w] = lo; else nxt_ws[w] = lo;
+        if (in_lds) L.nx[w] = lo; else nxt_ws[w] = lo;
     }
     __syncthreads();
     if (!in_lds) {                                       // huge window tables: the plain serial walk
         if (threadIdx.x == 0) {
             int nb = 0, w = 0;
             while (w < W) {
-                if (j.bun_tok) j.bun_tok[nb] = win_start[w];
-                bun_start[nb++] = w;
+                if (bun_tok) bun_tok[nb] = win_start[w];
+                if (bun_start) bun_start[nb] = w;
+                ++nb;
                 w = nxt_ws[w];
             }
-            bun_start[nb] = W;
-            if (j.bun_tok) j.bun_tok[nb] = j.n;
+            if (bun_start) bun_start[nb] = W;
+            if (bun_tok) bun_tok[nb] = j.n;
             num_bundles[0] = nb;
         }
+        __syncthreads();
         return;
     }
     // The walk 0 -> nx[0] -> nx[nx[0]] ... is one dependent LDS read per bundle (~300 at decoder size: most of this
     // kernel's 27 us, on the chain that gates the encoder).  Four rounds of pointer doubling give the 16-hop map;
     // one thread walks THAT (~20 reads) and records the anchors, then every anchor's thread fills its 16 bundles.
-    __shared__ int ja[8192 + 1];
-    __shared__ int jb[8192 + 1];
-    __shared__ int n_anchors;
-    if (threadIdx.x == 0) nx[W] = W;                      // sentinel: the walk stops at W
+    if (threadIdx.x == 0) L.nx[W] = W;                    // sentinel: the walk stops at W
     __syncthreads();
-    for (int w = threadIdx.x; w <= W; w += 1024) ja[w] = nx[nx[w]];          // 2 hops
+    for (int w = threadIdx.x; w <= W; w += 1024) L.ja[w] = L.nx[L.nx[w]];          // 2 hops
     __syncthreads();
-    for (int w = threadIdx.x; w <= W; w += 1024) jb[w] = ja[ja[w]];          // 4
+    for (int w = threadIdx.x; w <= W; w += 1024) L.jb[w] = L.ja[L.ja[w]];          // 4
     __syncthreads();
-    for (int w = threadIdx.x; w <= W; w += 1024) ja[w] = jb[jb[w]];          // 8
+    for (int w = threadIdx.x; w <= W; w += 1024) L.ja[w] = L.jb[L.jb[w]];          // 8
     __syncthreads();
-    for (int w = threadIdx.x; w <= W; w += 1024) jb[w] = ja[ja[w]];          // 16
+    for (int w = threadIdx.x; w <= W; w += 1024) L.jb[w] = L.ja[L.ja[w]];          // 16
     __syncthreads();
     if (threadIdx.x == 0) {
         int na = 0, w = 0;
-        while (w < W) { ja[na++] = w; w = jb[w]; }        // ja is free again: it now holds the anchors
-        n_anchors = na;
-        if (na == 0) { bun_start[0] = W; if (j.bun_tok) j.bun_tok[0] = j.n; num_bundles[0] = 0; }
+        while (w < W) { L.ja[na++] = w; w = L.jb[w]; }    // ja is free again: it now holds the anchors
+        L.n_anchors = na;
+        if (na == 0) { if (bun_start) bun_start[0] = W; if (bun_tok) bun_tok[0] = j.n; num_bundles[0] = 0; }
     }
     __syncthreads();
-    const int na = n_anchors;
+    const int na = L.n_anchors;
     for (int a = threadIdx.x; a < na; a += 1024) {
-        int w = ja[a], k = 0;
+        int w = L.ja[a], k = 0;
         for (; k < 16 && w < W; ++k) {
-            bun_start[16 * a + k] = w;
-            if (j.bun_tok) j.bun_tok[16 * a + k] = ws[w];
-            w = nx[w];
+            if (bun_start) bun_start[16 * a + k] = w;
+            if (bun_tok) bun_tok[16 * a + k] = L.ws[w];
+            w = L.nx[w];
         }
         if (a == na - 1) {                                // the last anchor's thread knows the bundle count
             const int nb = 16 * a + k;
-            bun_start[nb] = W;
-            if (j.bun_tok) j.bun_tok[nb] = j.n;
+            if (bun_start) bun_start[nb] = W;
+            if (bun_tok) bun_tok[nb] = j.n;
             num_bundles[0] = nb;
         }
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
+    const WinJob& j = J.j[blockIdx.y];
+    __shared__ BundleLds L;
+    const int W = j.num_windows[0];
+    const bool in_lds = W < 8192;
+    if (in_lds)
+        for (int t = threadIdx.x; t <= W; t += 1024) L.ws[t] = j.win_start[t];
+    __syncthreads();
+    bundle_pack(j, j.cap, j.bun_start, j.bun_tok, j.num_bundles, L, W, in_lds);
+    if (j.fbun_tok) bundle_pack(j, j.fcap, nullptr, j.fbun_tok, j.num_fbundles, L, W, in_lds);
 }
 
 // =====================================================================================
@@ -381,8 +394,8 @@ struct BundleCtx {
 // Loads the bundle's token list and, per token, its window (CSR index) and that window's position range into LDS.
 // From the CSR arrays this is a chain of four dependent global loads (bun_start -> win_start -> win_tokens ->
 // tok_win, then win_start again per tile) in front of the operand gather -- most of a workgroup's life at d_head =
-// 16.  The optional attention plan written by the window build (bun_tok [NB+1], pos_info [n] = (token, window, window
-// start, window end) per position) makes it two: bun_tok[b], then one 16-byte record per position.
+// 16.  The optional attention plan written by the window build (bun_tok [NB+1], pos_info [n] = (token, in-window
+// position, window start, window end) per position) makes it two: bun_tok[b], then one 16-byte record per position.
 struct AttnPlan {
     const int32_t *bun_start, *win_start, *win_tokens, *tok_win;     // CSR form (always valid)
     const int32_t* bun_tok; const int4* pos_info;                    // plan form, or null
@@ -410,7 +423,8 @@ __device__ __forceinline__ BundleCtx bundle_setup(int b, const AttnPlan& P, int*
                 pi.w = P.win_start[pi.y + 1];
             }
         }
-        toks[t] = pi.x; wid[t] = pi.y; wlo[t] = pi.z; whi[t] = pi.w;
+        // (plan form: a window is identified by the position where it starts)
+        toks[t] = pi.x; wid[t] = (P.pos_info && t < c.T) ? pi.z : pi.y; wlo[t] = pi.z; whi[t] = pi.w;
     }
     return c;
 }
@@ -785,6 +799,19 @@ extern "C" int geomae_debug_read_attn_stamps(unsigned long long* host) {
 }
 #endif
 
+// Bundle size of the SECOND packing of a layout (fbun_tok: the one-launch layer kernel's work items, sst_fused.hip; the
+// attention kernels keep whole-window bundles).  That kernel runs one workgroup per bundle whose dependent chain grows with
+// the bundle, on a 256-CU chip: small token sets want many small bundles.  GEOMAE_BUNDLE_CAP overrides.
+extern "C" int32_t geomae_window_bundle_cap(int32_t num_tokens, int32_t max_window_tokens) {
+    static const int forced = [] { const char* e = getenv("GEOMAE_BUNDLE_CAP"); return e ? atoi(e) : 0; }();
+    // <= 12288 tokens (the token sets the one-launch layer kernel takes, sst_stack.hip): three 16-token tiles per bundle
+    // (measured at 6.6 k tokens: 26.8 / 25.3 / 27.8 us per layer at caps 40 / 48 / 56); above: whole windows
+    int cap = forced > 0 ? forced : (num_tokens <= 12288 ? 48 : max_window_tokens);
+    if (cap < 16) cap = 16;
+    if (cap > max_window_tokens) cap = max_window_tokens;
+    return cap;
+}
+
 static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, int* slots_per_sample) {
     GEOMAE_REQUIRE(cfg, "window: null config");
     GEOMAE_REQUIRE(shift_index == 0 || shift_index == 1, "window: shift_index must be 0 or 1");
@@ -850,6 +877,10 @@ extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32
         GEOMAE_REQUIRE(in.num_tokens == 0 || (in.coors && in.win_tokens && in.tok_win && in.tok_pos),
                        "window_build: null argument");
         j.coors = (const int4*)in.coors; j.n = in.num_tokens; j.slots = batch_size * sps; j.cap = j.g.wx * j.g.wy;
+        j.fcap = geomae_window_bundle_cap(in.num_tokens, j.cap);
+        GEOMAE_REQUIRE((in.fbun_tok == nullptr) == (in.num_fbundles == nullptr), "window_build: pass both arrays of the second packing or none");
+        GEOMAE_REQUIRE(!in.fbun_tok || in.pos_info, "window_build: the second packing needs the attention plan");
+        j.fbun_tok = in.fbun_tok; j.num_fbundles = in.num_fbundles;
         j.win_start = in.win_start; j.win_tokens = in.win_tokens; j.tok_win = in.tok_win; j.tok_pos = in.tok_pos;
         j.num_windows = in.num_windows; j.bun_start = in.bun_start; j.num_bundles = in.num_bundles;
         GEOMAE_REQUIRE((in.bun_tok == nullptr) == (in.pos_info == nullptr), "window_build: pass both attention-plan arrays or none");
@@ -890,7 +921,7 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
                                    int32_t* num_windows, int32_t* bun_start, int32_t* num_bundles,
                                    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     GeomaeWindowBuildJob job = {coors, num_tokens, shift_index, win_start, win_tokens, tok_win, tok_pos,
-                                num_windows, bun_start, num_bundles, nullptr, nullptr};
+                                num_windows, bun_start, num_bundles, nullptr, nullptr, nullptr, nullptr};
     return geomae_window_build_batch(&job, 1, batch_size, cfg, workspace, workspace_bytes, stream);
 }
 

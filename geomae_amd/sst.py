@@ -58,8 +58,10 @@ class PackedLayers:
     def _build(self, dev):
         from ._lib import GeomaeSstLayerWeights
         n = len(self.layers)
-        self.packed = torch.zeros(n * self.PER_LAYER + 800 * 128, dtype=torch.bfloat16, device=dev)
-        self.head_w = self.packed[n * self.PER_LAYER:]
+        # [row-major blocks of the n layers | heads 800 x 128 | fragment-major blocks of the n layers]
+        self.packed = torch.zeros(2 * n * self.PER_LAYER + 800 * 128, dtype=torch.bfloat16, device=dev)
+        self.head_w = self.packed[n * self.PER_LAYER:n * self.PER_LAYER + 800 * 128]
+        frag0 = n * self.PER_LAYER + 800 * 128
         self.head_bias = torch.zeros(800, dtype=torch.float32, device=dev)
         base = self.packed.data_ptr()
         desc, self.structs = [], []
@@ -77,9 +79,12 @@ class PackedLayers:
                      [f(win) + 256 * 128, 128, 128, 1, o["wvT"]], [f(wo), 128, 128, 0, o["wo"]],
                      [f(wo), 128, 128, 1, o["woT"]], [f(w1), 256, 128, 0, o["w1"]], [f(w1), 256, 128, 1, o["w1T"]],
                      [f(w2), 128, 256, 0, o["w2"]], [f(w2), 128, 256, 1, o["w2T"]]]
+            # the same nine matrices fragment-major (descriptor mode | 4) for the one-launch layer kernels
+            desc += [[d[0], d[1], d[2], d[3] | 4, d[4] - off + frag0 + off] for d in desc[-9:]]
             st = GeomaeSstLayerWeights()
             for k, v in o.items():
                 setattr(st, k + "_p", base + 2 * v)
+            st.frag_p = base + 2 * (frag0 + off)
             st.bqkv, st.bo = a.in_proj_bias.data_ptr(), a.out_proj.bias.data_ptr()
             st.b1, st.b2 = L.linear1.bias.data_ptr(), L.linear2.bias.data_ptr()
             st.ln1_w, st.ln1_b = L.norm1.weight.data_ptr(), L.norm1.bias.data_ptr()
@@ -468,7 +473,11 @@ class MultiMAESSTSPChoose(nn.Module):
     def get_voxel_info(self, coors, batch_size):
         """CSR window layouts for both shifts (+ gathered positional embeddings for the composed path)."""
         coors = coors.int().contiguous()
-        layouts = [ops.window_build(coors, batch_size, self._wcfg, s) for s in range(len(self.shifts_list))]
+        ns = len(self.shifts_list)
+        if ns <= 4:          # one launch per build stage, and the attention plan the one-launch layer kernel needs
+            layouts = ops.window_build_batch([(coors, s) for s in range(ns)], batch_size, self._wcfg)
+        else:
+            layouts = [ops.window_build(coors, batch_size, self._wcfg, s) for s in range(ns)]
         pos = None if self.fused else [self.pos_table[L.tok_pos[:L.n].long()] for L in layouts]
         return layouts, pos
 

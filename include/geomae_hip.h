@@ -212,9 +212,13 @@ typedef struct GeomaeWindowBuildJob {
     int32_t num_tokens, shift_index;
     int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
     /* optional "attention plan" (both or neither): bun_tok [min(n, slots) + 1] = position in win_tokens where each
-     * bundle starts, pos_info [n][4] = (token, window, window start, window end) per position.  The attention kernels
+     * bundle starts, pos_info [n][4] = (token, in-window position, window start, window end) per position.  The attention kernels
      * then reach their operands through two dependent loads instead of five. */
     int32_t *bun_tok, *pos_info;
+    /* optional second packing (both or neither; needs the plan): the bundles of the one-launch layer kernel,
+     * geomae_sst_layer_forward -- at most geomae_window_bundle_cap(num_tokens, wx * wy) tokens each unless a single window is
+     * larger: fbun_tok [min(n, slots) + 1] positions where they start, num_fbundles [1] */
+    int32_t *fbun_tok, *num_fbundles;
 } GeomaeWindowBuildJob;
 int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens /*host [num_jobs]*/, int32_t num_jobs,
                                                   int32_t batch_size, const GeomaeWindowConfig* cfg);
@@ -224,6 +228,10 @@ int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs /*host [num_jobs]
 /* bytes of window tables at the start of geomae_window_build_batch's workspace (what the call clears first) */
 int64_t geomae_window_build_batch_table_bytes(const int32_t* num_tokens, int32_t num_jobs, int32_t batch_size,
                                               const GeomaeWindowConfig* cfg);
+/* Tokens per bundle of the SECOND packing (fbun_tok) that geomae_window_build_batch makes for a layout of num_tokens tokens
+ * (a window larger than the cap is a bundle of its own): small bundles for small token sets, whole windows
+ * (max_window_tokens = wx * wy) for large ones.  geomae_sst_layer_forward sizes its grid from it. */
+int32_t geomae_window_bundle_cap(int32_t num_tokens, int32_t max_window_tokens);
 
 /* Operator-level window plumbing (mmdet3d/ops/__init__.py:22-26; ops/sst/sst_ops.py:57-135, 225-251, 271-319, 371-388):
  * the hot path works on the CSR layout above and never calls these; they back the reference's function names
@@ -273,13 +281,19 @@ typedef struct GeomaeSstLayerWeights {
     const float *bqkv, *bo, *b1, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;                 /* the fp32 parameters   */
     int32_t d_model, d_ffn;                                                           /* must be 128, 256       */
     float ln_eps;
+    /* the same nine matrices FRAGMENT-MAJOR (pack descriptor transpose | 4), one block of 262144 bf16 with wqkv at element
+     * 0, wqkT 49152, wvT 81920, wo 98304, woT 114688, w1 131072, w1T 163840, w2 196608, w2T 229376 -- what
+     * geomae_sst_layer_forward reads; NULL: the one-launch layer kernels are not used. */
+    const void* frag_p;
 } GeomaeSstLayerWeights;
 typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into (views of .grad) */
     float *wqkv, *bqkv, *wo, *bo, *w1, *b1, *w2, *b2, *ln1_w, *ln1_b, *ln2_w, *ln2_b;
 } GeomaeSstLayerGrads;
 
 /* desc: device int64 [num_desc, 5] rows {src_offset, rows, cols, transpose, dst_offset} (elements);
- * writes bf16 dst[r][p] = W[r][perm(p)] or, transposed, dst[c][p] = W[perm(p)][c].  src_offset is relative
+ * writes bf16 dst[r][p] = W[r][perm(p)] or, transposed (transpose & 1), dst[c][p] = W[perm(p)][c]; transpose & 4: the
+ * same matrix stored fragment-major ([row / 16][p / 32][lane = 16 ((p / 8) % 4) + row % 16][p % 8]: the 1-KB piece one
+ * MFMA A fragment covers is contiguous).  src_offset is relative
  * to flat_params; flat_params may be NULL with src_offset = (device address / 4) for scattered tensors. */
 int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
                         void* packed_bf16, float* aux_f32 /* target of transpose==2 rows: plain fp32 gather */,
@@ -471,7 +485,28 @@ typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_b
     const int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *bun_start, *num_bundles;
     int32_t max_bundles;
     const int32_t *bun_tok, *pos_info;      /* the build's attention plan, or both NULL */
+    const int32_t *fbun_tok, *num_fbundles; /* the build's second packing (one-launch layer kernel), or both NULL */
 } GeomaeSstStackLayout;
+/* ------------------------------------------------------------------ A19-A22 one launch per layer (forward)
+ * EncoderLayer.forward + WindowAttention.forward (sst_basic_block.py:26-61, 85-102) as ONE kernel, one workgroup per bundle
+ * of windows: in-projection with the positional term, window attention (q, k, v, P in registers), out-projection +
+ * residual + LayerNorm + FFN(GELU) + residual + LayerNorm (csrc/sst_fused.hip).  x [ceil16(n),128] fp32 TILE-BLOCKED
+ * ([n/16][8][16 tokens][16 channels]); z likewise, or row-major [n,128] with z_blocked = 0.  `layout` must carry the
+ * build's plan and second packing (pos_info, fbun_tok, num_fbundles); bundle_cap = geomae_window_bundle_cap(num_tokens,
+ * wx * wy).  The nine save
+ * buffers (all or none; what geomae_sst_ffn_backward / geomae_window_attention_backward / geomae_sst_weight_grad read,
+ * tile-blocked bf16: qkv [n,384], attn, xhat1, xhat2, x, x + pos [n,128], hp [n,256]; fp32 lse [n,8], rstd [n,2]). */
+int geomae_sst_layer_forward(const float* x, int32_t num_tokens, const GeomaeSstLayerWeights* w /*host*/,
+                             const GeomaeSstStackLayout* layout /*host*/, int32_t bundle_cap, const float* pos_table,
+                             float* z, int32_t z_blocked, void* qkv_bf16, void* attn_bf16, float* lse, void* xhat1_bf16,
+                             void* xhat2_bf16, void* hp_bf16, float* rstd, void* x_bf16, void* xp_bf16,
+                             geomaeStream_t stream);
+/* How geomae_sst_stack_forward runs its layers.  1 (default): through geomae_sst_layer_forward when the layouts carry the
+ * plan, the layers have fragment-major weights and the token set is small enough for the one-launch kernel to win (<= 12288
+ * tokens); 2: whenever plan and weights allow; 0: always the three-launch form (qkv / attention / ffn kernels).
+ * Process-wide; A/B measurements and tests. */
+void geomae_sst_set_fused_layers(int32_t mode);
+
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
 /* scratch for a backward whose weight-gradient contractions are all deferred to geomae_flush_weight_grad (the step
@@ -743,7 +778,8 @@ enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_
        GEOMAE_KERNEL_ATTN_BWD = 5, GEOMAE_KERNEL_QKV_BWD = 6, GEOMAE_KERNEL_DW = 7,
        GEOMAE_KERNEL_FFN_BWD_DW = 8 /* the ffn-backward launches that carry a weight-gradient contraction
                                        (sst_ffn_bwd_dw_kernel); 4 = those that do not (sst_ffn_bwd_kernel) */,
-       GEOMAE_KERNEL_FFN_FWD_PAIR = 9 /* sst_ffn_fwd_pair_kernel launches; 3 = sst_ffn_fwd_kernel launches */ };
+       GEOMAE_KERNEL_FFN_FWD_PAIR = 9 /* sst_ffn_fwd_pair_kernel launches; 3 = sst_ffn_fwd_kernel launches */,
+       GEOMAE_KERNEL_LAYER_FWD = 10 /* sst_layer_fwd_kernel: the one-launch layer forward */ };
 void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches);
 int32_t geomae_profiler_read(void* profiler, float* ms_out, int32_t capacity);
 void geomae_profiler_destroy(void* profiler);

@@ -1,0 +1,101 @@
+"""GPU parity of the one-launch SST layer (csrc/sst_fused.hip) against the three-launch form (qkv / attention / ffn
+kernels) it replaces inside geomae_sst_stack_forward: same inputs, same packed weights, same window layouts."""
+import numpy as np
+import pytest
+import torch
+
+import geomae_oracle as O
+from geomae_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+RANGE = [-51.2, -51.2, -5.0, 51.2, 51.2, 3.0]
+TOP = (0.256, 0.256, 8)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from geomae_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _model(dev, enc, dec):
+    import geomae_amd
+    from geomae_amd.configs import mae_sst_model
+    cfg = mae_sst_model(encoder_num_blocks=enc, decoder_num_blocks=dec)
+    cfg["backbone"]["compute_dtype"] = "bf16"
+    model = geomae_amd.build_model(cfg).to(dev)
+    model.load_state_dict(O.make_params(7, enc, dec), strict=False)
+    return model.train()
+
+
+def _rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("case", ["encoder_small", "decoder_tail", "gather_rows"])
+def test_one_launch_layer_matches_three_launch_form(dev, case):
+    """Forward output, and -- through every saved activation -- the input gradient and all parameter gradients of the
+    (unfused) backward, of a training stack run both ways.  The two forms differ in rounding only (LayerNorm statistics
+    merged from per-wave partial moments; V projected in two orientations), so the bounds are those of bf16 noise.
+    encoder_small: a third of the pillars (small windows, bundles of <= 4 tiles); decoder_tail: all pillars with a fill
+    row for the last third (windows of up to 144 tokens: the 9-tile body); gather_rows: the stack's input row map."""
+    from geomae_amd import ops, _lib
+    lib = _lib.load()
+    model = _model(dev, 2, 2)
+    bb = model.backbone
+    frames = [synth.lidar_frame(71), synth.lidar_frame(72, beams=24, n_az=700), synth.lidar_frame(73, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, TOP, RANGE)
+    vc = O.unique_rows(coors)[0]
+    gen = torch.Generator().manual_seed(9)
+    if case == "encoder_small":
+        keep = np.sort(np.random.default_rng(3).permutation(vc.shape[0])[: vc.shape[0] // 3])
+        vc = vc[keep]
+    vc = torch.as_tensor(vc, device=dev)
+    n = vc.shape[0]
+    name = "enc" if case == "encoder_small" else "cen"
+    blocks = bb.encoder_blocks if name == "enc" else bb.decoder_centroid_blocks
+    nl = 2 * len(blocks)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, len(frames))
+    assert layouts[0].fbun_tok is not None
+    nb = int(layouts[0].num_fbundles.item())
+    sizes = (layouts[0].fbun_tok[1:nb + 1] - layouts[0].fbun_tok[:nb]).cpu().numpy()
+    assert sizes.min() >= 1 and sizes.max() <= 144
+    if case == "decoder_tail":
+        assert sizes.max() > 64, "the case is meant to reach the 9-tile body"
+    w = bb._packed.weight_array(bb._stack_base[name], nl)
+    kw = {}
+    if case == "decoder_tail":
+        n_in = n - n // 3 - 5
+        x = torch.randn(n_in, 128, generator=gen).to(dev)
+        kw["tail"] = (torch.randn(1, 128, generator=gen).to(dev), n - n_in)
+    elif case == "gather_rows":
+        V = n + n // 2 + 3
+        x = torch.randn(V, 128, generator=gen).to(dev)
+        kw["rows"] = torch.randperm(V, generator=gen)[:n].int().to(dev)
+    else:
+        x = torch.randn(n, 128, generator=gen).to(dev)
+    dz = torch.randn(n, 128, generator=gen).to(dev)
+    res = []
+    try:
+        for mode in (0, 2):
+            lib.geomae_sst_set_fused_layers(mode)
+            for p in bb.parameters():
+                p.grad = None
+            g = bb._packed.grad_array(bb._stack_base[name], nl)
+            z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0], **kw)
+            dx = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], saved)
+            torch.cuda.synchronize()
+            res.append((z.clone(), dx.clone(), {k: v.grad.clone() for k, v in blocks.named_parameters()}))
+    finally:
+        lib.geomae_sst_set_fused_layers(1)
+    (z0, d0, g0), (z1, d1, g1) = res
+    assert torch.isfinite(z1).all() and torch.isfinite(d1).all()
+    assert _rel(z1, z0) < 4e-3, _rel(z1, z0)
+    assert _rel(d1, d0) < 1e-2, _rel(d1, d0)
+    bad = {k: _rel(g1[k], g0[k]) for k in g0 if _rel(g1[k], g0[k]) > 2e-2}
+    assert not bad, bad

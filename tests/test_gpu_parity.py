@@ -387,8 +387,25 @@ def test_window_build_batch_equals_single(dev):
             if n:
                 tok = R.win_tokens[:n].long()
                 w = R.tok_win[:n].long()[tok]
-                want = torch.stack([tok, w, ws[w], ws[w + 1]], dim=1).int()
+                want = torch.stack([tok, R.tok_pos[:n].long()[tok], ws[w], ws[w + 1]], dim=1).int()
                 assert torch.equal(L.pos_info[:n], want)
+            # the second packing (bundles of the one-launch layer kernel): whole windows, greedy up to its cap -- the next
+            # window would overflow --, a window larger than the cap alone in its bundle
+            from geomae_amd import _lib
+            cap = _lib.load().geomae_window_bundle_cap(n, 144)
+            assert 16 <= cap <= 144
+            FB = int(L.num_fbundles.item())
+            fb = L.fbun_tok[:FB + 1].cpu().numpy()
+            wsn = ws.cpu().numpy()
+            assert fb[0] == 0 and fb[-1] == n and (np.diff(fb) > 0).all() if n else FB == 0
+            if n:
+                assert np.isin(fb, wsn).all()                      # bundles start and end at window boundaries
+                size = np.diff(fb)
+                first_w = np.searchsorted(wsn, fb[:-1])
+                nwin = np.searchsorted(wsn, fb[1:]) - first_w
+                assert (size[nwin > 1] <= cap).all() and size.max() <= 144
+                nxt = np.diff(wsn)[np.searchsorted(wsn, fb[1:-1])]     # size of the window that starts the next bundle
+                assert (size[:-1] + nxt > cap).all()
 
 
 def _ref_window_attention(qkv, win, nhead):
