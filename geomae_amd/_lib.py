@@ -217,6 +217,8 @@ SIGNATURES = {
     "geomae_pretrain_phase_times": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
     "geomae_pretrain_invalidate_packed": (ctypes.c_int, [c_void_p]),
     "geomae_pretrain_submit": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), P]),
+    "geomae_pretrain_submit_ex": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_int32, P]),
+    "geomae_pretrain_pending_slot": (c_int32, [c_void_p]),
     "geomae_pretrain_set_mask": (ctypes.c_int, [c_void_p, P, c_int32, P, c_int32, P]),
     "geomae_pretrain_set_mask_draws": (ctypes.c_int, [c_void_p, ctypes.c_uint64]),
     "geomae_pretrain_step": (ctypes.c_int, [c_void_p, POINTER(c_void_p), POINTER(c_int64), c_float, c_float, c_int32, P]),

@@ -88,6 +88,8 @@ bool window_tables_prezeroed();
 // operand slabs per layer (geomae_sst_stack_scratch_bytes_layers).
 void set_defer_all_weight_grads(bool on);
 bool defer_all_weight_grads();
+// forget every recorded-but-unlaunched contraction of this host thread (error paths; the start of a step)
+void drop_pending_weight_grads();
 struct LayerLayoutScope {
     explicit LayerLayoutScope(int flags) { set_layer_layout(flags); }
     ~LayerLayoutScope() { set_layer_layout(0); }

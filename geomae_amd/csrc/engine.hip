@@ -450,6 +450,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     }
     hipStream_t geo = e->geo, aux = e->aux;
     const int nh = c.num_heads, ne = c.encoder_layers, nd = c.decoder_layers;
+    drop_pending_weight_grads();       // (a step that failed between queueing and flushing leaves entries into a dead workspace)
 
     // ---------------- carve the step's buffers (sizes are all known on the host)
     Arena a;
@@ -891,8 +892,18 @@ extern "C" int geomae_pretrain_invalidate_packed(void* engine) {
     return GEOMAE_OK;
 }
 
+extern "C" int32_t geomae_pretrain_pending_slot(void* engine) {
+    Engine* e = (Engine*)engine;
+    return e ? e->pending : -1;
+}
+
 extern "C" int geomae_pretrain_submit(void* engine, const float* const* frame_points, const int64_t* frame_sizes,
                                       hipStream_t stream) {
+    return geomae_pretrain_submit_ex(engine, frame_points, frame_sizes, 0, stream);
+}
+
+extern "C" int geomae_pretrain_submit_ex(void* engine, const float* const* frame_points, const int64_t* frame_sizes,
+                                         int32_t flags, hipStream_t stream) {
     Engine* e = (Engine*)engine;
     GEOMAE_REQUIRE(e, "pretrain: null engine");
     // a batch submitted out of band: its slot must not be the one a pending batch occupies
@@ -901,7 +912,18 @@ extern "C" int geomae_pretrain_submit(void* engine, const float* const* frame_po
     // order behind everything of the previous step (its kernels may still read the slot's previous batch)
     if (e->have_step_end) GEOMAE_HIP(hipStreamWaitEvent(stream, e->ev[kStepEnd], 0));
     int rc = run_stage1(e, which, frame_points, frame_sizes, e->mask_draws + 1, stream);
-    if (rc == GEOMAE_OK) rc = exchange_moments(e, which, stream);
+    if (rc == GEOMAE_OK) {
+        if ((flags & GEOMAE_SUBMIT_MOMENTS_EXCHANGED) && exchanges(e->cfg) && e->cfg.sync_bn && e->m.bn_sync_feat_moments) {
+            // a RE-submission (the caller re-created the engine for a larger workspace on THIS rank only): the batch's
+            // rank-averaged feature moments were exchanged when it was first submitted and the caller put them back
+            // into this slot of bn_sync_feat_moments -- a second all-reduce here would have no partner on the ranks that
+            // did not grow (every later SyncBN collective would then pair with the wrong one)
+            GEOMAE_HIP(hipEventRecord(e->ev[which == 0 ? kMoments0 : kMoments1], stream));
+            e->batch[which].moments_exchanged = true;
+        } else {
+            rc = exchange_moments(e, which, stream);
+        }
+    }
     if (rc != GEOMAE_OK) { e->pending = -1; return rc; }
     e->pending = which;
     // the step's side streams read the batch: order them behind this stream's stage 1

@@ -228,9 +228,12 @@ __global__ __launch_bounds__(kMaskBlk) void random_mask_win_kernel(const int32_t
     }
     const uint32_t T = prefix;
     const int nwin = g.nwx * g.nwy;
+    // (clamped: bev_shape comes from the caller, the coordinates from the voxelizer's fp32 grid -- a pillar at or past
+    //  bev_shape must not index outside the LDS tables)
     auto window_of = [&](int p) {
         const int4 c = voxel_coors[p];
-        return (c.w / g.wx) * g.nwy + c.z / g.wy;
+        const int a = c.w / g.wx, b2 = c.z / g.wy;
+        return (a < g.nwx ? (a < 0 ? 0 : a) : g.nwx - 1) * g.nwy + (b2 < g.nwy ? (b2 < 0 ? 0 : b2) : g.nwy - 1);
     };
     // ---- pass A: keep flag per pillar (parked in token_row), pillars per (kind, window)
     for (int t = threadIdx.x; t < 2 * nwin; t += kMaskBlk) cur[t] = 0;
@@ -373,7 +376,9 @@ extern "C" int geomae_random_mask_windowed(const int32_t* sample_start, int32_t 
     g.wy = window->window_shape[1];
     g.nwx = (window->bev_shape[0] + g.wx - 1) / g.wx;
     g.nwy = (window->bev_shape[1] + g.wy - 1) / g.wy;
-    if ((int64_t)g.nwx * g.nwy > kMaxWinLds)           // a window table that does not fit in LDS: pillar order
+    // a window table that does not fit in LDS, or windows larger than the rank sort of pass C handles (its runs would keep
+    // their atomic arrival order: not reproducible run to run): pillar order
+    if ((int64_t)g.nwx * g.nwy > kMaxWinLds || g.wx * g.wy > kSortCap)
         return geomae_random_mask(sample_start, batch_size, keep_fraction, seed, ids_keep, ids_mask, token_row, counts, stream);
     hipLaunchKernelGGL(random_mask_win_kernel, dim3(batch_size), dim3(kMaskBlk), 0, stream, sample_start, batch_size,
                        keep_fraction, seed, (const int4*)voxel_coors, g, ids_keep, ids_mask, token_row, counts);

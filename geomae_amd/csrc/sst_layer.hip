@@ -989,7 +989,7 @@ static thread_local bool t_defer_weight_grad = false;
 // backward then consists of ffn / attention kernels only, and its weight-gradient contractions -- read by nothing but
 // the optimizer -- run later on another stream beside whatever the main stream does next.
 static thread_local bool t_defer_all = false;
-static thread_local std::vector<PendingDw>* t_dw_queue = nullptr;
+static thread_local std::vector<PendingDw> t_dw_queue;
 // partials a launched contraction left in its workspace: the next launch of this host thread (the next ffn-backward of
 // the stack, or the flush) sums them
 static thread_local DwReduce g_pending_reduce;
@@ -1206,8 +1206,7 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
     if (t_defer_weight_grad && t_defer_all) {          // queued for geomae_flush_weight_grad
         t_defer_weight_grad = false;
-        if (!t_dw_queue) t_dw_queue = new std::vector<PendingDw>();
-        t_dw_queue->push_back(PendingDw{T, 8, num_tokens, true});
+        t_dw_queue.push_back(PendingDw{T, 8, num_tokens, true});
         return GEOMAE_OK;
     }
     if (t_defer_weight_grad) {          // sst_stack_backward: ride on the next layer's ffn-backward launch
@@ -1222,6 +1221,12 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
 }
 
 void geomae::defer_next_weight_grad() { t_defer_weight_grad = true; }
+void geomae::drop_pending_weight_grads() {
+    t_defer_weight_grad = false;
+    g_pending_dw.active = false;
+    t_dw_queue.clear();
+    g_pending_reduce = DwReduce();
+}
 void geomae::set_defer_all_weight_grads(bool on) { t_defer_all = on; }
 bool geomae::defer_all_weight_grads() { return t_defer_all; }
 extern "C" int geomae_flush_weight_grad(hipStream_t stream) { return geomae::flush_pending_weight_grad(stream); }
@@ -1232,15 +1237,15 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
         g_pending_dw.active = false;
         rc = launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
     }
-    if (t_dw_queue) {                                    // "defer all": every contraction queued since the last flush
+    if (!t_dw_queue.empty()) {                           // "defer all": every contraction queued since the last flush
         // (one launch per layer.  Four layers of a stack in ONE launch -- 32 tasks, 768 workgroups -- were measured: the
         // queue is shorter, but such a launch takes the whole chip and the latency-bound encoder backward beside it lost
         // 0.09 instead of 0.05 ms)
         // (... and with FEWER workgroups per queued launch -- 16 / 12 / 8 token chunks per task instead of 24 -- the step
         // took 2.023 / 2.044 / 2.127 instead of 2.02 ms: the contractions then sit beside the encoder for longer)
-        for (const PendingDw& P : *t_dw_queue)
+        for (const PendingDw& P : t_dw_queue)
             if (rc == GEOMAE_OK) rc = launch_dw(P.tasks, P.num_tasks, P.num_tokens, stream);
-        t_dw_queue->clear();
+        t_dw_queue.clear();
     }
     if (g_pending_reduce.partial) {                      // the last contraction's own partials
         const DwReduce Rd = take_pending_reduce();

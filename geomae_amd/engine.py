@@ -223,12 +223,12 @@ class PretrainEngine:
             self._B = len(points)
             self._create(n)
 
-    def submit(self, points):
+    def submit(self, points, moments_exchanged=False):
         self._B = getattr(self, "_B", len(points))
         self._ensure(points)
         ptrs, sizes, _ = self._frames(points)
-        check(self.lib.geomae_pretrain_submit(ctypes.c_void_p(self.handle), ptrs, sizes, ops._stream()),
-              "geomae_pretrain_submit")
+        check(self.lib.geomae_pretrain_submit_ex(ctypes.c_void_p(self.handle), ptrs, sizes, int(bool(moments_exchanged)),
+                                                 ops._stream()), "geomae_pretrain_submit")
         self.pending, self._pending_keep = points, (ptrs, sizes)
 
     def set_mask(self, ids_keep, ids_mask):
@@ -265,10 +265,19 @@ class PretrainEngine:
                                    "results are invalid") from err
             if rc != ERR_WORKSPACE:
                 break
-            # more pillars than the workspace was sized for: nothing was enqueued; grow and resubmit
+            # more pillars than the workspace was sized for: nothing was enqueued (and no hook raised); grow and resubmit.
+            # The growth is a decision of THIS rank: the batch's feature moments were exchanged when it was first
+            # submitted, a second all-reduce would have no partner -- carry the exchanged moments over instead.
+            slot = self.lib.geomae_pretrain_pending_slot(ctypes.c_void_p(self.handle))
+            fm = getattr(self, "sync", {}).get("featmom") if self.exchange else None
+            keep = fm[144 * slot:144 * (slot + 1)].clone() if (fm is not None and slot >= 0) else None
             self.max_pillars = int(1.5 * self.max_pillars) + 1024
             self._create(sum(int(p.shape[0]) for p in points))
-            self.submit(points)
+            if keep is not None and "featmom" in self.sync:
+                self.sync["featmom"][:144].copy_(keep)          # a fresh engine submits into slot 0
+                self.submit(points, moments_exchanged=True)
+            else:
+                self.submit(points)
             if ids_keep is not None:
                 self.set_mask(ids_keep, ids_mask)
         check(rc, "geomae_pretrain_step")

@@ -143,7 +143,10 @@ def _wait_all(works):
     stream).  Other backends (gloo: host threads) are waited for one by one."""
     if not works:
         return
-    if dist.get_backend(_grad_group()) == "nccl":
+    # The single wait leans on ProcessGroupNCCL's one-communication-stream-per-group behaviour (an implementation detail of
+    # today's torch, not a documented contract): GEOMAE_WAIT_LAST_ONLY=0 waits for every work instead (~10 us each).
+    import os
+    if dist.get_backend(_grad_group()) == "nccl" and os.environ.get("GEOMAE_WAIT_LAST_ONLY", "1") != "0":
         works[-1][1].wait()
     else:
         for _, w in works:

@@ -738,6 +738,15 @@ int geomae_pretrain_invalidate_packed(void* engine);
  * array of batch_size DEVICE pointers ([n_b, num_features] fp32 each), frame_sizes: HOST array of row counts. */
 int geomae_pretrain_submit(void* engine, const float* const* frame_points, const int64_t* frame_sizes,
                            geomaeStream_t stream);
+/* geomae_pretrain_submit with flags.  GEOMAE_SUBMIT_MOMENTS_EXCHANGED: the batch is RE-submitted (to an engine re-created
+ * with a larger workspace after geomae_pretrain_step returned GEOMAE_ERR_WORKSPACE on this rank only) and its rank-averaged
+ * feature moments -- exchanged at its first submission -- were copied by the caller into the slot of bn_sync_feat_moments
+ * this submission uses (slot 0 of a fresh engine): no FEAT_MOMENTS hook is raised, so the sequence of collectives stays
+ * the same on every rank.  geomae_pretrain_pending_slot: slot (0 / 1) of the batch submitted last, -1 = none. */
+#define GEOMAE_SUBMIT_MOMENTS_EXCHANGED 1
+int geomae_pretrain_submit_ex(void* engine, const float* const* frame_points, const int64_t* frame_sizes, int32_t flags,
+                              geomaeStream_t stream);
+int32_t geomae_pretrain_pending_slot(void* engine);
 /* replace the random mask of the batch submitted last by caller-supplied pillar ids (DEVICE int32 arrays, any order,
  * together a permutation of 0..V-1; the reference's get_vanilla_mask_index output, ssl.py:287-304): what parity tests
  * use to run the ENGINE on the reference's own mask.  Waits for the batch's pillar-count readback (host).  Call it

@@ -43,9 +43,11 @@ def _worker(rank, world, port, tmp):
         fused = geomae_amd.build_model(cfg).cuda().train()
         import geomae_oracle as O
         fused.load_state_dict(O.make_params(7, 1, 1), strict=False)       # the weights of tests/golden/g_syncbn_w2.npz
+        fused_init = copy.deepcopy(fused)                      # the initial state, for the reference run of section 4
         composed = copy.deepcopy(fused)
         composed.voxel_encoder.use_fused = False               # torch ops + the NaiveSyncBatchNorm1d module
         fresh = copy.deepcopy(fused)                           # untouched running statistics, for section 3
+        fresh2 = copy.deepcopy(fused)                          # ... and for section 4
         pts = _frames(rank)
 
         # ---- 1. fused VFE with cross-rank BatchNorm statistics vs the composed module path (fp32 both)
@@ -160,6 +162,33 @@ def _worker(rank, world, port, tmp):
                 assert torch.allclose(b, G("v_buf." + k), rtol=1e-5, atol=1e-6), (k, float((b - G("v_buf." + k)).abs().max()))
             if k.endswith("num_batches_tracked"):
                 assert int(b) == 0, k
+        # ---- 4. workspace growth on ONE rank only (rank 1's engine is created for 200 pillars: its first step returns
+        #         GEOMAE_ERR_WORKSPACE, the wrapper re-creates the engine and re-submits the batch).  The batch's feature
+        #         moments were exchanged at its first submission; the re-submission must not raise a second all-reduce
+        #         that rank 0 never issues (every later SyncBN collective would pair with the wrong one, or hang).  Same
+        #         frames and weights as section 3: the running statistics must come out the same, on both ranks.
+        tr_grow = Trainer(fresh2)
+        eng = tr_grow.get_engine()
+        assert eng is not None and eng.world == 2
+        if rank == 1:
+            eng.max_pillars = 200
+        for _ in range(2):
+            losses_g, gnorm_g = tr_grow.train_step(pts)
+        torch.cuda.synchronize()
+        if rank == 1:
+            assert eng.max_pillars > 200                        # i.e. the growth path did run
+        assert all(torch.isfinite(v) for v in losses_g.values()) and torch.isfinite(gnorm_g)
+        mine = tr_grow.flat.flat.clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.equal(gathered[0], gathered[1])
+        tr_ref = Trainer(copy.deepcopy(fused_init))
+        for _ in range(2):
+            tr_ref.train_step(pts)
+        torch.cuda.synchronize()
+        for (k, b), (_, b2) in zip(fresh2.voxel_encoder.named_buffers(), tr_ref.model.voxel_encoder.named_buffers()):
+            if "running" in k:
+                assert torch.allclose(b, b2, rtol=1e-5, atol=1e-6), (k, float((b - b2).abs().max()))
         torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
         faulthandler.cancel_dump_traceback_later()
     except BaseException:
