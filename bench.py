@@ -193,15 +193,29 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    # (the stand-alone dw_kernel launches are not in the list: the schedule defers them to the geometry stream,
-    # geomae_flush_weight_grad, so the stack's event pair would bracket their recording, not their execution;
-    # profiles/*kernel_stats.csv has their durations)
-    # (the ffn launches come in two kernels each -- sst_ffn_bwd_kernel / sst_ffn_bwd_dw_kernel: without / with a
-    # weight-gradient contraction riding along; sst_ffn_fwd_kernel / sst_ffn_fwd_pair_kernel -- and are timed per
-    # kernel, under the names of the rocprofv3 table)
+    # The layer kernels, under the names of the rocprofv3 table.  The ffn launches come in two kernels each
+    # (sst_ffn_bwd_kernel / sst_ffn_bwd_dw_kernel: without / with a weight-gradient contraction riding along;
+    # sst_ffn_fwd_kernel / sst_ffn_fwd_pair_kernel); sst_layer_fwd_kernel is the one-launch layer forward (small token
+    # sets); dw_kernel's launches are deferred to the geometry stream and timed THERE (thread profiler, csrc/sst_layer.hip).
     TIMED = ("sst_ffn_bwd_kernel", "sst_ffn_bwd_dw_kernel", "win_attn_bwd_kernel", "sst_ffn_fwd_kernel",
-             "sst_ffn_fwd_pair_kernel", "sst_qkv_bwd_kernel", "win_attn_fwd_kernel", "sst_qkv_fwd_kernel")
-    DOMINANT = "sst_ffn_bwd_kernel"               # largest share in profiles/ (rocprofv3 --kernel-trace --stats)
+             "sst_ffn_fwd_pair_kernel", "sst_qkv_bwd_kernel", "win_attn_fwd_kernel", "sst_qkv_fwd_kernel",
+             "sst_layer_fwd_kernel", "dw_kernel")
+    # The kernel instrumented INSIDE the timed region is the TIMED kernel with the largest share of the committed
+    # rocprofv3 --kernel-trace --stats table of this workload (profiles/rNN_<workload>_kernel_stats.csv, newest round); the
+    # others are timed in extra steps behind it, and `roofline` reports whichever turned out largest by measured time per
+    # step (with `dominant_check` saying whether table and measurement agree).
+    def committed_table():
+        import csv, glob, re
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_kernel_stats.csv")))
+        if not files:
+            return None, {}
+        share = {}
+        for r in csv.DictReader(open(files[-1])):
+            name = re.sub(r"<.*", "", r["Name"].split("(")[0].replace("geomae::", "").replace("void ", "")).strip()
+            share[name] = share.get(name, 0.0) + float(r["Percentage"])
+        return os.path.relpath(files[-1], ROOT), share
+    table_path, table_share = committed_table()
+    DOMINANT = max(TIMED, key=lambda k: table_share.get(k, 0.0)) if table_share else "sst_ffn_bwd_kernel"
     lib = _lib.load()
     import ctypes
 
@@ -313,33 +327,45 @@ def main():
         # With the python step driver / GEOMAE_DW_DEFER_ALL=0 the decoders' 6 non-top launches carry a dW too.
         # 3 stand-alone F1 / B1 launches per step (one per stack); the stand-alone dw_kernel launches are not timed here.
         n_e, n_d = float(n_tok[0]), float(n_tok[-1])
+        sq_e, sq_d = float(np.sum(sq[:12])), float(np.sum(sq[12:]))   # sum over layers of sum_w n_w^2 (encoder / one decoder)
         F3, F1, DW = 2 * 81920.0, 2 * 49152.0, 2 * 131072.0           # FLOPs per token: ffn (3 GEMMs) / qkv / contractions
         lps = lambda k: (len(durations.get(k) or []) / steps_timed[k]) if durations.get(k) else 0.0     # launches per step
+        fused_enc = round(lps("sst_layer_fwd_kernel")) == 12          # the encoder's forward as one launch per layer
         dec_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 11
+        M_rows = float(n_d - n_e)
         flops_step = {"sst_ffn_bwd_kernel": F3 * (n_e + 8 * n_d) + F1 * 6 * n_d if dec_deferred else F3 * (n_e + 2 * n_d),
                       "sst_ffn_bwd_dw_kernel": (F3 + F1 + DW) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
                       "sst_ffn_fwd_kernel": F3 * 8 * n_d + F1 * 6 * n_d,
                       "sst_ffn_fwd_pair_kernel": F3 * 12 * n_e + F1 * 11 * n_e,
-                      "sst_qkv_fwd_kernel": F1 * (n_e + 2 * n_d), "sst_qkv_bwd_kernel": F1 * (n_e + 2 * n_d),
-                      "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * sq_sum, "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum}
+                      "sst_qkv_fwd_kernel": F1 * ((0 if fused_enc else n_e) + 2 * n_d), "sst_qkv_bwd_kernel": F1 * (n_e + 2 * n_d),
+                      "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * (sq_sum - (sq_e if fused_enc else 0.0)),
+                      "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum,
+                      "sst_layer_fwd_kernel": (F3 + F1) * 12 * n_e + 2 * 2 * 16 * 8 * sq_e,
+                      # every stand-alone contraction of the step: the decoders' 8 layers + the encoder's first layer (its
+                      # other 11 ride in sst_ffn_bwd_dw_kernel), the six heads (800 x 128 per masked row), VFE layer 1
+                      "dw_kernel": DW * ((8 * n_d if dec_deferred else 2 * n_d) + n_e) + 2 * 800 * 128 * M_rows + 2 * 128 * 128 * n_pts}
         expect = {"sst_ffn_bwd_kernel": 9.0 if dec_deferred else 3.0, "sst_ffn_bwd_dw_kernel": 11.0 if dec_deferred else 17.0,
-                  "sst_ffn_fwd_kernel": 8.0, "sst_ffn_fwd_pair_kernel": 12.0, "sst_qkv_fwd_kernel": 3.0,
-                  "sst_qkv_bwd_kernel": 3.0, "win_attn_fwd_kernel": 20.0, "win_attn_bwd_kernel": 20.0}
+                  "sst_ffn_fwd_kernel": 8.0, "sst_ffn_fwd_pair_kernel": 12.0, "sst_qkv_fwd_kernel": 2.0 if fused_enc else 3.0,
+                  "sst_qkv_bwd_kernel": 3.0, "win_attn_fwd_kernel": 8.0 if fused_enc else 20.0, "win_attn_bwd_kernel": 20.0,
+                  "sst_layer_fwd_kernel": 12.0, "dw_kernel": None}
         launches_step = {k: lps(k) for k in flops_step}
         report_name = {}
         peak = 2500.0                                             # dense bf16 MFMA TFLOP/s (MI355X_MICROARCH.md)
         # HBM bytes per launch are NOT measured in this run: they come from the stored PMC passes of tools/pmc.sh
         # (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 --pmc runs) and only apply to the workload they were taken on
         traffic, traffic_src = {}, None
-        for cand in (f"r03_{workload}_pmc_traffic.json",) + (("r02_pmc_traffic.json", "r01_pmc_traffic.json") if workload == "nuscenes1" else ()):
-            tpath = os.path.join(ROOT, "profiles", cand)
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_pmc_traffic.json")), reverse=True)
+        if workload == "nuscenes1":
+            cands += [os.path.join(ROOT, "profiles", c) for c in ("r02_pmc_traffic.json", "r01_pmc_traffic.json")]
+        for tpath in cands:
             if B == 4 and os.path.exists(tpath):
-                traffic, traffic_src = json.load(open(tpath)), "profiles/" + cand
+                traffic, traffic_src = json.load(open(tpath)), os.path.relpath(tpath, ROOT)
                 break
         kern = {}
         for k in TIMED:
             d = durations.get(k) or []
-            if d and abs(launches_step[k] - expect[k]) < 0.01:      # (another launch structure: no FLOP model here)
+            if d and (expect[k] is None or abs(launches_step[k] - expect[k]) < 0.01):      # (another launch structure: no FLOP model here)
                 ms_step = float(np.sum(d)) / (len(d) / launches_step[k])
                 ach = flops_step[k] / (ms_step * 1e-3) / 1e12
                 tr_b = traffic.get(report_name.get(k, k))
@@ -347,6 +373,7 @@ def main():
                            "frac": round(ach / peak, 5), "traffic": tr_b, "traffic_source": traffic_src if tr_b else None,
                            "avg_launch_ms": round(float(np.mean(d)), 5), "launches_timed": len(d),
                            "launches_per_step": round(launches_step[k], 2), "ms_per_step": round(ms_step, 4),
+                           "timed_in": "the timed region" if k == DOMINANT else "3 extra steps behind it",
                            # the same average less the empty event pair: comparable with rocprofv3's AverageNs
                            "avg_launch_ms_less_event_pair": round(float(np.mean(d)) - event_pair_ms, 5),
                            "empty_event_pair_ms": round(event_pair_ms, 5)}
@@ -354,7 +381,62 @@ def main():
                     gbs = tr_b / (float(np.mean(d)) * 1e-3) / 1e9
                     kern[k]["hbm_view"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(gbs / 8000.0, 4)}
-        dominant = DOMINANT if DOMINANT in kern else (max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None)
+        largest = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
+        dominant = largest
+        dominant_check = {"committed_table": table_path, "largest_share_in_table": DOMINANT,
+                          "largest_measured_ms_per_step": largest, "agree": largest == DOMINANT}
+        # ---- the whole step against both roofs: algorithmic FLOPs of one step (2 per MAC; forward = VFE + 20 SST layers +
+        # heads, a training step = 3 x forward: SURVEY 8(d)) and the stored PMC bytes of one step, each / ms_per_step / peak
+        fwd_flops = (2.0 * n_pts * (11 * 64 + 128 * 128) + (F3 + F1) * (12 * n_e + 8 * n_d) + 2 * 2 * 16 * 8 * sq_sum
+                     + 2.0 * M_rows * 128 * 800)
+        step_ms = elapsed / args.steps * 1e3
+        step_roofline = {"algorithmic_flop_per_step": int(3 * fwd_flops),
+                         "mfma": {"achieved": round(3 * fwd_flops / (step_ms * 1e-3) / 1e12, 2), "peak": peak, "unit": "TFLOP/s",
+                                  "frac": round(3 * fwd_flops / (step_ms * 1e-3) / 1e12 / peak, 5)}}
+        if traffic.get("_bytes_per_step"):
+            gbs = traffic["_bytes_per_step"] / (step_ms * 1e-3) / 1e9
+            step_roofline["hbm"] = {"bytes_per_step": int(traffic["_bytes_per_step"]), "source": traffic_src, "achieved": round(gbs, 1),
+                                    "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+        # ---- north_star's "per bucket" MFMA utilisation.  This build has no length buckets: windows are packed into bundles
+        # and the attention kernels issue 16 x 16 score tiles over the key-tile range of each query tile.  Density = useful
+        # score entries (sum_w n_w^2) / (256 x tiles issued): what fraction of an issued attention MFMA's rows x columns
+        # is a real (query, key) pair, per token set and shift, by bundle size class.
+        def tile_density(L, which):
+            NBn = int((L.num_fbundles if which == "layer" else L.num_bundles).item())
+            bt = (L.fbun_tok if which == "layer" else L.bun_tok)[:NBn + 1].cpu().numpy().astype(np.int64)
+            W = int(L.num_windows.item())
+            ws = L.win_start[:W + 1].cpu().numpy().astype(np.int64)
+            res = {}
+            for lo_, hi_ in ((1, 32), (33, 64), (65, 96), (97, 144)):
+                useful = issued = nb_ = 0
+                for b_ in range(NBn):
+                    s0_, s1_ = bt[b_], bt[b_ + 1]
+                    T_ = s1_ - s0_
+                    if not (lo_ <= T_ <= hi_):
+                        continue
+                    nb_ += 1
+                    w0, w1 = np.searchsorted(ws, s0_), np.searchsorted(ws, s1_)
+                    sizes = np.diff(ws[w0:w1 + 1])
+                    useful += int((sizes * sizes).sum())
+                    nt_ = (T_ + 15) // 16
+                    if which == "layer" and nt_ <= 4:
+                        issued += nt_ * nt_                          # the exact-size bodies compute every tile pair
+                    else:
+                        for it_ in range(nt_):                       # key-tile range of the windows touching query tile it_
+                            first, last = s0_ + 16 * it_, min(s0_ + 16 * it_ + 15, s1_ - 1)
+                            wf, wl_ = np.searchsorted(ws, first, side="right") - 1, np.searchsorted(ws, last, side="right") - 1
+                            issued += (ws[wl_ + 1] - 1 - s0_) // 16 - (ws[wf] - s0_) // 16 + 1
+                if nb_:
+                    res[f"{lo_}-{hi_} tokens"] = {"bundles": nb_, "useful_entries": useful, "tiles_issued": int(issued),
+                                                  "density": round(useful / (256.0 * issued), 4)}
+            return res
+        density = {}
+        with torch.no_grad():
+            for tag, toks in (("encoder", vc[ids_keep.long()]), ("decoder", vc)):
+                for s_, L in enumerate(ops.window_build_batch([(toks.contiguous(), 0), (toks.contiguous(), 1)], B, model.backbone._wcfg)):
+                    density[f"{tag} shift {s_} (attention kernels)"] = tile_density(L, "attn")
+                    if tag == "encoder" and fused_enc:
+                        density[f"{tag} shift {s_} (one-launch layer kernel)"] = tile_density(L, "layer")
         out = {
             "metric": "pretrain frames/sec (nuScenes SST-GeoMAE)",
             "value": round(world * B * args.steps / elapsed, 3), "unit": "frames/s",
@@ -376,7 +458,10 @@ def main():
             # engine also the share of it spent blocked on the pillar-count readback (= how far the host runs ahead)
             "host_ms_per_step": {"enqueue_loop": round(1e3 * t_enq / args.steps, 4)},
             "roofline": dict(kernel=report_name.get(dominant, dominant), **kern[dominant]) if dominant else None,
+            "dominant_check": dominant_check,
             "roofline_other_kernels": {report_name.get(k, k): v for k, v in kern.items() if k != dominant},
+            "step_roofline": step_roofline,
+            "attention_tile_density": density,
         }
         if h0 is not None:
             busy = (h1[0] - h0[0]) - (h1[1] - h0[1])
@@ -386,14 +471,17 @@ def main():
                                            engine_busy=round(1e3 * busy / args.steps, 4))
         # north_star: "MFMA utilisation on the bucketed attention".  Not measurable from inside this process (PMC needs
         # rocprofv3): the stored pass of tools/r2_profile.sh for this workload, labelled as such
-        for cand in (f"r03_{workload}_mfma_util.json",) + (("r02_mfma_util.json",) if workload == "nuscenes1" else ()):
-            upath = os.path.join(ROOT, "profiles", cand)
+        ucands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_mfma_util.json")), reverse=True)
+        if workload == "nuscenes1":
+            ucands.append(os.path.join(ROOT, "profiles", "r02_mfma_util.json"))
+        for upath in ucands:
             if B == 4 and os.path.exists(upath):
                 u = json.load(open(upath))
-                out["mfma_busy_stored"] = {"source": f"profiles/{cand} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
+                out["mfma_busy_stored"] = {"source": f"{os.path.relpath(upath, ROOT)} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
                                            **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
-                                                                                  "sst_ffn_fwd_kernel", "sst_ffn_fwd_pair_kernel",
-                                                                                  "sst_ffn_bwd_kernel", "sst_ffn_bwd_dw_kernel",
+                                                                                  "sst_layer_fwd_kernel", "sst_ffn_fwd_kernel",
+                                                                                  "sst_ffn_fwd_pair_kernel", "sst_ffn_bwd_kernel",
+                                                                                  "sst_ffn_bwd_dw_kernel", "dw_kernel",
                                                                                   "vfe_layer1_kernel") if k in u}}
                 break
         if phases is not None:

@@ -66,6 +66,13 @@ hipEvent_t take_mid_launch_event();
 // kernel asked for, so that its averages are those of ONE kernel of the rocprofv3 table
 void set_last_kernel_variant(int v);
 int last_kernel_variant();
+// The per-kernel launch timer (geomae_profiler_create, sst_stack.hip) of the step this host thread is enqueueing, for
+// launches made outside the stack calls that take it as an argument: the deferred weight-gradient contractions, which
+// geomae_flush_weight_grad launches on ANOTHER stream -- their event pairs are recorded there, around each dw_kernel.
+void set_thread_profiler(void* prof);
+void* thread_profiler();
+bool profiler_begin(void* prof, int kernel_id, hipStream_t s);      // true: a start event was recorded, call profiler_end
+void profiler_end(void* prof, hipStream_t s);
 // Split-K workspace of the geomae_sst_weight_grad calls of this host thread (set by geomae_sst_stack_backward for its own
 // layers): two buffers of kDwPartialBytes where the contraction's workgroups leave their partial sums instead of
 // atomically adding them to the gradients (sst_layer.hip dw_body); nullptr = atomics.

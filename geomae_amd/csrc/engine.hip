@@ -451,6 +451,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     hipStream_t geo = e->geo, aux = e->aux;
     const int nh = c.num_heads, ne = c.encoder_layers, nd = c.decoder_layers;
     drop_pending_weight_grads();       // (a step that failed between queueing and flushing leaves entries into a dead workspace)
+    struct ThreadProfilerScope {       // the contractions launched by geomae_flush_weight_grad are timed where they run
+        explicit ThreadProfilerScope(void* p) { set_thread_profiler(p); }
+        ~ThreadProfilerScope() { set_thread_profiler(nullptr); }
+    } prof_scope(e->profiler);
 
     // ---------------- carve the step's buffers (sizes are all known on the host)
     Arena a;

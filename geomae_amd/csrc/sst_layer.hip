@@ -1261,8 +1261,11 @@ int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream
     dw_grid(num_tasks, num_tokens, &G, &chunk, T.partial != nullptr);
     GEOMAE_REQUIRE(!T.partial || (long long)G * num_tasks * 65536 <= kDwPartialBytes, "weight_grad: split-K workspace too small");
     const DwReduce Rd = take_pending_reduce();
+    void* prof = thread_profiler();
+    const bool timed = profiler_begin(prof, GEOMAE_KERNEL_DW, stream);
     hipLaunchKernelGGL(dw_kernel, dim3(G, num_tasks + (Rd.partial ? cdiv(2 * kDwReduceBlocks, G) : 0)), dim3(256), 0, stream, T, num_tokens, chunk,
                        num_tasks, Rd);
+    if (timed) profiler_end(prof, stream);
     note_partials(T, num_tasks, G);
     return check_launch("dw_kernel");
 }

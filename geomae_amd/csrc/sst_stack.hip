@@ -122,6 +122,21 @@ struct Timed {
     }
 };
 
+static thread_local void* t_thread_profiler = nullptr;
+void set_thread_profiler(void* prof) { t_thread_profiler = prof; }
+void* thread_profiler() { return t_thread_profiler; }
+bool profiler_begin(void* prof, int kernel_id, hipStream_t s) {
+    Profiler* p = (Profiler*)prof;
+    if (!p || p->kernel_id != kernel_id || p->used + 2 > (int)p->ev.size()) return false;
+    (void)hipEventRecord(p->ev[p->used], s);
+    return true;
+}
+void profiler_end(void* prof, hipStream_t s) {
+    Profiler* p = (Profiler*)prof;
+    (void)hipEventRecord(p->ev[p->used + 1], s);
+    p->used += 2;
+}
+
 }  // namespace geomae
 
 using namespace geomae;
@@ -333,7 +348,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
             // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
             if (defer_last_weight_grad || defer_all) defer_next_weight_grad();
-            Timed t(profiler, GEOMAE_KERNEL_DW, stream);
+            // (timed inside launch_dw, on the stream it really runs on: thread_profiler)
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
