@@ -131,7 +131,7 @@ struct Engine {
     // results of the last step
     int64_t last_N = 0;
     int32_t last_V = 0, last_keep = 0, last_mask = 0;
-    int64_t off_losses = 0, off_ids_keep = 0, off_ids_mask = 0;
+    int64_t off_losses = 0, off_ids_keep = 0, off_ids_mask = 0, off_voxel_coors = 0;
     int32_t cells = 0, gz = 1, gy = 1, gx = 1, s_low = 1, s_med = 1;
     double host_step_s = 0.0, host_blocked_s = 0.0;      // cumulative wall time inside step calls / in the readback wait
     // a step that fails AFTER its first launch leaves streams, events and the workspace in an undefined state
@@ -537,6 +537,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     e->off_losses = (char*)losses - e->ws;
     e->off_ids_keep = (char*)b.ids_keep - e->ws;
     e->off_ids_mask = (char*)b.ids_mask - e->ws;
+    e->off_voxel_coors = (char*)b.voxel_coors - e->ws;
     e->last_N = N; e->last_V = V; e->last_keep = nk; e->last_mask = nm;
     e->steps += 1;
     e->mask_draws += 1;
@@ -994,6 +995,7 @@ extern "C" int64_t geomae_pretrain_result_offset(void* engine, int32_t what) {
         case 1: return (char*)e->gnorm - e->ws;
         case 2: return e->off_ids_keep;
         case 3: return e->off_ids_mask;
+        case 4: return e->off_voxel_coors;
         default: return -1;
     }
 }

@@ -344,6 +344,10 @@ class PretrainEngine:
         s = self.last_sizes()
         return self._view(2, s["n_keep"], torch.int32), self._view(3, s["n_mask"], torch.int32)
 
+    def last_voxel_coors(self):
+        """[V, 4] int32 (b, z, y, x) of the last step's batch, in pillar order (the order ids_keep / ids_mask index)."""
+        return self._view(4, 4 * self.last_sizes()["V"], torch.int32).view(-1, 4)
+
     def close(self):
         if self.handle is not None:
             torch.cuda.synchronize(self.dev)

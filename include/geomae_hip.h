@@ -771,7 +771,8 @@ int geomae_pretrain_step(void* engine, const float* const* next_frame_points, co
                          float lr, float grad_scale, int32_t run_optimizer, geomaeStream_t stream);
 int geomae_pretrain_optimizer(void* engine, float lr, float grad_scale, geomaeStream_t stream);
 /* what: 0 = losses of the LAST step ([6] f32; one of 4 ring slots: valid until three more steps were enqueued),
- * 1 = pre-clip gradient norm ([1] f32), 2 = ids_keep, 3 = ids_mask of the last step ([n_keep] / [n_mask] int32) */
+ * 1 = pre-clip gradient norm ([1] f32), 2 = ids_keep, 3 = ids_mask of the last step ([n_keep] / [n_mask] int32),
+ * 4 = voxel_coors of the last step's batch ([V, 4] int32 (b, z, y, x): valid until the step after next reuses the slot) */
 int64_t geomae_pretrain_result_offset(void* engine, int32_t what);
 /* measurement: cumulative host wall time (seconds) spent inside geomae_pretrain_step calls, the part of it spent
  * waiting for the pillar-count readback, and the number of steps: out[0..2] */

@@ -769,13 +769,15 @@ FT_DROP = {0: dict(max_tokens=30, drop_range=(0, 30)), 1: dict(max_tokens=60, dr
            2: dict(max_tokens=144, drop_range=(60, 100000))}
 
 
-@pytest.mark.parametrize("compute_dtype,tol", [("fp32", 3e-2), ("bf16", 5e-2)])
+@pytest.mark.parametrize("compute_dtype,tol", [("fp32", 3e-6), ("bf16", 5e-2)])
 def test_finetune_backbone_matches_reference_fixture(dev, golden_dir, compute_dtype, tol):
     """SSTInputLayer + SSTSecondPretrainedv1 (encoder through the SST kernels, recover_bev kernel, conv stack in
     PyTorch/MIOpen) vs the fixture produced by the reference's own modules (pure fp32) with identical seeded weights:
     stage outputs (sums, per-channel sums, a patch), the random-projection loss, input gradient and every
-    parameter-gradient norm.  The window attention core computes in bf16 in both modes (QK^T / PV operands), and the
-    train-mode BatchNorm of a 1-block network amplifies that: measured 0.6 % on the loss, 7 % on dx (fp32 mode)."""
+    parameter-gradient norm.  fp32 mode has no bf16 step (composed kernels + fp32 ATen GEMMs + the fp32 attention core,
+    sst.window_attention_fp32): measured (GEOMAE_TEST_VERBOSE=1, round 4) 6.7e-7 on the loss, <= 6.4e-7 on the outputs,
+    8.8e-7 on dx, 1.3e-6 on the worst gradient norm -- the bound is ~3x that.  bf16 mode (MFMA kernels; the train-mode
+    BatchNorm of a 1-block network amplifies their rounding): 1.1e-2 on the loss, 1.0e-1 on dx, 2.5e-2 on gradient norms."""
     import geomae_amd
     g = np.load(os.path.join(golden_dir, "g_finetune.npz"))
     mid = geomae_amd.SSTInputLayer(drop_info=(FT_DROP, FT_DROP), shifts_list=[(0, 0), (6, 6)], window_shape=(12, 12),
@@ -798,7 +800,19 @@ def test_finetune_backbone_matches_reference_fixture(dev, golden_dir, compute_dt
          for i in range(len(outs))]
     loss = sum((o * wi).sum() for o, wi in zip(outs, w)) * 1e-2
     loss.backward()
-    assert abs(float(loss) - float(g["loss"])) <= tol * abs(float(g["loss"]))
+    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
+    if os.environ.get("GEOMAE_TEST_VERBOSE"):
+        gn_ = {k: float(p.grad.double().norm()) for k, p in bb.named_parameters()}
+        e_out = []
+        for i, o in enumerate(outs):
+            o = o.detach().float()
+            e_out.append((abs(float(o.double().abs().sum()) - float(g[f"out{i}_abs"])) / float(g[f"out{i}_abs"]),
+                          np.abs(o.double().sum(dim=(0, 2, 3)).cpu().numpy() - g[f"out{i}_chan"]).max() / np.abs(g[f"out{i}_chan"]).max(),
+                          np.abs(o[:, :, 96:104, 96:104].cpu().numpy() - g[f"out{i}_patch"]).max() / max(1.0, np.abs(g[f"out{i}_patch"]).max())))
+        print(f"finetune [{compute_dtype}]: loss err {abs(float(loss.detach()) - float(g['loss'])) / abs(float(g['loss'])):.2e}, outputs (abs-sum, "
+              f"channel sums, patch) {[tuple(f'{v:.1e}' for v in e) for e in e_out]}, dx {rel(x.grad.cpu().numpy(), g['dx']):.2e}, "
+              f"worst gradient norm {max(abs(gn_[str(k)] - r) / max(r, 1e-6) for k, r in zip(g['grad_names'], g['grad_norms'])):.2e}", flush=True)
+    assert abs(float(loss.detach()) - float(g["loss"])) <= tol * abs(float(g["loss"]))
     for i, o in enumerate(outs):
         o = o.detach().float()
         assert tuple(o.shape) == tuple(int(v) for v in g[f"out{i}_shape"])
@@ -808,7 +822,6 @@ def test_finetune_backbone_matches_reference_fixture(dev, golden_dir, compute_dt
         assert np.abs(chan - g[f"out{i}_chan"]).max() <= tol * np.abs(g[f"out{i}_chan"]).max()
         patch = o[:, :, 96:104, 96:104].cpu().numpy()
         assert np.abs(patch - g[f"out{i}_patch"]).max() <= tol * max(1.0, np.abs(g[f"out{i}_patch"]).max())
-    rel = lambda a, b: np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-12)
     assert rel(x.grad.cpu().numpy(), g["dx"]) <= 4 * tol
     gn = {k: float(p.grad.double().norm()) for k, p in bb.named_parameters()}
     for k, ref in zip(g["grad_names"], g["grad_norms"]):
