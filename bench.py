@@ -286,9 +286,12 @@ def main():
         b_.record()
     torch.cuda.synchronize()
     event_pair_ms = float(np.median([a_.elapsed_time(b_) for a_, b_ in pairs]))
-    phases = None
+    phases, exposed = None, None
     if eng is not None:                           # where the main stream's time goes: 3 instrumented (untimed) steps
         eng.set_phase_timing(True)
+        measure_comm = world > 1 or forced
+        if measure_comm:                          # what the main stream waits for: in-line SyncBN all-reduces, the last segment
+            eng.comm_events, trainer.tail_comm_events = [], []
         acc = {}
         for i in range(3):
             step(i)
@@ -296,6 +299,26 @@ def main():
                 acc[k] = acc.get(k, 0.0) + v / 3
         eng.set_phase_timing(False)
         phases = {k: round(v, 4) for k, v in acc.items()}
+        if measure_comm:
+            torch.cuda.synchronize()
+            names = {0: "bn_fwd0", 1: "bn_fwd1", 2: "bn_bwd1", 3: "bn_bwd0"}
+            per = {}
+            for what, e0, e1 in eng.comm_events:
+                per[names[what]] = per.get(names[what], 0.0) + e0.elapsed_time(e1) / 3
+            tail_ms = sum(e0.elapsed_time(e1) for e0, e1 in trainer.tail_comm_events) / 3
+            exposed = {"syncbn_inline_ms_per_step": {k: round(v, 4) for k, v in per.items()},
+                       "syncbn_inline_total_ms_per_step": round(sum(per.values()), 4),
+                       "last_gradient_segment_wait_ms_per_step": round(tail_ms, 4),
+                       "note": "HIP event pairs on the main stream around each in-line SyncBN all-reduce and around the "
+                               "final gradient-segment all-reduce + wait (the two early segments and the feature-moment "
+                               "exchange run on side streams beside compute); 3 untimed steps"}
+            eng.comm_events = trainer.tail_comm_events = None
+    rank_devices = None
+    if world > 1 or forced:                       # every rank's device (index, name), gathered on the run's own process group
+        mine = [rank, int(torch.cuda.current_device()), torch.cuda.get_device_name(dev), int(local_rank)]
+        gathered = [None] * dist.get_world_size()
+        dist.all_gather_object(gathered, mine)
+        rank_devices = [{"rank": g_[0], "cuda_device": g_[1], "name": g_[2], "local_rank": g_[3]} for g_ in gathered]
     loss_val = float(sum(v.detach() for v in losses.values()))
     assert np.isfinite(loss_val), "non-finite loss"
 
@@ -447,7 +470,9 @@ def main():
                                    f"6+2+2 blocks), {B} frames/GPU, ~{int(n_pts / B)} pts/frame, fwd+bwd+allreduce+clip+AdamW",
                        "frames_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world}",
                        "step_driver": "python-explicit" if eng is None else "geomae_pretrain_step (C engine)",
-                       "exchange": "forced at world size 1 (RCCL, one rank)" if forced else ("rccl" if world > 1 else "none")},
+                       "exchange": "forced at world size 1 (RCCL, one rank)" if forced else
+                                   (("rccl" if dist.get_backend() == "nccl" else dist.get_backend() + " (GEOMAE_BENCH_SHARE_GPU test hook)")
+                                    if world > 1 else "none")},
             "loss": round(loss_val, 4),
             # how the step's side streams were chosen (geomae_amd.ops._pick_side_streams: measured queue sharing)
             "stream_probe": ops.STREAM_PROBE.get((dev.type, dev.index)),
@@ -484,6 +509,9 @@ def main():
                                                                                   "sst_ffn_bwd_dw_kernel", "dw_kernel",
                                                                                   "vfe_layer1_kernel") if k in u}}
                 break
+        if world > 1 or forced:      # the N > 1 line validates itself: what the process group says it is running on
+            out["distributed"] = {"world_size_reported": dist.get_world_size(), "backend": dist.get_backend(),
+                                  "rank_devices": rank_devices, "exposed_communication": exposed}
         if phases is not None:
             out["main_stream_phase_ms"] = phases
             out["main_stream_phase_sum_ms"] = round(float(sum(phases.values())), 4)

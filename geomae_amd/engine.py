@@ -189,8 +189,22 @@ class PretrainEngine:
             return cur
         return torch.cuda.ExternalStream(handle, device=self.dev)
 
+    # measurement (bench.py, world > 1): event pairs around the collectives the MAIN stream waits for -- the in-line SyncBN
+    # all-reduces (the feature-moment exchange and the early gradient segments run on side streams, beside compute)
+    comm_events = None                                  # a list while measuring: (what, start event, end event)
+
     def _hook_body(self, what, stream):
         group = self.bn_group if self.bn_group is not None else ops.BN_GROUP
+        inline = what in (HOOK_BN_FWD0, HOOK_BN_FWD1, HOOK_BN_BWD1, HOOK_BN_BWD0) and self.comm_events is not None
+        if inline:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self._stream_of(stream))
+        self._hook_collective(what, stream, group)
+        if inline:
+            e1.record(self._stream_of(stream))
+            self.comm_events.append((what, e0, e1))
+
+    def _hook_collective(self, what, stream, group):
         with torch.cuda.stream(self._stream_of(stream)):
             if what == HOOK_BN_FWD0:
                 dist.all_reduce(self.sync["mom0"], group=group)

@@ -483,11 +483,18 @@ class Trainer:
             eng.on_segment = segment_ready if len(self.flat.segments) > 2 else None
         losses, gnorm = eng.step(points, next_points, self.opt.lr, run_optimizer=not exchange)
         if exchange:
+            tail = getattr(self, "tail_comm_events", None)      # measurement (bench.py): the exposed end of the exchange
+            if tail is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             done = {i for i, _ in works}
             for i, (a, b, _) in enumerate(self.flat.segments):
                 if i not in done:
                     works.append((i, dist.all_reduce(self.flat.grad[a:b], op=dist.ReduceOp.SUM, group=_grad_group(), async_op=True)))
             _wait_all(works)
+            if tail is not None:
+                e1.record()
+                tail.append((e0, e1))
             tap = getattr(self, "on_reduced_grad", None)
             if tap is not None:
                 tap(self.flat.grad)
