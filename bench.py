@@ -519,6 +519,11 @@ def main():
             out["roofline_hbm_kernels"] = hbm_kernels(model, pool[0], B, torch, ops)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+        try:                                     # RCCL leaves a version banner in C stdio: out with it BEFORE the one JSON line
+            import ctypes as _ct
+            _ct.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if world > 1 or forced:
         dist.destroy_process_group()
