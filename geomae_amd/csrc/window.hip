@@ -598,7 +598,16 @@ __global__ __launch_bounds__(kAttnBlk, H == 1 ? 6 : (H == 2 ? 5 : 4)) void win_a
     }
 }
 
-// backward: dqkv [n, 3C] bf16 from dout [n, C] bf16, qkv, out, lse
+// backward: dqkv [n, 3C] bf16 from dout [n, C] bf16, qkv, out, lse.  Two passes over the tile pairs of a (bundle, head),
+// their tiles dealt round-robin to the 8 waves: a query-major one (dQ: a lane holds a query) and a key-major one (dK, dV:
+// a lane holds a key) -- dQ contracts over the keys and dK / dV over the queries, so with the tiles of one head spread
+// over waves one of the sums would cross waves in a single pass.  Measured alternatives (round 4, tools/attn_time.py):
+// one pass with dQ summed through LDS float atomics (ds_add_f32 serialises: 30 -> 180..470 us per decoder-size launch);
+// one WAVE per (bundle, head) walking every pair once with the P^T / dS^T tiles turned through LDS scratch (5 MFMAs per
+// pair, no barrier, no atomics -- but an eighth of the waves and a 64-thread gather: 75 us).  Round 4 keeps the two passes
+// and computes all three products TRANSPOSED, so that they come out in the T-layout (lane = token, 4 channels per lane
+// group) and leave as 8-byte row pieces straight from the registers: the two LDS output tiles, two of the three barriers
+// and the three un-stage passes are gone.
 __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned short* __restrict__ qkv,
                                                           const unsigned short* __restrict__ out,
                                                           const unsigned short* __restrict__ dout,
@@ -613,7 +622,6 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                                                           const int4* __restrict__ pos_info) {
     __shared__ __attribute__((aligned(16))) unsigned short Qs[kMaxT * kDh], Ks[kMaxT * kDh], Vs[kMaxT * kDh],
         dOs[kMaxT * kDh];
-    __shared__ __attribute__((aligned(16))) unsigned short G1[kMaxT * kDh], G2[kMaxT * kDh];   // dQ, then dK / dV
     __shared__ __attribute__((aligned(16))) float Ls[kMaxT], Ds[kMaxT];
     __shared__ __attribute__((aligned(16))) int toks[kMaxT], wid[kMaxT], wlo[kMaxT], whi[kMaxT];
     const AttnPlan P = {bun_start, win_start, win_tokens, tok_win, bun_tok, pos_info};
@@ -679,17 +687,21 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                     const float p = (Wr[r] == wq) ? __expf(s[r] * scale - Li) : 0.0f;
                     dsa[r] = (short)f2bf(p * (dp[r] - Di) * scale);
                 }
-                // dQ[i][d] += sum_j dS[i][j] K[j][d] : A = dS (row i = c, k = j), B = K[k=j][col=d] from K^T
-                const bf16x4 kb = lds4_tr(Ks, jt * 16 + 4 * g, c);
-                dq = mfma16(dsa, kb, dq);
+                // dQ^T[d][i] += sum_j K^T[d][j] dS^T[j][i]: A = K^T (lane = channel d: K[4g..4g+3][d], the transposing read),
+                // B = this lane's registers -> rows d = 4g + r, column i = c: the T-layout of query i (computed as
+                // dQ = dS K it came out [queries 4g + r][channel c] and went through an LDS tile, a barrier and an
+                // un-stage pass to reach memory in row pieces)
+                const bf16x4 kt = lds4_tr(Ks, jt * 16 + 4 * g, c);
+                dq = mfma16(kt, dsa, dq);
             }
+            if (it * 16 + c < T) {
+                union { bf16x4 v; uint2 u; } pq;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) G1[(it * 16 + 4 * g + r) * kDh + c] = f2bf(dq[r]);
+                for (int r = 0; r < 4; ++r) pq.v[r] = (short)f2bf(dq[r]);
+                *reinterpret_cast<uint2*>(dqkv + tok_elem(toks[it * 16 + c], 3 * C, h * kDh + 4 * g, blk)) = pq.u;
+            }
         }
-        __syncthreads();
         ATTN_STAMP(3);
-        unstage_store(G1, dqkv, 3 * C, h * kDh, toks, T, blk);
-        __syncthreads();
         ATTN_STAMP(4);
         // ---- pass 2: dK, dV.  S orientation: lane holds key j = jt*16 + c, queries i = it*16 + 4g + r
         for (int jt = wave; jt < nt; jt += kAttnBlk / 64) {
@@ -717,24 +729,24 @@ __global__ __launch_bounds__(kAttnBlk) void win_attn_bwd_kernel(const unsigned s
                     pa[r] = (short)f2bf(p);
                     dsa[r] = (short)f2bf(p * (dp[r] - Dr[r]) * scale);
                 }
-                // dV[j][d] += sum_i P[i][j] dO[i][d] : A = P^T (row j = c, k = i), B = dO[k=i][col=d] from dO^T
-                const bf16x4 dob = lds4_tr(dOs, it * 16 + 4 * g, c);
-                dv = mfma16(pa, dob, dv);
-                // dK[j][d] += sum_i dS[i][j] Q[i][d]
-                const bf16x4 qb = lds4_tr(Qs, it * 16 + 4 * g, c);
-                dk = mfma16(dsa, qb, dk);
+                // dV^T[d][j] += sum_i dO^T[d][i] P[i][j] ; dK^T[d][j] += sum_i Q^T[d][i] dS[i][j]: A = the transposing read of the
+                // row tile (lane = channel d), B = this lane's registers (lane = key j) -> the T-layout of key j
+                const bf16x4 dot = lds4_tr(dOs, it * 16 + 4 * g, c);
+                dv = mfma16(dot, pa, dv);
+                const bf16x4 qt = lds4_tr(Qs, it * 16 + 4 * g, c);
+                dk = mfma16(qt, dsa, dk);
             }
+            if (jt * 16 + c < T) {
+                const int tkj = toks[jt * 16 + c];
+                union { bf16x4 v; uint2 u; } pk, pv;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                G1[(jt * 16 + 4 * g + r) * kDh + c] = f2bf(dk[r]);
-                G2[(jt * 16 + 4 * g + r) * kDh + c] = f2bf(dv[r]);
+                for (int r = 0; r < 4; ++r) { pk.v[r] = (short)f2bf(dk[r]); pv.v[r] = (short)f2bf(dv[r]); }
+                *reinterpret_cast<uint2*>(dqkv + tok_elem(tkj, 3 * C, C + h * kDh + 4 * g, blk)) = pk.u;
+                *reinterpret_cast<uint2*>(dqkv + tok_elem(tkj, 3 * C, 2 * C + h * kDh + 4 * g, blk)) = pv.u;
             }
         }
-        __syncthreads();
         ATTN_STAMP(5);
-        unstage_store(G1, dqkv, 3 * C, C + h * kDh, toks, T, blk);
-        unstage_store(G2, dqkv, 3 * C, 2 * C + h * kDh, toks, T, blk);
-        __syncthreads();
+        __syncthreads();                                   // (the next item's staging overwrites the tiles)
         ATTN_STAMP(6);
     }
 }
