@@ -40,6 +40,10 @@ __device__ __forceinline__ int64_t row_key(const int32_t* __restrict__ coors, in
     return ok ? key_of(c, gz, gy, gx) : -1;
 }
 
+// (Round 4, measured and rejected: one returned atomic per RUN of equal keys inside a wave -- head lanes by ballot, the base
+//  handed on by shuffle.  The frames' point order is firing order (every beam of one azimuth step, then the next step) or,
+//  behind the training pipeline's PointShuffle, random: points of one pillar are never neighbours in the array, the runs
+//  have length one and the kernel kept its 138 us at 1.02 M points.)
 __global__ __launch_bounds__(kBlk) void hist_kernel(const int32_t* __restrict__ coors, int64_t n, int ndim, int nb, int gz,
                                                     int gy, int gx, int32_t* __restrict__ table,
                                                     int32_t* __restrict__ rank_in_cell) {
