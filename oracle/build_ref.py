@@ -5,10 +5,15 @@ TEST INFRASTRUCTURE ONLY.  Compiles the reference's pybind module `voxel_layer`
 scatter_points_cpu.cpp}; bound functions voxelization.cpp:5-11) from the sources where
 they lie, with g++ against the installed torch headers (no WITH_CUDA, so only the CPU
 paths exist: dynamic_voxelize, hard_voxelize).  Output goes to oracle/_ref/ only, which
-is git-ignored (binary travels to the GPU box with the snapshot; sources never do).
+is git-ignored (kept out of history) but NOT listed in .gpurunignore: the built binary is
+part of a `gpurun` snapshot like the in-tree HIP library; reference SOURCES never leave
+this container.
 
-Runs only where /root/reference exists (the build container).  On the GPU box the
-prebuilt oracle/_ref/voxel_layer_ref*.so is used as is.
+Built only where /root/reference exists (the build container), where it validates the
+oracle's plain-C voxelizer and generates the committed fixtures (tests/golden/*.npz).
+Nothing that runs on the GPU box -- `pytest -m gpu`, `__graft_entry__.smoke()`, `bench.py`
+-- loads it: those compare against the fixtures and the oracle (its only consumer is the
+CPU test tests/test_oracle_golden.py, which skips when the binary is absent).
 """
 import os
 import subprocess

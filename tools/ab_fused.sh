@@ -1,7 +1,9 @@
-python -m pytest tests -m gpu -q -x 2>&1 | tail -8
-for cfg in "1 0" "1 32" "1 48" "1 64" "1 144" "0 0" "0 144"; do set -- $cfg; 
-  GEOMAE_FUSED_LAYERS=$1 GEOMAE_BUNDLE_CAP=$2 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
+#!/bin/bash
+# alternating same-box A/B of the step with the one-launch layer forward on (1) / off (0): bash tools/ab_fused.sh [rounds]
+cd /root/repo
+for r in $(seq 1 ${1:-3}); do for m in 1 0; do
+  GEOMAE_FUSED_LAYERS=$m python bench.py --steps 40 --warmup 10 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); p=d['main_stream_phase_ms']
-print('fused=$1 cap=$2', d['ms_per_step'], {k:p[k] for k in ('enc_fwd','dec_fwd','dec_bwd','enc_bwd')})"
-done
+d=json.loads([l for l in sys.stdin.read().strip().splitlines() if l.startswith('{')][-1]); p=d['main_stream_phase_ms']
+print('fused=$m', d['ms_per_step'], d['step_ms']['p50'], {k:p[k] for k in ('enc_fwd','dec_fwd','dec_bwd','enc_bwd')})"
+done; done
