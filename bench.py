@@ -495,7 +495,7 @@ def main():
                                            busy=round(1e3 * (t_enq - (h1[1] - h0[1])) / args.steps, 4),
                                            engine_busy=round(1e3 * busy / args.steps, 4))
         # north_star: "MFMA utilisation on the bucketed attention".  Not measurable from inside this process (PMC needs
-        # rocprofv3): the stored pass of tools/r2_profile.sh for this workload, labelled as such
+        # rocprofv3): the stored pass of tools/archive/r2_profile.sh for this workload, labelled as such
         ucands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{workload}_mfma_util.json")), reverse=True)
         if workload == "nuscenes1":
             ucands.append(os.path.join(ROOT, "profiles", "r02_mfma_util.json"))

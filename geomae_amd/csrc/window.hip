@@ -52,7 +52,7 @@ __global__ __launch_bounds__(kWBlk) void win_hist_kernel(const int4* __restrict_
 
 // One launch of each build stage serves up to kMaxWinJobs layouts (blockIdx.y = job): a training step builds four
 // (encoder / decoder tokens x unshifted / shifted windows), and five tiny dependent kernels per layout, two of them
-// single-workgroup, were 24 launches = ~0.3 ms of a serial chain that gated the encoder (tools/phase_events.py).
+// single-workgroup, were 24 launches = ~0.3 ms of a serial chain that gated the encoder (tools/archive/phase_events.py).
 constexpr int kMaxWinJobs = 4;
 struct WinJob {
     const int4* coors;
@@ -289,7 +289,7 @@ __device__ __forceinline__ f32x4 mfma32_pair(bf16x4 a0, bf16x4 a1, bf16x4 b0, bf
 // The transposing LDS read (ds_read_b64_tr_b16) must not sit in a PREDICATED block: compiled as "s_and_saveexec;
 // ds_read_b64_tr_b16; s_or exec" without a branch around it, a false condition still left stale LDS contents in the
 // destination (gfx950; NaN rows in windows with an odd tile count, reproduced by polluting LDS with NaNs,
-// tools/dbg_attn.py): 0 * NaN in the absent half of a tile pair.  Two guards: the tile ranges live in SGPRs
+// tools/archive/dbg_attn.py): 0 * NaN in the absent half of a tile pair.  Two guards: the tile ranges live in SGPRs
 // (tile_range), so the conditions around these reads are scalar branches that skip the block; and the operand of an
 // absent tile passes through this select, whatever the read left behind.
 __device__ __forceinline__ bf16x4 keep_if(bool cond, bf16x4 v) {
@@ -298,7 +298,7 @@ __device__ __forceinline__ bf16x4 keep_if(bool cond, bf16x4 v) {
 }
 
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-// phase timing (tools/phase_timing_attn.py; a no-op in the product build)
+// phase timing (tools/archive/phase_timing_attn.py; a no-op in the product build)
 #ifdef GEOMAE_PHASE_TIMING
 static __device__ unsigned long long attn_stamps[512 * 16];
 #define ATTN_STAMP(i)                                                                                   \
@@ -379,7 +379,7 @@ __device__ __forceinline__ bf16x4 lds4(const unsigned short* p) { return *reinte
 // B operand (k = 4 consecutive tokens row0 .. row0+3, n = channel c = lane & 15) of a token contraction, read
 // straight from a ROW-MAJOR [T][16] head slice with ds_read_b64_tr_b16: lane m of a 16-lane group points at row
 // row0 + (m >> 2), channel chunk 4 * (m & 3); it receives channel m of the four rows (lane mapping measured in
-// tools/microbench_ds_read_tr.hip).  Replaces the transposed LDS copies (Q^T, K^T, dO^T, V^T) that cost
+// tools/archive/microbench_ds_read_tr.hip).  Replaces the transposed LDS copies (Q^T, K^T, dO^T, V^T) that cost
 // 8 two-byte LDS stores per 16-byte piece.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __device__ __forceinline__ bf16x4 lds4_tr(const unsigned short* rm, int row0, int c) {

@@ -154,7 +154,7 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         f32 = torch.float32
         # Everything that depends only on the points and the pillar coordinates runs beside the VFE forward, on two
         # streams, arranged so that the main stream waits for other queues as rarely as possible (a cross-queue wait
-        # costs ~15 us of queue time even when its event fired long ago, tools/phase_events.py):
+        # costs ~15 us of queue time even when its event fired long ago, tools/archive/phase_events.py):
         #   geometry stream : (random mask, unless `prefetch` drew it in the previous step) -> token coordinates -> the
         #                     four window layouts.  ONE event (layouts_ready) gates the encoder; the weights packed
         #                     ahead by the trainer are chained into it.

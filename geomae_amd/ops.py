@@ -39,7 +39,7 @@ class _timed:
         return False
 
 
-# optional phase marks (tools/phase_events.py): list of (name, event) recorded on the current stream at the phase
+# optional phase marks (tools/archive/phase_events.py): list of (name, event) recorded on the current stream at the phase
 # boundaries of the explicit training schedule; None = disabled (one attribute test per mark)
 PHASE_MARKS = None
 

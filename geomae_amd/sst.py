@@ -576,7 +576,7 @@ class MultiMAESSTSPChoose(nn.Module):
         if self._streams is None:
             self._streams = (None, ops.side_streams()["dec_b"])
         # The two decoder stacks run concurrently: one on a side stream, the other on the current stream itself.  A
-        # cross-queue wait costs ~10 us of queue time even when its event has long fired (tools/phase_events.py), so
+        # cross-queue wait costs ~10 us of queue time even when its event has long fired (tools/archive/phase_events.py), so
         # the fork / join is one wait on each side instead of two.
         _, sb_ = self._streams
         sb_.wait_stream(cur)

@@ -52,7 +52,7 @@ def test_engine_gradients_match_python_explicit_schedule():
     assert torch.equal(torch.sort(torch.cat([ik, im])).values, torch.arange(s["V"], dtype=torch.int32, device="cuda"))
     lp = torch.stack([losses_py[k] for k in m_py.LOSS_KEYS])
     # run-to-run noise of EITHER path (fp64 atomics order in the BatchNorm sums -> one-ulp scale differences -> bf16
-    # rounding flips): losses 2.3e-4 relative, per-parameter gradients <= 8e-4 (tools/engine_noise.py); bound = 6x that
+    # rounding flips): losses 2.3e-4 relative, per-parameter gradients <= 8e-4 (tools/archive/engine_noise.py); bound = 6x that
     assert torch.allclose(losses_c, lp, rtol=1.5e-3, atol=1e-6), (losses_c, lp)
     worst = (0.0, "")
     for name, off, p in zip(tr_py.flat.names, tr_py.flat.offsets, tr_py.flat.params):

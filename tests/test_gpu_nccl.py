@@ -97,7 +97,7 @@ def _worker(rank, port, tmp):
                 want = eng_f.aux.cuda_stream               # (stage 1 of the next batch runs on the decoder-B stream)
             assert s == want, (w, s, want)
         for i, (lp, lf, gp, gf) in enumerate(hist):
-            # the run-to-run noise of either path: 2e-4 on the losses (tools/engine_noise.py); bound = 6x
+            # the run-to-run noise of either path: 2e-4 on the losses (tools/archive/engine_noise.py); bound = 6x
             assert torch.allclose(lf, lp, rtol=1.5e-3, atol=1e-6), (i, lf, lp)
             assert abs(gf - gp) <= 2e-3 * gp, (i, gf, gp)
             assert abs(taps[i] - gf) <= 1e-4 * gf, (i, taps[i], gf)      # the optimizer read the exchanged buffer

@@ -620,7 +620,7 @@ def test_explicit_schedule_matches_autograd_path(dev):
     """detector.train_step_explicit (no autograd tape / engine) vs forward_train + backward through the autograd
     Functions: the same kernels in the same order.  Two runs of EITHER path differ by ~1e-4 on the losses (the order
     of the points inside a pillar is the atomic arrival order of the counting sort, the BatchNorm partial sums follow
-    it, and bf16 rounding downstream amplifies the last-bit differences; tools/determinism_check.py), so the
+    it, and bf16 rounding downstream amplifies the last-bit differences; tools/archive/determinism_check.py), so the
     comparison uses that noise floor, not bit equality."""
     import copy
     model, _ = _build(dev, 2, 1, "bf16")
