@@ -411,52 +411,66 @@ __device__ __forceinline__ void wave_global_sync() {
 }
 
 // Segmented reduction of a [16 x 64*CPL] tile over the tile's points, lane = channel (+64 per extra channel).
-// The carry holds the open pillar across tiles; a finished pillar's row goes to out[pid][c]: a plain store
-// when the pillar lies inside the wave's point range, an atomic combine when it straddles the range (its
+// The carry holds the open pillar's partial result across tiles; a finished pillar's row goes to out[pid][c]: a plain
+// store when the pillar lies inside the wave's point range, an atomic combine when it straddles the range (its
 // other parts belong to neighbouring waves; `out` is zero-filled).  Max rows are >= 0 (post-ReLU), so the
-// integer atomicMax on the float bits is exact and order independent; sums use float atomicAdd (a pillar
-// cut in more than two parts may round differently from run to run in the last bit).
+// integer atomicMax on the float bits is exact and order independent (and 0 is the neutral start of a run); sums use
+// float atomicAdd (a pillar cut in more than two parts may round differently from run to run in the last bit).
+// Everything that steers the walk over the 16 points is WAVE-UNIFORM and lives in SGPRs: the run ends are a ballot of
+// (pillar of point j + 1 differs), a finished run's pillar id a v_readlane, the branches scalar.  (Until round 4 every
+// step read the point's pillar id back from LDS and branched on it as a vector value: 16 dependent LDS round trips
+// per tile, 5.5 k cycles = 45 % of the layer-1 forward sweep (tools/vfe_time.py).  The segmented scan in registers --
+// T-layout rows are DPP rows: row_shr 1 / 2 / 4 / 8 under a same-pillar mask -- was measured too: 480 VALU
+// instructions per tile instead of 32, 6 k cycles.)
 template <int CPL>
 struct SegCarry {
-    int pid;
-    bool shared;
     float cur[CPL];
-    __device__ __forceinline__ void init(bool) { pid = -1; shared = false; }
+    int first_pid, last_pid;         // the pillars of the wave's first / last point: they may continue in a neighbour's range
+    bool first_shared, last_shared;
+    __device__ __forceinline__ void init(const VfeGeo& G, const WaveRange& R) {
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) cur[k] = 0.f;
+        first_pid = last_pid = -1;
+        first_shared = last_shared = false;
+        if (R.j_lo < R.j_hi) {
+            first_pid = __builtin_amdgcn_readfirstlane(G.pid[R.j_lo]);
+            last_pid = __builtin_amdgcn_readfirstlane(G.pid[R.j_hi - 1]);
+            first_shared = __builtin_amdgcn_readfirstlane(G.seg_start[first_pid]) < R.j_lo;
+            last_shared = __builtin_amdgcn_readfirstlane(G.seg_start[last_pid + 1]) > R.j_hi;
+        }
+    }
 };
-template <int CPL, bool IS_MAX>
-__device__ __forceinline__ void seg_row_out(int C, float* __restrict__ out, const SegCarry<CPL>& c, bool shared, int lane) {
-#pragma unroll
-    for (int k = 0; k < CPL; ++k) {
-        float* dst = out + (int64_t)c.pid * C + lane + 64 * k;
-        if (!shared) *dst = c.cur[k];
-        else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k]));
-        else atomicAdd(dst, c.cur[k]);
-    }
-}
+// the pillar of point j + 1, or -1 behind the wave's last point (loaded beside the point's own pillar id)
+__device__ __forceinline__ int pillar_next(const VfeGeo& G, int j, const WaveRange& R) { return j + 1 < R.j_hi ? G.pid[j + 1] : -1; }
+
 template <int CPL, bool IS_MAX, int LD>
-__device__ __forceinline__ void seg_scan(const float* tile, const int* pids, int npts, int C, float* __restrict__ out,
-                                         const int32_t* __restrict__ seg_start, const WaveRange& R,
+__device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_next, bool valid, int C, float* __restrict__ out,
                                          SegCarry<CPL>& c, int lane) {
-    for (int t = 0; t < npts; ++t) {
-        const int p = pids[t];
-        if (p != c.pid) {
-            if (c.pid >= 0) seg_row_out<CPL, IS_MAX>(C, out, c, c.shared, lane);     // ends inside the range
-            c.shared = c.pid < 0 && seg_start[p] < R.j_lo;                           // only the first can start outside
-            c.pid = p;
+    const unsigned int live = (unsigned int)__ballot(valid) & 0xffffu;                       // lanes 0..15 hold the tile's points
+    const unsigned int ends = (unsigned int)__ballot(valid && pid_next != pid) & 0xffffu;    // ... the last point of a pillar's run
+    float x[16][CPL];
 #pragma unroll
-            for (int k = 0; k < CPL; ++k) c.cur[k] = IS_MAX ? -INFINITY : 0.f;
-        }
+    for (int t = 0; t < 16; ++t)
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) {
-            const float v = tile[t * LD + lane + 64 * k];
-            c.cur[k] = IS_MAX ? fmaxf(c.cur[k], v) : c.cur[k] + v;
+        for (int k = 0; k < CPL; ++k) x[t][k] = tile[t * LD + lane + 64 * k];
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+        if (!((live >> t) & 1u)) break;
+#pragma unroll
+        for (int k = 0; k < CPL; ++k) c.cur[k] = IS_MAX ? fmaxf(c.cur[k], x[t][k]) : c.cur[k] + x[t][k];
+        if ((ends >> t) & 1u) {
+            const int p = __builtin_amdgcn_readlane(pid, t);
+            const bool shared = (p == c.first_pid && c.first_shared) || (p == c.last_pid && c.last_shared);
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) {
+                float* dst = out + (int64_t)p * C + lane + 64 * k;
+                if (!shared) *dst = c.cur[k];
+                else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k]));
+                else atomicAdd(dst, c.cur[k]);
+                c.cur[k] = 0.f;
+            }
         }
     }
-}
-template <int CPL, bool IS_MAX>
-__device__ __forceinline__ void seg_flush(int C, float* __restrict__ out, const int32_t* __restrict__ seg_start,
-                                          const WaveRange& R, const SegCarry<CPL>& c, int lane) {
-    if (c.pid >= 0) seg_row_out<CPL, IS_MAX>(C, out, c, c.shared || seg_start[c.pid + 1] > R.j_hi, lane);
 }
 
 // sum over the 16 points of the tile and accumulate per-lane partials (kept until the end of the kernel)
@@ -596,6 +610,28 @@ struct Bn0 { const float *scale, *shift, *mean, *invstd; };
 __device__ __forceinline__ Bn1 shifted(const Bn1& b, int z) { return Bn1{b.scale + z, b.shift + z, b.mean + z, b.invstd + z}; }
 __device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale + z, b.shift + z, b.mean + z, b.invstd + z}; }
 
+// phase timing of the point loops (timing build only): wave 0 of the last 512 workgroups accumulates the cycles between
+// the marks of every tile; slots: 0 staging, 1 + k = from mark k to mark k + 1, 7 = whole kernel
+#ifdef GEOMAE_PHASE_TIMING
+#define VFE_T_ENTRY() const unsigned long long vt_entry = clock64()
+#define VFE_T_BEGIN() unsigned long long vt_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long vt_last = clock64(); const unsigned long long vt_begin = vt_last
+#define VFE_T(k) do { const unsigned long long c_ = clock64(); if ((k) > 0) vt_acc[(k) - 1] += c_ - vt_last; vt_last = c_; } while (0)
+#define VFE_T_END()                                                                                            \
+    do {                                                                                                       \
+        if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x) {                               \
+            unsigned long long* o_ = geomae_stamps + (blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS;  \
+            o_[0] = vt_begin - vt_entry;                                                                       \
+            for (int q_ = 0; q_ < 6; ++q_) o_[1 + q_] = vt_acc[q_];                                            \
+            o_[7] = clock64() - vt_entry;                                                                      \
+        }                                                                                                      \
+    } while (0)
+#else
+#define VFE_T_ENTRY() do {} while (0)
+#define VFE_T_BEGIN() do {} while (0)
+#define VFE_T(k) do {} while (0)
+#define VFE_T_END() do {} while (0)
+#endif
+
 // sweep 1 of layer 0: per-channel sum / sum of squares of y0 = W0 f over all points
 __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, double* __restrict__ sums0) {
     __shared__ float W0s[64 * 16];
@@ -627,7 +663,6 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, d
 __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, float* __restrict__ m0) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
-    __shared__ int pids[kVfeWaves][16];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0_FWD(W, Wl)
     __syncthreads();
@@ -635,24 +670,22 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, f
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
     SegCarry<1> carry;
-    carry.init(true);
+    carry.init(G, R);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int pid_next = valid ? pillar_next(G, j, R) : -1;
         float f[4];
         build_features(G, j, valid, g, f);
         f32x4 y[4], h[4];
         layer0_linear(W0s, f, y, lane);
         bn_relu<4>(y, Wl.scale0, Wl.shift0, h, lane);
         tile_store<4, kTile0Ld>(tile, h, lane);
-        if (g == 0) pids[wave][lane & 15] = pid;
         wave_sync();
-        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-        seg_scan<1, true, kTile0Ld>(tile, pids[wave], npts, 64, m0, G.seg_start, R, carry, lane);
+        seg_scan<1, true, kTile0Ld>(tile, pid, pid_next, valid, 64, m0, carry, lane);
         wave_sync();
     }
-    seg_flush<1, true>(64, m0, G.seg_start, R, carry, lane);
 }
 
 // recompute h0 and g = [h0 | m0[pid]] for the lane's point (shared by every later sweep so that the values
@@ -715,8 +748,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
-    __shared__ int pids[kVfeWaves][16];
     __shared__ __attribute__((aligned(16))) float bn1f_s[2][128];
+    VFE_T_ENTRY();
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
     VFE_STAGE_BN0_FWD(W, Ws)
@@ -725,29 +758,34 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     Ws.scale1 = bn1f_s[0];
     Ws.shift1 = bn1f_s[1];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_T_BEGIN();
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
     SegCarry<2> carry;
-    carry.init(true);
+    carry.init(G, R);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int pid_next = valid ? pillar_next(G, j, R) : -1;
         const int oz = opaque_zero();
         const VfeW Wl = shifted(Ws, oz);
         f32x4 y0[4], gin[8], y1[8], h1[8];
+        VFE_T(0);
         recompute_g(G, Wl, W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        VFE_T(1);
         layer1_linear(W1s + oz, split_operand(gin), y1, lane);
+        VFE_T(2);
         bn_relu<8>(y1, Wl.scale1, Wl.shift1, h1, lane);
         tile_store<8, kTileLd>(tile, h1, lane);
-        if (g == 0) pids[wave][lane & 15] = pid;
         wave_sync();
-        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-        seg_scan<2, true, kTileLd>(tile, pids[wave], npts, 128, vf, G.seg_start, R, carry, lane);
+        VFE_T(3);
+        seg_scan<2, true, kTileLd>(tile, pid, pid_next, valid, 128, vf, carry, lane);
         wave_sync();
+        VFE_T(4);
     }
-    seg_flush<2, true>(128, vf, G.seg_start, R, carry, lane);
+    VFE_T_END();
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -835,7 +873,6 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
-    __shared__ int pids[kVfeWaves][16];
     __shared__ float bn1s[2][128];                                         // S1/n, S2/n
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0_FWD(W, Ws)
@@ -858,11 +895,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     stage_w1(W.w1, W1s, false);
     __syncthreads();
     SegCarry<1> carry;
-    carry.init(false);
+    carry.init(G, R);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
+        const int pid_next = valid ? pillar_next(G, j, R) : -1;
         const int oz = opaque_zero();
         const Bn1 bnl = shifted(bns, oz);
         const float* bs0 = bn1s[0] + oz;
@@ -910,13 +948,10 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
                 }
             }
         }
-        if (g == 0) pids[wave][lane & 15] = pid;
         wave_sync();
-        const int npts = (R.j_hi - j0) < 16 ? (R.j_hi - j0) : 16;
-        seg_scan<1, false, kTile0Ld>(tile, pids[wave], npts, 64, dm0, G.seg_start, R, carry, lane);
+        seg_scan<1, false, kTile0Ld>(tile, pid, pid_next, valid, 64, dm0, carry, lane);
         wave_sync();
     }
-    seg_flush<1, false>(64, dm0, G.seg_start, R, carry, lane);
     (void)dy1_f;                                   // (kept in the C ABI; no longer written)
 }
 
@@ -1153,6 +1188,17 @@ static int vfe_common(const GeomaeVfeArgs* a, VfeGeo* G, VfeW* W, const char* wh
     return GEOMAE_OK;
 }
 static dim3 vfe_grid(const GeomaeVfeArgs* a) { return dim3(cdiv(cdiv(a->num_points, kVfePts), kVfeWaves)); }
+
+#ifdef GEOMAE_PHASE_TIMING
+extern "C" void geomae_debug_read_vfe_stamps(unsigned long long* out, int clear) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geomae::geomae_stamps), sizeof(unsigned long long) * GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS);
+    if (clear) {
+        static unsigned long long zeros[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(geomae::geomae_stamps), zeros, sizeof(zeros));
+    }
+}
+#endif
 
 extern "C" int geomae_vfe_prepare(const float* points, int32_t num_features, int64_t num_points, const int32_t* order,
                                   const int32_t* inv, const float* pillar_mean, const int32_t* voxel_coors,

@@ -1,0 +1,50 @@
+"""The fused VFE alone: per-kernel times (rocprofv3-free: HIP events around forward / backward) and, with the timing build
+(python tools/build_timing.py), the cycle split of the layer-1 forward sweep's point loop.
+Usage: python tools/vfe_time.py [sweeps ...]     (default: 1 10 = BASELINE configs 2 and 3, 4 frames)"""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from geomae_amd import _lib
+TIMING = os.path.exists(os.path.join(ROOT, "tools", "libgeomae_timing.so")) and not os.environ.get("GEOMAE_PRODUCT_LIB")
+lib = _lib.load(path=os.path.join(ROOT, "tools", "libgeomae_timing.so")) if TIMING else _lib.load()
+import geomae_amd
+from geomae_amd import synth, ops
+from geomae_amd.configs import mae_sst_model
+SL, NBLK = 32, 512
+NAMES = ["staging", "features + layer 0 + m0 gather", "split + layer-1 GEMM issue", "BN/ReLU + tile -> LDS", "segmented max (scalar-steered walk)", "(loop back)"]
+def read():
+    buf = np.zeros(NBLK * SL, dtype=np.uint64)
+    lib.geomae_debug_read_vfe_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.geomae_debug_read_vfe_stamps(buf.ctypes.data_as(ctypes.c_void_p), 1)
+    return buf.reshape(NBLK, SL).astype(np.int64)
+def timed(fn, reps=10):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); e1.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+dev = torch.device("cuda:0")
+cfg = mae_sst_model(); cfg["backbone"]["compute_dtype"] = "bf16"
+model = geomae_amd.build_model(cfg).to(dev).train()
+ve = model.voxel_encoder
+for sweeps in [int(a) for a in sys.argv[1:]] or [1, 10]:
+    pts = [torch.as_tensor(synth.lidar_frame(10000 + b, sweeps=sweeps), device=dev) for b in range(4)]
+    with torch.no_grad():
+        voxels, top, med, low = model.voxelize_all(pts)
+        seg = ops.pillar_segment(top, len(pts), model.grid_size)
+        prepared = ve.prepare_points(voxels, seg)
+        vf, state = ve.forward_explicit(voxels, seg, prepared=prepared)
+        dvf = torch.randn_like(vf)
+        for p in ve.parameters(): p.grad = None
+        t_prep = timed(lambda: ve.prepare_points(voxels, seg))
+        t_fwd = timed(lambda: ve.forward_explicit(voxels, seg, prepared=prepared))
+        t_bwd = timed(lambda: ve.backward_explicit(state, dvf))
+    print(f"sweeps {sweeps}: {voxels.shape[0]} points, {seg.V} pillars: prepare {t_prep:.0f} us, forward sweeps {t_fwd:.0f} us, backward {t_bwd:.0f} us")
+    if TIMING:
+        read()
+        with torch.no_grad(): ve.forward_explicit(voxels, seg, prepared=prepared)
+        st = read(); s = st[st[:, 7] > 0]
+        print(f"  vfe_layer1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 7].mean():.0f} max {s[:, 7].max()} cycles")
+        for k, nm in enumerate(NAMES): print(f"    {nm:36s} mean {s[:, k].mean():8.0f}  max {s[:, k].max():8.0f}")
