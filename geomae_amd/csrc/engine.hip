@@ -187,7 +187,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes_layers((int32_t)n, c.decoder_layers));
     b += al256(nk * 512) + 4 * al256(n * 512);                                                             // z_enc, cen, den, dxa, dxb
     b += al256(M * 896 * 2) + 2 * al256(M * 128 * 2);                                                      // heads
-    b += 2 * al256(N * 128 * 2) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);                         // VFE backward
+    b += 2 * al256((N + 15) / 16 * 16 * 128 * 2) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);                         // VFE backward
     return b + 8192;
 }
 
@@ -525,7 +525,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* dxa = a.take<float>((int64_t)n * 128);
     float* dxb = a.take<float>((int64_t)n * 128);
     char* h_dl = a.bytes(M * 896 * 2); char* h_cm = a.bytes(M * 128 * 2); char* h_dm = a.bytes(M * 128 * 2);
-    char* dy1_b = a.bytes(N * 128 * 2); char* g_b = a.bytes(N * 128 * 2);
+    char* dy1_b = a.bytes((N + 15) / 16 * 16 * 128 * 2); char* g_b = a.bytes((N + 15) / 16 * 16 * 128 * 2);   // tile-blocked
     float* dw1_partial = (float*)a.bytes(2 * kDwPartialBytes);      // split-K workspace of the layer-1 weight gradient
     float* dh0 = a.take<float>(N * 64);
     if (a.overflow) {

@@ -791,19 +791,16 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
 // ------------------------------------------------------------------------------------------------ backward
 // one output tile of the layer-1 backward inputs: dh[t][c] = dvf[pid][c] where h1[t][c] == vf[pid][c] > 0
 // (max-pool + ReLU routing on the recomputed, bit-identical forward value), yhat = (y1 - mean) * invstd
-__device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const float* __restrict__ vf,
-                                            const float* __restrict__ dvf, int pid, bool valid, int ot, int lane,
-                                            f32x4* dh, f32x4* yhat) {
+// (m, d: the pillar's rows of vf / dvf for this channel tile, gathered by routed_rows at the TOP of the tile's iteration:
+// inside the channel-tile loop each pair of gathers was waited for where it was issued, 4 x ~3.5 k cycles per tile --
+// 58 % of the layer-1 backward sweep, tools/vfe_time.py)
+__device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const float4 m, const float4 d, bool valid, int ot,
+                                            int lane, f32x4* dh, f32x4* yhat) {
     const int g = lane >> 4, c0 = 16 * ot + 4 * g;
     const float4 s = *reinterpret_cast<const float4*>(bn.scale + c0);
     const float4 b = *reinterpret_cast<const float4*>(bn.shift + c0);
     const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c0);
     const float4 is = *reinterpret_cast<const float4*>(bn.invstd + c0);
-    float4 m = make_float4(0, 0, 0, 0), d = m;
-    if (valid) {
-        m = *reinterpret_cast<const float4*>(vf + (int64_t)pid * 128 + c0);
-        d = *reinterpret_cast<const float4*>(dvf + (int64_t)pid * 128 + c0);
-    }
     const float sc[4] = {s.x, s.y, s.z, s.w}, sh[4] = {b.x, b.y, b.z, b.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w},
                 iv[4] = {is.x, is.y, is.z, is.w}, mx[4] = {m.x, m.y, m.z, m.w}, dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -811,6 +808,21 @@ __device__ __forceinline__ void routed_tile(const f32x4 y, const Bn1& bn, const 
         const float h = fmaxf(y[r] * sc[r] + sh[r], 0.f);          // exactly bn_relu's expression
         (*dh)[r] = (valid && h > 0.f && h == mx[r]) ? dd[r] : 0.f;
         (*yhat)[r] = (y[r] - mn[r]) * iv[r];
+    }
+}
+
+template <int NT>
+__device__ __forceinline__ void routed_rows(const float* __restrict__ vf, const float* __restrict__ dvf, int pid, bool valid,
+                                            int ot0, int lane, float4 (&m)[NT], float4 (&d)[NT]) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+        m[u] = make_float4(0, 0, 0, 0);
+        d[u] = m[u];
+        if (valid) {
+            m[u] = *reinterpret_cast<const float4*>(vf + (int64_t)pid * 128 + 16 * (ot0 + u) + 4 * g);
+            d[u] = *reinterpret_cast<const float4*>(dvf + (int64_t)pid * 128 + 16 * (ot0 + u) + 4 * g);
+        }
     }
 }
 
@@ -840,6 +852,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
             const int pid = valid ? pillar_of(G, j) : 0;
             const int oz = opaque_zero();
             const Bn1 bnl = shifted(bns, oz);
+            float4 mrow[4], drow[4];
+            routed_rows<4>(vf, dvf, pid, valid, 4 * half, lane, mrow, drow);
             f32x4 y0[4], gin[8];
             recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
             const BSplit gs = split_operand(gin);
@@ -851,7 +865,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 dh, yh;
-                    routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot0 + u, lane, &dh, &yh);
+                    routed_tile(y4[u], bnl, mrow[q + u], drow[q + u], valid, ot0 + u, lane, &dh, &yh);
                     s1[ot0 + u] += dh;
                     s2[ot0 + u] += dh * yh;
                 }
@@ -871,6 +885,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     float* __restrict__ dy1_f, float* __restrict__ dh0, float* __restrict__ dm0, float* __restrict__ d_beta1,
     float* __restrict__ d_gamma1) {
     __shared__ float W0s[64 * 16];
+    VFE_T_ENTRY();
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
     __shared__ float bn1s[2][128];                                         // S1/n, S2/n
@@ -896,6 +911,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     __syncthreads();
     SegCarry<1> carry;
     carry.init(G, R);
+    VFE_T_BEGIN();
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
@@ -906,10 +922,14 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         const float* bs0 = bn1s[0] + oz;
         const float* bs1 = bn1s[1] + oz;
         f32x4 dy1[8];
+        VFE_T(0);
+        float4 mrow[8], drow[8];
+        routed_rows<8>(vf, dvf, pid, valid, 0, lane, mrow, drow);
         {
             f32x4 y0[4], gin[8];
             recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
-            store_rows_bf16<128>(g_b, R.j_hi, j, 128, 0, gin, lane);      // rows >= j_hi belong to the next wave: dropped
+            store_rows_bf16<128>(g_b, G.n_points, j, 128, 0, gin, lane, true);   // tile-blocked (pad rows of the last tile: unread)
+            VFE_T(1);
             const BSplit gs = split_operand(gin);
 #pragma unroll
             for (int ot0 = 0; ot0 < 8; ot0 += 2) {
@@ -919,18 +939,19 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
                 for (int u = 0; u < 2; ++u) {
                     const int ot = ot0 + u;
                     f32x4 dh, yh;
-                    routed_tile(y4[u], bnl, vf, dvf, pid, valid, ot, lane, &dh, &yh);
+                    routed_tile(y4[u], bnl, mrow[ot], drow[ot], valid, ot, lane, &dh, &yh);
                     const int c0 = 16 * ot + 4 * g;
                     const float4 sc = *reinterpret_cast<const float4*>(bnl.scale + c0);    // gamma * invstd
                     const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dy1[ot][r] = valid ? scv[r] * (dh[r] - bs0[c0 + r] - yh[r] * bs1[c0 + r]) : 0.f;
-                    if (valid) *reinterpret_cast<uint2*>(dy1_b + (int64_t)j * 128 + c0) = pack4(dy1[ot]);   // operand of dW1
+                    if (valid) *reinterpret_cast<uint2*>(dy1_b + ((int64_t)(j >> 4) * 8 + ot) * 256 + (j & 15) * 16 + 4 * g) = pack4(dy1[ot]);   // operand of dW1, tile-blocked
                 }
             }
         }
         // dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
         const float* W1l = W1s + opaque_zero();
+        VFE_T(2);
         const BSplit ds = split_operand(dy1);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
@@ -949,9 +970,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
             }
         }
         wave_sync();
+        VFE_T(3);
         seg_scan<1, false, kTile0Ld>(tile, pid, pid_next, valid, 64, dm0, carry, lane);
         wave_sync();
+        VFE_T(4);
     }
+    VFE_T_END();
     (void)dy1_f;                                   // (kept in the C ABI; no longer written)
 }
 
@@ -1394,6 +1418,7 @@ extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16,
     GEOMAE_REQUIRE(dy1_bf16 && g_bf16 && dw1, "vfe_weight_grad1: null argument");
     DwTasks T;
     T.t[0] = {(const bf16_t*)dy1_bf16, 128, 0, (const bf16_t*)g_bf16, 128, 0, dw1, 128, 0, 0, nullptr, 128};
+    T.blocked = 1;                   // (as vfe_bwd_layer1_kernel writes them)
     T.partial = dw_partial();        // a caller's split-K workspace (csrc/engine.hip), summed by its next geomae_flush_weight_grad
     return launch_dw(T, 1, (int)num_points, stream);
 }

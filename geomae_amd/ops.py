@@ -1306,8 +1306,8 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, sid
         params["g1"].grad.add_(bs1[128:])
         dist.all_reduce(bs1, group=group)
     n_eff = float(world * N)
-    dy1_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
-    g_b = torch.empty((N, 128), dtype=torch.bfloat16, device=dev)
+    dy1_b = torch.empty(((N + 15) // 16 * 16, 128), dtype=torch.bfloat16, device=dev)     # tile-blocked scratch operands
+    g_b = torch.empty(((N + 15) // 16 * 16, 128), dtype=torch.bfloat16, device=dev)
     dh0 = torch.empty((N, 64), dtype=torch.float32, device=dev)
     dm0 = _zeros_or_empty(zeros, (max(V, 1), 64), torch.float32, dev)
     bs0 = _zeros_or_empty(zeros, (128,), torch.float64, dev)

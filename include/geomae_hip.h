@@ -458,7 +458,7 @@ int geomae_vfe_backward_stats(const GeomaeVfeArgs* args, const GeomaeBnState* bn
                               geomaeStream_t stream);
 int geomae_vfe_backward_layer1(const GeomaeVfeArgs* args, const GeomaeBnState* bn, const float* m0,
                                const float* voxel_feats, const float* d_voxel_feats, const double* bsums1_global,
-                               float n_eff, void* dy1_bf16 /*[N,128]*/, void* g_bf16 /*[N,128]*/,
+                               float n_eff, void* dy1_bf16 /*[ceil16(N),128] tile-blocked*/, void* g_bf16 /*same*/,
                                float* dy1_f32 /* unused since the one-sweep kernel: may be NULL */, float* dh0 /*[N,64]*/, float* dm0 /*[V,64]*/,
                                double* bsums0 /*[128]*/, float* d_beta1 /*[128] += or NULL*/,
                                float* d_gamma1 /*[128] += or NULL*/, geomaeStream_t stream);
@@ -467,7 +467,10 @@ int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* b
                                const void* g_bf16, float* dw0 /*[64,11] +=*/, float* dw1 /*[128,128] +=*/,
                                float* d_beta0 /*[64] += or NULL*/, float* d_gamma0 /*[64] += or NULL*/,
                                geomaeStream_t stream);
-/* dw1 += dy1^T g (the layer-1 weight gradient): geomae_vfe_backward_layer0 runs it last unless its dw1 is NULL; a
+/* dy1_bf16 / g_bf16 are scratch operands between geomae_vfe_backward_layer1 and the dW1 contraction, in the TILE-BLOCKED
+ * layout of the layer stacks' slabs: [ceil(N/16)][8 channel tiles][16 points][16 channels] bf16 -- (N + 15) / 16 * 16 rows
+ * of 256 bytes; the sweep's T-layout lanes then store whole 512-byte blocks (row-major: 32-byte pieces of 16 rows).
+ * dw1 += dy1^T g (the layer-1 weight gradient): geomae_vfe_backward_layer0 runs it last unless its dw1 is NULL; a
  * caller may instead launch it on another stream right after geomae_vfe_backward_layer1, beside the two kernels of
  * the layer-0 backward (it is read only by the optimizer). */
 int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1 /*[128,128] +=*/,
