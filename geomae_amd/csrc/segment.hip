@@ -81,7 +81,7 @@ __device__ __forceinline__ int block_excl_scan(int v, int* total, int* smem /*>=
 // (published as soon as they are known), flag 2 = the inclusive prefix up to and including the tile.  A tile finds its
 // exclusive prefix by walking back over the status words: inclusive prefixes end the walk, aggregates are added and the
 // walk goes on, zero (= not yet published) is polled.  The value travels INSIDE the word that carries the flag, so no
-// fence is needed (an agent-scope fence is an L2 write-back on this 8-XCD part, ~20 us per launch: DESIGN section 4);
+// fence is needed (an agent-scope fence is an L2 write-back on this 8-XCD part, ~20 us per launch: docs/LAB_NOTES.md, rounds 1-3);
 // the words are written and read with agent-scope atomics, which bypass the non-coherent per-XCD L2.  Tiles are handed
 // out by a ticket counter, so a tile's predecessors have always started (no dependence on the dispatch order).
 // status [tiles] + ticket live in the caller's workspace and must be ZERO at launch.

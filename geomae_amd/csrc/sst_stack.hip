@@ -294,7 +294,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     // The weight-gradient contraction of layer l only feeds .grad: it rides inside the ffn-backward launch of layer
     // l-1 (sst_ffn_bwd_dw_kernel), reading the slab set the three kernels of layer l left behind while layer l-1
     // writes the other set.  (Running it on a second stream instead was tried and rejected: the cross-queue event
-    // hops cost more than the overlap gained)
+    // hops cost more than the overlap gained, docs/LAB_NOTES.md, rounds 1-3.)
     const char* base = (const char*)saved;
     char* w = (char*)scratch;
     struct DwPartialScope {                         // this stack's contractions sum through the scratch, not atomics

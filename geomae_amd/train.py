@@ -140,7 +140,7 @@ def _wait_all(works):
     """Make the current stream wait for the gradient-segment all-reduces.  On RCCL every collective of one process group
     runs on that group's communication stream, in issue order: waiting for the LAST one orders the current stream behind
     all of them with one cross-queue wait instead of one per segment (each costs ~10 us of queue time on the waiting
-    stream).  Other backends (gloo: host threads) are waited for one by one."""
+    stream, docs/LAB_NOTES.md rounds 1-3).  Other backends (gloo: host threads) are waited for one by one."""
     if not works:
         return
     # The single wait leans on ProcessGroupNCCL's one-communication-stream-per-group behaviour (an implementation detail of

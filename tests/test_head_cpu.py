@@ -5,7 +5,7 @@ The head is torch-only by design (SURVEY: "leave to MIOpen/PyTorch"), so this ru
 What the fixture pins: the reference's own Anchor3DHead / train_mixins / anchor generator / box coder code.  What it
 cannot pin: mmdet 2.20's MaxIoUAssigner, FocalLoss, SmoothL1Loss and bbox_overlaps, which are absent from the tree and
 the image -- the generator ran the reference head with the SAME restatements of them standing in (make_golden_head.py), so
-for target assignment and the loss formulas this is a self-consistency check ("parity unpinned", DESIGN section 5)."""
+for target assignment and the loss formulas this is a self-consistency check ("parity unpinned", DESIGN section 6)."""
 import os
 import sys
 
