@@ -88,6 +88,15 @@ __device__ __forceinline__ int blk_off(int tok, int ld, int ct, int g) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p), 0, kFOor, 0x00020000);   // (offsets >= kFOor are out of range)
 }
+// (timing ablations: FUSED_ABL_NO_SAVE drops every store of the saved activations -- descriptors of zero records --,
+// FUSED_ABL_NO_Z the layer's output too: what the bytes a launch leaves dirty in L2 cost at its end)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t saved_rsrc(const void* p) {
+#ifdef FUSED_ABL_NO_SAVE
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p), 0, 0, 0x00020000);
+#else
+    return whole_rsrc(p);
+#endif
+}
 __device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
 }
@@ -187,7 +196,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t xres = whole_rsrc(A.M.src ? A.M.src : A.x);
         const __amdgpu_buffer_rsrc_t pres = whole_rsrc(A.pos_table);
-        const __amdgpu_buffer_rsrc_t xb_r = whole_rsrc(A.xb), xp_r = whole_rsrc(A.xp);
+        const __amdgpu_buffer_rsrc_t xb_r = saved_rsrc(A.xb), xp_r = saved_rsrc(A.xp);
         f32x4 pv[NT];
         FOR_TILES(it) {
             const int tk = rec[it].x;
@@ -235,7 +244,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     // ---- phase B: q, k (T-layout), v (T-layout for the backward, untransposed for P V) of head w
     uint2 qf[NT], kf[NT], vtf[NT];
     {
-        const __amdgpu_buffer_rsrc_t qkv_r = whole_rsrc(A.qkv);
+        const __amdgpu_buffer_rsrc_t qkv_r = saved_rsrc(A.qkv);
         const f32x4 bq = load_f4(prm + kPBq + 16 * w + 4 * g), bk = load_f4(prm + kPBq + 128 + 16 * w + 4 * g);
         const f32x4 bv = load_f4(prm + kPBq + 256 + 16 * w + 4 * g);
         const float bvn = prm[kPBq + 256 + 16 * w + t];
@@ -270,7 +279,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 
     // ---- phase C: attention of head w over the bundle, block-diagonal by window
     {
-        const __amdgpu_buffer_rsrc_t attn_r = whole_rsrc(A.attn), lse_r = whole_rsrc(A.lse);
+        const __amdgpu_buffer_rsrc_t attn_r = saved_rsrc(A.attn), lse_r = saved_rsrc(A.lse);
         const float scale = 0.25f;                                   // 1 / sqrt(16)
         FOR_TILES(it) {
             const int first = 16 * it;
@@ -355,7 +364,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     __syncthreads();                                                                           // (3) LayerNorm-1 statistics
     FUSED_STAMP(7);
     {
-        const __amdgpu_buffer_rsrc_t xh1_r = whole_rsrc(A.xh1), rstd_r = whole_rsrc(A.rstd);
+        const __amdgpu_buffer_rsrc_t xh1_r = saved_rsrc(A.xh1), rstd_r = saved_rsrc(A.rstd);
         const f32x4 g1 = load_f4(prm + kPG1 + 16 * w + 4 * g), be1 = load_f4(prm + kPBe1 + 16 * w + 4 * g);
         FOR_TILES(it) {
             float mean, rstd;
@@ -375,7 +384,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 
     // ---- phase E: h = gelu(y W1^T + b1), channel tiles 2w, 2w + 1
     {
-        const __amdgpu_buffer_rsrc_t hp_r = whole_rsrc(A.hp);
+        const __amdgpu_buffer_rsrc_t hp_r = saved_rsrc(A.hp);
         const f32x4 b1a = load_f4(prm + kPB1 + 32 * w + 4 * g), b1b = load_f4(prm + kPB1 + 32 * w + 16 + 4 * g);
         FOR_TILES(it) {
             const char* yrow = X + (16 * it + t) * kFRow + 16 * g;
@@ -417,7 +426,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     __syncthreads();                                                                           // (6) LayerNorm-2 statistics
     FUSED_STAMP(13);
     {
-        const __amdgpu_buffer_rsrc_t xh2_r = whole_rsrc(A.xh2), rstd_r = whole_rsrc(A.rstd), z_r = whole_rsrc(A.z);
+        const __amdgpu_buffer_rsrc_t xh2_r = saved_rsrc(A.xh2), rstd_r = saved_rsrc(A.rstd), z_r = whole_rsrc(A.z);
         const f32x4 g2 = load_f4(prm + kPG2 + 16 * w + 4 * g), be2 = load_f4(prm + kPBe2 + 16 * w + 4 * g);
         FOR_TILES(it) {
             float mean, rstd;
@@ -430,7 +439,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             }
             const f32x4 zz = xh * g2 + be2;
             const int zo = tk < 0 ? kFOor : (A.z_blocked ? blk_off<4>(tk, 128, w, g) : tk * 512 + 64 * w + 16 * g);
+#ifndef FUSED_ABL_NO_Z
             buf_store_f32x4(z_r, zo, zz);
+#endif
         }
     }
     FUSED_STAMP(14);
