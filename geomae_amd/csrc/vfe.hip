@@ -616,10 +616,11 @@ __device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale
 #define VFE_T_ENTRY() const unsigned long long vt_entry = clock64()
 #define VFE_T_BEGIN() unsigned long long vt_acc[6] = {0, 0, 0, 0, 0, 0}; unsigned long long vt_last = clock64(); const unsigned long long vt_begin = vt_last
 #define VFE_T(k) do { const unsigned long long c_ = clock64(); if ((k) > 0) vt_acc[(k) - 1] += c_ - vt_last; vt_last = c_; } while (0)
-#define VFE_T_END()                                                                                            \
+#define VFE_T_END() VFE_T_END_AT(0)
+#define VFE_T_END_AT(base_)                                                                                    \
     do {                                                                                                       \
         if (threadIdx.x == 0 && blockIdx.x + GEOMAE_STAMP_BLOCKS >= gridDim.x) {                               \
-            unsigned long long* o_ = geomae_stamps + (blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS;  \
+            unsigned long long* o_ = geomae_stamps + (blockIdx.x % GEOMAE_STAMP_BLOCKS) * GEOMAE_STAMP_SLOTS + (base_);  \
             o_[0] = vt_begin - vt_entry;                                                                       \
             for (int q_ = 0; q_ < 6; ++q_) o_[1 + q_] = vt_acc[q_];                                            \
             o_[7] = clock64() - vt_entry;                                                                      \
@@ -630,6 +631,7 @@ __device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale
 #define VFE_T_BEGIN() do {} while (0)
 #define VFE_T(k) do {} while (0)
 #define VFE_T_END() do {} while (0)
+#define VFE_T_END_AT(base_) do {} while (0)
 #endif
 
 // sweep 1 of layer 0: per-channel sum / sum of squares of y0 = W0 f over all points
@@ -992,14 +994,13 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
                                                                  const double* __restrict__ moments, float inv_n,
                                                                  float* __restrict__ dw0_acc) {
     __shared__ float W0s[64 * 16];
+    VFE_T_ENTRY();
     __shared__ float red[kVfeWaves * 2 * 64];
     __shared__ __attribute__((aligned(16))) float tiles[ACC ? kVfeWaves : 1][ACC ? 16 * kTile0Ld : 4];   // [t][0..63] dh0, [t][64..79] ft
-    __shared__ float acc_s[ACC ? 64 * 16 : 4];
     __shared__ float mu_s[16];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0(bn0, bn0l)
     if (ACC) {
-        for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) acc_s[e] = 0.f;
         if (threadIdx.x < 16) mu_s[threadIdx.x] = threadIdx.x < 11 ? (float)(moments[threadIdx.x] * (double)inv_n) : 0.f;
     }
     __syncthreads();
@@ -1009,7 +1010,9 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
     f32x4 s1[4], s2[4], dw[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; dw[ot] = f32x4{0, 0, 0, 0}; }
+    VFE_T_BEGIN();
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        VFE_T(0);
         const int j = j0 + (lane & 15);
         const bool valid = j < R.j_hi;
         const int pid = valid ? pillar_of(G, j) : 0;
@@ -1019,6 +1022,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
         build_features(G, j, valid, g, f);
         f32x4 y0[4];
         layer0_linear(W0s + oz, f, y0, lane);
+        VFE_T(1);
         f32x4 dhv[4];
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot) {
@@ -1048,6 +1052,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
             }
             if (!ACC && valid) *reinterpret_cast<float4*>(dh0 + (int64_t)j * 64 + c0) = make_float4(dhv[ot][0], dhv[ot][1], dhv[ot][2], dhv[ot][3]);
         }
+        VFE_T(2);
         if (ACC) {
             // A[o][k] += sum_t dh0[t][o] ft[t][k]: token contraction -> tile through LDS, MFMA with k = t
             tile_store<4, kTile0Ld>(tile, dhv, lane);
@@ -1060,6 +1065,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
             }
             *reinterpret_cast<float4*>(tile + (lane & 15) * kTile0Ld + 64 + 4 * g) = ft;
             wave_sync();
+            VFE_T(3);
             const int o = lane & 15;
 #pragma unroll
             for (int ot = 0; ot < 4; ++ot)
@@ -1070,18 +1076,31 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
                     dw[ot] = mfma_f32(a, b, dw[ot]);
                 }
             wave_sync();
+            VFE_T(4);
         }
     }
+    VFE_T(5);
+    // the waves' partial contractions meet in LDS as plain stores into per-wave slices of the (now free) tile buffer and are
+    // summed by the flush below.  (LDS float atomics into one [64][16] array serialise: 31 k of the kernel's 60 k cycles.)
+    float* part = &tiles[0][0];                                      // [kVfeWaves][64 * 16]
+    static_assert(!ACC || kVfeWaves * 16 * kTile0Ld >= kVfeWaves * 64 * 16, "the tile buffer must hold the partials");
     if (ACC) {
+        __syncthreads();                                             // every wave is done with its tile
         // dw[ot][r] = A[16*ot + 4g + r][feature = lane & 15]
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) atomicAdd(&acc_s[(16 * ot + 4 * g + r) * 16 + (lane & 15)], dw[ot][r]);
+            for (int r = 0; r < 4; ++r) part[wave * 1024 + (16 * ot + 4 * g + r) * 16 + (lane & 15)] = dw[ot][r];
     }
     flush_channel_sums<4>(s1, s2, bsums0, 64, red, lane, wave);      // (contains the workgroup barrier the flush below needs)
     if (ACC)
-        for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) atomicAdd(dw0_acc + e, acc_s[e]);
+        for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w8 = 0; w8 < kVfeWaves; ++w8) sum += part[w8 * 1024 + e];
+            atomicAdd(dw0_acc + e, sum);
+        }
+    if (ACC) { VFE_T_END_AT(8); }
 }
 
 // dW0 from the accumulated contraction and the feature moments (one workgroup; fp64 arithmetic):
@@ -1129,11 +1148,9 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
                                                                  float* __restrict__ d_gamma0) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];     // [t][0..63] dy0, [t][64..79] f
-    __shared__ float acc_s[64 * 16];
     __shared__ float bn0s[2][64];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0(bn0, bn0l)
-    for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) acc_s[e] = 0.f;
     for (int c = threadIdx.x; c < 64; c += kVfeBlk) {
         bn0s[0][c] = (float)(bsums0[c] / (double)n_eff);
         bn0s[1][c] = (float)(bsums0[64 + c] / (double)n_eff);
@@ -1187,15 +1204,21 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer0_kernel(VfeGeo G, VfeW 
             }
         wave_sync();
     }
-    // dw[ot][r] = dW0[16*ot + 4g + r][feature = lane & 15]
+    // dw[ot][r] = dW0[16*ot + 4g + r][feature = lane & 15]: per-wave slices of the tile buffer, summed below (no LDS atomics,
+    // as in vfe_bwd_route0_kernel)
+    __syncthreads();                                                 // every wave is done with its tile
+    float* part = &tiles[0][0];                                      // [kVfeWaves][64 * 16]
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) atomicAdd(&acc_s[(16 * ot + 4 * g + r) * 16 + (lane & 15)], dw[ot][r]);
+        for (int r = 0; r < 4; ++r) part[wave * 1024 + (16 * ot + 4 * g + r) * 16 + (lane & 15)] = dw[ot][r];
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
         const int r = e >> 4, c = e & 15;
-        if (c < 11) atomicAdd(dw0 + r * 11 + c, acc_s[e]);
+        float sum = 0.f;
+#pragma unroll
+        for (int w8 = 0; w8 < kVfeWaves; ++w8) sum += part[w8 * 1024 + e];
+        if (c < 11) atomicAdd(dw0 + r * 11 + c, sum);
     }
 }
 

@@ -14,6 +14,7 @@ from geomae_amd.configs import mae_sst_model
 SL, NBLK = 32, 512
 NAMES = ["staging", "features + layer 0 + m0 gather", "split + layer-1 GEMM issue", "BN/ReLU + tile -> LDS", "segmented max (scalar-steered walk)", "(loop back)"]
 NAMES_B = ["staging", "features + layer 0 + m0 gather + g store", "GEMM 1 + routing gathers + dy1 stores", "GEMM 2 (W1^T) + dh0 stores + tile", "segmented sum"]
+NAMES_R = ["staging", "features + layer 0", "routing (m0 / dm0 / dh0 gathers)", "tile + features -> LDS", "contraction MFMAs", "(loop back)", "after the loop"]
 def read():
     buf = np.zeros(NBLK * SL, dtype=np.uint64)
     lib.geomae_debug_read_vfe_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -54,3 +55,6 @@ for sweeps in [int(a) for a in sys.argv[1:]] or [1, 10]:
         st = read(); s = st[st[:, 7] > 0]
         print(f"  vfe_bwd_layer1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 7].mean():.0f} max {s[:, 7].max()} cycles")
         for k, nm in enumerate(NAMES_B): print(f"    {nm:36s} mean {s[:, k].mean():8.0f}  max {s[:, k].max():8.0f}")
+        s = st[st[:, 15] > 0]
+        print(f"  vfe_bwd_route0_kernel<true>: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 15].mean():.0f} max {s[:, 15].max()} cycles")
+        for k, nm in enumerate(NAMES_R): print(f"    {nm:36s} mean {s[:, 8 + k].mean():8.0f}  max {s[:, 8 + k].max():8.0f}")
