@@ -47,7 +47,7 @@ class GeomaeSstStackLayout(ctypes.Structure):
 class GeomaeVfeArgs(ctypes.Structure):
     _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("num_points", c_int64),
                 ("max_pillars", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
-                ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p)]
+                ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p), ("pillar_ties", c_void_p)]
 
 
 class GeomaeSweepInfo(ctypes.Structure):

@@ -175,7 +175,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
     const int64_t n = V < 1 ? 1 : V, M = n, nk = n;
     int64_t b = 0;
     b += al256(256 * 8) + al256(128 * 8) + 3 * al256(n * 512) + al256(n * 512) + al256(n * 256) + al256(4096);   // zeros_late
-    b += 6 * al256(128 * 4) + al256(256 * 4) * 2 + al256(128 * 8) + al256(n * 256) + al256(256 * 8) + al256(n * 512);  // zeros_fwd
+    b += 6 * al256(128 * 4) + al256(256 * 4) * 2 + al256(128 * 8) + al256(n * 256) + al256(256 * 8) + al256(n * 512) + al256(n);  // zeros_fwd
     b += al256(n * 16);                                                                                    // coors_all
     b += 2 * window_layout_bytes(c, nk) + 2 * window_layout_bytes(c, n);
     int32_t ns[4] = {(int32_t)nk, (int32_t)nk, (int32_t)n, (int32_t)n};
@@ -480,6 +480,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* m0 = a.take<float>((int64_t)V * 64);
     double* sums1 = a.take<double>(256);
     float* vf = a.take<float>((int64_t)V * 128);
+    uint8_t* vfe_ties = a.take<uint8_t>((int64_t)V);       // pillars whose maximum two points may share (GeomaeVfeArgs.pillar_ties)
     const int64_t zf_bytes = (a.base + a.off) - zf0;
     int32_t* coors_all = a.take<int32_t>((int64_t)n * 4);
     WinLayout lay[4];
@@ -613,7 +614,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     va.num_points = N; va.max_pillars = V;
     va.w0 = m.vfe_w0; va.w1 = m.vfe_w1;
     va.scale0 = bn_scale0; va.shift0 = bn_shift0; va.scale1 = bn_scale1; va.shift1 = bn_shift1;
-    va.moments = b.moments; va.dw0_acc = dw0_acc;
+    va.moments = b.moments; va.dw0_acc = dw0_acc; va.pillar_ties = vfe_ties;
     if (b.moments_exchanged) {
         // (mean, mean of squares) of all ranks straight from the averaged moments: no collective in the VFE forward
         GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[e->pending == 0 ? kMoments0 : kMoments1], 0));

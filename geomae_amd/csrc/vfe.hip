@@ -427,7 +427,9 @@ struct SegCarry {
     float cur[CPL];
     int first_pid, last_pid;         // the pillars of the wave's first / last point: they may continue in a neighbour's range
     bool first_shared, last_shared;
+    bool tie;                        // (TRACK) the open run: two of its points shared the running maximum (> 0) of a lane's channel
     __device__ __forceinline__ void init(const VfeGeo& G, const WaveRange& R) {
+        tie = false;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) cur[k] = 0.f;
         first_pid = last_pid = -1;
@@ -443,9 +445,12 @@ struct SegCarry {
 // the pillar of point j + 1, or -1 behind the wave's last point (loaded beside the point's own pillar id)
 __device__ __forceinline__ int pillar_next(const VfeGeo& G, int j, const WaveRange& R) { return j + 1 < R.j_hi ? G.pid[j + 1] : -1; }
 
-template <int CPL, bool IS_MAX, int LD>
+// ties (max only, or null): ties[p] = 1 for every pillar whose maximum MAY be held by more than one point in some channel
+// -- conservatively: any equality with the RUNNING maximum of the run counts, and so does a part of a straddling pillar
+// that finds its own maximum already stored by another part.  A pillar that stays 0 has exactly one arg-max per channel.
+template <int CPL, bool IS_MAX, int LD, bool TRACK = false>
 __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_next, bool valid, int C, float* __restrict__ out,
-                                         SegCarry<CPL>& c, int lane) {
+                                         SegCarry<CPL>& c, int lane, unsigned char* __restrict__ ties = nullptr) {
     const unsigned int live = (unsigned int)__ballot(valid) & 0xffffu;                       // lanes 0..15 hold the tile's points
     const unsigned int ends = (unsigned int)__ballot(valid && pid_next != pid) & 0xffffu;    // ... the last point of a pillar's run
     float x[16][CPL];
@@ -457,7 +462,10 @@ __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_nex
     for (int t = 0; t < 16; ++t) {
         if (!((live >> t) & 1u)) break;
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) c.cur[k] = IS_MAX ? fmaxf(c.cur[k], x[t][k]) : c.cur[k] + x[t][k];
+        for (int k = 0; k < CPL; ++k) {
+            if (TRACK) c.tie |= x[t][k] == c.cur[k] && x[t][k] > 0.f;
+            c.cur[k] = IS_MAX ? fmaxf(c.cur[k], x[t][k]) : c.cur[k] + x[t][k];
+        }
         if ((ends >> t) & 1u) {
             const int p = __builtin_amdgcn_readlane(pid, t);
             const bool shared = (p == c.first_pid && c.first_shared) || (p == c.last_pid && c.last_shared);
@@ -465,29 +473,50 @@ __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_nex
             for (int k = 0; k < CPL; ++k) {
                 float* dst = out + (int64_t)p * C + lane + 64 * k;
                 if (!shared) *dst = c.cur[k];
+                else if (IS_MAX && TRACK) c.tie |= atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k])) == __float_as_int(c.cur[k]) && c.cur[k] > 0.f;
                 else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k]));
                 else atomicAdd(dst, c.cur[k]);
                 c.cur[k] = 0.f;
+            }
+            if (TRACK) {
+                if (ties && __any(c.tie) && lane == 0) ties[p] = 1;
+                c.tie = false;
             }
         }
     }
 }
 
-// sum over the 16 points of the tile and accumulate per-lane partials (kept until the end of the kernel)
+// End of a statistics sweep: the lanes' partial sums s1 / s2 (T-layout: lane = point slot t of every tile the wave swept,
+// lane group g = 4 channels of every 16) -> per-channel sums over all points, added to out[2C] in fp64.
+// The sum over the 16 point lanes goes through LDS: the wave stores a tensor token-major into its slice of `scratch`
+// (NT x ds_write_b128), every lane then sums one channel column over the 16 rows; the waves' columns meet in `red`
+// and one thread per channel adds the workgroup's sum with a single fp64 atomic.  (In registers the same reduction is
+// 4 DPP steps for each of the 8 NT values of a lane plus a leader-lane store per value: ~800 instructions, 10.9 k
+// cycles at the end of vfe_bwd_stats1_kernel = 17 % of it, tools/vfe_time.py.)
+// scratch: LDS, kVfeWaves * 16 * (16 NT + 4) floats, free at the call (the caller's weight / tile buffer); the function
+// starts with the workgroup barrier that makes it so.
 template <int NT>
 __device__ __forceinline__ void flush_channel_sums(const f32x4 (&s1)[NT], const f32x4 (&s2)[NT], double* __restrict__ out, int C,
-                                                   float* red /* LDS [waves][2*C] */, int lane, int wave) {
-    const int g = lane >> 4;
+                                                   float* red /* LDS [waves][2*C] */, float* scratch, int lane, int wave) {
+    constexpr int LD = 16 * NT + 4;
+    float* mine = scratch + wave * 16 * LD;
+    __syncthreads();                                                  // every wave is done with the buffer behind `scratch`
 #pragma unroll
-    for (int ot = 0; ot < NT; ++ot)
+    for (int half = 0; half < 2; ++half) {
+        tile_store<NT, LD>(mine, half == 0 ? s1 : s2, lane);
+        wave_sync();
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = tok_sum(s1[ot][r]), b = tok_sum(s2[ot][r]);
-            if ((lane & 15) == 0) {
-                red[wave * 2 * C + 16 * ot + 4 * g + r] = a;
-                red[wave * 2 * C + C + 16 * ot + 4 * g + r] = b;
+        for (int k = 0; k < (16 * NT + 63) / 64; ++k) {
+            const int c = lane + 64 * k;
+            if (c < 16 * NT) {
+                float sum = 0.f;
+#pragma unroll
+                for (int t = 0; t < 16; ++t) sum += mine[t * LD + c];
+                red[wave * 2 * C + half * C + c] = sum;
             }
         }
+        wave_sync();
+    }
     __syncthreads();
     for (int e = threadIdx.x; e < 2 * C; e += kVfeBlk) {
         float s = 0.f;
@@ -638,6 +667,7 @@ __device__ __forceinline__ Bn0 shifted(const Bn0& b, int z) { return Bn0{b.scale
 __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, double* __restrict__ sums0) {
     __shared__ float W0s[64 * 16];
     __shared__ float red[kVfeWaves * 2 * 64];
+    __shared__ __attribute__((aligned(16))) float fl_s[kVfeWaves * 16 * 68];
     stage_w0(W.w0, W0s);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
@@ -657,7 +687,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, d
             for (int ot = 0; ot < 4; ++ot) { s1[ot] += y[ot]; s2[ot] += y[ot] * y[ot]; }
         }
     }
-    flush_channel_sums<4>(s1, s2, sums0, 64, red, lane, wave);
+    flush_channel_sums<4>(s1, s2, sums0, 64, red, fl_s, lane, wave);
 }
 
 // sweep 2 of layer 0: h0 = ReLU(BN(y0)), m0 = segmented max (m0 zero-filled by the caller: rows of pillars
@@ -741,12 +771,13 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
             }
         }
     }
-    flush_channel_sums<8>(s1, s2, sums1, 128, red, lane, wave);
+    static_assert(128 * kW1Ld >= kVfeWaves * 16 * 132, "the W1 buffer must hold the flush scratch");
+    flush_channel_sums<8>(s1, s2, sums1, 128, red, W1s, lane, wave);
 }
 
 // sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max (zero-filled by the caller)
 __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
-                                                             float* __restrict__ vf) {
+                                                             float* __restrict__ vf, unsigned char* __restrict__ ties) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
@@ -783,7 +814,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
         tile_store<8, kTileLd>(tile, h1, lane);
         wave_sync();
         VFE_T(3);
-        seg_scan<2, true, kTileLd>(tile, pid, pid_next, valid, 128, vf, carry, lane);
+        seg_scan<2, true, kTileLd, true>(tile, pid, pid_next, valid, 128, vf, carry, lane, ties);
         wave_sync();
         VFE_T(4);
     }
@@ -828,10 +859,80 @@ __device__ __forceinline__ void routed_rows(const float* __restrict__ vf, const 
     }
 }
 
+// The same two sums from the pillar rows alone, for the pillars with exactly one arg-max point per channel (ties[p] == 0,
+// GeomaeVfeArgs.pillar_ties): the routed gradient of channel c over the pillar's points is d_vf[p][c] at that one point if
+// vf[p][c] > 0 and nothing otherwise, and the point's yhat is ((vf - shift) / scale - mean) * invstd.  [V,128] x 2 rows
+// instead of a sweep of layer 0 + the 128 x 128 GEMM over all points; the sweep below handles the flagged pillars' points
+// (two distinct points DO produce the same fp32 maximum now and then: ~1 in 10^6 (pillar, channel) pairs on LiDAR frames).
+__global__ __launch_bounds__(1024) void vfe_bwd_stats1_pillars_kernel(const float* __restrict__ vf, const float* __restrict__ dvf,
+                                                                       int num_pillars, Bn1 bn,
+                                                                       const unsigned char* __restrict__ ties,
+                                                                       double* __restrict__ bsums1) {
+    // 32 pillar lanes x 32 channel quads per workgroup (16 bytes per load, four pillars' loads in flight per thread), FEW
+    // workgroups: every workgroup ends in 256 fp64 atomics on the same 256 words, and same-address atomics serialise
+    __shared__ float part[32][2][128];
+    const int q = threadIdx.x & 31, pl = threadIdx.x >> 5, c = 4 * q;
+    const float4 sc = *reinterpret_cast<const float4*>(bn.scale + c), sh = *reinterpret_cast<const float4*>(bn.shift + c);
+    const float4 mu = *reinterpret_cast<const float4*>(bn.mean + c), is = *reinterpret_cast<const float4*>(bn.invstd + c);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int stride = gridDim.x * 32;
+    for (int p0 = blockIdx.x * 32 + pl; p0 < num_pillars; p0 += 4 * stride) {
+        float4 h[4], d[4];
+        bool use[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = p0 + k * stride;
+            const bool in = p < num_pillars;
+            h[k] = in ? *reinterpret_cast<const float4*>(vf + (int64_t)p * 128 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            d[k] = in ? *reinterpret_cast<const float4*>(dvf + (int64_t)p * 128 + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            use[k] = in && ties[p] == 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float hv[4] = {h[k].x, h[k].y, h[k].z, h[k].w}, dv[4] = {d[k].x, d[k].y, d[k].z, d[k].w};
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+            const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (hv[r] > 0.f && use[k]) {
+                    s1[r] += dv[r];
+                    s2[r] += dv[r] * (((hv[r] - shv[r]) / scv[r] - muv[r]) * isv[r]);
+                }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { part[pl][0][c + r] = s1[r]; part[pl][1][c + r] = s2[r]; }
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int k = threadIdx.x >> 7, ch = threadIdx.x & 127;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 32; ++w) sum += part[w][k][ch];
+        atomicAdd(bsums1 + 128 * k + ch, (double)sum);
+    }
+}
+
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                                  const float* __restrict__ vf, const float* __restrict__ dvf,
-                                                                 Bn1 bn, double* __restrict__ bsums1) {
+                                                                 Bn1 bn, double* __restrict__ bsums1,
+                                                                 const unsigned char* __restrict__ ties) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
+    // ties: only the points of flagged pillars count (vfe_bwd_stats1_pillars_kernel has done the rest); a wave sweeps only
+    // the tiles that hold such a point, a workgroup without one leaves before it stages anything
+    unsigned int tile_mask = 0xfu;
+    if (ties) {
+        tile_mask = 0u;
+#pragma unroll
+        for (int k = 0; k < kVfePts / 16; ++k) {
+            const int j = R.j_lo + 16 * k + (lane & 15);
+            const bool f = j < R.j_hi && ties[pillar_of(G, j)] != 0;
+            if (__any(f)) tile_mask |= 1u << k;
+        }
+        if (!__syncthreads_or(tile_mask != 0u)) return;
+    }
     __shared__ float W0s[64 * 16];
+    VFE_T_ENTRY();
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
@@ -839,25 +940,27 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
     VFE_STAGE_BN0_FWD(W, Ws)
     VFE_STAGE_BN1(bn, bns)
     __syncthreads();
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     // two passes over the points, 4 output tiles each: 16 instead of 32 accumulator vectors live across the
     // loop (the single-pass version spilled); layer 0 is recomputed twice, layer 1's MFMA count is unchanged
+    VFE_T_BEGIN();
     f32x4 s1[8], s2[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+            if (!((tile_mask >> ((j0 - R.j_lo) >> 4)) & 1u)) continue;
             const int j = j0 + (lane & 15);
-            const bool valid = j < R.j_hi;
-            const int pid = valid ? pillar_of(G, j) : 0;
+            const int pid = j < R.j_hi ? pillar_of(G, j) : 0;
+            const bool valid = j < R.j_hi && (!ties || ties[pid] != 0);
             const int oz = opaque_zero();
             const Bn1 bnl = shifted(bns, oz);
+            VFE_T(0);
             float4 mrow[4], drow[4];
             routed_rows<4>(vf, dvf, pid, valid, 4 * half, lane, mrow, drow);
             f32x4 y0[4], gin[8];
             recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+            VFE_T(1);
             const BSplit gs = split_operand(gin);
 #pragma unroll
             for (int q = 0; q < 4; q += 2) {
@@ -872,9 +975,13 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
                     s2[ot0 + u] += dh * yh;
                 }
             }
+            VFE_T(2);
         }
     }
-    flush_channel_sums<8>(s1, s2, bsums1, 128, red, lane, wave);
+    VFE_T(0);
+    flush_channel_sums<8>(s1, s2, bsums1, 128, red, W1s, lane, wave);
+    VFE_T(3);
+    VFE_T_END_AT(16);
 }
 
 // layer-1 backward sweep:
@@ -996,7 +1103,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
     __shared__ float W0s[64 * 16];
     VFE_T_ENTRY();
     __shared__ float red[kVfeWaves * 2 * 64];
-    __shared__ __attribute__((aligned(16))) float tiles[ACC ? kVfeWaves : 1][ACC ? 16 * kTile0Ld : 4];   // [t][0..63] dh0, [t][64..79] ft
+    __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];   // [t][0..63] dh0, [t][64..79] ft; then the flush's scratch
     __shared__ float mu_s[16];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0(bn0, bn0l)
@@ -1006,7 +1113,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
-    float* tile = tiles[ACC ? wave : 0];
+    float* tile = tiles[wave];
     f32x4 s1[4], s2[4], dw[4];
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; dw[ot] = f32x4{0, 0, 0, 0}; }
@@ -1083,16 +1190,16 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
     // the waves' partial contractions meet in LDS as plain stores into per-wave slices of the (now free) tile buffer and are
     // summed by the flush below.  (LDS float atomics into one [64][16] array serialise: 31 k of the kernel's 60 k cycles.)
     float* part = &tiles[0][0];                                      // [kVfeWaves][64 * 16]
-    static_assert(!ACC || kVfeWaves * 16 * kTile0Ld >= kVfeWaves * 64 * 16, "the tile buffer must hold the partials");
+    static_assert(kVfeWaves * 16 * kTile0Ld >= kVfeWaves * 64 * 16, "the tile buffer must hold the partials");
+    flush_channel_sums<4>(s1, s2, bsums0, 64, red, part, lane, wave);    // (its barriers: every wave done with its tile / its scratch)
     if (ACC) {
-        __syncthreads();                                             // every wave is done with its tile
         // dw[ot][r] = A[16*ot + 4g + r][feature = lane & 15]
 #pragma unroll
         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
             for (int r = 0; r < 4; ++r) part[wave * 1024 + (16 * ot + 4 * g + r) * 16 + (lane & 15)] = dw[ot][r];
+        __syncthreads();
     }
-    flush_channel_sums<4>(s1, s2, bsums0, 64, red, lane, wave);      // (contains the workgroup barrier the flush below needs)
     if (ACC)
         for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
             float sum = 0.f;
@@ -1352,7 +1459,8 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     if (rc) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
     GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
-    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats);
+    if (a->pillar_ties) GEOMAE_ZERO(a->pillar_ties, (size_t)a->max_pillars, stream);
+    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties);
     return check_launch("vfe_layer1_kernel");
 }
 
@@ -1375,8 +1483,16 @@ extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnS
     if ((rc = bn_of(bnst, 1, &bn.scale, &bn.shift, &bn.mean, &bn.invstd))) return rc;
     GEOMAE_REQUIRE(m0 && voxel_feats && d_voxel_feats && bsums1, "vfe_backward_stats: null argument");
     GEOMAE_ZERO(bsums1, 256 * sizeof(double), stream);
+    if (a->pillar_ties) {
+        int gx = cdiv(a->max_pillars, 32 * 8);                        // ~8 pillars per pillar lane, <= 256 workgroups
+        gx = gx < 1 ? 1 : (gx > 256 ? 256 : gx);
+        hipLaunchKernelGGL(vfe_bwd_stats1_pillars_kernel, dim3(gx), dim3(1024), 0, stream, voxel_feats, d_voxel_feats,
+                           (int)a->max_pillars, bn, (const unsigned char*)a->pillar_ties, bsums1);
+        const int rc2 = check_launch("vfe_bwd_stats1_pillars_kernel");
+        if (rc2) return rc2;
+    }
     hipLaunchKernelGGL(vfe_bwd_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats,
-                       d_voxel_feats, bn, bsums1);
+                       d_voxel_feats, bn, bsums1, (const unsigned char*)a->pillar_ties);
     return check_launch("vfe_bwd_stats1_kernel");
 }
 

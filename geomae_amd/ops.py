@@ -1165,6 +1165,7 @@ def heads_weight_grad(n_mask, dl, cm_b, dm_b, grads):
 
 # ------------------------------------------------------------------------------------ fused VFE
 VFE_MOMENTS = True       # False: the sweep forms of the layer-0 statistics / weight gradient (A/B, tests)
+VFE_PILLAR_STATS = True  # False: the layer-1 BatchNorm-backward sums always by the sweep over the points (A/B, tests)
 
 
 def vfe_prepare_points(points, seg, voxel_size, center_offset, zeros=None):
@@ -1257,7 +1258,7 @@ def vfe_forward_zero_specs(cap, V, prepared=False):
     """(shape, dtype) of the buffers VfePlan + vfe_forward carve from a ZeroArena, in carve order."""
     V1 = max(int(V), 1)
     return [((2, 4, 128), torch.float32), ((128,), torch.float64), ((V1, 64), torch.float32),
-                    ((256,), torch.float64), ((V1, 128), torch.float32)]
+                    ((256,), torch.float64), ((V1, 128), torch.float32), ((V1,), torch.uint8)]
 
 
 def vfe_backward_zero_specs(V):
@@ -1276,6 +1277,10 @@ def vfe_forward(plan, norm0, norm1, world=1, group=None, zeros=None):
     check(lib.geomae_vfe_layer0(a, _ptr(m0), _ptr(sums1), _stream()), "geomae_vfe_layer0")
     _bn_finalize(plan, 1, sums1, norm1, world, group)
     vf = _zeros_or_empty(zeros, (max(plan.V, 1), 128), torch.float32, dev)
+    # a byte per pillar that the layer-1 sweep sets where two points may share the pillar's maximum: for the others the
+    # backward's BatchNorm sums come from the pillar rows alone (GeomaeVfeArgs.pillar_ties)
+    plan.pillar_ties = _zeros_or_empty(zeros, (max(plan.V, 1),), torch.uint8, dev)
+    plan.args.pillar_ties = plan.pillar_ties.data_ptr() if VFE_PILLAR_STATS else None
     check(lib.geomae_vfe_layer1(a, _ptr(m0), _ptr(vf), _stream()), "geomae_vfe_layer1")
     return vf[:plan.V], m0
 

@@ -419,6 +419,15 @@ typedef struct GeomaeVfeArgs {
                                                         With them geomae_vfe_stats0 needs no sweep over the points, and
                                                         together with dw0_acc the layer-0 backward needs none either */
     float* dw0_acc;                                  /* [64,16] scratch of the layer-0 weight gradient, or NULL        */
+    uint8_t* pillar_ties;                            /* [max_pillars] bytes, cleared by geomae_vfe_layer1 like its other
+                                                        outputs, or NULL.  The layer-1 sweep marks every pillar whose maximum
+                                                        may be held by more than one of its points in some channel (exact
+                                                        duplicates of a point, or two points that round to the same fp32 value:
+                                                        ~1 in 10^6 (pillar, channel) pairs).  For an unmarked pillar the
+                                                        max-pool routes the gradient of a channel to ONE point, so its share
+                                                        of the BatchNorm-backward sums of geomae_vfe_backward_stats follows
+                                                        from its [128] rows alone (sum d_vf, sum d_vf * yhat(vf) where vf > 0):
+                                                        only the marked pillars' points are swept.  NULL: all points are */
 } GeomaeVfeArgs;
 /* decorated point features [x y z i dt | xyz - pillar mean | xyz - pillar centre | 0...] in pillar order
  * (voxel_encoder.py:372-397); voxel_size (vx,vy,vz) and center_offset = v/2 + range_min are host arrays */

@@ -551,6 +551,40 @@ def test_vfe_moment_form_equals_sweep_form(dev):
         assert torch.allclose(b_m[k], b_s[k], rtol=1e-5, atol=1e-6), k
 
 
+@pytest.mark.parametrize("duplicates", [False, True])
+def test_vfe_pillar_form_of_the_bn_backward_sums(dev, duplicates):
+    """While no two points of a pillar share its maximum in a channel, the max-pool routes a pillar's gradient to exactly one
+    point and the layer-1 BatchNorm-backward sums follow from the [V,128] pillar rows (vfe_bwd_stats1_pillars_kernel);
+    the layer-1 sweep marks the other pillars (GeomaeVfeArgs.pillar_ties) and only their points are swept (duplicates=True:
+    4000 points of the first frame twice).  Both against the sweep form (ops.VFE_PILLAR_STATS = False)."""
+    from geomae_amd import ops
+    f0 = synth.lidar_frame(71, sweeps=2)
+    frames = [np.concatenate([f0, f0[:4000]]) if duplicates else f0, synth.lidar_frame(72, beams=16, n_az=500)]
+    res = {}
+    for mode in (True, False):
+        ops.VFE_PILLAR_STATS = mode
+        try:
+            model, _ = _build(dev, 1, 1, "fp32")
+            pts = [torch.as_tensor(f, device=dev) for f in frames]
+            voxels, coors, _, _ = model.voxelize_all(pts)
+            seg = ops.pillar_segment(coors, 2, (1, 400, 400))
+            vf, state = model.voxel_encoder.forward_explicit(voxels, seg)
+            flag = int(state[0].pillar_ties.sum().item()) if mode else None
+            for p in model.voxel_encoder.parameters():
+                p.grad = None
+            w = torch.randn(vf.shape, generator=torch.Generator().manual_seed(2)).to(dev)
+            model.voxel_encoder.backward_explicit(state, w)
+            res[mode] = (flag, {k: p.grad.clone() for k, p in model.voxel_encoder.named_parameters()})
+        finally:
+            ops.VFE_PILLAR_STATS = True
+    (flag, g_p), (_, g_s) = res[True], res[False]
+    assert (flag > 100) if duplicates else (flag < 20), flag      # (a few fp32 coincidences exist without duplicates)
+    for k in g_s:
+        rel = float((g_p[k] - g_s[k]).norm() / g_s[k].norm().clamp(min=1e-12))
+        # same sums in another order (pillar form: fp32 per workgroup, fp64 across); float atomics of pillars cut by waves
+        assert rel < 4e-3, (k, rel)          # (run-to-run noise of the float atomics alone: 5e-4 .. 2.4e-3)
+
+
 # (loss, gradient-norm, full-gradient Frobenius) tolerances ~2x the measured maxima this test prints with
 # GEOMAE_TEST_VERBOSE=1; the full-size versions of the same comparison are tests/test_gpu_fullsize.py
 # measured: fp32 composed path with the fp32 attention core (round 3: no bf16 step left) 3.1e-4 / 1.0e-3 / 1.3e-3 (tiny),

@@ -43,6 +43,7 @@ for sweeps in [int(a) for a in sys.argv[1:]] or [1, 10]:
         t_prep = timed(lambda: ve.prepare_points(voxels, seg))
         t_fwd = timed(lambda: ve.forward_explicit(voxels, seg, prepared=prepared))
         t_bwd = timed(lambda: ve.backward_explicit(state, dvf))
+    print("pillars marked as possible ties:", int(state[0].pillar_ties.sum().item()))
     print(f"sweeps {sweeps}: {voxels.shape[0]} points, {seg.V} pillars: prepare {t_prep:.0f} us, forward sweeps {t_fwd:.0f} us, backward {t_bwd:.0f} us")
     if TIMING:
         read()
@@ -55,6 +56,11 @@ for sweeps in [int(a) for a in sys.argv[1:]] or [1, 10]:
         st = read(); s = st[st[:, 7] > 0]
         print(f"  vfe_bwd_layer1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 7].mean():.0f} max {s[:, 7].max()} cycles")
         for k, nm in enumerate(NAMES_B): print(f"    {nm:36s} mean {s[:, k].mean():8.0f}  max {s[:, k].max():8.0f}")
+        s = st[st[:, 23] > 0]
+        print(f"  vfe_bwd_stats1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 23].mean():.0f} max {s[:, 23].max()} cycles")
+        for k, nm in enumerate(["staging", "gathers + features + layer 0 (both passes)", "GEMM half + routing (both passes)", "flush of the channel sums"]):
+            kk = [0, 1, 2, 3][k]
+            print(f"    {nm:44s} mean {s[:, 16 + kk].mean():8.0f}  max {s[:, 16 + kk].max():8.0f}")
         s = st[st[:, 15] > 0]
         print(f"  vfe_bwd_route0_kernel<true>: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 15].mean():.0f} max {s[:, 15].max()} cycles")
         for k, nm in enumerate(NAMES_R): print(f"    {nm:36s} mean {s[:, 8 + k].mean():8.0f}  max {s[:, 8 + k].max():8.0f}")
