@@ -328,6 +328,21 @@ __device__ __forceinline__ void bn_relu(const f32x4 (&y)[NT], const float* __res
     }
 }
 
+template <int NT>
+__device__ __forceinline__ void bn_affine(const f32x4 (&y)[NT], const float* __restrict__ scale,
+                                          const float* __restrict__ shift, f32x4 (&h)[NT], int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ot = 0; ot < NT; ++ot) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + 16 * ot + 4 * g);
+        const float4 b = *reinterpret_cast<const float4*>(shift + 16 * ot + 4 * g);
+        h[ot][0] = y[ot][0] * s.x + b.x;
+        h[ot][1] = y[ot][1] * s.y + b.y;
+        h[ot][2] = y[ot][2] * s.z + b.z;
+        h[ot][3] = y[ot][3] * s.w + b.w;
+    }
+}
+
 __device__ __forceinline__ void stage_w0(const float* __restrict__ w0, float* W0s) {
     for (int e = threadIdx.x; e < 64 * 16; e += kVfeBlk) {
         const int r = e >> 4, c = e & 15;
@@ -422,16 +437,33 @@ __device__ __forceinline__ void wave_global_sync() {
 // per tile, 5.5 k cycles = 45 % of the layer-1 forward sweep (tools/vfe_time.py).  The segmented scan in registers --
 // T-layout rows are DPP rows: row_shr 1 / 2 / 4 / 8 under a same-pillar mask -- was measured too: 480 VALU
 // instructions per tile instead of 32, 6 k cycles.)
+// fmaxf of two values that may come straight from memory compiles to THREE instructions (llvm.maxnum canonicalises both
+// inputs: v_max x, x, x twice); the instruction itself already returns the other operand for a NaN
+__device__ __forceinline__ float vmax_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <int CPL>
 struct SegCarry {
     float cur[CPL];
     int first_pid, last_pid;         // the pillars of the wave's first / last point: they may continue in a neighbour's range
     bool first_shared, last_shared;
-    bool tie;                        // (TRACK) the open run: two of its points shared the running maximum (> 0) of a lane's channel
-    __device__ __forceinline__ void init(const VfeGeo& G, const WaveRange& R) {
-        tie = false;
+    unsigned long long tie;          // (TRACK) the open run: lanes in whose channels two points shared the running maximum
+    // (TRACK) the wave's parts of its (at most two) straddling pillars, combined by seg_resolve at the END of the sweep with
+    // atomics that RETURN what was stored (a part that finds its own maximum there: a tie across waves); issued and
+    // compared inside the walk each of them cost the wave a memory round trip
+    float pend_val[2][CPL];
+    int pend_pid[2];
+    __device__ __forceinline__ void init(const VfeGeo& G, const WaveRange& R, float start = 0.f) {
+        tie = 0ull;
+        pend_pid[0] = pend_pid[1] = -1;
 #pragma unroll
-        for (int k = 0; k < CPL; ++k) cur[k] = 0.f;
+        for (int k = 0; k < CPL; ++k) {
+            cur[k] = start;
+            pend_val[0][k] = pend_val[1][k] = 0.f;
+        }
         first_pid = last_pid = -1;
         first_shared = last_shared = false;
         if (R.j_lo < R.j_hi) {
@@ -448,6 +480,9 @@ __device__ __forceinline__ int pillar_next(const VfeGeo& G, int j, const WaveRan
 // ties (max only, or null): ties[p] = 1 for every pillar whose maximum MAY be held by more than one point in some channel
 // -- conservatively: any equality with the RUNNING maximum of the run counts, and so does a part of a straddling pillar
 // that finds its own maximum already stored by another part.  A pillar that stays 0 has exactly one arg-max per channel.
+// With TRACK the tile holds the values BEFORE the ReLU clamp (max and clamp commute) and a run starts at -inf: clamped
+// zeros would be equal to each other all the time, unclamped values coincide as rarely as positive ones -- one compare
+// per value instead of two, and the clamp moves from every value to every finished run.
 template <int CPL, bool IS_MAX, int LD, bool TRACK = false>
 __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_next, bool valid, int C, float* __restrict__ out,
                                          SegCarry<CPL>& c, int lane, unsigned char* __restrict__ ties = nullptr) {
@@ -463,8 +498,8 @@ __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_nex
         if (!((live >> t) & 1u)) break;
 #pragma unroll
         for (int k = 0; k < CPL; ++k) {
-            if (TRACK) c.tie |= x[t][k] == c.cur[k] && x[t][k] > 0.f;
-            c.cur[k] = IS_MAX ? fmaxf(c.cur[k], x[t][k]) : c.cur[k] + x[t][k];
+            if (TRACK) c.tie |= __ballot(x[t][k] == c.cur[k]);        // (a lane mask in SGPRs: v_cmp + s_or)
+            c.cur[k] = IS_MAX ? vmax_f32(c.cur[k], x[t][k]) : c.cur[k] + x[t][k];
         }
         if ((ends >> t) & 1u) {
             const int p = __builtin_amdgcn_readlane(pid, t);
@@ -472,18 +507,45 @@ __device__ __forceinline__ void seg_scan(const float* tile, int pid, int pid_nex
 #pragma unroll
             for (int k = 0; k < CPL; ++k) {
                 float* dst = out + (int64_t)p * C + lane + 64 * k;
-                if (!shared) *dst = c.cur[k];
-                else if (IS_MAX && TRACK) c.tie |= atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k])) == __float_as_int(c.cur[k]) && c.cur[k] > 0.f;
-                else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(c.cur[k]));
-                else atomicAdd(dst, c.cur[k]);
-                c.cur[k] = 0.f;
+                const float v = TRACK ? fmaxf(c.cur[k], 0.f) : c.cur[k];
+                if (!shared) *dst = v;
+                else if (IS_MAX && TRACK) {
+                    if (p == c.first_pid && c.first_shared) { c.pend_val[0][k] = v; c.pend_pid[0] = p; }
+                    else { c.pend_val[1][k] = v; c.pend_pid[1] = p; }
+                }
+                else if (IS_MAX) atomicMax(reinterpret_cast<int*>(dst), __float_as_int(v));
+                else atomicAdd(dst, v);
+                c.cur[k] = TRACK ? -INFINITY : 0.f;
             }
             if (TRACK) {
-                if (ties && __any(c.tie) && lane == 0) ties[p] = 1;
-                c.tie = false;
+                if (ties && c.tie != 0ull && lane == 0) ties[p] = 1;
+                c.tie = 0ull;
             }
         }
     }
+}
+
+// (TRACK) the straddling pillars' parts: combine, and mark the pillar if a part finds its own maximum (> 0) already stored
+template <int CPL>
+__device__ __forceinline__ void seg_resolve(const SegCarry<CPL>& c, float* __restrict__ out, int C,
+                                            unsigned char* __restrict__ ties, int lane) {
+    int old[2][CPL];
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+        if (c.pend_pid[sl] >= 0) {                                    // wave-uniform
+#pragma unroll
+            for (int k = 0; k < CPL; ++k)
+                old[sl][k] = atomicMax(reinterpret_cast<int*>(out + (int64_t)c.pend_pid[sl] * C + lane + 64 * k),
+                                       __float_as_int(c.pend_val[sl][k]));
+        }
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+        if (c.pend_pid[sl] >= 0) {
+            bool eq = false;
+#pragma unroll
+            for (int k = 0; k < CPL; ++k) eq |= old[sl][k] == __float_as_int(c.pend_val[sl][k]) && c.pend_val[sl][k] > 0.f;
+            if (ties && __any(eq) && lane == 0) ties[c.pend_pid[sl]] = 1;
+        }
 }
 
 // End of a statistics sweep: the lanes' partial sums s1 / s2 (T-layout: lane = point slot t of every tile the wave swept,
@@ -737,6 +799,40 @@ __device__ __forceinline__ void recompute_g(const VfeGeo& G, const VfeW& W, cons
     }
 }
 
+// The same from inputs that were loaded a tile AHEAD: a wave walks its 4 tiles one after the other, and with the loads at the
+// top of each iteration every tile began with a memory round trip (features / pillar id, then the dependent gather of the
+// pillar's layer-0 maxima).  The ids and features of tile k + 1 are requested at the top of iteration k, its gather in the
+// middle of it.  (Worth 1.4 k cycles of the phase it removes, of which the layer-1 forward sweep keeps nothing -- its
+// second wave per SIMD already covered that wait -- and the statistics sweep ~6 %: 21.7 -> 20.4 us at config 2.)
+struct TileIn {
+    float f[4];
+    float4 m[4];                  // m0[pid][16 ct + 4 g ..]
+    int pid, pid_next;
+    bool valid;
+};
+__device__ __forceinline__ void tile_ids_issue(const VfeGeo& G, const WaveRange& R, int j0, int lane, bool want_next, TileIn& t) {
+    const int j = j0 + (lane & 15);
+    t.valid = j < R.j_hi;
+    t.pid = t.valid ? pillar_of(G, j) : 0;
+    t.pid_next = want_next && t.valid ? pillar_next(G, j, R) : -1;
+    build_features(G, j, t.valid, lane >> 4, t.f);
+}
+__device__ __forceinline__ void tile_m0_issue(const float* __restrict__ m0, int lane, TileIn& t) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+        t.m[ct] = make_float4(0, 0, 0, 0);
+        if (t.valid) t.m[ct] = *reinterpret_cast<const float4*>(m0 + (int64_t)t.pid * 64 + 16 * ct + 4 * g);
+    }
+}
+__device__ __forceinline__ void recompute_g_from(const VfeW& W, const float* W0s, const TileIn& t, int lane, f32x4 (&y0)[4],
+                                                 f32x4 (&gin)[8]) {
+    layer0_linear(W0s, t.f, y0, lane);
+    bn_relu<4>(y0, W.scale0, W.shift0, reinterpret_cast<f32x4(&)[4]>(gin), lane);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) gin[4 + ct] = f32x4{t.m[ct].x, t.m[ct].y, t.m[ct].z, t.m[ct].w};
+}
+
 // sweep 1 of layer 1: statistics of y1 = W1 [h0 | m0]
 __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                              double* __restrict__ sums1) {
@@ -752,15 +848,19 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
     f32x4 s1[8], s2[8];
 #pragma unroll
     for (int ot = 0; ot < 8; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; }
+    TileIn cur, nxt;
+    tile_ids_issue(G, R, R.j_lo, lane, false, cur);
+    tile_m0_issue(m0, lane, cur);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-        const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
+        const bool more = j0 + 16 < R.j_hi;
+        if (more) tile_ids_issue(G, R, j0 + 16, lane, false, nxt);
+        const bool valid = cur.valid;
         const int oz = opaque_zero();
         const float* W1l = W1s + oz;
         f32x4 y0[4], gin[8];
-        recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        recompute_g_from(shifted(Ws, oz), W0s + oz, cur, lane, y0, gin);
         const BSplit gs = split_operand(gin);
+        if (more) tile_m0_issue(m0, lane, nxt);
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 y2[2];
@@ -770,6 +870,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
                 for (int u = 0; u < 2; ++u) { s1[ot0 + u] += y2[u]; s2[ot0 + u] += y2[u] * y2[u]; }
             }
         }
+        cur = nxt;
     }
     static_assert(128 * kW1Ld >= kVfeWaves * 16 * 132, "the W1 buffer must hold the flush scratch");
     flush_channel_sums<8>(s1, s2, sums1, 128, red, W1s, lane, wave);
@@ -796,28 +897,34 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
     float* tile = tiles[wave];
     SegCarry<2> carry;
-    carry.init(G, R);
+    carry.init(G, R, -INFINITY);
+    TileIn cur, nxt;
+    tile_ids_issue(G, R, R.j_lo, lane, true, cur);
+    tile_m0_issue(m0, lane, cur);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
-        const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
-        const int pid_next = valid ? pillar_next(G, j, R) : -1;
+        const bool more = j0 + 16 < R.j_hi;
+        if (more) tile_ids_issue(G, R, j0 + 16, lane, true, nxt);
+        const bool valid = cur.valid;
+        const int pid = cur.pid, pid_next = cur.pid_next;
         const int oz = opaque_zero();
         const VfeW Wl = shifted(Ws, oz);
         f32x4 y0[4], gin[8], y1[8], h1[8];
         VFE_T(0);
-        recompute_g(G, Wl, W0s + oz, m0, j, pid, valid, lane, y0, gin);
+        recompute_g_from(Wl, W0s + oz, cur, lane, y0, gin);
         VFE_T(1);
         layer1_linear(W1s + oz, split_operand(gin), y1, lane);
+        if (more) tile_m0_issue(m0, lane, nxt);
         VFE_T(2);
-        bn_relu<8>(y1, Wl.scale1, Wl.shift1, h1, lane);
+        bn_affine<8>(y1, Wl.scale1, Wl.shift1, h1, lane);             // (the clamp follows the max: seg_scan TRACK)
         tile_store<8, kTileLd>(tile, h1, lane);
         wave_sync();
         VFE_T(3);
         seg_scan<2, true, kTileLd, true>(tile, pid, pid_next, valid, 128, vf, carry, lane, ties);
         wave_sync();
         VFE_T(4);
+        cur = nxt;
     }
+    seg_resolve(carry, vf, 128, ties, lane);
     VFE_T_END();
 }
 
