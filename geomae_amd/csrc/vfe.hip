@@ -1104,13 +1104,17 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     VFE_T_ENTRY();
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];      // W1, then W1^T (dg = dy1 W1)
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
-    __shared__ float bn1s[2][128];                                         // S1/n, S2/n
+    // dy1 = scale * (dh - S1/n - yhat * S2/n) with yhat = (y - mean) * invstd, folded per channel into
+    // dy1 = scale * dh + A + y * B:  B = -scale * (S2/n) * invstd,  A = -scale * (S1/n) - mean * B
+    __shared__ __attribute__((aligned(16))) float bn1s[2][128];            // A, B
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0_FWD(W, Ws)
     VFE_STAGE_BN1(bn, bns)
     for (int c = threadIdx.x; c < 128; c += kVfeBlk) {
-        bn1s[0][c] = (float)(bsums1[c] / (double)n_eff);
-        bn1s[1][c] = (float)(bsums1[128 + c] / (double)n_eff);
+        const float t1 = (float)(bsums1[c] / (double)n_eff), t2 = (float)(bsums1[128 + c] / (double)n_eff);
+        const float bq = -bn.scale[c] * t2 * bn.invstd[c];
+        bn1s[1][c] = bq;
+        bn1s[0][c] = -bn.scale[c] * t1 - bn.mean[c] * bq;
         if (d_beta1 && blockIdx.x == 0) {          // single process: the sums ARE d beta / d gamma (one writer: no atomics)
             d_beta1[c] += (float)bsums1[c];
             d_gamma1[c] += (float)bsums1[128 + c];
@@ -1128,41 +1132,61 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     SegCarry<1> carry;
     carry.init(G, R);
     VFE_T_BEGIN();
+    // ids / features / layer-0 maxima a tile ahead (tile_ids_issue); the 16 row gathers of the routing are issued BEHIND them:
+    // the memory counter retires in order, and what the tile needs first must not queue behind what it needs last
+    TileIn cur, nxt;
+    tile_ids_issue(G, R, R.j_lo, lane, true, cur);
+    tile_m0_issue(m0, lane, cur);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
+        const bool more = j0 + 16 < R.j_hi;
+        if (more) tile_ids_issue(G, R, j0 + 16, lane, true, nxt);
         const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
-        const int pid_next = valid ? pillar_next(G, j, R) : -1;
+        const bool valid = cur.valid;
+        const int pid = cur.pid, pid_next = cur.pid_next;
         const int oz = opaque_zero();
         const Bn1 bnl = shifted(bns, oz);
-        const float* bs0 = bn1s[0] + oz;
-        const float* bs1 = bn1s[1] + oz;
+        const float* cA = bn1s[0] + oz;
+        const float* cB = bn1s[1] + oz;
         f32x4 dy1[8];
         VFE_T(0);
         float4 mrow[8], drow[8];
         routed_rows<8>(vf, dvf, pid, valid, 0, lane, mrow, drow);
         {
             f32x4 y0[4], gin[8];
-            recompute_g(G, shifted(Ws, oz), W0s + oz, m0, j, pid, valid, lane, y0, gin);
+            recompute_g_from(shifted(Ws, oz), W0s + oz, cur, lane, y0, gin);
             store_rows_bf16<128>(g_b, G.n_points, j, 128, 0, gin, lane, true);   // tile-blocked (pad rows of the last tile: unread)
             VFE_T(1);
             const BSplit gs = split_operand(gin);
+            // the MFMAs of channel-tile pair k + 1 are issued before the routing arithmetic of pair k
+            f32x4 ya[2], yb[2];
+            layer1_group<2>(W1s + oz, gs, 0, ya, lane);
+            if (more) tile_m0_issue(m0, lane, nxt);
 #pragma unroll
             for (int ot0 = 0; ot0 < 8; ot0 += 2) {
-                f32x4 y4[2];
-                layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
+                if (ot0 + 2 < 8) layer1_group<2>(W1s + oz, gs, ot0 + 2, yb, lane);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int ot = ot0 + u;
-                    f32x4 dh, yh;
-                    routed_tile(y4[u], bnl, mrow[ot], drow[ot], valid, ot, lane, &dh, &yh);
                     const int c0 = 16 * ot + 4 * g;
                     const float4 sc = *reinterpret_cast<const float4*>(bnl.scale + c0);    // gamma * invstd
-                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
+                    const float4 sh = *reinterpret_cast<const float4*>(bnl.shift + c0);
+                    const float4 a4 = *reinterpret_cast<const float4*>(cA + c0);
+                    const float4 b4 = *reinterpret_cast<const float4*>(cB + c0);
+                    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+                    const float av[4] = {a4.x, a4.y, a4.z, a4.w}, bv[4] = {b4.x, b4.y, b4.z, b4.w};
+                    const float mx[4] = {mrow[ot].x, mrow[ot].y, mrow[ot].z, mrow[ot].w};
+                    const float dd[4] = {drow[ot].x, drow[ot].y, drow[ot].z, drow[ot].w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) dy1[ot][r] = valid ? scv[r] * (dh[r] - bs0[c0 + r] - yh[r] * bs1[c0 + r]) : 0.f;
+                    for (int r = 0; r < 4; ++r) {
+                        const float y = ya[u][r];
+                        const float h = fmaxf(y * scv[r] + shv[r], 0.f);          // exactly bn_relu's expression
+                        const float dh = (h > 0.f && h == mx[r]) ? dd[r] : 0.f;   // max-pool + ReLU routing
+                        dy1[ot][r] = valid ? scv[r] * dh + (av[r] + y * bv[r]) : 0.f;
+                    }
                     if (valid) *reinterpret_cast<uint2*>(dy1_b + ((int64_t)(j >> 4) * 8 + ot) * 256 + (j & 15) * 16 + 4 * g) = pack4(dy1[ot]);   // operand of dW1, tile-blocked
                 }
+                ya[0] = yb[0];
+                ya[1] = yb[1];
             }
         }
         // dg[t][k] = sum_o W1[o][k] dy1[t][o]; two output tiles at a time
@@ -1190,6 +1214,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
         seg_scan<1, false, kTile0Ld>(tile, pid, pid_next, valid, 64, dm0, carry, lane);
         wave_sync();
         VFE_T(4);
+        cur = nxt;
     }
     VFE_T_END();
     (void)dy1_f;                                   // (kept in the C ABI; no longer written)
