@@ -463,6 +463,40 @@ __device__ __forceinline__ float gelu_f(float x) {
     gelu_parts(x, &c, &p);
     return x * c;
 }
+// The same on the four values of an accumulator register group, two at a time on the packed fp32 pipe (v_pk_mul_f32 /
+// v_pk_fma_f32 process two floats per lane and issue slot): 17 full-rate + 4 quarter-rate instructions per PAIR instead
+// of 14 + 2 per value.  The GELU arithmetic is VALU-bound: 64 evaluations per lane and kernel were 7.2 k of the 46 k
+// cycles of a workgroup in sst_ffn_bwd_kernel (tools/archive/phase_timing.py).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2* cdf, f32x2* pdf) {
+    const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const f32x2 z = ax * 0.70710678118654752f;
+    const f32x2 den = z * 0.3275911f + 1.0f;
+    const f32x2 t = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const f32x2 a2 = z * z * -1.4426950408889634f;                    // exp(-z^2) = exp2(-z^2 log2 e)
+    const f32x2 e = {__builtin_amdgcn_exp2f(a2.x), __builtin_amdgcn_exp2f(a2.y)};
+    const f32x2 poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const f32x2 erf_abs = 1.0f - poly * e;
+    const f32x2 sg = {__builtin_copysignf(erf_abs.x, x.x), __builtin_copysignf(erf_abs.y, x.y)};
+    *cdf = sg * 0.5f + 0.5f;
+    *pdf = e * 0.3989422804014327f;
+}
+__device__ __forceinline__ f32x4 gelu4(const f32x4 x) {
+    f32x2 c0, c1, p0, p1;
+    gelu_parts2(f32x2{x[0], x[1]}, &c0, &p0);
+    gelu_parts2(f32x2{x[2], x[3]}, &c1, &p1);
+    return f32x4{x[0] * c0.x, x[1] * c0.y, x[2] * c1.x, x[3] * c1.y};
+}
+// h = x * cdf(x) and d(x gelu)/dx = cdf + x * pdf
+__device__ __forceinline__ void gelu_fwd_bwd4(const f32x4 x, f32x4* h, f32x4* grad) {
+    f32x2 c0, c1, p0, p1;
+    const f32x2 x0 = {x[0], x[1]}, x1 = {x[2], x[3]};
+    gelu_parts2(x0, &c0, &p0);
+    gelu_parts2(x1, &c1, &p1);
+    const f32x2 h0 = x0 * c0, h1 = x1 * c1, g0 = c0 + x0 * p0, g1 = c1 + x1 * p1;
+    *h = f32x4{h0.x, h0.y, h1.x, h1.y};
+    *grad = f32x4{g0.x, g0.y, g1.x, g1.y};
+}
 __device__ __forceinline__ float gelu_grad(float x) {
     float c, p;
     gelu_parts(x, &c, &p);

@@ -400,8 +400,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
                 buf_store_b64(hp_r, o2, pack4(ha));
                 buf_store_b64(hp_r, o2 + 512, pack4(hb));
             }
-            const f32x4 ga = {gelu_f(ha[0]), gelu_f(ha[1]), gelu_f(ha[2]), gelu_f(ha[3])};
-            const f32x4 gb = {gelu_f(hb[0]), gelu_f(hb[1]), gelu_f(hb[2]), gelu_f(hb[3])};
+            const f32x4 ga = gelu4(ha), gb = gelu4(hb);
             const uint2 pa = pack4(ga), pb = pack4(gb);
             *reinterpret_cast<uint4*>(H + (16 * it + t) * kFRowH + 2 * (32 * w + 8 * g)) = make_uint4(pa.x, pa.y, pb.x, pb.y);
         }

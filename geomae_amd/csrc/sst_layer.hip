@@ -260,7 +260,7 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane, blk);
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
-            f32x4 h = {gelu_f(hp[ct][0]), gelu_f(hp[ct][1]), gelu_f(hp[ct][2]), gelu_f(hp[ct][3])};
+            const f32x4 h = gelu4(hp[ct]);
             hb[ct] = pack4(h);
         }
     }
@@ -391,12 +391,12 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
             uint2 a, b;
             {
                 const f32x4 v = hp[2 * i];
-                const f32x4 hv = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                const f32x4 hv = gelu4(v);
                 a = pack4(hv);
             }
             {
                 const f32x4 v = hp[2 * i + 1];
-                const f32x4 hv = {gelu_f(v[0]), gelu_f(v[1]), gelu_f(v[2]), gelu_f(v[3])};
+                const f32x4 hv = gelu4(v);
                 b = pack4(hv);
             }
             mine[i] = make_uint4(a.x, a.y, b.x, b.y);
@@ -604,14 +604,9 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
 #pragma unroll
         for (int ct = 0; ct < 16; ++ct) {
             const f32x4 hp = unpack4(hpb[ct]);
-            f32x4 h;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float c, p;
-                gelu_parts(hp[r], &c, &p);
-                h[r] = hp[r] * c;
-                dh[ct][r] *= c + hp[r] * p;
-            }
+            f32x4 h, gr;
+            gelu_fwd_bwd4(hp, &h, &gr);
+            dh[ct] *= gr;
             dhpb[ct] = pack4(dh[ct]);
             const uint2 hb2 = pack4(h);
             __builtin_amdgcn_raw_buffer_store_b64(u32x2{hb2.x, hb2.y}, h_a.r, h_a.voff, ct * h_a.ct_stride, 0);
