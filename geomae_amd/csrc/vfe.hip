@@ -1250,17 +1250,33 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) { s1[ot] = f32x4{0, 0, 0, 0}; s2[ot] = f32x4{0, 0, 0, 0}; dw[ot] = f32x4{0, 0, 0, 0}; }
     VFE_T_BEGIN();
+    // ids / features / layer-0 maxima a tile ahead (TileIn); the tile's own gathers (dm0 rows, dh0) at the top of its iteration
+    TileIn cur, nxt;
+    tile_ids_issue(G, R, R.j_lo, lane, false, cur);
+    tile_m0_issue(m0, lane, cur);
     for (int j0 = R.j_lo; j0 < R.j_hi; j0 += 16) {
         VFE_T(0);
+        const bool more = j0 + 16 < R.j_hi;
+        if (more) tile_ids_issue(G, R, j0 + 16, lane, false, nxt);
         const int j = j0 + (lane & 15);
-        const bool valid = j < R.j_hi;
-        const int pid = valid ? pillar_of(G, j) : 0;
+        const bool valid = cur.valid;
+        const int pid = cur.pid;
         const int oz = opaque_zero();
         const Bn0 b0 = shifted(bn0l, oz);
-        float f[4];
-        build_features(G, j, valid, g, f);
+        float4 dmr[4], ddr[4];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            dmr[ot] = make_float4(0, 0, 0, 0);
+            ddr[ot] = dmr[ot];
+            if (valid) {
+                dmr[ot] = *reinterpret_cast<const float4*>(dm0 + (int64_t)pid * 64 + 16 * ot + 4 * g);
+                ddr[ot] = *reinterpret_cast<const float4*>(dh0 + (int64_t)j * 64 + 16 * ot + 4 * g);
+            }
+        }
+        float f[4] = {cur.f[0], cur.f[1], cur.f[2], cur.f[3]};
         f32x4 y0[4];
         layer0_linear(W0s + oz, f, y0, lane);
+        if (more) tile_m0_issue(m0, lane, nxt);
         VFE_T(1);
         f32x4 dhv[4];
 #pragma unroll
@@ -1270,12 +1286,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
             const float4 b = *reinterpret_cast<const float4*>(b0.shift + c0);
             const float4 mu = *reinterpret_cast<const float4*>(b0.mean + c0);
             const float4 is = *reinterpret_cast<const float4*>(b0.invstd + c0);
-            float4 m = make_float4(0, 0, 0, 0), dm = m, dd = m;
-            if (valid) {
-                m = *reinterpret_cast<const float4*>(m0 + (int64_t)pid * 64 + c0);
-                dm = *reinterpret_cast<const float4*>(dm0 + (int64_t)pid * 64 + c0);
-                dd = *reinterpret_cast<const float4*>(dh0 + (int64_t)j * 64 + c0);
-            }
+            const float4 m = cur.m[ot], dm = dmr[ot], dd = ddr[ot];
             const float sc[4] = {s.x, s.y, s.z, s.w}, sh[4] = {b.x, b.y, b.z, b.w}, mn[4] = {mu.x, mu.y, mu.z, mu.w},
                         iv[4] = {is.x, is.y, is.z, is.w}, mx[4] = {m.x, m.y, m.z, m.w}, dmv[4] = {dm.x, dm.y, dm.z, dm.w},
                         ddv[4] = {dd.x, dd.y, dd.z, dd.w};
@@ -1317,6 +1328,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_route0_kernel(VfeGeo G, VfeW 
             wave_sync();
             VFE_T(4);
         }
+        cur = nxt;
     }
     VFE_T(5);
     // the waves' partial contractions meet in LDS as plain stores into per-wave slices of the (now free) tile buffer and are
