@@ -50,6 +50,12 @@ class GeomaeVfeArgs(ctypes.Structure):
                 ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p), ("pillar_ties", c_void_p)]
 
 
+class GeomaeBnFold(ctypes.Structure):
+    _fields_ = [("count", c_double), ("gamma", c_void_p), ("beta", c_void_p), ("eps", c_float), ("momentum", c_float),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("invstd", c_void_p), ("moments", c_void_p), ("num_batches_tracked", c_void_p)]
+
+
 class GeomaeSweepInfo(ctypes.Structure):
     _fields_ = [("rot", c_double * 9), ("trans", c_double * 3), ("dt", c_float), ("frame", c_int32),
                 ("remove_close", c_int32), ("has_transform", c_int32)]
@@ -148,6 +154,8 @@ SIGNATURES = {
     "geomae_vfe_stats0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P]),
     "geomae_vfe_layer0": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
     "geomae_vfe_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), P, P, P]),
+    "geomae_vfe_layer0_bn": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnFold), P, P, P]),
+    "geomae_vfe_layer1_bn": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnFold), P, P, P, P]),
     "geomae_vfe_backward_stats": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, P]),
     "geomae_vfe_backward_layer1": (ctypes.c_int, [POINTER(GeomaeVfeArgs), POINTER(GeomaeBnState), P, P, P, P, c_float,
                                                   P, P, P, P, P, P, P, P, P]),

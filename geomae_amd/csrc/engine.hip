@@ -624,13 +624,31 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         ENG_CALL(geomae_bn_finalize(sums0, 1.0, nullptr, 64, m.bn_gamma[0], m.bn_beta[0], c.bn_eps, c.bn_momentum, 0,
                                     m.bn_running_mean[0], m.bn_running_var[0], bn_scale0, bn_shift0, bn_invstd0, bn_mom0,
                                     nullptr, main));
-    } else {
-        ENG_CALL(geomae_vfe_stats0(&va, sums0, main));
-        ENG_CALL(bn_forward(e, 0, sums0, (double)N, bn_scale0, bn_shift0, bn_invstd0, bn_mom0, main));
     }
-    ENG_CALL(geomae_vfe_layer0(&va, m0, sums1, main));
-    ENG_CALL(bn_forward(e, 1, sums1, (double)N, bn_scale1, bn_shift1, bn_invstd1, bn_mom1, main));
-    ENG_CALL(geomae_vfe_layer1(&va, m0, vf, main));
+    // single process (nothing to exchange between the statistics and their use): both BatchNorm finalisations ride in the
+    // heads of the sweeps that use them (GeomaeBnFold) -- three single-workgroup launches fewer on the critical path
+    const bool fold_bn = !b.moments_exchanged && (!exchanges(c) || !c.sync_bn) && b.moments != nullptr;
+    auto fold_of = [&](int layer, float* scale, float* shift, float* invstd, float* mom) {
+        GeomaeBnFold f;
+        f.count = (double)N; f.gamma = m.bn_gamma[layer]; f.beta = m.bn_beta[layer]; f.eps = c.bn_eps; f.momentum = c.bn_momentum;
+        f.running_mean = m.bn_running_mean[layer]; f.running_var = m.bn_running_var[layer];
+        f.scale = scale; f.shift = shift; f.invstd = invstd; f.moments = mom; f.num_batches_tracked = m.bn_num_batches[layer];
+        return f;
+    };
+    if (fold_bn) {
+        const GeomaeBnFold f0 = fold_of(0, bn_scale0, bn_shift0, bn_invstd0, bn_mom0);
+        const GeomaeBnFold f1 = fold_of(1, bn_scale1, bn_shift1, bn_invstd1, bn_mom1);
+        ENG_CALL(geomae_vfe_layer0_bn(&va, &f0, m0, sums1, main));
+        ENG_CALL(geomae_vfe_layer1_bn(&va, &f1, sums1, m0, vf, main));
+    } else {
+        if (!b.moments_exchanged) {
+            ENG_CALL(geomae_vfe_stats0(&va, sums0, main));
+            ENG_CALL(bn_forward(e, 0, sums0, (double)N, bn_scale0, bn_shift0, bn_invstd0, bn_mom0, main));
+        }
+        ENG_CALL(geomae_vfe_layer0(&va, m0, sums1, main));
+        ENG_CALL(bn_forward(e, 1, sums1, (double)N, bn_scale1, bn_shift1, bn_invstd1, bn_mom1, main));
+        ENG_CALL(geomae_vfe_layer1(&va, m0, vf, main));
+    }
     mark(e, pVfeFwd, main);
     ENG_CALL(order_after(e, kVfeDone, main, aux));
 

@@ -752,13 +752,63 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats0_kernel(VfeGeo G, VfeW W, d
     flush_channel_sums<4>(s1, s2, sums0, 64, red, fl_s, lane, wave);
 }
 
+// BatchNorm finalisation folded into the head of a sweep (GeomaeBnFold): channel c's (sum, sum of squares) -> scale / shift
+// into LDS for this workgroup; workgroup 0 also writes what bn_finalize_kernel writes.  Same arithmetic as that kernel
+// (variance from the fp64 sums, unbiased running variance).
+struct BnFoldDev {
+    double count;
+    const float *gamma, *beta;
+    float eps, momentum;
+    float *running_mean, *running_var, *scale, *shift, *invstd, *moments;
+    long long* nbt;
+    bool on;
+};
+__device__ __forceinline__ void bn_fold_channel(const BnFoldDev& F, int C, int c, double s1, double s2, float* scale_lds,
+                                                float* shift_lds) {
+    const double m = s1 / F.count;
+    const float mean = (float)m, msq = (float)(s2 / F.count);
+    const float var = (float)(s2 / F.count - m * m);
+    const float invstd = rsqrtf(var + F.eps);
+    const float sc = F.gamma[c] * invstd, sh = F.beta[c] - mean * sc;
+    scale_lds[c] = sc;
+    shift_lds[c] = sh;
+    if (blockIdx.x == 0) {
+        F.scale[c] = sc; F.shift[c] = sh; F.invstd[c] = invstd;
+        F.moments[c] = mean; F.moments[C + c] = msq;
+        if (F.running_mean) {
+            const float rv = var * (float)(F.count / (F.count - 1.0));
+            F.running_mean[c] += F.momentum * (mean - F.running_mean[c]);
+            F.running_var[c] += F.momentum * (rv - F.running_var[c]);
+        }
+        if (F.nbt && c == 0) F.nbt[0] += 1;
+    }
+}
+
 // sweep 2 of layer 0: h0 = ReLU(BN(y0)), m0 = segmented max (m0 zero-filled by the caller: rows of pillars
 // that straddle waves are combined with integer atomicMax, exact because h0 >= 0)
-__global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, float* __restrict__ m0) {
+__global__ __launch_bounds__(kVfeBlk) void vfe_layer0_kernel(VfeGeo G, VfeW W, float* __restrict__ m0, BnFoldDev F,
+                                                             const double* __restrict__ moments) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTile0Ld];
     stage_w0(W.w0, W0s);
     VFE_STAGE_BN0_FWD(W, Wl)
+    if (F.on && threadIdx.x < 64) {
+        // y0 = W0 f is linear: sum y0_c = W0[c] . S1, sum y0_c^2 = W0[c] S2 W0[c]^T (vfe_stats0_from_moments_kernel)
+        const int c = threadIdx.x;
+        double w[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) w[k] = (double)W.w0[c * 11 + k];
+        double m1 = 0.0, m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 11; ++k) {
+            m1 += w[k] * moments[k];
+            double r = 0.0;
+#pragma unroll
+            for (int l = 0; l < 11; ++l) r += w[l] * moments[kMomS2 + k * 11 + l];
+            m2 += w[k] * r;
+        }
+        bn_fold_channel(F, 64, c, m1, m2, bn0f_s[0], bn0f_s[1]);     // (overwrites what VFE_STAGE_BN0_FWD staged)
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4;
     const WaveRange R = wave_range(G, blockIdx.x * kVfeWaves + wave);
@@ -878,7 +928,8 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
 
 // sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max (zero-filled by the caller)
 __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
-                                                             float* __restrict__ vf, unsigned char* __restrict__ ties) {
+                                                             float* __restrict__ vf, unsigned char* __restrict__ ties,
+                                                             BnFoldDev F, const double* __restrict__ sums1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ __attribute__((aligned(16))) float tiles[kVfeWaves][16 * kTileLd];
@@ -887,8 +938,12 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     stage_w0(W.w0, W0s);
     stage_w1(W.w1, W1s, false);
     VFE_STAGE_BN0_FWD(W, Ws)
-    stage_vec(W.scale1, bn1f_s[0], 128);
-    stage_vec(W.shift1, bn1f_s[1], 128);
+    if (F.on) {
+        if (threadIdx.x < 128) bn_fold_channel(F, 128, threadIdx.x, sums1[threadIdx.x], sums1[128 + threadIdx.x], bn1f_s[0], bn1f_s[1]);
+    } else {
+        stage_vec(W.scale1, bn1f_s[0], 128);
+        stage_vec(W.shift1, bn1f_s[1], 128);
+    }
     Ws.scale1 = bn1f_s[0];
     Ws.shift1 = bn1f_s[1];
     __syncthreads();
@@ -1591,7 +1646,34 @@ extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums
     GEOMAE_REQUIRE(m0 && sums1 && a->scale0 && a->shift0, "vfe_layer0: null argument");
     GEOMAE_ZERO(sums1, 256 * sizeof(double), stream);
     GEOMAE_ZERO(m0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
-    hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0);
+    hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, BnFoldDev{}, (const double*)nullptr);
+    if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
+    hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
+    return check_launch("vfe_stats1_kernel");
+}
+
+static int bn_fold_of(const GeomaeBnFold* f, BnFoldDev* d, const char* who) {
+    GEOMAE_REQUIRE(f && f->count > 1.0 && f->gamma && f->beta && f->scale && f->shift && f->invstd && f->moments,
+                   "%s: incomplete GeomaeBnFold", who);
+    GEOMAE_REQUIRE((f->running_mean == nullptr) == (f->running_var == nullptr), "%s: pass both running statistics or none", who);
+    d->count = f->count; d->gamma = f->gamma; d->beta = f->beta; d->eps = f->eps; d->momentum = f->momentum;
+    d->running_mean = f->running_mean; d->running_var = f->running_var; d->scale = f->scale; d->shift = f->shift;
+    d->invstd = f->invstd; d->moments = f->moments; d->nbt = (long long*)f->num_batches_tracked; d->on = true;
+    return GEOMAE_OK;
+}
+
+extern "C" int geomae_vfe_layer0_bn(const GeomaeVfeArgs* a, const GeomaeBnFold* bn0, float* m0, double* sums1,
+                                    hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_layer0_bn");
+    if (rc) return rc;
+    BnFoldDev F;
+    if ((rc = bn_fold_of(bn0, &F, "vfe_layer0_bn"))) return rc;
+    GEOMAE_REQUIRE(m0 && sums1 && a->moments && a->scale0 == bn0->scale && a->shift0 == bn0->shift,
+                   "vfe_layer0_bn: needs the feature moments, and args->scale0 / shift0 = the fold's outputs");
+    GEOMAE_ZERO(sums1, 256 * sizeof(double), stream);
+    GEOMAE_ZERO(m0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
+    hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, F, a->moments);
     if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
     hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
     return check_launch("vfe_stats1_kernel");
@@ -1604,7 +1686,23 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
     GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
     if (a->pillar_ties) GEOMAE_ZERO(a->pillar_ties, (size_t)a->max_pillars, stream);
-    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties);
+    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties,
+                       BnFoldDev{}, (const double*)nullptr);
+    return check_launch("vfe_layer1_kernel");
+}
+
+extern "C" int geomae_vfe_layer1_bn(const GeomaeVfeArgs* a, const GeomaeBnFold* bn1, const double* sums1, const float* m0,
+                                    float* voxel_feats, hipStream_t stream) {
+    VfeGeo G; VfeW W;
+    int rc = vfe_common(a, &G, &W, "vfe_layer1_bn");
+    if (rc) return rc;
+    BnFoldDev F;
+    if ((rc = bn_fold_of(bn1, &F, "vfe_layer1_bn"))) return rc;
+    GEOMAE_REQUIRE(m0 && voxel_feats && sums1 && a->scale0 && a->shift0 && a->scale1 == bn1->scale && a->shift1 == bn1->shift,
+                   "vfe_layer1_bn: null argument, or args->scale1 / shift1 are not the fold's outputs");
+    GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
+    if (a->pillar_ties) GEOMAE_ZERO(a->pillar_ties, (size_t)a->max_pillars, stream);
+    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties, F, sums1);
     return check_launch("vfe_layer1_kernel");
 }
 

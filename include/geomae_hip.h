@@ -455,6 +455,25 @@ int geomae_bn_finalize(const double* sums, double count, const float* moments_in
 int geomae_vfe_stats0(const GeomaeVfeArgs* args /*host*/, double* sums0 /*[128]*/, geomaeStream_t stream);
 int geomae_vfe_layer0(const GeomaeVfeArgs* args, float* m0 /*[V,64]*/, double* sums1 /*[256]*/, geomaeStream_t stream);
 int geomae_vfe_layer1(const GeomaeVfeArgs* args, const float* m0, float* voxel_feats /*[V,128]*/, geomaeStream_t stream);
+/* The same two sweeps with the BatchNorm finalisation FOLDED into them (single-process training: no exchange between the
+ * statistics and their use): every workgroup derives scale / shift itself -- layer 0 from the feature moments of the
+ * args (W0 S W0^T, fp64), layer 1 from the [256] sums of the statistics sweep -- and workgroup 0 writes what
+ * geomae_bn_finalize would have written (scale, shift, invstd, moments = (mean, mean of squares), running statistics with
+ * the unbiased variance, the batch counter).  Three single-workgroup launches fewer per forward (vfe_stats0_from_moments,
+ * two bn_finalize): ~25 us of a 110 us VFE forward at BASELINE config 2.  args->scale0 / shift0 / scale1 / shift1 must be
+ * the `scale` / `shift` arrays of the fold structs (the later sweeps read them there). */
+typedef struct GeomaeBnFold {
+    double count;                                    /* points behind the statistics */
+    const float *gamma, *beta;                       /* [C] */
+    float eps, momentum;
+    float *running_mean, *running_var;               /* [C], or NULL */
+    float *scale, *shift, *invstd, *moments;         /* outputs: [C], [C], [C], [2C] */
+    int64_t* num_batches_tracked;                    /* += 1, or NULL */
+} GeomaeBnFold;
+int geomae_vfe_layer0_bn(const GeomaeVfeArgs* args /* moments != NULL */, const GeomaeBnFold* bn0, float* m0 /*[V,64]*/,
+                         double* sums1 /*[256]*/, geomaeStream_t stream);
+int geomae_vfe_layer1_bn(const GeomaeVfeArgs* args, const GeomaeBnFold* bn1, const double* sums1 /*[256]*/, const float* m0,
+                         float* voxel_feats /*[V,128]*/, geomaeStream_t stream);
 /* backward.  GeomaeBnState = what geomae_bn_finalize produced in the forward (scale = gamma * invstd,
  * shift = beta - mean * scale, mean, invstd) for the two BatchNorms.  bsums [2C] fp64 = (sum dh, sum dh * yhat)
  * over the local points: they ARE d beta and d gamma; for naiveSyncBN1d the caller all-reduces them before the
