@@ -56,6 +56,15 @@ for sweeps in [int(a) for a in sys.argv[1:]] or [1, 10]:
         st = read(); s = st[st[:, 7] > 0]
         print(f"  vfe_bwd_layer1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 7].mean():.0f} max {s[:, 7].max()} cycles")
         for k, nm in enumerate(NAMES_B): print(f"    {nm:36s} mean {s[:, k].mean():8.0f}  max {s[:, k].max():8.0f}")
+        try:
+            lib.geomae_debug_read_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+            b2 = np.zeros(NBLK * SL, dtype=np.uint64)
+            lib.geomae_debug_read_stamps(b2.ctypes.data_as(ctypes.c_void_p), 1)
+            d = b2.reshape(NBLK, SL).astype(np.int64); d = d[d[:, 26] > 0]
+            print(f"  dw_kernel (dW1 = dy1^T g): {len(d)} workgroups stamped, loop mean {(d[:, 25] - d[:, 24]).mean():.0f} max {(d[:, 25] - d[:, 24]).max()} cycles, "
+                  f"epilogue mean {(d[:, 26] - d[:, 25]).mean():.0f}")
+        except Exception as ex:
+            print("  (no dw stamps:", ex, ")")
         s = st[st[:, 23] > 0]
         print(f"  vfe_bwd_stats1_kernel: {len(s)} workgroups stamped (wave 0), whole kernel mean {s[:, 23].mean():.0f} max {s[:, 23].max()} cycles")
         for k, nm in enumerate(["staging", "gathers + features + layer 0 (both passes)", "GEMM half + routing (both passes)", "flush of the channel sums"]):
