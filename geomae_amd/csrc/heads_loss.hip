@@ -11,6 +11,7 @@
 // into loss terms and d(logit) in registers, and immediately contracted back through the SAME LDS tile
 // into d(decoder output) -- the [M,726] prediction tensors never exist.  Head weight gradients are the
 // token contraction dl^T x, done by dw_kernel from the bf16 dl / x copies this kernel writes.
+#include <type_traits>
 #include "common.h"
 #include "../../include/geomae_hip.h"
 #include "sst_device.h"
@@ -90,6 +91,8 @@ template <int MODE>
 __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __restrict__ smem, float (*red)[6]) {
     constexpr int kFirst = MODE == 3 ? 6 : ((MODE == 2 || MODE == 4) ? 3 : 0), kLast = MODE == 1 ? 3 : (MODE == 4 ? 6 : 7);
     float* const d_cen_out = (MODE == 2 || MODE == 4) ? A.d_cen2 : A.d_cen;
+    constexpr int SB = MODE == 1 ? 0 : (MODE == 4 ? 10 : 20);         // phase stamps (timing build): per kind of workgroup
+    GEOMAE_STAMP(SB);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int tile = blockIdx.x * (kLayerBlk / 64) + wave;
@@ -102,6 +105,12 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
     const float inv_cl = A.w_cls_low / ((float)A.M * 256.f), inv_cm = A.w_cls_med / ((float)A.M * 32.f);
     float l_nor = 0.f, l_low = 0.f, l_med = 0.f, l_top = 0.f, l_cl = 0.f, l_cm = 0.f;
 
+    // the first chunk's weights before anything else: the oldest entry of the in-order memory counter, in flight together
+    // with the rows (the rows first, then the weights: 28-35 k cycles until the first GEMM was done)
+    WStage<128, 128> st;                                        // (chunk 6 stages its 32 rows through the first quarter)
+    if (kFirst < 6) stage_issue<128, 128>(A.wp + (size_t)(128 * kFirst) * 128, st);
+    else stage_issue<128, 32>(A.wp + (size_t)768 * 128, reinterpret_cast<WStage<128, 32>&>(st));
+    __builtin_amdgcn_sched_barrier(0);
     uint2 xb[8];
     if (MODE != 3) {
         f32x4 x[8];
@@ -114,36 +123,18 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // weights of chunk c+1 are requested right after chunk c's matrix is in LDS: the loads fly under the loss
-    // arithmetic and the dX GEMM instead of stalling the next chunk's first MFMA
-#pragma unroll
-    for (int chunk = kFirst; chunk < kLast; ++chunk) {
-        if (chunk == 6) {
-            // flush d_cen, switch the input to the density decoder
-            if (MODE != 3) {
-#pragma unroll
-                for (int ct = 0; ct < 8; ++ct)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
-                        if (rr < A.M) d_cen_out[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
-                    }
-            }
-            f32x4 x[8];
-            load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) {
-                xb[ct] = pack4(x[ct]);
-                dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            store_rows_bf16<128>(A.dm_b, A.M, (int)row, 128, 0, x, lane);
-        }
-        const int row0 = chunk < 6 ? 128 * chunk : 768;         // first output row of this chunk
-        // Targets of the five sub-voxel-low chunks (most of the kernel's target bytes), requested BEFORE the GEMM and
-        // unconditionally: inside the loss loop they were a mask load, a branch on it and a dependent target load per
-        // element, none of which could start before the logits existed (22 us of the kernel, measured by removing them).
-        f32x4 tl[8];                                            // chunks 0-2: regression targets of this lane's 32 outputs
-        unsigned int mk[8];                                     // per ct: two mask bytes (see below)
+    // Software pipeline over the chunks (everything below is resolved at compile time: `chunk` is a constant of the unrolled
+    // loop).  The weights of chunk c + 1 are requested right after chunk c's matrix is in LDS (their staging registers are
+    // free then) and its targets after chunk c's loss arithmetic (their registers are free then): both fly under the rest of
+    // chunk c, and the weights are OLDER than the targets in the in-order memory counter, so the LDS commit of chunk c + 1
+    // does not wait for target rows.  (Before: targets, then weights, requested at the top of their own chunk -- "loads +
+    // GEMM" 10-12 k cycles per chunk for a 32-MFMA GEMM -- and the medium / top targets of chunk 5 loaded element by
+    // element inside the loss loop, a mask load, a branch and a dependent target load each: 30 k cycles,
+    // tools/heads_time.py.)
+    f32x4 tl[8];                                                // regression targets of this lane's 32 outputs (chunks 0-2, 5)
+    unsigned int mk[8];                                         // per ct: mask / class bytes (see targets_issue)
+    auto targets_issue = [&](auto CH) {
+        constexpr int chunk = decltype(CH)::value;
         if (chunk < 5) {
             const __amdgpu_buffer_rsrc_t mr = rows_rsrc(A.m_low, A.M, 128);
             if (chunk < 3) {
@@ -164,19 +155,78 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
                     mk[ct] = __builtin_amdgcn_raw_buffer_load_b16(mr, (int)row * 128 + (og >> 1), 0, 0);
                 }
             }
+        } else if (chunk == 5) {
+            // outputs 0-47: medium regression (targets t_med [M,48], masks m_med [M,16]: bytes o/3, (o+3)/3);
+            // 48-79: medium class logits (bytes (o-48)/2, +1); 80-82: the top centroid (t_top [M,3])
+            const __amdgpu_buffer_rsrc_t mm = rows_rsrc(A.m_med, A.M, 16), tm = rows_rsrc(A.t_med, A.M, 192);
+            const __amdgpu_buffer_rsrc_t tt = rows_rsrc(A.t_top, A.M, 12);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int o = 16 * ct + 4 * g;
+                tl[ct] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(tm, (int)row * 192 + 4 * o, 0, 0));
+                const unsigned int b0 = __builtin_amdgcn_raw_buffer_load_b8(mm, (int)row * 16 + o / 3, 0, 0);
+                const unsigned int b1 = __builtin_amdgcn_raw_buffer_load_b8(mm, (int)row * 16 + (o + 3) / 3, 0, 0);
+                mk[ct] = b0 | (b1 << 8);
+            }
+#pragma unroll
+            for (int ct = 3; ct < 5; ++ct) mk[ct] = __builtin_amdgcn_raw_buffer_load_b16(mm, (int)row * 16 + ((16 * ct + 4 * g - 48) >> 1), 0, 0);
+            tl[5] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g == 0) {                                       // outputs 80, 81, 82 (+ one unused)
+                tl[5][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tt, (int)row * 12, 0, 0));
+                tl[5][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tt, (int)row * 12 + 4, 0, 0));
+                tl[5][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tt, (int)row * 12 + 8, 0, 0));
+            }
+        } else {
+            tl[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (g == 0) {                                       // the normal's three components
+                const __amdgpu_buffer_rsrc_t tn = rows_rsrc(A.t_nor, A.M, 12);
+                tl[0][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tn, (int)row * 12, 0, 0));
+                tl[0][1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tn, (int)row * 12 + 4, 0, 0));
+                tl[0][2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(tn, (int)row * 12 + 8, 0, 0));
+            }
+        }
+    };
+    targets_issue(std::integral_constant<int, kFirst>{});
+#pragma unroll
+    for (int chunk = kFirst; chunk < kLast; ++chunk) {
+        const int row0 = chunk < 6 ? 128 * chunk : 768;         // first output row of this chunk
+        if (chunk == 6 && MODE != 3) {
+            // flush d_cen, switch the input to the density decoder
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int64_t rr = (int64_t)tile * 16 + 4 * g + r;
+                    if (rr < A.M) d_cen_out[(A.n_keep + rr) * 128 + kperm(16 * ct + (lane & 15))] = dx[ct][r];
+                }
+        }
+        if (chunk == 6) {
+            f32x4 x[8];
+            load_rows_f32<128>(A.den, A.n_keep + A.M, (int)tok, x, lane);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) {
+                xb[ct] = pack4(x[ct]);
+                dx[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            store_rows_bf16<128>(A.dm_b, A.M, (int)row, 128, 0, x, lane);
         }
         f32x4 z[8];
         if (chunk < 6) {
             load_bias<128>(A.bias + row0, z, lane);
-            gemm_t<128, 128>(A.wp + (size_t)row0 * 128, smem, xb, z, lane);
+            gemm_staged<128, 128>(st, smem, xb, z, lane);
         } else {
             // last chunk holds 32 rows (nor_top + zero padding); the other 96 rows of the tile are stale
             // weights multiplied by dl = 0 below
             load_bias<32>(A.bias + row0, reinterpret_cast<f32x4(&)[2]>(z), lane);
 #pragma unroll
             for (int ct = 2; ct < 8; ++ct) z[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gemm_t<128, 32>(A.wp + (size_t)row0 * 128, smem, xb, reinterpret_cast<f32x4(&)[2]>(z), lane);
+            gemm_staged<128, 32>(reinterpret_cast<WStage<128, 32>&>(st), smem, xb, reinterpret_cast<f32x4(&)[2]>(z), lane);
         }
+        if (chunk + 1 < kLast) {                                // the next chunk's weights: in flight under this chunk's arithmetic
+            if (chunk + 1 < 6) stage_issue<128, 128>(A.wp + (size_t)(128 * (chunk + 1)) * 128, st);
+            else stage_issue<128, 32>(A.wp + (size_t)768 * 128, reinterpret_cast<WStage<128, 32>&>(st));
+        }
+        GEOMAE_STAMP(SB + 1 + 3 * ((chunk - kFirst) % 3));
         // ---- loss terms and d(logit) for the 32 outputs this lane holds
         uint2 dlb[8];
 #pragma unroll
@@ -204,26 +254,28 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
                         l_cl += l;
                         d[r] = dd * inv_cl;
                     } else if (chunk == 5) {
-                        if (o < 48) {
-                            if (A.m_med[row * 16 + o / 3]) {
-                                const float df = x - A.t_med[row * 48 + o];
+                        if (ct < 3) {                            // o < 48
+                            const unsigned int m = ((o / 3 == (o - r) / 3) ? mk[ct] : (mk[ct] >> 8)) & 0xffu;
+                            if (m) {
+                                const float df = x - tl[ct][r];
                                 l_med += df * df * (1.f / 3.f);
                                 d[r] = df * (2.f / 3.f) * inv_med;
                             }
-                        } else if (o < 80) {
+                        } else if (ct < 5) {                     // 48 <= o < 80
                             const int og = o - 48;
-                            const float y = ((int)A.m_med[row * 16 + (og >> 1)] == (og & 1)) ? 1.f : 0.f;
+                            const int cls = (int)((mk[ct] >> (8 * (r >> 1))) & 0xffu);
+                            const float y = (cls == (og & 1)) ? 1.f : 0.f;
                             float l, dd;
                             bce(x, y, &l, &dd);
                             l_cm += l;
                             d[r] = dd * inv_cm;
-                        } else if (o < 83) {
-                            const float df = x - A.t_top[row * 3 + (o - 80)];
+                        } else if (ct == 5 && g == 0 && r < 3) { // 80 <= o < 83
+                            const float df = x - tl[5][r];
                             l_top += df * df * (1.f / 3.f);
                             d[r] = df * (2.f / 3.f) * inv_top;
                         }
-                    } else if (o < 3) {
-                        const float df = x - A.t_nor[row * 3 + o];
+                    } else if (ct == 0 && g == 0 && r < 3) {     // chunk 6: o < 3
+                        const float df = x - tl[0][r];
                         l_nor += df * df * (1.f / 3.f);
                         d[r] = df * (2.f / 3.f) * inv_nor;
                     }
@@ -233,11 +285,24 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
             if (valid && (chunk < 6 || ct < 2))
                 *reinterpret_cast<uint2*>(A.dl + row * kDlLd + row0 + 16 * ct + 4 * g) = dlb[ct];
         }
+        GEOMAE_STAMP(SB + 2 + 3 * ((chunk - kFirst) % 3));
+        // the next chunk's targets: their registers are free now, they fly under the dX GEMM and the next forward GEMM
+        if (chunk + 1 < kLast) {
+            switch (chunk + 1) {
+                case 1: targets_issue(std::integral_constant<int, 1>{}); break;
+                case 2: targets_issue(std::integral_constant<int, 2>{}); break;
+                case 3: targets_issue(std::integral_constant<int, 3>{}); break;
+                case 4: targets_issue(std::integral_constant<int, 4>{}); break;
+                case 5: targets_issue(std::integral_constant<int, 5>{}); break;
+                default: targets_issue(std::integral_constant<int, 6>{}); break;
+            }
+        }
         // (chunk 6 stages 32 rows; in a launch of its own -- MODE 3 -- the other 96 rows of the LDS tile are whatever the last
         //  kernel left there, and 0 x NaN is NaN: only the 32 rows are read.  Behind chunk 5 they are stale finite weights
         //  against dl = 0, as before.)
         if (MODE == 3) accumulate_dx<1>(smem, dlb, dx, lane);
         else accumulate_dx(smem, dlb, dx, lane);
+        GEOMAE_STAMP(SB + 3 + 3 * ((chunk - kFirst) % 3));
     }
     float* const d_last = MODE == 1 ? A.d_cen : (MODE == 4 ? A.d_cen2 : A.d_den);   // MODE 1 / 4 end on the centroid decoder's chunks
 #pragma unroll
@@ -261,6 +326,7 @@ __device__ __forceinline__ void heads_loss_body(const HeadArgs& A, bf16_t* __res
     __syncthreads();
     if (threadIdx.x < 6) atomicAdd(A.loss + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] +
                                                           red[2][threadIdx.x] + red[3][threadIdx.x]);
+    GEOMAE_STAMP(MODE == 1 ? 30 : (MODE == 4 ? 31 : 29));
 }
 
 __global__ __launch_bounds__(kLayerBlk, 2) void heads_loss_kernel(HeadArgs A) {
@@ -276,6 +342,17 @@ __global__ __launch_bounds__(kLayerBlk, 2) void heads_loss_kernel(HeadArgs A) {
 }  // namespace geomae
 
 using namespace geomae;
+
+#ifdef GEOMAE_PHASE_TIMING
+extern "C" void geomae_debug_read_heads_stamps(unsigned long long* out, int clear) {
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(geomae::geomae_stamps), sizeof(unsigned long long) * GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS);
+    if (clear) {
+        static unsigned long long zeros[GEOMAE_STAMP_BLOCKS * GEOMAE_STAMP_SLOTS];
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(geomae::geomae_stamps), zeros, sizeof(zeros));
+    }
+}
+#endif
 
 static int heads_loss_launch(const float* dec_centroid, const float* dec_density, int32_t num_keep,
                              int32_t num_mask, const void* head_w_packed, const float* head_bias,
