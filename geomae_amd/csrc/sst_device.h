@@ -128,10 +128,14 @@ __device__ __forceinline__ void load_bias(const float* __restrict__ b, f32x4 (&a
 
 // `bias`: optional [N] floats the accumulators start from, read AFTER the barriers -- the way to hand over a vector
 // that sits in LDS and was written by other threads since the last barrier (stage_params below)
+// gemm_staged_then: `after_commit()` runs between the LDS commit of the matrix and its MFMA loop -- the place to request
+// the NEXT matrix: the staging registers of this one are free from there on, and the request gets the whole GEMM as extra
+// lead (requested behind the GEMM, the W2 stage of sst_ffn_fwd_kernel arrived ~8 k cycles late at decoder size:
+// tools/ffn_fwd_time.py).
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+// the two halves of a staged GEMM: the matrix into LDS (both barriers), and the MFMA loop over NOT output tiles from OT0
 template <int K, int N>
-__device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __restrict__ smem,
-                                            const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100,
-                                            const float* bias = nullptr) {
+__device__ __forceinline__ void gemm_commit(const WStage<K, N>& st, bf16_t* __restrict__ smem, int sb = -100) {
     constexpr int LD = K + kPad;
     constexpr int CH = K / 8;
     constexpr int PASSES = N * CH / kLayerBlk;
@@ -146,23 +150,42 @@ __device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __re
     }
     __syncthreads();
     GEOMAE_STAMP(sb + 2);
-    if (bias) load_bias<N>(bias, acc, lane);
+}
+template <int K, int OT0, int NOT>
+__device__ __forceinline__ void gemm_run(const bf16_t* __restrict__ smem, const uint2 (&xb)[K / 16], f32x4 (&acc)[NOT], int lane) {
+    constexpr int LD = K + kPad;
     const int o = lane & 15, g = lane >> 4;
     // groups of 4 output tiles advance together over K: consecutive MFMAs hit independent accumulators, so the
     // dependent-accumulator latency of a chain (kk inner loop: 38 % issue stalls in profiles/r01 PMC) is hidden
-    constexpr int GRP = (N / 16) < 4 ? (N / 16) : 4;
+    constexpr int GRP = NOT < 4 ? NOT : 4;
 #pragma unroll
-    for (int ot0 = 0; ot0 < N / 16; ot0 += GRP) {
+    for (int ot0 = 0; ot0 < NOT; ot0 += GRP) {
 #pragma unroll
         for (int kk = 0; kk < K / 32; ++kk) {
             const uint4 b = make_uint4(xb[2 * kk].x, xb[2 * kk].y, xb[2 * kk + 1].x, xb[2 * kk + 1].y);
 #pragma unroll
             for (int u = 0; u < GRP; ++u) {
-                const uint4 a = *reinterpret_cast<const uint4*>(smem + (16 * (ot0 + u) + o) * LD + 8 * g + 32 * kk);
+                const uint4 a = *reinterpret_cast<const uint4*>(smem + (16 * (OT0 + ot0 + u) + o) * LD + 8 * g + 32 * kk);
                 acc[ot0 + u] = mfma32(a, b, acc[ot0 + u]);
             }
         }
     }
+}
+template <int K, int N, typename F>
+__device__ __forceinline__ void gemm_staged_then(const WStage<K, N>& st, bf16_t* __restrict__ smem,
+                                                 const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, F&& after_commit,
+                                                 int sb = -100, const float* bias = nullptr) {
+    gemm_commit<K, N>(st, smem, sb);
+    after_commit();
+    if (bias) load_bias<N>(bias, acc, lane);
+    gemm_run<K, 0, N / 16>(smem, xb, acc, lane);
+}
+
+template <int K, int N>
+__device__ __forceinline__ void gemm_staged(const WStage<K, N>& st, bf16_t* __restrict__ smem,
+                                            const uint2 (&xb)[K / 16], f32x4 (&acc)[N / 16], int lane, int sb = -100,
+                                            const float* bias = nullptr) {
+    gemm_staged_then<K, N>(st, smem, xb, acc, lane, NoHook{}, sb, bias);
 }
 
 // Column-split form (the "pair" kernels of sst_layer.hip): two waves share one 16-token tile, wave half h computes the

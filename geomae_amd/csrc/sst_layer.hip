@@ -216,6 +216,9 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
                                                                 float* __restrict__ rstd_out, NextQkv N, int lay,
                                                                 int wg0 /* first workgroup (64 tokens each) that runs */) {
     const bool blk = lay & kLayBlocked;
+#ifdef FFN_ABL_NO_SAVE                      // (timing ablation: what the saved-activation stores cost this kernel)
+    xh1_out = nullptr; xh2_out = nullptr; hp_out = nullptr; rstd_out = nullptr; N.x_b = nullptr;
+#endif
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ __attribute__((aligned(16))) float prm[kPrmFloats];
     PrmRegs prm_r;
@@ -235,9 +238,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         f32x4 xr[8];
         load_rows_f32<128>(x, n, tok, xr, lane, lay & kLayXBlocked);                 // needed after the GEMM: in flight under it
         ffn_params_commit(prm, N.wqkv != nullptr, prm_r);
-        gemm_staged<128, 128>(s_wo, smem, ob, u, lane, -100, prm + kPrmBo);
-        GEOMAE_FSTAMP(1);
-        stage_issue<128, 256>(W.w1, s_w1);                            // lands under the LayerNorm arithmetic
+        gemm_staged_then<128, 128>(s_wo, smem, ob, u, lane, [&] { stage_issue<128, 256>(W.w1, s_w1); }, -100, prm + kPrmBo);
+        GEOMAE_FSTAMP(1);                                             // (W1: requested behind Wo's LDS commit)
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) u[ct] += xr[ct];
     }
@@ -250,26 +252,31 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         uint2 yb[8];
 #pragma unroll
         for (int ct = 0; ct < 8; ++ct) yb[ct] = pack4(y[ct]);
-        f32x4 hp[16];
-        load_bias<256>(prm + kPrmB1, hp, lane);
         GEOMAE_FSTAMP(2);
-        gemm_staged<128, 256>(s_w1, smem, yb, hp, lane);
-        GEOMAE_FSTAMP(3);
-        stage_issue<256, 128>(W.w2, s_w2);                            // lands under the GELU arithmetic
-        __builtin_amdgcn_sched_barrier(0);                            // (the scheduler otherwise sinks these loads below the GELU)
-        if (hp_out) store_rows_bf16<256>(hp_out, n, tok, 256, 0, hp, lane, blk);
+        // W1 in two halves of 128 hidden channels: 32 accumulator registers at a time instead of 64, which makes room to
+        // request W2 right behind W1's LDS commit (behind the whole GEMM it arrived ~8 k cycles late at decoder size, inside
+        // the one-piece GEMM it cost 89 spills); same accumulation order per output tile: bit-identical results
+        gemm_commit<128, 256>(s_w1, smem);
+        stage_issue<256, 128>(W.w2, s_w2);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ct = 0; ct < 16; ++ct) {
-            const f32x4 h = gelu4(hp[ct]);
-            hb[ct] = pack4(h);
+        for (int half = 0; half < 2; ++half) {
+            f32x4 hp[8];
+            load_bias<128>(prm + kPrmB1 + 128 * half, hp, lane);
+            if (half == 0) gemm_run<128, 0, 8>(smem, yb, hp, lane);
+            else gemm_run<128, 8, 8>(smem, yb, hp, lane);
+            if (half == 1) GEOMAE_FSTAMP(3);
+            if (hp_out) store_rows_bf16<128>(hp_out, n, tok, 256, 128 * half, hp, lane, blk);
+#pragma unroll
+            for (int ct = 0; ct < 8; ++ct) hb[8 * half + ct] = pack4(gelu4(hp[ct]));
         }
     }
     load_bias<128>(prm + kPrmB2, u, lane);
     GEOMAE_FSTAMP(4);
-    gemm_staged<256, 128>(s_w2, smem, hb, u, lane);
-    GEOMAE_FSTAMP(5);
     const bool has_next = N.wqkv != nullptr;
     WStage<128, 256> s_qk;
+    gemm_staged<256, 128>(s_w2, smem, hb, u, lane);
+    GEOMAE_FSTAMP(5);
     if (has_next) stage_issue<128, 256>(N.wqkv, s_qk);                // lands under the LayerNorm arithmetic
 #pragma unroll
     for (int ct = 0; ct < 8; ++ct) u[ct] += y[ct];
@@ -304,9 +311,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
         f32x4 acc[16];
         load_bias<256>(prm + kPrmQkv, acc, lane);
         GEOMAE_FSTAMP(7);
-        gemm_staged<128, 256>(s_qk, smem, xpb, acc, lane);
+        gemm_staged_then<128, 256>(s_qk, smem, xpb, acc, lane, [&] { stage_issue<128, 128>(N.wqkv + 256 * 128, s_v); });
         GEOMAE_FSTAMP(8);
-        stage_issue<128, 128>(N.wqkv + 256 * 128, s_v);
         store_rows_bf16<256>(N.qkv, n, tok, 384, 0, acc, lane, blk);
     }
     {
