@@ -44,6 +44,7 @@ const int32_t* output_rows(int* num_rows_out);
 // Second summand of the NEXT geomae_sst_ffn_backward's dz on this host thread (dz + dz2, row-major like dz): set by
 // geomae_sst_stack_backward around its top layer only.
 void set_dz_addend(const float* dz2);
+void set_y_from_xhat(bool on, const float* gamma1 = nullptr, const float* beta1 = nullptr);   // sst_layer.hip
 const float* dz_addend();
 // Column sums of the rows >= from_row of the NEXT geomae_sst_qkv_backward's output on this host thread, ADDED into
 // sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).

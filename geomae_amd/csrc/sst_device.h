@@ -587,6 +587,11 @@ struct DwTask {
     float* C; int ldc, c_row0, c_col0;
     float* dbias;
     int rows_valid;          // only rows i < rows_valid of the 128-row block exist
+    // B formed on load: B[t][c] = b_scale[c] * B[t][c] + b_shift[c] (or null).  How dW1 = dhp^T y reads the SAVED xhat1 of the
+    // forward instead of a y = affine(xhat1) copy that the ffn backward used to store for it (256 of the 2.5 KB it wrote per
+    // token: the decoder-size launches run at the HBM roof)
+    const float* b_scale = nullptr;
+    const float* b_shift = nullptr;
 };
 constexpr int kMaxDwTasks = 12;
 struct DwTasks {

@@ -559,7 +559,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
         store_rows_bf16<128>(dattn, n, tok, 128, 0, z8, lane, blk);
         store_rows_bf16<128>(du_b, n, tok, 128, 0, z8, lane, blk);
         store_rows_bf16<128>(dv_b, n, tok, 128, 0, z8, lane, blk);
-        store_rows_bf16<128>(y_b, n, tok, 128, 0, z8, lane, blk);
+        if (y_b) store_rows_bf16<128>(y_b, n, tok, 128, 0, z8, lane, blk);
         store_rows_bf16<256>(dhp_b, n, tok, 256, 0, z16, lane, blk);
         store_rows_bf16<256>(h_b, n, tok, 256, 0, z16, lane, blk);
         return;
@@ -628,7 +628,7 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
     stage_issue<128, 128>(W.woT, s_woT);                              // lands under the LayerNorm arithmetic
     // ---- LN1 backward
     {
-        {
+        if (y_b) {                                                    // (null: the contraction forms y from the saved xhat1)
             f32x4 y[8];
             affine_t(xh1, W.g1, W.be1, y, lane);
             store_rows_bf16<128>(y_b, n, tok, 128, 0, y, lane, blk);
@@ -759,6 +759,14 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
     float bsum[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) bsum[e] = 0.f;
+    // operand B formed on load (DwTask.b_scale): this thread's eight channels' constants
+    float bsc[8], bsh[8];
+    const bool b_affine = T.b_scale != nullptr;                       // workgroup-uniform
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        bsc[e] = b_affine ? T.b_scale[T.b_col0 + 8 * cch + e] : 1.f;
+        bsh[e] = b_affine ? T.b_shift[T.b_col0 + 8 * cch + e] : 0.f;
+    }
     // Operand slabs travel global -> registers -> LDS.  A register ring of kDwStages slabs keeps kDwStages - 1 slabs
     // of loads in flight: with a single stage the loads issued under one slab's MFMAs (~0.3 us) were needed one
     // slab later and each slab paid most of the memory latency.  Slabs of 64 tokens: a slab's life is a serial chain
@@ -794,7 +802,18 @@ __device__ __forceinline__ void dw_body(const DwTask& T, int n, int chunk, int b
 #pragma unroll
                 for (int k = 0; k < kDwPieces; ++k) {
                     *reinterpret_cast<u32x4*>(As + (tk0 + 16 * k) * kDwLd + 8 * cch) = ra[st][k];
-                    *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = rb[st][k];
+                    u32x4 vb = rb[st][k];
+                    if (b_affine) {
+                        // (rows past the chunk: A is zero there.  Rows the forward SKIPPED -- the dead rows of a decoder's last
+                        //  layer -- hold whatever the buffer held; their A rows are zero, but 0 x NaN is NaN: clamp to finite)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float lo = fminf(fmaxf(bf_lo(vb[e]), -65504.f), 65504.f);
+                            const float hi = fminf(fmaxf(bf_hi(vb[e]), -65504.f), 65504.f);
+                            vb[e] = pack2(lo * bsc[2 * e] + bsh[2 * e], hi * bsc[2 * e + 1] + bsh[2 * e + 1]);
+                        }
+                    }
+                    *reinterpret_cast<u32x4*>(Bs + (tk0 + 16 * k) * kDwLd + 8 * cch) = vb;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         bsum[2 * e] += bf_lo(ra[st][k][e]);
@@ -1116,6 +1135,14 @@ extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, con
                                       nullptr, nullptr, nullptr, stream);
 }
 
+// geomae_sst_stack_backward (saved activations in bf16): the next geomae_sst_ffn_backward of this thread stores no y copy and
+// the next geomae_sst_weight_grad takes its `y_bf16` argument as the SAVED xhat1 and forms y = g1 * xhat1 + be1 on load
+static thread_local bool t_y_from_xhat = false;
+static thread_local const float *t_y_gamma = nullptr, *t_y_beta = nullptr;
+void geomae::set_y_from_xhat(bool on, const float* gamma1, const float* beta1) {
+    t_y_from_xhat = on; t_y_gamma = gamma1; t_y_beta = beta1;
+}
+
 extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, const void* hp_bf16,
                                        const float* rstd, const float* dz, const GeomaeSstLayerWeights* w,
                                        int32_t num_tokens, float* dx_res, void* dattn_bf16, void* du_bf16,
@@ -1135,7 +1162,8 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
     }
     GEOMAE_REQUIRE(grads && grads->ln1_w && grads->ln1_b && grads->ln2_w && grads->ln2_b, "sst_ffn_backward: null grads");
     const FfnBwdArgs A = {xhat1, xhat2, (const bf16_t*)hp_bf16, rstd, dz, to_layer(w), num_tokens, dx_res,
-                          (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16, (bf16_t*)y_bf16,
+                          (bf16_t*)dattn_bf16, (bf16_t*)du_bf16, (bf16_t*)dv_bf16, (bf16_t*)dhp_bf16,
+                          t_y_from_xhat ? nullptr : (bf16_t*)y_bf16,
                           (bf16_t*)h_bf16, grads->ln1_w, grads->ln1_b, grads->ln2_w, grads->ln2_b,
                           (const bf16_t*)up_dqkv_bf16, up_dx_res, up_w ? (const bf16_t*)up_w->wqkT_p : nullptr,
                           up_w ? (const bf16_t*)up_w->wvT_p : nullptr, layer_layout(), dz ? dz_addend() : nullptr,
@@ -1203,6 +1231,11 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     T.t[3] = {du,   128, 0,   at, 128, 0, g->wo,   128, 0,   0,  g->bo,   128};   // dWo
     T.t[4] = {dhp,  256, 0,   y,  128, 0, g->w1,   128, 0,   0,  g->b1,   128};   // dW1 rows 0..127
     T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1,   128};   // dW1 rows 128..255
+    if (t_y_from_xhat) {                                // `y` is the saved xhat1: y = g1 * xhat1 + be1 formed on load
+        GEOMAE_REQUIRE(t_y_gamma && t_y_beta, "sst_weight_grad: y from xhat1 needs the LayerNorm-1 parameters");
+        T.t[4].b_scale = T.t[5].b_scale = t_y_gamma;
+        T.t[4].b_shift = T.t[5].b_shift = t_y_beta;
+    }
     T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2,   128};  // dW2 cols 0..127
     T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
     if (t_defer_weight_grad && t_defer_all) {          // queued for geomae_flush_weight_grad

@@ -309,6 +309,11 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         const bool top = l + 1 == num_layers;
         LayerLayoutScope lay(kBlk | saved_flag());  // dz (top layer) and dx_out are the row-major boundary tensors
         const char* ws_up = w + sc.set0 + (defer_all ? (l + 1 < num_layers ? l + 1 : l) : ((l + 1) & 1)) * sc.set_bytes;   // slabs of the layer above
+        // saved activations in bf16: the ffn backward stores no y = affine(xhat1) copy for dW1, the contraction forms it from
+        // the forward's saved xhat1 while it loads its slabs (DwTask.b_scale)
+        static const bool y_switch = [] { const char* e = getenv("GEOMAE_Y_FROM_XHAT"); return !(e && e[0] == '0'); }();   // (A/B)
+        const bool y_from_xhat = y_switch && saved_flag() == kSavedBf16;
+        set_y_from_xhat(y_from_xhat, layers[l].ln1_w, layers[l].ln1_b);
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
@@ -343,16 +348,17 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         if (l > 0) {
             defer_next_weight_grad();               // recorded now, launched inside B3(l-1)
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
-                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
+                                        ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         } else {
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
             // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
             if (defer_last_weight_grad || defer_all) defer_next_weight_grad();
             // (timed inside launch_dw, on the stream it really runs on: thread_profiler)
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
-                                        ws + sc.dhp, ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
+                                        ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
+    set_y_from_xhat(false);
     if (!((defer_last_weight_grad || defer_all) && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
         rc = GEOMAE_ERR_HIP;                                                                         // error paths only
     return rc;
