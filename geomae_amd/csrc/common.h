@@ -45,6 +45,9 @@ const int32_t* output_rows(int* num_rows_out);
 // geomae_sst_stack_backward around its top layer only.
 void set_dz_addend(const float* dz2);
 void set_y_from_xhat(bool on, const float* gamma1 = nullptr, const float* beta1 = nullptr);   // sst_layer.hip
+void set_x_from_xhat(bool on, const float* gamma2 = nullptr, const float* beta2 = nullptr);   // sst_layer.hip: dW_v's operand
+void set_skip_x_copy(bool on);      // the next layer forward of this thread stores no bf16 copy of x (only x + pos)
+bool skip_x_copy();
 const float* dz_addend();
 // Column sums of the rows >= from_row of the NEXT geomae_sst_qkv_backward's output on this host thread, ADDED into
 // sum[128] (set by geomae_sst_stack_backward around its last kernel only: the decoders' mask-token gradient).

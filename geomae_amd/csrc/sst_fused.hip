@@ -230,7 +230,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             *reinterpret_cast<uint2*>(XP + idx * kFRow + perm_b) = xpb;
             if (save) {
                 const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor;
-                buf_store_b64(xb_r, o2, xb);
+                if (A.xb) buf_store_b64(xb_r, o2, xb);             // (null: geomae::set_skip_x_copy -- layers above the first)
                 buf_store_b64(xp_r, o2, xpb);
             }
             if (w == 0 && g == 0) { wl[idx] = rec[it].z; wh[idx] = rec[it].w; }
@@ -512,7 +512,7 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
     A.x = x; A.M = M; A.bun_tok = layout->fbun_tok; A.plan = (const int4*)layout->pos_info; A.num_bundles = layout->num_fbundles;
     A.pos_table = pos_table; A.W = to_layer(w); A.n = num_tokens; A.eps = w->ln_eps; A.z = z; A.z_blocked = z_blocked;
     A.qkv = (bf16_t*)qkv_bf16; A.attn = (bf16_t*)attn_bf16; A.xh1 = (bf16_t*)xhat1_bf16; A.xh2 = (bf16_t*)xhat2_bf16;
-    A.hp = (bf16_t*)hp_bf16; A.xb = (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
+    A.hp = (bf16_t*)hp_bf16; A.xb = skip_x_copy() ? nullptr : (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
     const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
     hipLaunchKernelGGL(sst_layer_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
     return check_launch("sst_layer_fwd_kernel");

@@ -302,8 +302,8 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
             xpb[ct] = pack4(y[ct] + pv);
         }
     }
-    if (N.x_b) {
-        store_rows_packed<128>(N.x_b, n, tok, 128, 0, xb, lane, blk);
+    if (N.xp_b) {                                  // (x_b alone may be null: geomae::set_skip_x_copy)
+        if (N.x_b) store_rows_packed<128>(N.x_b, n, tok, 128, 0, xb, lane, blk);
         store_rows_packed<128>(N.xp_b, n, tok, 128, 0, xpb, lane, blk);
     }
     WStage<128, 128> s_v;
@@ -462,11 +462,11 @@ __global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_fwd_pair_kernel(const fl
             xpb[ct] = pack4(y[ct] + pv);
         }
     }
-    if (N.x_b) {
+    if (N.xp_b) {
         uint2 m0[4], m1[4];
         half_of<4>(xb, h, m0);
         half_of<4>(xpb, h, m1);
-        store_rows_packed<64>(N.x_b, n, tok, 128, 64 * h, m0, lane, blk);
+        if (N.x_b) store_rows_packed<64>(N.x_b, n, tok, 128, 64 * h, m0, lane, blk);
         store_rows_packed<64>(N.xp_b, n, tok, 128, 64 * h, m1, lane, blk);
     }
     WStage<128, 128> s_v;
@@ -1110,7 +1110,7 @@ extern "C" int geomae_sst_ffn_qkv_forward(const float* x, const void* attn_bf16,
         GEOMAE_REQUIRE(next_tok_pos && pos_table && next_qkv_bf16, "sst_ffn_qkv_forward: null argument for the next layer");
         GEOMAE_REQUIRE((next_x_bf16 == nullptr) == (next_xp_bf16 == nullptr), "sst_ffn_qkv_forward: pass both operand copies or none");
         N = NextQkv{(const bf16_t*)next_w->wqkv_p, next_w->bqkv, next_tok_pos, pos_table, (bf16_t*)next_qkv_bf16,
-                    (bf16_t*)next_x_bf16, (bf16_t*)next_xp_bf16};
+                    skip_x_copy() ? nullptr : (bf16_t*)next_x_bf16, (bf16_t*)next_xp_bf16};
     }
     const int tiles = cdiv(num_tokens, 16);
     if (use_pair_kernels(tiles) && !(t_skip_rows >= 64 && !next_w)) {
@@ -1139,6 +1139,13 @@ extern "C" int geomae_sst_ffn_forward(const float* x, const void* attn_bf16, con
 // the next geomae_sst_weight_grad takes its `y_bf16` argument as the SAVED xhat1 and forms y = g1 * xhat1 + be1 on load
 static thread_local bool t_y_from_xhat = false;
 static thread_local const float *t_y_gamma = nullptr, *t_y_beta = nullptr;
+static thread_local bool t_x_from_xhat = false, t_skip_x_copy = false;
+static thread_local const float *t_x_gamma = nullptr, *t_x_beta = nullptr;
+void geomae::set_x_from_xhat(bool on, const float* gamma2, const float* beta2) {
+    t_x_from_xhat = on; t_x_gamma = gamma2; t_x_beta = beta2;
+}
+void geomae::set_skip_x_copy(bool on) { t_skip_x_copy = on; }
+bool geomae::skip_x_copy() { return t_skip_x_copy; }
 void geomae::set_y_from_xhat(bool on, const float* gamma1, const float* beta1) {
     t_y_from_xhat = on; t_y_gamma = gamma1; t_y_beta = beta1;
 }
@@ -1228,6 +1235,11 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     T.t[0] = {dqkv, 384, 0,   xp, 128, 0, g->wqkv, 128, 0,   0,  g->bqkv, 128};   // dWq
     T.t[1] = {dqkv, 384, 128, xp, 128, 0, g->wqkv, 128, 128, 0,  g->bqkv, 128};   // dWk
     T.t[2] = {dqkv, 384, 256, xb, 128, 0, g->wqkv, 128, 256, 0,  g->bqkv, 128};   // dWv
+    if (t_x_from_xhat) {                                // `x` is the saved xhat2 of the layer below: x = g2 * xhat2 + be2 on load
+        GEOMAE_REQUIRE(t_x_gamma && t_x_beta, "sst_weight_grad: x from xhat2 needs the LayerNorm-2 parameters of the layer below");
+        T.t[2].b_scale = t_x_gamma;
+        T.t[2].b_shift = t_x_beta;
+    }
     T.t[3] = {du,   128, 0,   at, 128, 0, g->wo,   128, 0,   0,  g->bo,   128};   // dWo
     T.t[4] = {dhp,  256, 0,   y,  128, 0, g->w1,   128, 0,   0,  g->b1,   128};   // dW1 rows 0..127
     T.t[5] = {dhp,  256, 128, y,  128, 0, g->w1,   128, 128, 0,  g->b1,   128};   // dW1 rows 128..255

@@ -54,6 +54,13 @@ static int saved_flag() {
     return f;
 }
 
+// dW_v's operand x of the layers above the first: formed by the contraction from the layer below's saved xhat2 (bf16 saves
+// only; GEOMAE_X_FROM_XHAT=0: the stored copy, A/B runs).  The forward then stores no x copy for those layers.
+static bool x_from_xhat_enabled() {
+    static const bool on = [] { const char* e = getenv("GEOMAE_X_FROM_XHAT"); return !(e && e[0] == '0'); }();
+    return on && saved_flag() == kSavedBf16;
+}
+
 // The stack's own buffers are tile-blocked ([n/16][C/16][16][16], sst_device.h "Row layouts"): sized for ceil16(n) rows
 static SavedOffsets saved_offsets(int64_t n, int heads) {
     SavedOffsets o;
@@ -219,10 +226,12 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
             float* z = next ? (float*)(sv + so.stride + so.x) : z_out;
             Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
             if (l == 0) set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
+            set_skip_x_copy(l > 0 && x_from_xhat_enabled());      // (the contraction forms x from the layer below's saved xhat2)
             rc = geomae_sst_layer_forward((const float*)(sv + so.x), num_tokens, &layers[l], &layouts[l & 1], cap, pos_table, z,
                                           next ? 1 : 0, sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1,
                                           sv + so.xh2, sv + so.hp, (float*)(sv + so.rstd), sv + so.xb, sv + so.xp, stream);
             if (l == 0) set_input_map(SstInputMap{nullptr, 0, nullptr, nullptr});
+            set_skip_x_copy(false);
             if (rc) return rc;
         }
         return GEOMAE_OK;
@@ -257,13 +266,15 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
             LiveRowScope live(next ? 0 : live_row);               // only the LAST layer's output rows can be dead
-            if ((rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
+            set_skip_x_copy(x_from_xhat_enabled());               // (layer l + 1 >= 1: its x copy is never read)
+            rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
                                                  (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd),
                                                  next ? &layers[l + 1] : nullptr, next ? layouts[(l + 1) & 1].tok_pos : nullptr,
                                                  pos_table, next ? sv + so.stride + so.qkv : nullptr,
                                                  next ? sv + so.stride + so.xb : nullptr, next ? sv + so.stride + so.xp : nullptr,
-                                                 stream)))
-                return rc;
+                                                 stream);
+            set_skip_x_copy(false);
+            if (rc) return rc;
         }
     }
     return GEOMAE_OK;
@@ -314,6 +325,10 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         static const bool y_switch = [] { const char* e = getenv("GEOMAE_Y_FROM_XHAT"); return !(e && e[0] == '0'); }();   // (A/B)
         const bool y_from_xhat = y_switch && saved_flag() == kSavedBf16;
         set_y_from_xhat(y_from_xhat, layers[l].ln1_w, layers[l].ln1_b);
+        // ... and dW_v's x of the layers above the first from the saved xhat2 of the layer below (x = z of that layer)
+        const bool x_from_xhat = l > 0 && x_from_xhat_enabled();
+        set_x_from_xhat(x_from_xhat, x_from_xhat ? layers[l - 1].ln2_w : nullptr, x_from_xhat ? layers[l - 1].ln2_b : nullptr);
+        const char* x_operand = x_from_xhat ? base + so.stride * (l - 1) + so.xh2 : sv + so.xb;
         {
             // B3(l); for l < L-1 its head is B1(l+1) (dz stays in registers) and dW(l+1) rides in the same launch
             Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
@@ -347,18 +362,19 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         }
         if (l > 0) {
             defer_next_weight_grad();               // recorded now, launched inside B3(l-1)
-            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, x_operand, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         } else {
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
             // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
             if (defer_last_weight_grad || defer_all) defer_next_weight_grad();
             // (timed inside launch_dw, on the stream it really runs on: thread_profiler)
-            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, sv + so.xb, ws + sc.du, sv + so.attn,
+            rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, x_operand, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
     set_y_from_xhat(false);
+    set_x_from_xhat(false);
     if (!((defer_last_weight_grad || defer_all) && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
         rc = GEOMAE_ERR_HIP;                                                                         // error paths only
     return rc;
