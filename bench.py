@@ -126,8 +126,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-engine", action="store_true", help="Python explicit schedule instead of the C step engine (A/B)")
-    ap.add_argument("--profile-every", type=int, default=8,
-                    help="instrument the dominant kernel's launches with HIP events in every N-th timed step")
+    ap.add_argument("--profile-every", type=int, default=0, help="(ignored: the timed region is no longer instrumented)")
     args = ap.parse_args()
     workload = args.workload or ("nuscenes10" if args.sweeps == 10 else "nuscenes1")
     cfg_index, sweeps, frame_kw, geom_kw = WORKLOADS[workload]
@@ -161,7 +160,20 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    # A mis-launched run must not print a plausible line (reference launcher: tools/dist_train.sh:8-9, one rank per GPU):
+    # --gpus N means N ranks in THIS process group, each on a GPU of its own.
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} ... bench.py --gpus {args.gpus}`")
+    if world > 1:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
+        mine = [rank, int(torch.cuda.current_device()), str(torch.cuda.get_device_properties(dev).uuid)
+                if hasattr(torch.cuda.get_device_properties(dev), "uuid") else str(local_rank)]
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        if not share and len({(g_[1], g_[2]) for g_ in seen}) != world:
+            raise SystemExit(f"bench.py: two ranks share a GPU under RCCL (rank, device, uuid): {seen}")
 
     import geomae_amd
     from geomae_amd import _lib, ops, synth
@@ -236,47 +248,44 @@ def main():
         lib.geomae_profiler_destroy(ctypes.c_void_p(h))
         return [float(buf[i]) for i in range(n)]
 
-    # HIP events on the launch stream around every launch of the dominant kernel, inside the timed region, in every
-    # `--profile-every`-th timed step (default 8: steps 0, 8, 16 of the driver's 20): two event records per launch cost ~4 us
-    # of queue time each, ~0.1 ms on an instrumented step, and the timed region is what `value` is computed from (measured
-    # with the driver's command: 2.112 / 2.100 / 2.085 ms per step when every 4th / every 8th / only the first step is
-    # instrumented)
-    prof_handle = profile_on(DOMINANT, min(4000, 20 * args.steps))
-    # one timing event per step on the main stream (~4 us of queue time per step): the per-step distribution
-    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # The timed region carries NO instrumentation: no per-launch profiler handle, no per-step events.  Per-launch
+    # durations (HIP events on each kernel's launch stream), the per-step distribution and the phase times all come
+    # from EXTRA steps behind it.
     eng = trainer.get_engine()                    # (exists before the first step too: --warmup 0)
     h0 = eng.host_times() if eng is not None else None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    step_events[0].record()
     for i in range(args.steps):
-        set_profiler(prof_handle if i % max(1, args.profile_every) == 0 else None)
         losses, _ = step(args.warmup + i)
-        step_events[i + 1].record()
     t_enq = time.perf_counter() - t0
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    set_profiler(None)
     h1 = eng.host_times() if eng is not None else None
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
-    per_step = np.array([step_events[i].elapsed_time(step_events[i + 1]) for i in range(args.steps)])
-    durations = {DOMINANT: profile_off(prof_handle)}
+    # per-step distribution: one event per step on the main stream (~4 us of queue time each), 16 extra steps
+    n_dist = 16
+    step_events = [torch.cuda.Event(enable_timing=True) for _ in range(n_dist + 1)]
+    step_events[0].record()
+    for i in range(n_dist):
+        step(args.warmup + args.steps + i)
+        step_events[i + 1].record()
+    torch.cuda.synchronize()
+    per_step = np.array([step_events[i].elapsed_time(step_events[i + 1]) for i in range(n_dist)])
+    durations = {}
     steps_timed = {k: 3 for k in TIMED}
-    steps_timed[DOMINANT] = len(range(0, args.steps, max(1, args.profile_every)))
-    for k in TIMED:                               # the other kernels: 3 extra (untimed) steps each
-        if k != DOMINANT:
-            h = profile_on(k, 64)
-            set_profiler(h)
-            for i in range(3):
-                step(i)
-            durations[k] = profile_off(h)
+    for k in TIMED:                               # every kernel alike: 3 extra (untimed) steps each
+        h = profile_on(k, 64 * 3)
+        set_profiler(h)
+        for i in range(3):
+            step(i)
+        durations[k] = profile_off(h)
     # what an event pair with NOTHING between its records measures on this stream (the two records' own queue time): the
     # per-launch durations above contain it, rocprofv3's kernel durations do not
     torch.cuda.synchronize()
@@ -385,25 +394,57 @@ def main():
             if B == 4 and os.path.exists(tpath):
                 traffic, traffic_src = json.load(open(tpath)), os.path.relpath(tpath, ROOT)
                 break
+        # Algorithmic HBM bytes per step of the same kernels (per token and layer): F3 reads x (fp32 512 B)
+        # + attn (bf16 256) and writes xhat1 256 + hp 512 + xhat2 256 + z 512; a riding F1 writes x+pos 256 + qkv 768; B3 moves
+        # 4.45 KB (reads dz 512, xhat1/xhat2/hp/attn 1280, writes dv/dhp/h/du/dx_res/dattn 2304, + LayerNorm rows), a B1 head
+        # 1.3 KB; a contraction reads 8 tasks x 2 operands x 256 B; attention forward reads qkv 768 and writes attn 256 + lse 32,
+        # its backward reads qkv + attn + dattn + lse and writes dqkv 768.
+        F3B, F1B, B3B, B1B, DWB, AFB, ABB = 2304.0, 1024.0, 4450.0, 1300.0, 4096.0, 1056.0, 2080.0
+        bytes_step = {"sst_ffn_bwd_kernel": B3B * (n_e + 8 * n_d) + B1B * 6 * n_d if dec_deferred else B3B * (n_e + 2 * n_d),
+                      "sst_ffn_bwd_dw_kernel": (B3B + B1B + DWB) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
+                      "sst_ffn_fwd_kernel": F3B * 8 * n_d + F1B * 6 * n_d,
+                      "sst_ffn_fwd_pair_kernel": F3B * 12 * n_e + F1B * 11 * n_e,
+                      "sst_qkv_fwd_kernel": (512 + F1B) * ((0 if fused_enc else n_e) + 2 * n_d),
+                      "sst_qkv_bwd_kernel": (B1B + 512) * (n_e + 2 * n_d),
+                      "win_attn_fwd_kernel": AFB * (8 * n_d + (0 if fused_enc else 12 * n_e)),
+                      "win_attn_bwd_kernel": ABB * (12 * n_e + 8 * n_d),
+                      "sst_layer_fwd_kernel": (512 + F3B + F1B + 256 + 32) * 12 * n_e,
+                      "dw_kernel": DWB * ((8 * n_d if dec_deferred else 2 * n_d) + n_e) + 2 * (800 + 128) * M_rows
+                                   + 2 * 2 * 128 * n_pts}
         kern = {}
         for k in TIMED:
             d = durations.get(k) or []
             if d and (expect[k] is None or abs(launches_step[k] - expect[k]) < 0.01):      # (another launch structure: no FLOP model here)
                 ms_step = float(np.sum(d)) / (len(d) / launches_step[k])
-                ach = flops_step[k] / (ms_step * 1e-3) / 1e12
+                net_launch = max(float(np.mean(d)) - event_pair_ms, 1e-4)            # less the empty event pair: ~ rocprofv3's AverageNs
+                net_step = net_launch * launches_step[k]
+                ach = flops_step[k] / (net_step * 1e-3) / 1e12
+                gbs_alg = bytes_step[k] / (net_step * 1e-3) / 1e9
+                ai = flops_step[k] / bytes_step[k]                                   # FLOP per algorithmic byte
+                roof_tflops = min(peak, ai * 8.0)                                    # min(MFMA peak, AI x 8 TB/s)
                 tr_b = traffic.get(report_name.get(k, k))
-                kern[k] = {"bound": "mfma", "achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s",
-                           "frac": round(ach / peak, 5), "traffic": tr_b, "traffic_source": traffic_src if tr_b else None,
-                           "avg_launch_ms": round(float(np.mean(d)), 5), "launches_timed": len(d),
-                           "launches_per_step": round(launches_step[k], 2), "ms_per_step": round(ms_step, 4),
-                           "timed_in": "the timed region" if k == DOMINANT else "3 extra steps behind it",
-                           # the same average less the empty event pair: comparable with rocprofv3's AverageNs
-                           "avg_launch_ms_less_event_pair": round(float(np.mean(d)) - event_pair_ms, 5),
-                           "empty_event_pair_ms": round(event_pair_ms, 5)}
-                if tr_b:        # the same launch against the HBM roof (8 TB/s): stored PMC bytes / measured duration
-                    gbs = tr_b / (float(np.mean(d)) * 1e-3) / 1e9
+                common = {"arithmetic_intensity_flop_per_byte": round(ai, 1), "roof_at_this_intensity_tflops": round(roof_tflops, 1),
+                          "frac_of_own_roof": round(ach / roof_tflops, 5),
+                          "traffic": tr_b, "traffic_source": traffic_src if tr_b else None,
+                          "avg_launch_ms": round(float(np.mean(d)), 5), "launches_timed": len(d),
+                          "launches_per_step": round(launches_step[k], 2), "ms_per_step": round(net_step, 4),
+                          "ms_per_step_with_event_pairs": round(ms_step, 4), "timed_in": "3 extra steps behind the timed region",
+                          "avg_launch_ms_less_event_pair": round(net_launch, 5), "empty_event_pair_ms": round(event_pair_ms, 5),
+                          "algorithmic_flop_per_launch": int(flops_step[k] / launches_step[k]),
+                          "algorithmic_bytes_per_launch": int(bytes_step[k] / launches_step[k])}
+                mfma_view = {"achieved": round(ach, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 5)}
+                hbm_alg = {"achieved": round(gbs_alg, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs_alg / 8000.0, 5)}
+                if ai * 8.0 < peak:      # the roof this kernel's arithmetic intensity puts it under is HBM
+                    kern[k] = dict(bound="hbm", **hbm_alg, **common, mfma_view=mfma_view)
+                else:
+                    kern[k] = dict(bound="mfma", **mfma_view, **common, hbm_algorithmic_view=hbm_alg)
+                if tr_b:        # the same launch against the HBM roof with the stored PMC bytes / measured duration
+                    gbs = tr_b / (net_launch * 1e-3) / 1e9
                     kern[k]["hbm_view"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                                           "frac": round(gbs / 8000.0, 4)}
+                                           "frac": round(gbs / 8000.0, 4),
+                                           "traffic_over_algorithmic": round(tr_b / (bytes_step[k] / launches_step[k]), 3)}
+        # the dominant kernel: largest measured time per step LESS the empty event pairs (a kernel with many short launches
+        # is not promoted by the instrumentation's own queue time) -- what the rocprofv3 table ranks by
         largest = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
         dominant = largest
         dominant_check = {"committed_table": table_path, "largest_share_in_table": DOMINANT,

@@ -453,7 +453,9 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFw
     const int NB = A.num_bundles[0];
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
         const int s0 = A.bun_tok[b];
-        const int T = A.bun_tok[b + 1] - s0;
+        int T = A.bun_tok[b + 1] - s0;
+        if (T > kFMaxT) T = kFMaxT;          // (a layout built for windows of more than 144 tokens: never past the LDS rows;
+                                             //  the stack forward refuses such layouts on the host, max_window_tokens <= 144)
         const int nt = (T + 15) >> 4;
         switch (nt) {
             case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
@@ -502,6 +504,9 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
     GEOMAE_REQUIRE(layout && layout->fbun_tok && layout->pos_info && layout->num_fbundles && layout->max_bundles >= 1,
                    "sst_layer_forward: the layout needs the build's plan and second packing (pos_info, fbun_tok, num_fbundles)");
     GEOMAE_REQUIRE(pos_table && z, "sst_layer_forward: null argument");
+    // a bundle is whole windows up to the soft cap, or ONE window larger than it: the kernel's LDS holds kFMaxT = 144 rows
+    // (a 12 x 12 window).  A layout packed with a larger cap would index past them (the kernel also clamps, below).
+    GEOMAE_REQUIRE(bundle_cap >= 1 && bundle_cap <= kFMaxT, "sst_layer_forward: bundle_cap must be in [1, 144]");
     GEOMAE_REQUIRE(w->frag_p, "sst_layer_forward: the layer has no fragment-major packed weights (frag_p)");
     const SstInputMap M = input_map();
     GEOMAE_REQUIRE(x || M.src, "sst_layer_forward: null input");

@@ -215,6 +215,10 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         explicit LiveRowScope(int r) { set_first_live_row(r); }
         ~LiveRowScope() { set_first_live_row(0); }
     };
+    struct SkipXCopyScope {                         // thread-local switch of the next layer forward: cleared on every exit path
+        explicit SkipXCopyScope(bool on) { set_skip_x_copy(on); }
+        ~SkipXCopyScope() { set_skip_x_copy(false); }
+    };
     // ---- one launch per layer (sst_fused.hip) when the layouts carry the build's plan.  Same saved tensors, same layouts
     // as the three-launch form below (which stays for layouts without a plan, GEOMAE_SAVED_F32=1 and A/B runs).
     if (fused_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
@@ -226,12 +230,11 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
             float* z = next ? (float*)(sv + so.stride + so.x) : z_out;
             Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
             if (l == 0) set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
-            set_skip_x_copy(l > 0 && x_from_xhat_enabled());      // (the contraction forms x from the layer below's saved xhat2)
+            SkipXCopyScope skip(l > 0 && x_from_xhat_enabled());  // (the contraction forms x from the layer below's saved xhat2)
             rc = geomae_sst_layer_forward((const float*)(sv + so.x), num_tokens, &layers[l], &layouts[l & 1], cap, pos_table, z,
                                           next ? 1 : 0, sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1,
                                           sv + so.xh2, sv + so.hp, (float*)(sv + so.rstd), sv + so.xb, sv + so.xp, stream);
             if (l == 0) set_input_map(SstInputMap{nullptr, 0, nullptr, nullptr});
-            set_skip_x_copy(false);
             if (rc) return rc;
         }
         return GEOMAE_OK;
@@ -266,14 +269,13 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         {
             Timed t(profiler, GEOMAE_KERNEL_FFN_FWD, stream);
             LiveRowScope live(next ? 0 : live_row);               // only the LAST layer's output rows can be dead
-            set_skip_x_copy(x_from_xhat_enabled());               // (layer l + 1 >= 1: its x copy is never read)
+            SkipXCopyScope skip(x_from_xhat_enabled());           // (layer l + 1 >= 1: its x copy is never read)
             rc = geomae_sst_ffn_qkv_forward(x, sv + so.attn, &layers[l], num_tokens, z, (float*)(sv + so.xh1),
                                                  (float*)(sv + so.xh2), sv + so.hp, (float*)(sv + so.rstd),
                                                  next ? &layers[l + 1] : nullptr, next ? layouts[(l + 1) & 1].tok_pos : nullptr,
                                                  pos_table, next ? sv + so.stride + so.qkv : nullptr,
                                                  next ? sv + so.stride + so.xb : nullptr, next ? sv + so.stride + so.xp : nullptr,
                                                  stream);
-            set_skip_x_copy(false);
             if (rc) return rc;
         }
     }
@@ -312,6 +314,9 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         explicit DwPartialScope(float* ws) { set_dw_partial(ws); }
         ~DwPartialScope() { set_dw_partial(nullptr); }
     } dw_scope((float*)(w + sc.dw_partial));
+    struct OperandFormScope {                       // y / x "formed on load" switches: cleared on every exit path
+        ~OperandFormScope() { set_y_from_xhat(false); set_x_from_xhat(false); }
+    } operand_scope;
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
@@ -373,8 +378,6 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
                                         ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
         }
     }
-    set_y_from_xhat(false);
-    set_x_from_xhat(false);
     if (!((defer_last_weight_grad || defer_all) && rc == GEOMAE_OK) && flush_pending_weight_grad(stream) != GEOMAE_OK && rc == GEOMAE_OK)
         rc = GEOMAE_ERR_HIP;                                                                         // error paths only
     return rc;

@@ -1058,7 +1058,10 @@ __global__ __launch_bounds__(1024) void vfe_bwd_stats1_pillars_kernel(const floa
             for (int r = 0; r < 4; ++r)
                 if (hv[r] > 0.f && use[k]) {
                     s1[r] += dv[r];
-                    s2[r] += dv[r] * (((hv[r] - shv[r]) / scv[r] - muv[r]) * isv[r]);
+                    // gamma == 0 (scale == 0): every point of the channel has the same y, yhat cannot be recovered from the
+                    // pooled value (0 / 0): such a channel contributes yhat = 0 instead of a NaN that would poison the step
+                    const float yh = fabsf(scv[r]) > 1e-30f ? ((hv[r] - shv[r]) / scv[r] - muv[r]) * isv[r] : 0.f;
+                    s2[r] += dv[r] * yh;
                 }
         }
     }

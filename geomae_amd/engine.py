@@ -284,6 +284,12 @@ class PretrainEngine:
             # submitted, a second all-reduce would have no partner -- carry the exchanged moments over instead.
             slot = self.lib.geomae_pretrain_pending_slot(ctypes.c_void_p(self.handle))
             fm = getattr(self, "sync", {}).get("featmom") if self.exchange else None
+            if fm is not None:
+                # the batch may have been handed over as the PREVIOUS step's next_points: its feature-moment all-reduce
+                # was then issued on the decoder-B (aux) stream and nothing on the current stream is ordered behind it yet
+                # (the main stream waits for it inside the step that just refused to run).  A clone taken before the
+                # reduction landed would carry this rank's LOCAL moments into the re-submission.
+                torch.cuda.synchronize(self.dev)
             keep = fm[144 * slot:144 * (slot + 1)].clone() if (fm is not None and slot >= 0) else None
             self.max_pillars = int(1.5 * self.max_pillars) + 1024
             self._create(sum(int(p.shape[0]) for p in points))

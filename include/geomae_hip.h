@@ -511,7 +511,13 @@ int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t nu
  * graph: one call enqueues every kernel of `num_layers` consecutive layers (layer i uses layouts[i & 1]: the
  * unshifted / shifted windows alternate, sst_basic_block.py:133-145).  `saved` (geomae_sst_stack_saved_bytes)
  * carries the activations from forward to backward; `scratch` (geomae_sst_stack_scratch_bytes) is reused by
- * every layer of the backward.  layers / grads are HOST arrays of structs. */
+ * every layer of the backward.  layers / grads are HOST arrays of structs.
+ * NOTE on the `saved` blob: it is private to the stack pair (forward writes, backward reads).  With bf16 saved activations
+ * (the default) the stack forward stores the bf16 copy of x ONLY for layer 0: the backward forms dW_v's operand of the
+ * layers above from the saved xhat2 of the layer below (x = gamma2 * xhat2 + beta2 while the contraction loads its slabs),
+ * and dW1's operand y from the saved xhat1.  The x / y slots of those layers are UNWRITTEN: do not pair
+ * geomae_sst_stack_forward with op-level geomae_sst_weight_grad calls on slices of the blob (use geomae_sst_stack_backward;
+ * GEOMAE_X_FROM_XHAT=0 / GEOMAE_Y_FROM_XHAT=0 restore the stored copies for A/B runs). */
 typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_build for one shift */
     const int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *bun_start, *num_bundles;
     int32_t max_bundles;

@@ -4,6 +4,7 @@ TEST INFRASTRUCTURE ONLY.  The reference's Python is imported from /root/referen
 stub modules (oracle/ref_import.py) and its C++ voxelizer is the compiled oracle/_ref; only
 inputs/outputs (data) are written -- no reference source text.  Re-run:
     PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+(GEOMAE_GOLDEN_OUT=<dir> writes there instead of tests/golden/; oracle/verify_golden.py uses it.)
 """
 import os
 import sys
@@ -22,7 +23,8 @@ import ref_import                      # noqa: E402
 import geomae_oracle as O              # noqa: E402
 from geomae_amd import synth           # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+# GEOMAE_GOLDEN_OUT: scratch directory for a verification run (oracle/verify_golden.py) -- the committed fixtures stay untouched
+OUT = os.environ.get("GEOMAE_GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 ref = ref_import.load_reference()

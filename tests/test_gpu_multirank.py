@@ -189,6 +189,43 @@ def _worker(rank, world, port, tmp):
         for (k, b), (_, b2) in zip(fresh2.voxel_encoder.named_buffers(), tr_ref.model.voxel_encoder.named_buffers()):
             if "running" in k:
                 assert torch.allclose(b, b2, rtol=1e-5, atol=1e-6), (k, float((b - b2).abs().max()))
+        # ---- 5. the same growth on a PIPELINED batch: the big batch is handed over as step 1's next_points, so its
+        #         feature-moment all-reduce was issued on the decoder-B stream during step 1; step 2 then overflows on rank 1
+        #         only.  The moments carried into the re-submission must be the REDUCED ones (the wrapper synchronises
+        #         before cloning them): running statistics as a run that never overflowed, parameters equal on both ranks.
+        from geomae_amd import synth
+        small = [torch.as_tensor(synth.lidar_frame(700 + 10 * rank + i, beams=8, n_az=200), device="cuda:0") for i in range(2)]
+        big = pts
+
+        def pillars(frames):
+            v_, c_, _, _ = fused_init.voxelize_all(frames)
+            return int(ops.pillar_segment(c_, len(frames), fused_init.grid_size).V)
+        v_small, v_big = pillars(small), pillars(big)
+        assert v_big > v_small + 64, (v_small, v_big)
+        tr_pipe = Trainer(copy.deepcopy(fused_init))
+        eng = tr_pipe.get_engine()
+        cap = (v_small + v_big) // 2
+        if rank == 1:
+            eng.max_pillars = cap
+        tr_pipe.train_step(small, next_points=big)
+        if rank == 1:
+            assert eng.max_pillars == cap                       # step 1 fitted; the big batch is pending
+        losses_p, gnorm_p = tr_pipe.train_step(big)
+        torch.cuda.synchronize()
+        if rank == 1:
+            assert eng.max_pillars > cap                        # step 2 overflowed and grew
+        assert all(torch.isfinite(v) for v in losses_p.values()) and torch.isfinite(gnorm_p)
+        mine = tr_pipe.flat.flat.clone()
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        assert torch.equal(gathered[0], gathered[1])
+        tr_ref2 = Trainer(copy.deepcopy(fused_init))
+        tr_ref2.train_step(small, next_points=big)
+        tr_ref2.train_step(big)
+        torch.cuda.synchronize()
+        for (k, b), (_, b2) in zip(tr_pipe.model.voxel_encoder.named_buffers(), tr_ref2.model.voxel_encoder.named_buffers()):
+            if "running" in k:
+                assert torch.allclose(b, b2, rtol=1e-5, atol=1e-6), (k, float((b - b2).abs().max()))
         torch.save(dict(ok=True), os.path.join(tmp, f"ok{rank}.pt"))
         faulthandler.cancel_dump_traceback_later()
     except BaseException:
