@@ -80,9 +80,17 @@ void profiler_end(void* prof, hipStream_t s);
 // Split-K workspace of the geomae_sst_weight_grad calls of this host thread (set by geomae_sst_stack_backward for its own
 // layers): two buffers of kDwPartialBytes where the contraction's workgroups leave their partial sums instead of
 // atomically adding them to the gradients (sst_layer.hip dw_body); nullptr = atomics.
-constexpr long long kDwPartialBytes = 8ll * 24 * 128 * 128 * 4;       // 8 tasks x <= 24 token chunks x [128,128] fp32
+// (round 5: sized for the layer-form contraction, csrc/dw_device.h -- 16 jobs x 8 token chunks x (16 tiles x 512 threads x 16 B
+//  + 256 bias floats) per buffer; the two buffers together hold a four-layer launch at 16 chunks per job.  The old form's
+//  8 tasks x 24 chunks x [128,128] fp32 = 12.6 MB fits in one.)
+constexpr long long kDwPartialBytes = 16ll * 8 * (16 * 512 * 16 + 1024);
 void set_dw_partial(float* ws);
 float* dw_partial();
+// rows [0, r) of the NEXT geomae_sst_weight_grad's token range are DEAD (the top layer of a decoder stack: their dY rows are
+// zero and their saved forward rows were never written, set_first_live_row): the layer-form contraction starts behind them
+// in the jobs whose dY operand is zero there.  Thread-local, consumed by that call.
+void set_dw_dead_rows(int rows);
+int take_dw_dead_rows();
 // Input map of the NEXT geomae_sst_qkv_forward of this host thread (set by geomae_sst_stack_forward around F1 of its first
 // layer): instead of reading its tile-blocked x, the kernel gathers token t from row rows[t] (or t) of the row-major
 // `src` for t < n_src and takes `fill` for the tokens behind, and WRITES the tile-blocked x (what the stack's other
@@ -98,6 +106,13 @@ bool window_tables_prezeroed();
 // they are queued and launched by the next geomae_flush_weight_grad on ITS stream.  The stack then needs one set of
 // operand slabs per layer (geomae_sst_stack_scratch_bytes_layers).
 void set_defer_all_weight_grads(bool on);
+// "defer all" with flushes on the way: every `every` layers geomae_sst_stack_backward records `ev` on its stream, makes `side`
+// wait for it and launches the contractions queued so far there (geomae_flush_weight_grad(side)) -- the caller flushes the
+// rest behind the stack.  How the ENCODER's contractions leave its backward launches (round 5): merged launches of four layers
+// on the geometry stream beside the layers still to come, instead of riding in every ffn-backward launch.
+struct DwMidFlush { hipStream_t side = nullptr; hipEvent_t ev = nullptr; int every = 0; };
+void set_dw_mid_flush(const DwMidFlush& f);
+DwMidFlush dw_mid_flush();
 bool defer_all_weight_grads();
 // forget every recorded-but-unlaunched contraction of this host thread (error paths; the start of a step)
 void drop_pending_weight_grads();

@@ -40,6 +40,12 @@ int last_kernel_variant() { return g_last_kernel_variant; }
 static thread_local float* g_dw_partial = nullptr;
 void set_dw_partial(float* ws) { g_dw_partial = ws; }
 float* dw_partial() { return g_dw_partial; }
+static thread_local DwMidFlush g_dw_mid_flush;
+void set_dw_mid_flush(const DwMidFlush& f) { g_dw_mid_flush = f; }
+DwMidFlush dw_mid_flush() { return g_dw_mid_flush; }
+static thread_local int g_dw_dead_rows = 0;
+void set_dw_dead_rows(int rows) { g_dw_dead_rows = rows > 0 ? rows : 0; }
+int take_dw_dead_rows() { const int r = g_dw_dead_rows; g_dw_dead_rows = 0; return r; }
 static thread_local bool g_win_prezeroed = false;
 void set_window_tables_prezeroed(bool on) { g_win_prezeroed = on; }
 bool window_tables_prezeroed() { return g_win_prezeroed; }

@@ -99,7 +99,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kNumEv };
+          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kEncMid, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -184,7 +184,7 @@ int64_t step_region_bytes(const GeomaePretrainConfig& c, int64_t N, int64_t V) {
          al256(M * 24) + al256(n * 12) + al256(n * s_med * 12) + al256(n * s_med) + al256(M * 24) + 256;   // targets
     b += al256(geomae_sst_stack_saved_bytes((int32_t)nk, c.encoder_layers, c.num_heads)) +
          2 * al256(geomae_sst_stack_saved_bytes((int32_t)n, c.decoder_layers, c.num_heads));
-    b += al256(geomae_sst_stack_scratch_bytes((int32_t)nk)) + 2 * al256(geomae_sst_stack_scratch_bytes_layers((int32_t)n, c.decoder_layers));
+    b += al256(geomae_sst_stack_scratch_bytes_layers((int32_t)nk, c.encoder_layers)) + 2 * al256(geomae_sst_stack_scratch_bytes_layers((int32_t)n, c.decoder_layers));
     b += al256(nk * 512) + 4 * al256(n * 512);                                                             // z_enc, cen, den, dxa, dxb
     b += al256(M * 896 * 2) + 2 * al256(M * 128 * 2);                                                      // heads
     b += 2 * al256((N + 15) / 16 * 16 * 128 * 2) + al256(N * 64 * 4) + al256(2 * kDwPartialBytes);                         // VFE backward
@@ -506,7 +506,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     float* t_cov = a.take<float>(M * 6);
     int32_t* t_occ = a.take<int32_t>(2);
     const int64_t sb_enc = geomae_sst_stack_saved_bytes(nk, ne, nh), sb_dec = geomae_sst_stack_saved_bytes(n, nd, nh);
-    const int64_t wb_enc = geomae_sst_stack_scratch_bytes(nk), wb_dec = geomae_sst_stack_scratch_bytes_layers(n, nd);
+    const int64_t wb_enc = geomae_sst_stack_scratch_bytes_layers(nk, ne), wb_dec = geomae_sst_stack_scratch_bytes_layers(n, nd);
     // The weight-gradient contractions of the two DECODER stacks run on the geometry stream after their stack's backward,
     // beside the encoder backward (GEOMAE_DW_DEFER_ALL=0: riding in the stacks' ffn-backward launches, round 2's form).
     // The decoder backward is at the memory system's roof (two stacks, 7 TB/s between L2 and fabric): without the
@@ -718,8 +718,23 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kAuxBwd], 0));
     mark(e, pDecBwd, main);
     if (e->hook && exchanges(c)) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_EARLY, geo);
-    ENG_CALL(geomae_sst_stack_backward(dxa, dxb, nk, L_enc, G_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, w_enc,
-                                       wb_enc, d_vf, b.ids_keep, V, nullptr, 0, 1, e->profiler, main));
+    {
+        // (round 5) the ENCODER's contractions leave its backward launches too: queued per layer and flushed to the geometry
+        // stream every `every` layers as one merged launch of the layer-form contraction (csrc/dw_device.h) -- the ffn-backward
+        // launches carry no riders (GEOMAE_ENC_DW_DEFER=0: riding as in rounds 2-4; GEOMAE_ENC_DW_EVERY: layers per flush)
+        static const bool defer_enc_dw = [] { const char* v = getenv("GEOMAE_ENC_DW_DEFER"); return !v || v[0] != '0'; }();
+        static const int enc_every = [] { const char* v = getenv("GEOMAE_ENC_DW_EVERY"); return v ? atoi(v) : 4; }();
+        DeferAllScope defer(defer_enc_dw);
+        struct MidFlushScope {
+            explicit MidFlushScope(const DwMidFlush& f) { set_dw_mid_flush(f); }
+            ~MidFlushScope() { set_dw_mid_flush(DwMidFlush()); }
+        };
+        DwMidFlush mf;
+        if (defer_enc_dw && enc_every > 0) { mf.side = geo; mf.ev = e->ev[kEncMid]; mf.every = enc_every; }
+        MidFlushScope mid(mf);
+        ENG_CALL(geomae_sst_stack_backward(dxa, dxb, nk, L_enc, G_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, w_enc,
+                                           wb_enc, d_vf, b.ids_keep, V, nullptr, 0, 1, e->profiler, main));
+    }
     ENG_CALL(order_after(e, kEncBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));
     if (e->hook && exchanges(c)) e->hook(e->hook_user, GEOMAE_HOOK_GRADS_ENCODER, geo);

@@ -27,6 +27,7 @@
 #include "../../include/geomae_hip.h"
 
 #include "sst_device.h"
+#include "dw_device.h"
 #include <vector>
 
 namespace geomae {
@@ -1001,8 +1002,11 @@ static void dw_grid(int num_tasks, int num_tokens, int* gx, int* chunk_out, bool
 
 // hand-over between geomae_sst_weight_grad (deferred) and the next geomae_sst_ffn_backward on the same host
 // thread; only sst_stack_backward uses it (defer_next_weight_grad), the plain C-ABI calls launch immediately
-struct PendingDw { DwTasks tasks; int num_tasks, num_tokens; bool active; };
+// `layer`: the same contraction as the four jobs of the layer-form kernel (dw_device.h; stacks only: blocked operands +
+// a split-K workspace), `partial_base` the stack's whole workspace (both buffers)
+struct PendingDw { DwTasks tasks; int num_tasks, num_tokens; bool active; bool has_layer = false; DlJob layer[4]; float* partial_base = nullptr; };
 static thread_local PendingDw g_pending_dw = {{}, 0, 0, false};
+static int launch_dw_layers(const PendingDw* P, int count, hipStream_t stream);
 static thread_local bool t_defer_weight_grad = false;
 // "defer all" mode (common.h set_defer_all_weight_grads): every deferred contraction of this host thread is QUEUED instead
 // of riding in the next ffn-backward launch; geomae_flush_weight_grad launches the queue on its stream.  A stack's
@@ -1250,19 +1254,41 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     }
     T.t[6] = {dv,   128, 0,   h,  256, 0,   g->w2, 256, 0,   0,   g->b2,   128};  // dW2 cols 0..127
     T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
+    PendingDw P{T, 8, num_tokens, true};
+    const int dead = take_dw_dead_rows();
+    static const bool layer_form = [] { const char* e = getenv("GEOMAE_DW_LAYER_FORM"); return !(e && e[0] == '0'); }();   // (A/B)
+    if (layer_form && T.blocked && dw_partial()) {      // the stacks' contractions: four jobs of the layer-form kernel
+        P.has_layer = true;
+        P.partial_base = dw_partial();
+        DlJob* J = P.layer;
+        memset(J, 0, sizeof(P.layer));
+        const int dead64 = dead / 64 * 64;              // (the forward skips whole 64-token workgroups)
+        J[0].kind = kDlTall; J[0].tok_begin = 0;                                     // [dq | dk]^T (x + pos)
+        J[0].s[0] = {dqkv, 24, 0, 16}; J[0].s[1] = {xp, 8, 0, 8};
+        J[0].out[0] = {g->wqkv, g->bqkv, nullptr, nullptr, 128, 0};
+        J[1].kind = kDlTall; J[1].tok_begin = dead64;                                // dhp^T y
+        J[1].s[0] = {dhp, 16, 0, 16}; J[1].s[1] = {y, 8, 0, 8};
+        J[1].out[0] = {g->w1, g->b1, t_y_from_xhat ? t_y_gamma : nullptr, t_y_from_xhat ? t_y_beta : nullptr, 128, 0};
+        J[2].kind = kDlWide; J[2].tok_begin = dead64;                                // dv^T gelu(hp)
+        J[2].s[0] = {dv, 8, 0, 8}; J[2].s[1] = {h, 16, 0, 16};
+        J[2].out[0] = {g->w2, g->b2, nullptr, nullptr, 256, 0};
+        J[3].kind = kDlDual; J[3].tok_begin = 0;                                     // dv_^T x  |  du^T attn
+        J[3].s[0] = {dqkv, 24, 16, 8}; J[3].s[1] = {xb, 8, 0, 8};
+        J[3].s[2] = {du, 8, 0, 8}; J[3].s[3] = {at, 8, 0, 8};
+        J[3].out[0] = {g->wqkv + 256 * 128, g->bqkv + 256, t_x_from_xhat ? t_x_gamma : nullptr, t_x_from_xhat ? t_x_beta : nullptr, 128, 0};
+        J[3].out[1] = {g->wo, g->bo, nullptr, nullptr, 128, 0};
+    }
     if (t_defer_weight_grad && t_defer_all) {          // queued for geomae_flush_weight_grad
         t_defer_weight_grad = false;
-        t_dw_queue.push_back(PendingDw{T, 8, num_tokens, true});
+        t_dw_queue.push_back(P);
         return GEOMAE_OK;
     }
-    if (t_defer_weight_grad) {          // sst_stack_backward: ride on the next layer's ffn-backward launch
+    if (t_defer_weight_grad) {          // sst_stack_backward: ride on the next layer's ffn-backward launch (or wait for the flush)
         t_defer_weight_grad = false;
-        g_pending_dw.tasks = T;
-        g_pending_dw.num_tasks = 8;
-        g_pending_dw.num_tokens = num_tokens;
-        g_pending_dw.active = true;
+        g_pending_dw = P;
         return GEOMAE_OK;
     }
+    if (P.has_layer) return launch_dw_layers(&P, 1, stream);
     return launch_dw(T, 8, num_tokens, stream);
 }
 
@@ -1281,7 +1307,8 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
     int rc = GEOMAE_OK;
     if (g_pending_dw.active) {
         g_pending_dw.active = false;
-        rc = launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
+        rc = g_pending_dw.has_layer ? launch_dw_layers(&g_pending_dw, 1, stream)
+                                    : launch_dw(g_pending_dw.tasks, g_pending_dw.num_tasks, g_pending_dw.num_tokens, stream);
     }
     if (!t_dw_queue.empty()) {                           // "defer all": every contraction queued since the last flush
         // (one launch per layer.  Four layers of a stack in ONE launch -- 32 tasks, 768 workgroups -- were measured: the
@@ -1289,8 +1316,18 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
         // 0.09 instead of 0.05 ms)
         // (... and with FEWER workgroups per queued launch -- 16 / 12 / 8 token chunks per task instead of 24 -- the step
         // took 2.023 / 2.044 / 2.127 instead of 2.02 ms: the contractions then sit beside the encoder for longer)
-        for (const PendingDw& P : t_dw_queue)
-            if (rc == GEOMAE_OK) rc = launch_dw(P.tasks, P.num_tasks, P.num_tokens, stream);
+        // (round 5, layer form: up to FOUR layers of a stack are one launch of <= 16 jobs x 12 chunks = 192 workgroups of one
+        // per CU -- the fixed costs of a launch once per stack, a quarter of the split-K partials; dw_device.h)
+        for (size_t k = 0; k < t_dw_queue.size() && rc == GEOMAE_OK;) {
+            const PendingDw& P = t_dw_queue[k];
+            if (!P.has_layer) { rc = launch_dw(P.tasks, P.num_tasks, P.num_tokens, stream); ++k; continue; }
+            size_t m = 1;
+            while (m < 4 && k + m < t_dw_queue.size() && t_dw_queue[k + m].has_layer && t_dw_queue[k + m].num_tokens == P.num_tokens &&
+                   t_dw_queue[k + m].partial_base == P.partial_base)
+                ++m;
+            rc = launch_dw_layers(&t_dw_queue[k], (int)m, stream);
+            k += m;
+        }
         t_dw_queue.clear();
     }
     if (g_pending_reduce.partial) {                      // the last contraction's own partials
@@ -1300,6 +1337,45 @@ int geomae::flush_pending_weight_grad(hipStream_t stream) {
         if (rc == GEOMAE_OK) rc = rc2;
     }
     return rc;
+}
+
+// `count` <= 4 layers of one stack (same token set, same workspace) as ONE launch of the layer-form contraction + its reduction
+int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) {
+    GEOMAE_REQUIRE(count >= 1 && 4 * count <= kDlMaxJobs, "weight_grad: more than four layers per launch");
+    // partials an old-form launch left in the same workspace: summed first (stream order keeps them intact until then)
+    if (g_pending_reduce.partial) {
+        const DwReduce Rd = take_pending_reduce();
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(4 * kDwReduceBlocks), dim3(256), 0, stream, Rd);
+        const int rc0 = check_launch("dw_reduce_kernel");
+        if (rc0) return rc0;
+    }
+    DlArgs A;
+    memset(&A, 0, sizeof(A));
+    A.njobs = 4 * count; A.n = P[0].num_tokens; A.partial = P[0].partial_base;
+    for (int l = 0; l < count; ++l) memcpy(&A.job[4 * l], P[l].layer, sizeof(P[l].layer));
+    // workgroups = jobs x token chunks, one per CU (129 KB of LDS): 192 fill the memory system (tools/dw_bench.hip: 4 layers at
+    // 22 k tokens 87 / 71 / 65 / 65 us at 6 / 8 / 12 / 16 chunks; one layer 58 / 44 / 37 / 33 us at 8 / 12 / 16 / 24)
+    static const int g_env = [] { const char* e = getenv("GEOMAE_DW_CHUNKS"); return e ? atoi(e) : 0; }();                // (A/B)
+    int G = 192 / A.njobs;
+    if (G > 24) G = 24;
+    if (g_env > 0) G = g_env;
+    const int by_tokens = cdiv(A.n, 2 * kDlSlabTok);                   // at least two slabs per workgroup
+    if (G > by_tokens) G = by_tokens;
+    if (G > kDlMaxChunks) G = kDlMaxChunks;
+    while (G > 1 && (long long)A.njobs * G * kDlPartialFloats * 4 > 2 * kDwPartialBytes) --G;
+    if (G < 1) G = 1;
+    A.G = G;
+    void* prof = thread_profiler();
+    const bool timed = profiler_begin(prof, GEOMAE_KERNEL_DW, stream);
+    hipLaunchKernelGGL(dw_layer_kernel, dim3(A.njobs * G), dim3(kDlThreads), 0, stream, A);
+    if (timed) profiler_end(prof, stream);
+    int rc = check_launch("dw_layer_kernel");
+    if (rc) return rc;
+    DlReduce R;
+    R.partial = A.partial; R.njobs = A.njobs; R.G = G;
+    for (int j = 0; j < A.njobs; ++j) { R.job[j].kind = A.job[j].kind; R.job[j].pad_ = 0; R.job[j].out[0] = A.job[j].out[0]; R.job[j].out[1] = A.job[j].out[1]; }
+    hipLaunchKernelGGL(dw_layer_reduce_kernel, dim3(cdiv(A.njobs * kDlTileSlots, 256)), dim3(256), 0, stream, R);
+    return check_launch("dw_layer_reduce_kernel");
 }
 
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {

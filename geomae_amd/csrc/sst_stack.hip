@@ -315,7 +315,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         ~DwPartialScope() { set_dw_partial(nullptr); }
     } dw_scope((float*)(w + sc.dw_partial));
     struct OperandFormScope {                       // y / x "formed on load" switches: cleared on every exit path
-        ~OperandFormScope() { set_y_from_xhat(false); set_x_from_xhat(false); }
+        ~OperandFormScope() { set_y_from_xhat(false); set_x_from_xhat(false); (void)take_dw_dead_rows(); }
     } operand_scope;
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
@@ -365,10 +365,18 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
             set_tail_sum(nullptr, 0);
             if (rc) break;
         }
+        if (top && live_row > 0) set_dw_dead_rows(live_row);       // (consumed by the geomae_sst_weight_grad below)
         if (l > 0) {
             defer_next_weight_grad();               // recorded now, launched inside B3(l-1)
             rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, x_operand, ws + sc.du, sv + so.attn,
                                         ws + sc.dhp, y_from_xhat ? sv + so.xh1 : ws + sc.y, ws + sc.dv, ws + sc.h, &grads[l], stream);
+            // flushes on the way (common.h DwMidFlush): the layers queued so far go to the side stream now
+            const DwMidFlush mf = dw_mid_flush();
+            if (rc == GEOMAE_OK && defer_all && mf.side && mf.ev && mf.every > 0 && (num_layers - l) % mf.every == 0) {
+                GEOMAE_HIP(hipEventRecord(mf.ev, stream));
+                GEOMAE_HIP(hipStreamWaitEvent(mf.side, mf.ev, 0));
+                rc = flush_pending_weight_grad(mf.side);
+            }
         } else {
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
             // leaves it recorded and launches it there (geomae_flush_weight_grad), beside whatever follows on `stream`
