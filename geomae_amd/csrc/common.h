@@ -89,6 +89,7 @@ float* dw_partial();
 // rows [0, r) of the NEXT geomae_sst_weight_grad's token range are DEAD (the top layer of a decoder stack: their dY rows are
 // zero and their saved forward rows were never written, set_first_live_row): the layer-form contraction starts behind them
 // in the jobs whose dY operand is zero there.  Thread-local, consumed by that call.
+constexpr int kStackSyncBytes = 2048;      // the persistent stack forward's grid-barrier counters, behind a stack's saved tensors
 void set_dw_dead_rows(int rows);
 int take_dw_dead_rows();
 // Input map of the NEXT geomae_sst_qkv_forward of this host thread (set by geomae_sst_stack_forward around F1 of its first

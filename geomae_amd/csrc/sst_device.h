@@ -623,6 +623,11 @@ struct LayerW {
 constexpr int kOffWqkv = 0, kOffWqkT = 49152, kOffWvT = 81920, kOffWo = 98304, kOffWoT = 114688, kOffW1 = 131072,
               kOffW1T = 163840, kOffW2 = 196608, kOffW2T = 229376, kPackedPerLayer = 262144;
 #ifdef GEOMAE_HIP_H
+// sst_fused.hip: every layer of a stack in ONE persistent launch (grid barrier between layers); +1: not applicable
+int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
+                                 int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
+                                 long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
+                                 unsigned* sync, hipStream_t stream);
 inline LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
     L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;

@@ -78,6 +78,9 @@ struct FusedFwd {
     // saved for the backward (token order, tile-blocked; all or none)
     bf16_t *qkv, *attn, *xh1, *xh2, *hp, *xb, *xp;
     float *lse, *rstd;
+    // persistent form (sst_stack_fwd_kernel): x was written by OTHER workgroups of this launch (read past the L1: sc1), z is
+    // read by other workgroups of this launch (written through: sc0 sc1)
+    int coh_in = 0, coh_out = 0;
 };
 
 // byte offset of lane (token, g)'s 4 channels of channel tile ct in a tile-blocked [.][ld] tensor of E-byte elements
@@ -209,7 +212,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             } else {
                 off = tk >= 0 ? blk_off<4>(tk, 128, w, g) : kFOor;
             }
-            xr[it] = buf_load_f32x4(xres, off);
+            xr[it] = A.coh_in ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 16)) : buf_load_f32x4(xres, off);
             pv[it] = buf_load_f32x4(pres, tk >= 0 ? rec[it].y * 512 + 64 * w + 16 * g : kFOor);
         }
         // the in-projection's weights BEHIND the row loads: the rows (the longer dependent chain: plan -> row) are not
@@ -439,7 +442,8 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             const f32x4 zz = xh * g2 + be2;
             const int zo = tk < 0 ? kFOor : (A.z_blocked ? blk_off<4>(tk, 128, w, g) : tk * 512 + 64 * w + 16 * g);
 #ifndef FUSED_ABL_NO_Z
-            buf_store_f32x4(z_r, zo, zz);
+            if (A.coh_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), z_r, zo, 0, 17);
+            else buf_store_f32x4(z_r, zo, zz);
 #endif
         }
     }
@@ -468,6 +472,112 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFw
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// PERSISTENT form (round 5): all layers of a stack in ONE launch.  A launch per layer costs the stack a kernel boundary, the
+// dispatch ramp and a cold start per layer (~5-9 us of the 24.5 us a layer took at config 2, with 163 workgroups of 15-19 us
+// each); here the workgroups stay, and layers are separated by a grid barrier built for what crosses it:
+//  * the only data layer l + 1 reads from OTHER workgroups is z (the residual stream): written through (sc0 sc1 stores) and
+//    read past the L1 (sc1 loads) -- no agent-scope release (an L2 write-back of every line the 140 KB of saved activations
+//    per workgroup left dirty: ~6 us, MI355X_MICROARCH.md) and no acquire;
+//  * arrival: each wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE relaxed agent-scope add on the counter
+//    of the workgroup's slot class (blockIdx & 7: eight counters 128 B apart, ~20 arrivals each instead of 163 on one word);
+//    departure: eight lanes poll the eight counters (sc1 loads, s_sleep between polls) until each holds its expected count;
+//  * every workgroup must be resident: the grid is capped at the CU count (one 134-KB-LDS workgroup per CU) and workgroups
+//    loop over bundles; a bounded spin (kSpinLimit polls, ~0.3 s) raises an error word instead of hanging the device.
+// The saved activations are plain stores: only later launches (the backward) read them.
+constexpr int kPMaxLayers = 12;
+constexpr int kSyncStrideWords = 32;             // counters 128 B apart
+constexpr int kSyncErrWord = 8 * kSyncStrideWords;
+constexpr int kSpinLimit = 1 << 19;
+struct FusedStack {
+    const float* x0; SstInputMap M;              // layer 0 input: tile-blocked x0, or the row-major source map
+    const int32_t* bun_tok[2]; const int4* plan[2]; const int32_t* num_bundles[2];
+    const float* pos_table;
+    const bf16_t* frag[kPMaxLayers];
+    const float* prm[kPMaxLayers][8];            // bqkv, bo, g1, be1, b1, b2, g2, be2
+    char* saved; long long stride;               // layer l's saved tensors at saved + l * stride + off_*
+    long long off_x, off_qkv, off_attn, off_lse, off_xh1, off_xh2, off_hp, off_rstd, off_xb, off_xp;
+    float* z_out;                                // last layer's output, row-major
+    int n, num_layers, skip_x_above0;
+    float eps;
+    unsigned* sync;                              // zeroed by the host before the launch: 8 counters + error word
+};
+static_assert(sizeof(FusedStack) <= 2048, "kernel arguments");
+
+__device__ __forceinline__ void stack_grid_barrier(unsigned* sync, int phase /* 1, 2, ... */) {
+    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wave's stores (z written through) have completed
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_fetch_add(sync + (blockIdx.x & 7) * kSyncStrideWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // slot class c holds the blocks b with b % 8 == c: ceil((grid - c) / 8) of them
+        const unsigned expect = lane < 8 ? (unsigned)(((int)gridDim.x - lane + 7) / 8) * (unsigned)phase : 0u;
+        int spins = 0;
+        for (;;) {
+            const unsigned v = lane < 8 ? __hip_atomic_load(sync + lane * kSyncStrideWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            if (__builtin_amdgcn_ballot_w64(v < expect) == 0) break;
+            if (++spins > kSpinLimit || __hip_atomic_load(sync + kSyncErrWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                if (lane == 0) __hip_atomic_store(sync + kSyncErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;                           // (results of this launch are invalid; the host can read the error word)
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+}
+
+// -DGEOMAE_PERSIST_STAMPS (tools/persist_time.py with a timing build): s_memrealtime (100 MHz, one clock for the device) at
+// the start of every layer, the end of its bundles and behind its barrier, per workgroup
+#ifdef GEOMAE_PERSIST_STAMPS
+static __device__ unsigned long long persist_stamps[256 * 40];
+#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) persist_stamps[blockIdx.x * 40 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PSTAMP(i) do {} while (0)
+#endif
+
+__global__ __launch_bounds__(kFusedThreads, 2) void sst_stack_fwd_kernel(FusedStack S) {
+    __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
+    for (int l = 0; l < S.num_layers; ++l) {
+        PSTAMP(3 * l);
+        FusedFwd A;
+        char* sv = S.saved + S.stride * l;
+        const bool last = l + 1 == S.num_layers;
+        A.x = l == 0 ? S.x0 : reinterpret_cast<const float*>(sv + S.off_x);
+        A.M = l == 0 ? S.M : SstInputMap{nullptr, 0, nullptr, nullptr};
+        A.bun_tok = S.bun_tok[l & 1]; A.plan = S.plan[l & 1]; A.num_bundles = S.num_bundles[l & 1];
+        A.pos_table = S.pos_table;
+        A.W.frag = S.frag[l];
+        A.W.bqkv = S.prm[l][0]; A.W.bo = S.prm[l][1]; A.W.g1 = S.prm[l][2]; A.W.be1 = S.prm[l][3];
+        A.W.b1 = S.prm[l][4]; A.W.b2 = S.prm[l][5]; A.W.g2 = S.prm[l][6]; A.W.be2 = S.prm[l][7];
+        A.n = S.n; A.eps = S.eps;
+        A.z = last ? S.z_out : reinterpret_cast<float*>(sv + S.stride + S.off_x);
+        A.z_blocked = last ? 0 : 1;
+        A.qkv = (bf16_t*)(sv + S.off_qkv); A.attn = (bf16_t*)(sv + S.off_attn); A.xh1 = (bf16_t*)(sv + S.off_xh1);
+        A.xh2 = (bf16_t*)(sv + S.off_xh2); A.hp = (bf16_t*)(sv + S.off_hp);
+        A.xb = (l > 0 && S.skip_x_above0) ? nullptr : (bf16_t*)(sv + S.off_xb);
+        A.xp = (bf16_t*)(sv + S.off_xp); A.lse = (float*)(sv + S.off_lse); A.rstd = (float*)(sv + S.off_rstd);
+        A.coh_in = l > 0; A.coh_out = !last;
+        const int NB = A.num_bundles[0];
+        for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+            const int s0 = A.bun_tok[b];
+            int T = A.bun_tok[b + 1] - s0;
+            if (T > kFMaxT) T = kFMaxT;
+            const int nt = (T + 15) >> 4;
+            switch (nt) {
+                case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
+                case 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
+                case 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
+                case 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
+                default: fused_fwd_body<9, false>(A, s0, T, nt, lds); break;
+            }
+            __syncthreads();                      // the LDS rows are free for the next bundle / layer
+        }
+        PSTAMP(3 * l + 1);
+        if (!last) stack_grid_barrier(S.sync, l + 1);
+        PSTAMP(3 * l + 2);
+    }
+}
+
 // one workgroup per bundle; the bundle count lives on the device, its bound from the greedy packing is 2 n / cap + 1
 static int fused_grid(int num_tokens, int max_bundles, int cap) {
     int64_t nb = 2 * (int64_t)num_tokens / (cap > 0 ? cap : 1) + 2;
@@ -489,6 +599,53 @@ extern "C" int geomae_debug_read_fused_stamps(unsigned long long* host, int clea
         hipMemcpyToSymbol(HIP_SYMBOL(geomae_stamps), zeros, sizeof(zeros));
     }
     return 0;
+}
+#endif
+
+// All layers of a stack in one launch (sst_stack_fwd_kernel).  -> GEOMAE_OK / error, or +1 when this stack cannot take that form (the
+// caller then launches layer by layer).  `sync` = kStackSyncBytes of device memory, zeroed here on `stream`.
+int geomae::sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
+                                         int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
+                                         long long stride, const long long* off /* x qkv attn lse xh1 xh2 hp rstd xb xp */,
+                                         float* z_out, bool skip_x_above0, int bundle_cap, unsigned* sync, hipStream_t stream) {
+    if (num_layers > kPMaxLayers || num_layers < 2 || bundle_cap > kFMaxT) return 1;
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n;
+    }();
+    if (cus < 8) return 1;
+    FusedStack S;
+    memset(&S, 0, sizeof(S));
+    S.x0 = x_in; S.M = M;
+    for (int k = 0; k < 2; ++k) {
+        S.bun_tok[k] = layouts[k].fbun_tok; S.plan[k] = (const int4*)layouts[k].pos_info; S.num_bundles[k] = layouts[k].num_fbundles;
+    }
+    S.pos_table = pos_table;
+    for (int l = 0; l < num_layers; ++l) {
+        const GeomaeSstLayerWeights& w = layers[l];
+        if (!w.frag_p || !w.bqkv || !w.bo || !w.ln1_w || !w.ln1_b || !w.b1 || !w.b2 || !w.ln2_w || !w.ln2_b || w.ln_eps != layers[0].ln_eps)
+            return 1;
+        S.frag[l] = (const bf16_t*)w.frag_p;
+        const float* prm[8] = {w.bqkv, w.bo, w.ln1_w, w.ln1_b, w.b1, w.b2, w.ln2_w, w.ln2_b};
+        for (int k = 0; k < 8; ++k) S.prm[l][k] = prm[k];
+    }
+    S.saved = saved; S.stride = stride;
+    S.off_x = off[0]; S.off_qkv = off[1]; S.off_attn = off[2]; S.off_lse = off[3]; S.off_xh1 = off[4]; S.off_xh2 = off[5];
+    S.off_hp = off[6]; S.off_rstd = off[7]; S.off_xb = off[8]; S.off_xp = off[9];
+    S.z_out = z_out; S.n = num_tokens; S.num_layers = num_layers; S.skip_x_above0 = skip_x_above0 ? 1 : 0;
+    S.eps = layers[0].ln_eps; S.sync = sync;
+    int grid = fused_grid(num_tokens, layouts[0].max_bundles < layouts[1].max_bundles ? layouts[0].max_bundles : layouts[1].max_bundles, bundle_cap);
+    if (grid > cus) grid = cus;                  // every workgroup must be resident: one per CU (134 KB of LDS)
+    GEOMAE_HIP(hipMemsetAsync(sync, 0, kStackSyncBytes, stream));
+    hipLaunchKernelGGL(sst_stack_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, S);
+    return check_launch("sst_stack_fwd_kernel");
+}
+
+#ifdef GEOMAE_PERSIST_STAMPS
+extern "C" int geomae_debug_read_persist_stamps(unsigned long long* host) {
+    hipDeviceSynchronize();
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(persist_stamps), sizeof(unsigned long long) * 256 * 40);
 }
 #endif
 

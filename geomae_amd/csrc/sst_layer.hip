@@ -1353,10 +1353,14 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     memset(&A, 0, sizeof(A));
     A.njobs = 4 * count; A.n = P[0].num_tokens; A.partial = P[0].partial_base;
     for (int l = 0; l < count; ++l) memcpy(&A.job[4 * l], P[l].layer, sizeof(P[l].layer));
-    // workgroups = jobs x token chunks, one per CU (129 KB of LDS): 192 fill the memory system (tools/dw_bench.hip: 4 layers at
-    // 22 k tokens 87 / 71 / 65 / 65 us at 6 / 8 / 12 / 16 chunks; one layer 58 / 44 / 37 / 33 us at 8 / 12 / 16 / 24)
+    // workgroups = jobs x token chunks, one per CU (129 KB of LDS).  Alone, 192 fill the memory system (tools/dw_bench.hip: 4
+    // layers at 22 k tokens 87 / 71 / 65 / 65 us at 6 / 8 / 12 / 16 chunks; one layer 58 / 44 / 37 / 33 us at 8 / 12 / 16 / 24) --
+    // but these launches run on a side stream BESIDE the backward of the next stack, which needs the CUs more than they do:
+    // in the step 96 workgroups are the optimum at every size (config 2: 1.860 / 1.860 / 1.86 / 1.91 ms at 4 / 6 / 8 / 12 chunks
+    // of 16 jobs; config 3: 7.29 / 6.37 / 6.07 / 5.91 / 6.00 / 6.15 ms at 2 / 3 / 4 / 6 / 8 / 12 -- fewer do not finish before
+    // the step's join, more slow the main stream's kernels)
     static const int g_env = [] { const char* e = getenv("GEOMAE_DW_CHUNKS"); return e ? atoi(e) : 0; }();                // (A/B)
-    int G = 192 / A.njobs;
+    int G = 96 / A.njobs;
     if (G > 24) G = 24;
     if (g_env > 0) G = g_env;
     const int by_tokens = cdiv(A.n, 2 * kDlSlabTok);                   // at least two slabs per workgroup

@@ -24,6 +24,14 @@
 #include <vector>
 
 namespace geomae {
+// sst_fused.hip: every layer of a stack in ONE persistent launch (grid barrier between layers); +1: not applicable
+int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
+                                 int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
+                                 long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
+                                 unsigned* sync, hipStream_t stream);
+}
+
+namespace geomae {
 // sst_layer.hip: lets the weight-gradient contraction of a layer ride inside the next ffn-backward launch
 void defer_next_weight_grad();
 int flush_pending_weight_grad(hipStream_t stream);
@@ -41,7 +49,8 @@ static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 // decoders' sizes (tools/fused_layer_time.py).  Automatic = token sets of at most kFusedMaxTokens.
 static int g_fused_mode = [] { const char* e = getenv("GEOMAE_FUSED_LAYERS"); return e ? atoi(e) : 1; }();
 constexpr int kFusedMaxTokens = 12288;
-static bool fused_layers_enabled(int num_tokens) { return g_fused_mode == 2 || (g_fused_mode == 1 && num_tokens <= kFusedMaxTokens); }
+static bool fused_layers_enabled(int num_tokens) { return g_fused_mode == 2 || ((g_fused_mode == 1 || g_fused_mode == 3) && num_tokens <= kFusedMaxTokens); }
+// mode 3: as 1, but one launch per LAYER (never the persistent whole-stack launch): A/B runs
 
 struct SavedOffsets {
     int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
@@ -177,7 +186,7 @@ extern "C" void geomae_profiler_destroy(void* prof) {
 }
 
 extern "C" int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads) {
-    return saved_offsets(num_tokens, num_heads).stride * num_layers;
+    return saved_offsets(num_tokens, num_heads).stride * num_layers + kStackSyncBytes;   // (+ the persistent forward's counters)
 }
 extern "C" int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens) { return scratch_offsets(num_tokens).total; }
 extern "C" int64_t geomae_sst_stack_scratch_bytes_layers(int32_t num_tokens, int32_t num_layers) {
@@ -224,6 +233,21 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     if (fused_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
         saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
         const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
+        // ... or ONE launch for the whole stack (sst_stack_fwd_kernel: the workgroups stay, a grid barrier between layers);
+        // its counters live behind the layers' saved tensors.  GEOMAE_PERSISTENT_FWD=0: a launch per layer.
+        // Measured (tools/persist_time.py, s_memrealtime stamps per layer and workgroup, config 2's encoder): the barrier costs
+        // 1-2 us behind the last arrival, a bundle's chain 20 us (median) to 21-27 us (the layer's longest) -- the stack takes
+        // 308-314 us either way (launch per layer: 310-317), and in the step a launch that holds every CU's LDS for 300 us
+        // keeps the decoder-B stream's kernels out (dec_bwd +0.07 ms).  OFF by default (GEOMAE_PERSISTENT_FWD=1: on).
+        static const bool persistent = [] { const char* e = getenv("GEOMAE_PERSISTENT_FWD"); return e && e[0] == '1'; }();
+        if (persistent && g_fused_mode != 3 && saved_bytes >= so.stride * num_layers + kStackSyncBytes) {
+            const long long off[10] = {so.x, so.qkv, so.attn, so.lse, so.xh1, so.xh2, so.hp, so.rstd, so.xb, so.xp};
+            Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
+            rc = sst_stack_forward_persistent(x_in, SstInputMap{x_in, num_input_rows, fill_row, input_rows}, num_tokens, layers,
+                                              num_layers, layouts, pos_table, base, so.stride, off, z_out, x_from_xhat_enabled(), cap,
+                                              (unsigned*)(base + so.stride * num_layers), stream);
+            if (rc <= 0) return rc;             // (+1: this stack cannot take that form)
+        }
         for (int l = 0; l < num_layers; ++l) {
             char* sv = base + so.stride * l;
             const bool next = l + 1 < num_layers;
