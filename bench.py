@@ -224,6 +224,7 @@ def main():
         share = {}
         for r in csv.DictReader(open(files[-1])):
             name = re.sub(r"<.*", "", r["Name"].split("(")[0].replace("geomae::", "").replace("void ", "")).strip()
+            name = {"dw_layer_kernel": "dw_kernel"}.get(name, name)      # (one profiler id: the contraction in both forms)
             share[name] = share.get(name, 0.0) + float(r["Percentage"])
         return os.path.relpath(files[-1], ROOT), share
     table_path, table_share = committed_table()
