@@ -354,19 +354,25 @@ def main():
         # Fusion structure of a stack of L layers (12-layer encoder, two 4-layer decoders; csrc/sst_stack.hip):
         #   forward : F1(0) | attn | F3(l)+F1(l+1) ... | F3(L-1)      -> L-1 of a stack's L ffn-forward launches carry an F1
         #   backward: B3(L-1) | battn | B1(l+1)+B3(l) [+ dW(l+1)] ... | B1(0) | dW(0)
-        # The encoder's launches carry the contraction dW(l+1) (sst_ffn_bwd_dw_kernel, 11 per step; its top layer's
-        # launch is a plain sst_ffn_bwd_kernel); the decoders' contractions are queued for the geometry stream
-        # (csrc/engine.hip, GEOMAE_DW_DEFER_ALL), so their 8 launches are plain ones (B3, 6 of them with a B1 head).
-        # With the python step driver / GEOMAE_DW_DEFER_ALL=0 the decoders' 6 non-top launches carry a dW too.
-        # 3 stand-alone F1 / B1 launches per step (one per stack); the stand-alone dw_kernel launches are not timed here.
+        # Round 5 (engine default): NO launch carries a contraction -- 20 plain sst_ffn_bwd_kernel launches per step (17 with a
+        # B1 head); every layer's contraction runs in the layer-form launches on the geometry stream (profiler id "dw_kernel":
+        # 2 decoder launches of 4 layers, 3 encoder launches of 4 layers, + the old-form heads and VFE launches).
+        # GEOMAE_ENC_DW_DEFER=0: the encoder's launches carry dW(l+1) again (sst_ffn_bwd_dw_kernel, 11 per step);
+        # GEOMAE_DW_DEFER_ALL=0 / the python step driver: the decoders' 6 non-top launches too.
+        # 3 stand-alone F1 / B1 launches per step (one per stack).
         n_e, n_d = float(n_tok[0]), float(n_tok[-1])
         sq_e, sq_d = float(np.sum(sq[:12])), float(np.sum(sq[12:]))   # sum over layers of sum_w n_w^2 (encoder / one decoder)
         F3, F1, DW = 2 * 81920.0, 2 * 49152.0, 2 * 131072.0           # FLOPs per token: ffn (3 GEMMs) / qkv / contractions
         lps = lambda k: (len(durations.get(k) or []) / steps_timed[k]) if durations.get(k) else 0.0     # launches per step
         fused_enc = round(lps("sst_layer_fwd_kernel")) == 12          # the encoder's forward as one launch per layer
         dec_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 11
+        # round 5: the encoder's contractions leave its backward launches too (csrc/engine.hip GEOMAE_ENC_DW_DEFER): no
+        # sst_ffn_bwd_dw_kernel launch at all, 20 plain ffn-backward launches (17 of them with a B1 head), and every layer's
+        # contraction in the layer-form launches on the geometry stream (csrc/dw_device.h: <= 4 layers per launch)
+        all_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 0 and round(lps("sst_ffn_bwd_kernel")) == 20
         M_rows = float(n_d - n_e)
-        flops_step = {"sst_ffn_bwd_kernel": F3 * (n_e + 8 * n_d) + F1 * 6 * n_d if dec_deferred else F3 * (n_e + 2 * n_d),
+        flops_step = {"sst_ffn_bwd_kernel": (F3 * (12 * n_e + 8 * n_d) + F1 * (11 * n_e + 6 * n_d)) if all_deferred else
+                                            (F3 * (n_e + 8 * n_d) + F1 * 6 * n_d if dec_deferred else F3 * (n_e + 2 * n_d)),
                       "sst_ffn_bwd_dw_kernel": (F3 + F1 + DW) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
                       "sst_ffn_fwd_kernel": F3 * 8 * n_d + F1 * 6 * n_d,
                       "sst_ffn_fwd_pair_kernel": F3 * 12 * n_e + F1 * 11 * n_e,
@@ -376,8 +382,10 @@ def main():
                       "sst_layer_fwd_kernel": (F3 + F1) * 12 * n_e + 2 * 2 * 16 * 8 * sq_e,
                       # every stand-alone contraction of the step: the decoders' 8 layers + the encoder's first layer (its
                       # other 11 ride in sst_ffn_bwd_dw_kernel), the six heads (800 x 128 per masked row), VFE layer 1
-                      "dw_kernel": DW * ((8 * n_d if dec_deferred else 2 * n_d) + n_e) + 2 * 800 * 128 * M_rows + 2 * 128 * 128 * n_pts}
-        expect = {"sst_ffn_bwd_kernel": 9.0 if dec_deferred else 3.0, "sst_ffn_bwd_dw_kernel": 11.0 if dec_deferred else 17.0,
+                      "dw_kernel": DW * ((8 * n_d if (dec_deferred or all_deferred) else 2 * n_d) + (12 * n_e if all_deferred else n_e))
+                                   + 2 * 800 * 128 * M_rows + 2 * 128 * 128 * n_pts}
+        expect = {"sst_ffn_bwd_kernel": 20.0 if all_deferred else (9.0 if dec_deferred else 3.0),
+                  "sst_ffn_bwd_dw_kernel": 11.0 if dec_deferred else 17.0,
                   "sst_ffn_fwd_kernel": 8.0, "sst_ffn_fwd_pair_kernel": 12.0, "sst_qkv_fwd_kernel": 2.0 if fused_enc else 3.0,
                   "sst_qkv_bwd_kernel": 3.0, "win_attn_fwd_kernel": 8.0 if fused_enc else 20.0, "win_attn_bwd_kernel": 20.0,
                   "sst_layer_fwd_kernel": 12.0, "dw_kernel": None}
@@ -401,7 +409,8 @@ def main():
         # 1.3 KB; a contraction reads 8 tasks x 2 operands x 256 B; attention forward reads qkv 768 and writes attn 256 + lse 32,
         # its backward reads qkv + attn + dattn + lse and writes dqkv 768.
         F3B, F1B, B3B, B1B, DWB, AFB, ABB = 2304.0, 1024.0, 4450.0, 1300.0, 4096.0, 1056.0, 2080.0
-        bytes_step = {"sst_ffn_bwd_kernel": B3B * (n_e + 8 * n_d) + B1B * 6 * n_d if dec_deferred else B3B * (n_e + 2 * n_d),
+        bytes_step = {"sst_ffn_bwd_kernel": (B3B * (12 * n_e + 8 * n_d) + B1B * (11 * n_e + 6 * n_d)) if all_deferred else
+                                            (B3B * (n_e + 8 * n_d) + B1B * 6 * n_d if dec_deferred else B3B * (n_e + 2 * n_d)),
                       "sst_ffn_bwd_dw_kernel": (B3B + B1B + DWB) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
                       "sst_ffn_fwd_kernel": F3B * 8 * n_d + F1B * 6 * n_d,
                       "sst_ffn_fwd_pair_kernel": F3B * 12 * n_e + F1B * 11 * n_e,
@@ -410,8 +419,10 @@ def main():
                       "win_attn_fwd_kernel": AFB * (8 * n_d + (0 if fused_enc else 12 * n_e)),
                       "win_attn_bwd_kernel": ABB * (12 * n_e + 8 * n_d),
                       "sst_layer_fwd_kernel": (512 + F3B + F1B + 256 + 32) * 12 * n_e,
-                      "dw_kernel": DWB * ((8 * n_d if dec_deferred else 2 * n_d) + n_e) + 2 * (800 + 128) * M_rows
-                                   + 2 * 2 * 128 * n_pts}
+                      # (algorithmic: 8 tasks x 2 operands x 256 B per token and layer -- SURVEY's figure; the layer-form kernel
+                      #  reads 3.25 KB of it once, dw_device.h)
+                      "dw_kernel": DWB * ((8 * n_d if (dec_deferred or all_deferred) else 2 * n_d) + (12 * n_e if all_deferred else n_e))
+                                   + 2 * (800 + 128) * M_rows + 2 * 2 * 128 * n_pts}
         kern = {}
         for k in TIMED:
             d = durations.get(k) or []

@@ -250,7 +250,12 @@ __device__ __forceinline__ void join_halves(const f32x4 (&mine)[NT], const f32x4
 template <int NT, typename T>
 __device__ __forceinline__ void half_of(const T (&full)[2 * NT], int h, T (&mine)[NT]) {
 #pragma unroll
-    for (int i = 0; i < NT; ++i) mine[i] = h ? full[NT + i] : full[i];
+    for (int i = 0; i < NT; ++i) {
+        // (both values first: `h ? full[NT + i] : full[i]` became a select of two ADDRESSES in sst_ffn_bwd_pair_kernel and
+        //  sent the whole array to scratch, 211 scratch accesses)
+        const T a = full[i], b = full[NT + i];
+        mine[i] = h ? b : a;
+    }
 }
 
 template <int K, int N>

@@ -162,7 +162,8 @@ __device__ __forceinline__ f32x4 params_issue(const LayerW& W) {
 // NT: tiles the body is unrolled for.  EXACT: the bundle has exactly NT tiles -- straight-line code (the scheduler overlaps
 // the tiles' chains), all tile pairs of the attention computed (the mask does the block-diagonal).  !EXACT: nt <= NT tiles
 // behind scalar branches, key-tile ranges.  Weight fragments are fetched two phases ahead of their first use.
-template <int NT, bool EXACT>
+// COH: the persistent form's coherent residual-stream accesses (FusedFwd.coh_in / coh_out); compiled out of the per-layer launch
+template <int NT, bool EXACT, bool COH = false>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, const int T, const int nt_in, char* lds) {
     const int nt = EXACT ? NT : nt_in;
 #define FOR_TILES(it) _Pragma("unroll") for (int it = 0; it < NT; ++it) if (EXACT || it < nt)
@@ -212,7 +213,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             } else {
                 off = tk >= 0 ? blk_off<4>(tk, 128, w, g) : kFOor;
             }
-            xr[it] = A.coh_in ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 16)) : buf_load_f32x4(xres, off);
+            xr[it] = (COH && A.coh_in) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 16)) : buf_load_f32x4(xres, off);
             pv[it] = buf_load_f32x4(pres, tk >= 0 ? rec[it].y * 512 + 64 * w + 16 * g : kFOor);
         }
         // the in-projection's weights BEHIND the row loads: the rows (the longer dependent chain: plan -> row) are not
@@ -442,7 +443,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             const f32x4 zz = xh * g2 + be2;
             const int zo = tk < 0 ? kFOor : (A.z_blocked ? blk_off<4>(tk, 128, w, g) : tk * 512 + 64 * w + 16 * g);
 #ifndef FUSED_ABL_NO_Z
-            if (A.coh_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), z_r, zo, 0, 17);
+            if (COH && A.coh_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), z_r, zo, 0, 17);
             else buf_store_f32x4(z_r, zo, zz);
 #endif
         }
@@ -564,11 +565,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_stack_fwd_kernel(FusedSt
             if (T > kFMaxT) T = kFMaxT;
             const int nt = (T + 15) >> 4;
             switch (nt) {
-                case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
-                case 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
-                case 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
-                case 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
-                default: fused_fwd_body<9, false>(A, s0, T, nt, lds); break;
+                case 1: fused_fwd_body<1, true, true>(A, s0, T, nt, lds); break;
+                case 2: fused_fwd_body<2, true, true>(A, s0, T, nt, lds); break;
+                case 3: fused_fwd_body<3, true, true>(A, s0, T, nt, lds); break;
+                case 4: fused_fwd_body<4, true, true>(A, s0, T, nt, lds); break;
+                default: fused_fwd_body<9, false, true>(A, s0, T, nt, lds); break;
             }
             __syncthreads();                      // the LDS rows are free for the next bundle / layer
         }

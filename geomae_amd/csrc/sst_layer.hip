@@ -670,178 +670,12 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A)
     ffn_bwd_body(A, blockIdx.x, smem, red);
 }
 
-// Pair form of B3 (+ the fused B1 head) for SMALL token counts (round 5; the forward has had one since round 2).  At
-// encoder size the kernel above is ~105 workgroups of one wave per SIMD walking a ~46 k-cycle dependent chain (seven GEMMs
-// of 256 MFMAs in all, two LayerNorm backwards, the GELU backward) on a 256-CU chip.  Here a workgroup takes 32 tokens and two
-// waves share each 16-token tile: wave half h computes half of every GEMM's output channels from the full-K operand and does
-// the elementwise work (GELU backward, stores) of its half; the halves meet through LDS where the next step needs the whole
-// row (dz, dhp, dy: three exchanges), the LayerNorm backwards run on the full rows in both waves, and each LayerNorm's
-// parameter gradients are summed by ONE of the two (LN2: half 0, LN1: half 1).  Every value is computed by the same
-// instruction sequence as in the single-wave form: outputs bit-identical, the LayerNorm parameter gradients up to the order
-// of their atomics.  (Round 2 built this once and dropped it: the launches then carried the weight-gradient contraction as
-// extra workgroups, and twice the ffn workgroups left them no CUs.  The contractions have left these launches: dw_device.h.)
-__device__ __forceinline__ void ffn_bwd_pair_body(const FfnBwdArgs& A, int block, bf16_t* __restrict__ smem,
-                                                  float (*red)[4][128], uint4* __restrict__ xch) {
-    const LayerW& W = A.W; const int n = A.n;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int h = wave >> 1;                                          // which half of the output channels
-    const int tile = block * 2 + (wave & 1);
-    const int tok = tile * 16 + (lane & 15);
-    const bool blk = A.lay & kLayBlocked, valid = tok < n;
-    float* red_scratch = reinterpret_cast<float*>(smem) + wave * kRedWaveFloats;
-    if (block < 2 * A.wg0) {          // dead rows (two 32-token workgroups per 64-token unit of wg0): zeros, this wave's half
-        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 z4a[4], z8[8];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) z4a[ct] = z4;
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) z8[ct] = z4;
-        store_rows_f32_cols<64>(A.dx_res, n, tok, 128, 64 * h, z4a, lane, blk);
-        store_rows_bf16<64>(A.dattn, n, tok, 128, 64 * h, z4a, lane, blk);
-        store_rows_bf16<64>(A.du_b, n, tok, 128, 64 * h, z4a, lane, blk);
-        store_rows_bf16<64>(A.dv_b, n, tok, 128, 64 * h, z4a, lane, blk);
-        if (A.y_b) store_rows_bf16<64>(A.y_b, n, tok, 128, 64 * h, z4a, lane, blk);
-        store_rows_bf16<128>(A.dhp_b, n, tok, 256, 128 * h, z8, lane, blk);
-        store_rows_bf16<128>(A.h_b, n, tok, 256, 128 * h, z8, lane, blk);
-        return;
-    }
-    const uint2 rs = buf_load_b64(rows_rsrc(A.rstd_in, n, 8), tok * 8);
-    const float r1 = __uint_as_float(rs.x), r2 = __uint_as_float(rs.y);
-    f32x4 dv[8];                                                      // the running gradient row (full, in both waves)
-    if (A.up_dqkv) {                  // B1 of the layer above: dz = up_dx_res + dqk Wqk + dv Wv, this wave's 64 channels
-        WStage<256, 128> s_qk;
-        WStage<128, 128> s_v;
-        stage_issue<256, 128>(A.up_wqkT, s_qk);
-        f32x4 acc[4], other[4];
-        load_rows_f32_cols<64>(A.up_dx_res, n, tok, 128, 64 * h, acc, lane, blk);
-        uint2 d[16], dvr[8];
-        load_rows_bf16<256>(A.up_dqkv, n, tok, 384, 0, d, lane, blk);
-        load_rows_bf16<128>(A.up_dqkv, n, tok, 384, 256, dvr, lane, blk);
-        stage_issue<128, 128>(A.up_wvT, s_v);
-        gemm_staged_half<256, 128>(s_qk, smem, d, acc, lane, h);
-        gemm_staged_half<128, 128>(s_v, smem, dvr, acc, lane, h);
-        pair_exchange<4>(xch, wave, lane, reinterpret_cast<const uint4(&)[4]>(acc), reinterpret_cast<uint4(&)[4]>(other));
-        join_halves<4>(acc, other, h, dv);
-    } else {
-        load_rows_f32<128>(A.dz, n, tok, dv, lane);
-        if (A.dz_add) {
-            f32x4 d2[8];
-            load_rows_f32<128>(A.dz_add, n, tok, d2, lane);
-#pragma unroll
-            for (int ct = 0; ct < 8; ++ct) dv[ct] += d2[ct];
-        }
-    }
-    WStage<128, 256> s_w2T;
-    // ---- LN2 backward (full rows in both waves; the parameter gradients by half 0)
-    {
-        f32x4 xh2[8];
-        load_xhat(A.xh2_in, n, tok, xh2, lane, blk, A.lay & kLaySavedBf16);
-        stage_issue<128, 256>(W.w2T, s_w2T);
-        // (the scratch of ln_param_grads_t aliases the weight buffer: behind B1 the exchange's barrier followed the last
-        //  GEMM's reads; without B1 nothing has used the buffer yet)
-        if (h == 0) ln_param_grads_t(dv, xh2, red_scratch, red[wave], 0, lane, valid);
-        layer_norm_bwd_t(dv, xh2, W.g2, r2, lane);                    // dv = d(y + f)
-    }
-    {
-        f32x4 mine[4];
-        half_of<4>(dv, h, mine);
-        store_rows_bf16<64>(A.dv_b, n, tok, 128, 64 * h, mine, lane, blk);
-    }
-    // ---- FFN backward: dh = dv W2 ; dhp = dh * gelu'(hp) ; dy = dv + dhp W1 -- this wave's 128 hidden channels
-    uint2 dhpb[16];
-    WStage<256, 128> s_w1T;
-    {
-        uint2 hpb[8];
-        load_rows_bf16<128>(A.hp_in, n, tok, 256, 128 * h, hpb, lane, blk);   // needed after the GEMM: in flight under it
-        uint2 dvb[8];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) dvb[ct] = pack4(dv[ct]);
-        f32x4 dh[8];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) dh[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_staged_half<128, 256>(s_w2T, smem, dvb, dh, lane, h);
-        stage_issue<256, 128>(W.w1T, s_w1T);                          // lands under the GELU arithmetic
-        const RowAddr h_a = row_addr<2>(A.h_b, n, tok, 256, 128 * h, lane, blk), dhp_a = row_addr<2>(A.dhp_b, n, tok, 256, 128 * h, lane, blk);
-        uint2 half_b[8];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const f32x4 hp = unpack4(hpb[ct]);
-            f32x4 hh, gr;
-            gelu_fwd_bwd4(hp, &hh, &gr);
-            dh[ct] *= gr;
-            half_b[ct] = pack4(dh[ct]);
-            const uint2 hb2 = pack4(hh);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{hb2.x, hb2.y}, h_a.r, h_a.voff, ct * h_a.ct_stride, 0);
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2{half_b[ct].x, half_b[ct].y}, dhp_a.r, dhp_a.voff, ct * dhp_a.ct_stride, 0);
-        }
-        uint4 mine[4], other[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) mine[i] = make_uint4(half_b[2 * i].x, half_b[2 * i].y, half_b[2 * i + 1].x, half_b[2 * i + 1].y);
-        pair_exchange<4>(xch, wave, lane, mine, other);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 lo = h ? other[i] : mine[i], hi = h ? mine[i] : other[i];
-            dhpb[2 * i] = make_uint2(lo.x, lo.y);
-            dhpb[2 * i + 1] = make_uint2(lo.z, lo.w);
-            dhpb[8 + 2 * i] = make_uint2(hi.x, hi.y);
-            dhpb[8 + 2 * i + 1] = make_uint2(hi.z, hi.w);
-        }
-    }
-    f32x4 xh1[8];
-    load_xhat(A.xh1_in, n, tok, xh1, lane, blk, A.lay & kLaySavedBf16);        // in flight under the GEMM
-    {
-        f32x4 acc[4], other[4];
-        half_of<4>(dv, h, acc);
-        gemm_staged_half<256, 128>(s_w1T, smem, dhpb, acc, lane, h);          // acc = this half of dy
-        pair_exchange<4>(xch, wave, lane, reinterpret_cast<const uint4(&)[4]>(acc), reinterpret_cast<uint4(&)[4]>(other));
-        join_halves<4>(acc, other, h, dv);                                   // dv now holds dy
-    }
-    WStage<128, 128> s_woT;
-    stage_issue<128, 128>(W.woT, s_woT);                              // lands under the LayerNorm arithmetic
-    // ---- LN1 backward (parameter gradients by half 1; the exchange's barrier followed the W1^T GEMM's reads)
-    {
-        if (A.y_b) {
-            f32x4 y[8], mine[4];
-            affine_t(xh1, W.g1, W.be1, y, lane);
-            half_of<4>(y, h, mine);
-            store_rows_bf16<64>(A.y_b, n, tok, 128, 64 * h, mine, lane, blk);
-        }
-        if (h == 1) ln_param_grads_t(dv, xh1, red_scratch, red[wave], 2, lane, valid);
-        layer_norm_bwd_t(dv, xh1, W.g1, r1, lane);                    // dv now holds du = d(x + a)
-    }
-    {
-        f32x4 mine[4];
-        half_of<4>(dv, h, mine);
-        store_rows_f32_cols<64>(A.dx_res, n, tok, 128, 64 * h, mine, lane, blk);
-        store_rows_bf16<64>(A.du_b, n, tok, 128, 64 * h, mine, lane, blk);
-    }
-    {
-        uint2 dub[8];
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) dub[ct] = pack4(dv[ct]);
-        f32x4 da[4];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) da[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
-        gemm_staged_half<128, 128>(s_woT, smem, dub, da, lane, h);
-        store_rows_bf16<64>(A.dattn, n, tok, 128, 64 * h, da, lane, blk);
-    }
-    // ---- flush LayerNorm parameter gradients: LN2's (k = 0, 1) sit in the rows of waves 0, 1, LN1's (2, 3) in those of 2, 3
-    __syncthreads();
-    for (int e = threadIdx.x; e < 4 * 128; e += kLayerBlk) {
-        const int k = e >> 7, c = e & 127;
-        const float s = k < 2 ? red[0][k][c] + red[1][k][c] : red[2][k][c] + red[3][k][c];
-        float* dst = k == 0 ? A.dg2 : (k == 1 ? A.dbe2 : (k == 2 ? A.dg1 : A.dbe1));
-        atomicAdd(dst + c, s);
-    }
-}
-
-__global__ __launch_bounds__(kLayerBlk, 1) void sst_ffn_bwd_pair_kernel(FfnBwdArgs A) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
-    __shared__ float red[4][4][128];
-    __shared__ uint4 xch[4 * 4 * 64];
-    ffn_bwd_pair_body(A, blockIdx.x, smem, red, xch);
-}
+// (Round 5: a PAIR form of this kernel -- 32 tokens per workgroup, two waves per 16-token tile each computing half of every
+// GEMM's output channels, three LDS exchanges, like sst_ffn_fwd_pair_kernel -- was built again now that the launches carry no
+// contraction, checked against this one (operands identical, dx within 1 ulp of fp32) and measured: 24.0 us per encoder-size
+// launch against 19.8-21 us for this kernel, enc_bwd 0.49 -> 0.55 ms with the contraction launches beside it.  Both waves of a
+// pair run the two LayerNorm backwards on full rows and one of them the parameter-gradient reduction while the other waits:
+// the elementwise phases, not the GEMMs, are this kernel's chain.  Removed; docs/LAB_NOTES.md round 5.)
 
 // ------------------------------------------------------------------------------------------------
 // B1: dx = dx_res + dqk Wqk + dv Wv.  Stand-alone only for the first layer of a stack; for every other layer it is
@@ -1354,12 +1188,6 @@ extern "C" int geomae_sst_ffn_backward(const float* xhat1, const float* xhat2, c
                           dz ? t_skip_rows / 64 : 0};
     const int n_ffn = cdiv(cdiv(num_tokens, 16), kLayerBlk / 64);
     if (!g_pending_dw.active) {
-        // small token sets (one 32-token workgroup per CU covers the launch): two waves per tile, half the chain per wave
-        static const bool pair_bwd = [] { const char* e = getenv("GEOMAE_PAIR_BWD"); return !(e && e[0] == '0'); }();          // (A/B)
-        if (pair_bwd && use_pair_kernels(cdiv(num_tokens, 16))) {
-            hipLaunchKernelGGL(sst_ffn_bwd_pair_kernel, dim3(cdiv(cdiv(num_tokens, 16), 2)), dim3(kLayerBlk), 0, stream, A);
-            return check_launch("sst_ffn_bwd_pair_kernel");
-        }
         hipLaunchKernelGGL(sst_ffn_bwd_kernel, dim3(n_ffn), dim3(kLayerBlk), 0, stream, A);
         return check_launch("sst_ffn_bwd_kernel");
     }
