@@ -43,11 +43,15 @@ constexpr int kDlLdsBias = kDlRing * kDlSlabBytes;
 constexpr int kDlLdsBytes = kDlLdsBias + 256 * 4;
 constexpr int kDlTileSlots = 16 * kDlThreads;     // f32x4 slots of one workgroup's partial: 16 tiles x 512 threads
 constexpr int kDlPartialFloats = kDlTileSlots * 4 + 256;   // + the job's 256 column sums of dY
-constexpr int kDlMaxChunks = 32;
+constexpr int kDlMaxChunks = 96;             // (one SPLIT job over 10^5-10^6 points: up to 96 workgroups)
 constexpr int kDlOor = 0x7fff0000;
 
 enum { kDlTall = 0 /* [256 x 128]: A 16 blocks, B 8 */, kDlWide = 1 /* [128 x 256]: A 8, B 16 */,
-       kDlDual = 2 /* two [128 x 128]: (A0, B0, A1, B1), 8 blocks each */ };
+       kDlDual = 2 /* two [128 x 128]: (A0, B0, A1, B1), 8 blocks each */,
+       kDlSplit = 3 /* ONE [128 x 128] over 64-token slabs: waves 0-3 take tokens 0..31 of a slab, waves 4-7 tokens 32..63 --
+                       the DUAL image with (A1, B1) = (A0, B0) two token blocks further on (blk0 + 2 ldblk); the two halves'
+                       partials are summed by the reduction.  The VFE's layer-1 weight gradient: one product over 10^5-10^6
+                       points (vfe.hip geomae_vfe_weight_grad1) */ };
 
 constexpr int kDlMaxJobs = 16;                    // four layers of a stack per launch
 struct DlStream { const bf16_t* base; int ldblk; short blk0, nblk; };     // tile-blocked [n16][ldblk][16][16]; blocks blk0 .. blk0 + nblk
@@ -68,7 +72,7 @@ static_assert(sizeof(DlArgs) <= 3072 && sizeof(DlReduce) <= 3072, "kernel argume
 __device__ __forceinline__ void dl_wave_role(int kind, int w, int* half, int* wr, int* wc) {
     if (kind == kDlTall) { *half = 0; *wr = w >> 1; *wc = w & 1; }
     else if (kind == kDlWide) { *half = 0; *wr = w >> 2; *wc = w & 3; }
-    else { *half = w >> 2; *wr = (w >> 1) & 1; *wc = w & 1; }
+    else { *half = w >> 2; *wr = (w >> 1) & 1; *wc = w & 1; }           // DUAL, SPLIT
 }
 
 __device__ __forceinline__ void dl_wait_vm(int n) {          // s_waitcnt vmcnt(n) only (gfx9 encoding)
@@ -100,15 +104,25 @@ __device__ __forceinline__ void dl_reduce(const DlReduce& R, int first, int stri
         float cv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[r] = c0[(int64_t)r * O.ldc];
+        const bool split = R.job[jb].kind == kDlSplit;
+        if (split && half) continue;                               // (the first half's thread sums both halves' partials)
         const float* p = R.partial + (size_t)jb * R.G * kDlPartialFloats + 4 * q;
-        f32x4 v[kDlMaxChunks];
-#pragma unroll
-        for (int u = 0; u < kDlMaxChunks; ++u)
-            if (u < R.G) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)u * kDlPartialFloats);
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int u0 = 0; u0 < R.G; u0 += 16) {                     // 16 (SPLIT: 32) partials of the slot in flight at once
+            f32x4 v[16], v2[16];
 #pragma unroll
-        for (int u = 0; u < kDlMaxChunks; ++u)
-            if (u < R.G) s += v[u];
+            for (int u = 0; u < 16; ++u)
+                if (u0 + u < R.G) {
+                    v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(u0 + u) * kDlPartialFloats);
+                    if (split) v2[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(u0 + u) * kDlPartialFloats + 4 * 256);
+                }
+#pragma unroll
+            for (int u = 0; u < 16; ++u)
+                if (u0 + u < R.G) {
+                    s += v[u];
+                    if (split) s += v2[u];
+                }
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) c0[(int64_t)r * O.ldc] = cv[r] + s[r];
     }
@@ -118,7 +132,7 @@ __device__ __forceinline__ void dl_reduce(const DlReduce& R, int first, int stri
         const int kind = R.job[jb].kind;
         float* dst = nullptr;
         if (kind == kDlTall) dst = R.job[jb].out[0].dbias ? R.job[jb].out[0].dbias + row : nullptr;
-        else if (kind == kDlWide) dst = (row < 128 && R.job[jb].out[0].dbias) ? R.job[jb].out[0].dbias + row : nullptr;
+        else if (kind == kDlWide || kind == kDlSplit) dst = (row < 128 && R.job[jb].out[0].dbias) ? R.job[jb].out[0].dbias + row : nullptr;
         else dst = R.job[jb].out[row >> 7].dbias ? R.job[jb].out[row >> 7].dbias + (row & 127) : nullptr;
         if (!dst) continue;
         const float* p = R.partial + (size_t)jb * R.G * kDlPartialFloats + kDlTileSlots * 4 + row;
@@ -140,12 +154,13 @@ __device__ __forceinline__ void dl_job_body(const DlJob& J, const int n, const i
     dl_wave_role(kind, w, &half, &wr, &wc);
 
     // ---- this workgroup's token range: [t_begin, t_end), multiples of 32 but for the stack's end
+    const int slab_tok = kind == kDlSplit ? 2 * kDlSlabTok : kDlSlabTok;     // SPLIT: each half of the waves takes 32 of 64 tokens
     const int span = n - J.tok_begin;
     int chunk = (span + G - 1) / G;
-    chunk = (chunk + kDlSlabTok - 1) / kDlSlabTok * kDlSlabTok;
+    chunk = (chunk + slab_tok - 1) / slab_tok * slab_tok;
     const int t_begin = J.tok_begin + chunk_idx * chunk;
     const int t_end = t_begin + chunk < n ? t_begin + chunk : n;
-    const int nslab = t_end > t_begin ? (t_end - t_begin + kDlSlabTok - 1) / kDlSlabTok : 0;
+    const int nslab = t_end > t_begin ? (t_end - t_begin + slab_tok - 1) / slab_tok : 0;
 
     // ---- the LDS image of a slab: streams in order, two 16-token blocks each, nblk x 512 B per block.  Wave w issues the
     // 1-KB pieces q = w, w + 8, ...; piece q of stream s, token block tb, KB kb comes from
@@ -165,7 +180,7 @@ __device__ __forceinline__ void dl_job_body(const DlJob& J, const int n, const i
         const int n16 = (n + 15) >> 4;
         rs[i] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(S.base), 0, n16 * S.ldblk * 512, 0x00020000);
         voff[i] = (((t_begin >> 4) + tb) * S.ldblk + S.blk0) * 512 + kb * 1024 + lane * 16;
-        vstep[i] = 2 * S.ldblk * 512;
+        vstep[i] = (slab_tok >> 4) * S.ldblk * 512;
     }
     auto issue = [&](int slab) {                 // slab index within the chunk; past its end: out-of-range loads (no traffic)
         char* dst = lds + (slab & (kDlRing - 1)) * kDlSlabBytes + w * 1024;
@@ -216,9 +231,9 @@ __device__ __forceinline__ void dl_job_body(const DlJob& J, const int n, const i
             const uint2 hi = tr_read(reinterpret_cast<const bf16_t*>(slab + laneB + b * 512 + 256));
             bf[b] = make_uint4(lo.x, lo.y, hi.x, hi.y);
         }
-        const int t0 = t_begin + k * kDlSlabTok;
-        if (t0 + kDlSlabTok > t_end) {                        // the stack's last slab: tokens >= n hold anything (workgroup-uniform)
-            const int tlo = t0 + 16 * (g >> 1) + 4 * (g & 1);
+        const int t0 = t_begin + k * slab_tok;
+        if (t0 + slab_tok > t_end) {                          // the stack's last slab: tokens >= n hold anything (workgroup-uniform)
+            const int tlo = t0 + (kind == kDlSplit ? kDlSlabTok * half : 0) + 16 * (g >> 1) + 4 * (g & 1);
             unsigned int mk[4];
 #pragma unroll
             for (int h = 0; h < 2; ++h)
@@ -253,7 +268,7 @@ __device__ __forceinline__ void dl_job_body(const DlJob& J, const int n, const i
 
     // ---- epilogue: the job's 256 column sums of dY meet in LDS (row index = position among the job's A rows)
     float* bs = reinterpret_cast<float*>(lds + kDlLdsBias);
-    const int arow0 = (kind == kDlDual ? 128 * half : 0) + 64 * wr;
+    const int arow0 = (kind == kDlDual || kind == kDlSplit ? 128 * half : 0) + 64 * wr;
     if (m == 0) {
         if (nshare == 2) {
 #pragma unroll
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(kDlThreads, 2) void dw_layer_kernel(DlArgs A) {
     __shared__ __attribute__((aligned(1024))) char lds[kDlLdsBytes];
     const int jb = blockIdx.x % A.njobs, chunk = blockIdx.x / A.njobs;
     float* pout = A.partial + (size_t)(jb * A.G + chunk) * kDlPartialFloats;
-    if (A.job[jb].kind == kDlDual) dl_job_body<4>(A.job[jb], A.n, chunk, A.G, pout, lds);
+    if (A.job[jb].kind == kDlDual || A.job[jb].kind == kDlSplit) dl_job_body<4>(A.job[jb], A.n, chunk, A.G, pout, lds);
     else dl_job_body<3>(A.job[jb], A.n, chunk, A.G, pout, lds);
 }
 

@@ -613,6 +613,9 @@ struct DwReduce {
 };
 constexpr int kDwReduceBlocks = 64;          // workgroups a carrying launch adds for the reduction
 int launch_dw(const DwTasks& tasks, int num_tasks, int num_tokens, hipStream_t stream);
+// C[128,128] += A^T B over n tokens, A / B tile-blocked [n,128] bf16, through the layer-form kernel (dw_device.h SPLIT job);
+// `partial`: the caller's split-K workspace (2 * kDwPartialBytes)
+int launch_dw_split(const bf16_t* A, const bf16_t* B, int n, float* C, float* partial, hipStream_t stream);
 // the next geomae_sst_weight_grad call of this host thread only records its tasks; the following
 // geomae_sst_ffn_backward launches them inside its own kernel (sst_ffn_bwd_dw_kernel)
 void defer_next_weight_grad();

@@ -1389,6 +1389,40 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     return check_launch("dw_layer_reduce_kernel");
 }
 
+// ONE [128,128] product over n tokens of two tile-blocked [n,128] operands (the VFE's layer-1 weight gradient) as a SPLIT
+// job of the layer-form kernel + its reduction: C += A^T B.  tools/dw_bench.hip at 106 k points: 29 us with the reduction at
+// 96 workgroups (32 / 48 / 64: 40 / 33 / 30) against 33 + 11 us for dw_kernel + dw_reduce_kernel; 1.03 M points: 133 us.
+int geomae::launch_dw_split(const bf16_t* A, const bf16_t* B, int n, float* C, float* partial, hipStream_t stream) {
+    if (g_pending_reduce.partial) {                      // (an old-form launch's partials in the same workspace first)
+        const DwReduce Rd = take_pending_reduce();
+        hipLaunchKernelGGL(dw_reduce_kernel, dim3(4 * kDwReduceBlocks), dim3(256), 0, stream, Rd);
+        const int rc0 = check_launch("dw_reduce_kernel");
+        if (rc0) return rc0;
+    }
+    DlArgs S;
+    memset(&S, 0, sizeof(S));
+    S.njobs = 1; S.n = n; S.partial = partial;
+    S.job[0].kind = kDlSplit;
+    S.job[0].s[0] = {A, 8, 0, 8}; S.job[0].s[1] = {B, 8, 0, 8}; S.job[0].s[2] = {A, 8, 16, 8}; S.job[0].s[3] = {B, 8, 16, 8};
+    S.job[0].out[0] = {C, nullptr, nullptr, nullptr, 128, 0};
+    int G = cdiv(n, 4 * 2 * kDlSlabTok);                 // at least four 64-token slabs per workgroup
+    if (G > kDlMaxChunks) G = kDlMaxChunks;
+    while (G > 1 && (long long)G * kDlPartialFloats * 4 > 2 * kDwPartialBytes) --G;
+    if (G < 1) G = 1;
+    S.G = G;
+    void* prof = thread_profiler();
+    const bool timed = profiler_begin(prof, GEOMAE_KERNEL_DW, stream);
+    hipLaunchKernelGGL(dw_layer_kernel, dim3(G), dim3(kDlThreads), 0, stream, S);
+    if (timed) profiler_end(prof, stream);
+    int rc = check_launch("dw_layer_kernel");
+    if (rc) return rc;
+    DlReduce R;
+    R.partial = partial; R.njobs = 1; R.G = G;
+    R.job[0].kind = kDlSplit; R.job[0].pad_ = 0; R.job[0].out[0] = S.job[0].out[0]; R.job[0].out[1] = S.job[0].out[1];
+    hipLaunchKernelGGL(dw_layer_reduce_kernel, dim3(cdiv(kDlTileSlots, 256)), dim3(256), 0, stream, R);
+    return check_launch("dw_layer_reduce_kernel");
+}
+
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {
     int G, chunk;
     dw_grid(num_tasks, num_tokens, &G, &chunk, T.partial != nullptr);

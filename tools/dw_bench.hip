@@ -121,6 +121,7 @@ static double check(const char* name, const Tensor& A, int a0, int rows, const T
     std::vector<float> got((size_t)rows * ldc), gb(rows);
     CK(hipMemcpy(got.data(), dC, got.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(gb.data(), dbias, rows * 4, hipMemcpyDeviceToHost));
+    if (!sc && dC && rows == 128 && cols == 128 && name[0] == 'd') for (auto& b : bias) b = 0;      // (SPLIT: no bias output)
     double emax = 0, cmax = 0, bmax = 0, bref = 0;
     int bad_nan = 0;
     for (int i = 0; i < rows; ++i) {
@@ -151,7 +152,7 @@ int main(int argc, char** argv) {
     CK(hipStreamCreate(&s));
     double worst = 0;
     float* partial;
-    CK(hipMalloc(&partial, (size_t)kDlMaxJobs * 16 * kDlPartialFloats * 4));
+    CK(hipMalloc(&partial, (size_t)kDlMaxJobs * 16 * kDlPartialFloats * 4));      // (also >= 96 chunks of one SPLIT job)
     for (int variant = 0; variant < 2; ++variant) {
         const int n = variant == 0 ? 4013 : 2500, dead = variant == 0 ? 0 : 640;
         Layer L0, L1;
@@ -180,7 +181,50 @@ int main(int argc, char** argv) {
             worst = fmax(worst, check("W2", L.dv, 0, 128, L.h, 0, 256, nullptr, nullptr, dead, L.g_w2, 256, L.g_b2));
         }
     }
+    // ---- the SPLIT kind: one [128 x 128] product over many tokens (the VFE's layer-1 weight gradient)
+    {
+        const int n = 5003;
+        Tensor A, B;
+        A.init(n, 128, 41, NAN); B.init(n, 128, 42, NAN);
+        float *gC, *gb;
+        CK(hipMalloc(&gC, 128 * 128 * 4)); CK(hipMemset(gC, 0, 128 * 128 * 4)); CK(hipMalloc(&gb, 128 * 4)); CK(hipMemset(gb, 0, 128 * 4));
+        DlArgs S;
+        memset(&S, 0, sizeof(S));
+        S.njobs = 1; S.n = n; S.G = 13; S.partial = partial;
+        S.job[0].kind = kDlSplit;
+        S.job[0].s[0] = {A.d, 8, 0, 8}; S.job[0].s[1] = {B.d, 8, 0, 8}; S.job[0].s[2] = {A.d, 8, 16, 8}; S.job[0].s[3] = {B.d, 8, 16, 8};
+        S.job[0].out[0] = {gC, nullptr, nullptr, nullptr, 128, 0};
+        launch(S, s); reduce(S, s);
+        CK(hipStreamSynchronize(s));
+        printf("SPLIT job, n = %d, G = %d:\n", n, S.G);
+        worst = fmax(worst, check("dW1", A, 0, 128, B, 0, 128, nullptr, nullptr, 0, gC, 128, gb) - 0.0);
+    }
     printf("worst relative error %.3e -> %s\n", worst, worst < 2e-5 ? "OK" : "FAIL");
+    for (int n : {106000, 1030000}) {
+        Tensor A, B;
+        A.init(n, 128, 51, 0.f); B.init(n, 128, 52, 0.f);
+        float* gC;
+        CK(hipMalloc(&gC, 128 * 128 * 4)); CK(hipMemset(gC, 0, 128 * 128 * 4));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        for (int Gt : {32, 48, 64, 96}) {
+            DlArgs S;
+            memset(&S, 0, sizeof(S));
+            S.njobs = 1; S.n = n; S.G = Gt; S.partial = partial;
+            S.job[0].kind = kDlSplit;
+            S.job[0].s[0] = {A.d, 8, 0, 8}; S.job[0].s[1] = {B.d, 8, 0, 8}; S.job[0].s[2] = {A.d, 8, 16, 8}; S.job[0].s[3] = {B.d, 8, 16, 8};
+            S.job[0].out[0] = {gC, nullptr, nullptr, nullptr, 128, 0};
+            for (int i = 0; i < 3; ++i) { launch(S, s); reduce(S, s); }
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) { launch(S, s); reduce(S, s); }
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("SPLIT n = %7d G = %2d: %.1f us with its reduction, operands %.1f MB -> %.2f TB/s\n", n, Gt, ms * 1e3 / reps, 512e-6 * n,
+                   512.0 * n / (ms * 1e3 / reps) * 1e-6);
+        }
+    }
 
     // ---- timing: `layers` layers per launch + its reduction, back to back
     hipEvent_t e0, e1, e2;
