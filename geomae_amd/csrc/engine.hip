@@ -99,7 +99,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kEncMid, kNumEv };
+          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kEncMid, kDecMidA, kDecMidB, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -699,8 +699,18 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(geomae_heads_weight_grad(nm, h_dl, h_cm, h_dm, &m.head_grads, geo));
     mark(e, pHeads, main);
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
+    // (GEOMAE_DEC_DW_EVERY=k: the decoders' contractions flushed to the geometry stream every k layers instead of behind the
+    //  whole stack -- A/B; default 0 = behind the stack)
+    static const int dec_every = [] { const char* v = getenv("GEOMAE_DEC_DW_EVERY"); return v ? atoi(v) : 0; }();
+    struct MidFlushScopeD {
+        explicit MidFlushScopeD(const DwMidFlush& f) { set_dw_mid_flush(f); }
+        ~MidFlushScopeD() { set_dw_mid_flush(DwMidFlush()); }
+    };
     {
         DeferAllScope defer(defer_dec_dw);
+        DwMidFlush mfd;
+        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidB]; mfd.every = dec_every; }
+        MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
                                            w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
     }
@@ -710,6 +720,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     {
         DeferAllScope defer(defer_dec_dw);
+        DwMidFlush mfd;
+        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidA]; mfd.every = dec_every; }
+        MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
                                            w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
     }
@@ -769,15 +782,17 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     (void)take_mid_launch_event();                       // (an early error return leaves it set)
     ENG_CALL(rc_l1);
     mark(e, pVfeL1, main);
-    GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
-    // one [128,128] output contracted over all N points by 124 workgroups: through the split-K workspace + a reduction
-    // launch instead of 124 x 16 k float atomics on the same 64 KB (deterministic; the phase time did not change, and
-    // neither did it with this contraction on the main stream: it is not what the VFE backward waits for)
+    // one [128,128] output contracted over all N points: through the split-K workspace + a reduction launch (round 5: a SPLIT
+    // job of the layer-form contraction, 29 us with its reduction at 106 k points).  GEOMAE_VFE_DW1_MAIN=1: on the main stream,
+    // in line behind the layer-1 sweep (A/B).
+    static const bool dw1_on_main = [] { const char* v = getenv("GEOMAE_VFE_DW1_MAIN"); return v && v[0] == '1'; }();
+    hipStream_t dw1_stream = dw1_on_main ? main : geo;
+    if (!dw1_on_main) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
     set_dw_partial(dw1_partial);
-    int rc_dw1 = geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, geo);
+    int rc_dw1 = geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, dw1_stream);
     set_dw_partial(nullptr);
     ENG_CALL(rc_dw1);
-    ENG_CALL(geomae_flush_weight_grad(geo));
+    ENG_CALL(geomae_flush_weight_grad(dw1_stream));
     if (!fold) {
         ENG_CALL(geomae_bn_param_grad_add(use_bs0, 64, m.bn_dbeta[0], m.bn_dgamma[0], main));
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD0, main);
