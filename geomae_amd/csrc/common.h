@@ -89,6 +89,14 @@ float* dw_partial();
 // rows [0, r) of the NEXT geomae_sst_weight_grad's token range are DEAD (the top layer of a decoder stack: their dY rows are
 // zero and their saved forward rows were never written, set_first_live_row): the layer-form contraction starts behind them
 // in the jobs whose dY operand is zero there.  Thread-local, consumed by that call.
+// The one-launch layer forward (sst_fused.hip) runs bundles of more than four tiles in a SECOND launch per layer.  A caller that
+// knows a layout has no such bundle (the step engine: window.hip window_max_keep, a step ahead) says so before
+// geomae_sst_stack_forward: bit s = layout s (unshifted / shifted) may hold one.  Thread-local, consumed by that call;
+// default: both may.
+void set_fused_big_layouts(int mask);
+int take_fused_big_layouts();
+void set_fused_big_next(bool possible);          // ... handed on to the next geomae_sst_layer_forward of this thread
+bool take_fused_big_next();
 constexpr int kStackSyncBytes = 2048;      // the persistent stack forward's grid-barrier counters, behind a stack's saved tensors
 void set_dw_dead_rows(int rows);
 int take_dw_dead_rows();

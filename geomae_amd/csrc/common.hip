@@ -40,6 +40,12 @@ int last_kernel_variant() { return g_last_kernel_variant; }
 static thread_local float* g_dw_partial = nullptr;
 void set_dw_partial(float* ws) { g_dw_partial = ws; }
 float* dw_partial() { return g_dw_partial; }
+static thread_local int g_fused_big_layouts = 3;
+void set_fused_big_layouts(int mask) { g_fused_big_layouts = mask & 3; }
+int take_fused_big_layouts() { const int m = g_fused_big_layouts; g_fused_big_layouts = 3; return m; }
+static thread_local bool g_fused_big_next = true;
+void set_fused_big_next(bool possible) { g_fused_big_next = possible; }
+bool take_fused_big_next() { const bool b = g_fused_big_next; g_fused_big_next = true; return b; }
 static thread_local DwMidFlush g_dw_mid_flush;
 void set_dw_mid_flush(const DwMidFlush& f) { g_dw_mid_flush = f; }
 DwMidFlush dw_mid_flush() { return g_dw_mid_flush; }

@@ -20,6 +20,9 @@
 #include <vector>
 
 namespace geomae {
+// window.hip: kept pillars in the fullest window of the unshifted / shifted layout -> out[2] (pinned host memory)
+int window_max_keep(const int32_t* ids_keep, const int32_t* counts, const int32_t* voxel_coors, int batch_size,
+                    const GeomaeWindowConfig* cfg, int32_t* out, hipStream_t stream);
 namespace {
 
 __global__ void bn_param_grad_add_kernel(const double* __restrict__ bsums, int C, float* __restrict__ d_beta,
@@ -88,6 +91,9 @@ struct Batch {
     int32_t* host_offs = nullptr;      // pinned [B + 1]
     int32_t* host_counts = nullptr;    // pinned [B + 1]
     hipEvent_t readback = nullptr;
+    int32_t* host_maxkeep = nullptr;   // pinned [2]: kept pillars in the fullest window, unshifted / shifted (window_max_keep)
+    hipEvent_t readback2 = nullptr;    // ... written behind the random mask of stage 1
+    bool mask_injected = false;        // geomae_pretrain_set_mask replaced the drawn mask: host_maxkeep says nothing about it
     int32_t V = 0, n_keep = 0, n_mask = 0;
     bool moments_exchanged = false;    // the rank-averaged feature moments of this batch are in bn_sync_feat_moments[slot]
 };
@@ -298,6 +304,11 @@ int run_stage1(Engine* e, int which, const float* const* frames, const int64_t* 
     // window-major token lists: a 16-token tile of the stacks' activations then belongs to one or two attention windows
     ENG_CALL(geomae_random_mask_windowed(b.sample_start, c.batch_size, c.keep_fraction, (c.mask_seed << 32) + draw,
                                          b.voxel_coors, &c.window, b.ids_keep, b.ids_mask, b.token_row, b.counts, s));
+    // the fullest window's kept pillars, both layouts, into pinned memory: by the time this batch is consumed the host knows
+    // whether the one-launch encoder layers need their second launch (window.hip window_max_keep)
+    ENG_CALL(window_max_keep(b.ids_keep, b.counts, b.voxel_coors, c.batch_size, &c.window, b.host_maxkeep, s));
+    GEOMAE_HIP(hipEventRecord(b.readback2, s));
+    b.mask_injected = false;
     b.valid = true;
     b.counts_read = false;
     return GEOMAE_OK;
@@ -661,6 +672,17 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // ---------------- main: encoder, decoders
     GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kLayouts], 0));
     mark(e, pLayouts, main);
+    {
+        // which of the encoder's two layouts hold a window with more than 64 kept pillars (= a bundle of more than four tiles:
+        // the one-launch layer's second kernel): known since the batch's stage 1, a step ago
+        int big = 3;
+        static const bool skip_big = [] { const char* v = getenv("GEOMAE_FUSED_SKIP_BIG"); return !v || v[0] != '0'; }();
+        if (skip_big && !b.mask_injected && b.host_maxkeep) {
+            GEOMAE_HIP(hipEventSynchronize(b.readback2));            // (stage 1 of this batch ended during the previous step)
+            big = (b.host_maxkeep[0] < 0 || b.host_maxkeep[0] > 64 ? 1 : 0) | (b.host_maxkeep[1] < 0 || b.host_maxkeep[1] > 64 ? 2 : 0);
+        }
+        set_fused_big_layouts(big);
+    }
     ENG_CALL(geomae_sst_stack_forward(vf, nk, L_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, sb_enc, z_enc, nk,
                                       nullptr, b.ids_keep, e->profiler, main));
     mark(e, pEncFwd, main);
@@ -884,6 +906,8 @@ extern "C" void* geomae_pretrain_create(const GeomaePretrainConfig* cfg, const G
     for (int i = 0; i < kNumPhase; ++i) ok = ok && hipEventCreate(&e->phase_ev[i]) == hipSuccess;
     for (int k = 0; k < 2; ++k) {
         ok = ok && hipEventCreateWithFlags(&e->batch[k].readback, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&e->batch[k].readback2, hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipHostMalloc((void**)&e->batch[k].host_maxkeep, 2 * 4, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&e->batch[k].host_offs, (size_t)(cfg->batch_size + 1) * 4, hipHostMallocDefault) == hipSuccess;
         ok = ok && hipHostMalloc((void**)&e->batch[k].host_counts, (size_t)(cfg->batch_size + 1) * 4, hipHostMallocDefault) == hipSuccess;
     }
@@ -908,6 +932,8 @@ extern "C" void geomae_pretrain_destroy(void* engine) {
     for (int i = 0; i < kNumPhase; ++i) if (e->phase_ev[i]) (void)hipEventDestroy(e->phase_ev[i]);
     for (int k = 0; k < 2; ++k) {
         if (e->batch[k].readback) (void)hipEventDestroy(e->batch[k].readback);
+        if (e->batch[k].readback2) (void)hipEventDestroy(e->batch[k].readback2);
+        if (e->batch[k].host_maxkeep) (void)hipHostFree(e->batch[k].host_maxkeep);
         if (e->batch[k].host_offs) (void)hipHostFree(e->batch[k].host_offs);
         if (e->batch[k].host_counts) (void)hipHostFree(e->batch[k].host_counts);
     }
@@ -1004,6 +1030,7 @@ extern "C" int geomae_pretrain_set_mask(void* engine, const int32_t* ids_keep, i
     ENG_CALL(check_launch("token_rows_from_ids_kernel"));
     b.n_keep = num_keep;
     b.n_mask = num_mask;
+    b.mask_injected = true;              // (host_maxkeep describes the drawn mask, not this one)
     // the step's side streams read the mask: order them behind this stream
     GEOMAE_HIP(hipEventRecord(e->ev[kFirstMain], stream));
     GEOMAE_HIP(hipStreamWaitEvent(e->geo, e->ev[kFirstMain], 0));

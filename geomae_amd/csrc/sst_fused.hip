@@ -452,29 +452,70 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 #undef FOR_TILES
 }
 
-// (The generic 5-9-tile body shares this kernel with the exact bodies and sets its register report: 256 VGPRs, 69 spilled, 280 B
-//  of scratch per lane, all inside the generic body.  Measured alternatives, round 5: the generic body as a noinline call -- the
-//  kernel then saves / restores around a call it almost never makes: 35.5 instead of 26 us per layer; a separate launch for the
-//  large bundles costs a launch per layer (~2-3 us x 12) whether or not a layout has one.  The spills are paid only by a
-//  workgroup that runs that body.)
+// The exact bodies (bundles of 1-4 tiles: every bundle of the packing but a single window that kept more than 64 pillars) and
+// the generic 5-9-tile body are TWO kernels (round 5).  In one kernel the generic body set the register allocation of
+// everything -- 256 VGPRs, 69 spilled, 280 B of scratch per lane -- and the layer took 26.3 us; the exact bodies alone (212 / 234
+// VGPRs, no scratch) take 21.4 us (tools/persist_time.py, config 2's encoder).  The second launch finds the large bundles
+// itself (the bundle count and sizes live on the device): every workgroup scans the bundle table, the k-th large bundle goes
+// to workgroup k mod grid; a layout without one costs that launch a scan (~2 us).  (Measured and dropped: the generic body as
+// a noinline call inside one kernel -- 35.5 us per layer.)
 __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFwd A) {
     __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
     // (bun_tok holds max_bundles + 1 >= gridDim.x + 1 words: read before the bundle count is known, one round trip less)
     const int NB = A.num_bundles[0];
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
         const int s0 = A.bun_tok[b];
-        int T = A.bun_tok[b + 1] - s0;
-        if (T > kFMaxT) T = kFMaxT;          // (a layout built for windows of more than 144 tokens: never past the LDS rows;
-                                             //  the stack forward refuses such layouts on the host, max_window_tokens <= 144)
+        const int T = A.bun_tok[b + 1] - s0;
         const int nt = (T + 15) >> 4;
         switch (nt) {
             case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
             case 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
             case 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
             case 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
-            default: fused_fwd_body<9, false>(A, s0, T, nt, lds); break;
+            default: break;                                  // 5-9 tiles: sst_layer_fwd_big_kernel
         }
         if (b + (int)gridDim.x < NB) __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_big_kernel(FusedFwd A) {
+    __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
+    __shared__ int wave_cnt[kFusedThreads / 64];
+    const int NB = A.num_bundles[0];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int base = 0;                                            // large bundles in front of the current chunk of the table
+    for (int b0 = 0; b0 < NB; b0 += kFusedThreads) {         // (workgroup-uniform trip count)
+        const int b = b0 + threadIdx.x;
+        int s0 = 0, T = 0;
+        if (b < NB) { s0 = A.bun_tok[b]; T = A.bun_tok[b + 1] - s0; }
+        const bool big = T > 64;
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
+        if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
+        __syncthreads();
+        int before = base, total = base;
+#pragma unroll
+        for (int w = 0; w < kFusedThreads / 64; ++w) {
+            const int c = wave_cnt[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        __syncthreads();                                     // (wave_cnt is rewritten by the next chunk)
+        // the chunk's large bundles, in table order: this workgroup runs those with rank % grid == its index.  The body needs
+        // the whole workgroup: the ranks go through LDS one at a time.
+        const int my_rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
+        for (int r = base + ((int)blockIdx.x + (int)gridDim.x - base % (int)gridDim.x) % (int)gridDim.x; r < total; r += gridDim.x) {
+            int* slot = reinterpret_cast<int*>(lds);         // (free between bodies)
+            if (big && my_rank == r) { slot[0] = s0; slot[1] = T; }
+            __syncthreads();
+            const int rs0 = slot[0];
+            int rT = slot[1];
+            __syncthreads();
+            if (rT > kFMaxT) rT = kFMaxT;    // (a layout built for windows of more than 144 tokens: never past the LDS rows;
+                                             //  the stack forward refuses such layouts on the host, max_window_tokens <= 144)
+            fused_fwd_body<9, false>(A, rs0, rT, (rT + 15) >> 4, lds);
+            __syncthreads();
+        }
+        base = total;
     }
 }
 
@@ -660,6 +701,7 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
                                         float* z, int32_t z_blocked, void* qkv_bf16, void* attn_bf16, float* lse,
                                         void* xhat1_bf16, void* xhat2_bf16, void* hp_bf16, float* rstd, void* x_bf16,
                                         void* xp_bf16, hipStream_t stream) {
+    const bool big_possible = take_fused_big_next();
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_weights(w, "sst_layer_forward");
     if (rc) return rc;
@@ -683,5 +725,12 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
     A.hp = (bf16_t*)hp_bf16; A.xb = skip_x_copy() ? nullptr : (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
     const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
     hipLaunchKernelGGL(sst_layer_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
-    return check_launch("sst_layer_fwd_kernel");
+    rc = check_launch("sst_layer_fwd_kernel");
+    if (rc) return rc;
+    // the bundles of 5-9 tiles (a window that kept more than 64 pillars): rare in the token sets this form is chosen for, the
+    // rule at the decoders' sizes (geomae_sst_set_fused_layers(2), tests)
+    const int big_grid = num_tokens <= 12288 ? 16 : (grid < 256 ? grid : 256);
+    if (!big_possible) return GEOMAE_OK;         // (the caller knows this layout's fullest window: common.h set_fused_big_layouts)
+    hipLaunchKernelGGL(sst_layer_fwd_big_kernel, dim3(big_grid), dim3(kFusedThreads), 0, stream, A);
+    return check_launch("sst_layer_fwd_big_kernel");
 }

@@ -208,6 +208,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
                                         const int32_t* input_rows, void* profiler, hipStream_t stream) {
     const int live_row = first_live_row();          // caller's promise (common.h): consumed first, applied per layer below
     set_first_live_row(0);
+    const int big_layouts = take_fused_big_layouts();    // (likewise: which layouts may hold a bundle of more than four tiles)
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_forward");
     if (rc) return rc;
@@ -255,6 +256,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
             Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
             if (l == 0) set_input_map(SstInputMap{x_in, num_input_rows, fill_row, input_rows});
             SkipXCopyScope skip(l > 0 && x_from_xhat_enabled());  // (the contraction forms x from the layer below's saved xhat2)
+            set_fused_big_next((big_layouts >> (l & 1)) & 1);
             rc = geomae_sst_layer_forward((const float*)(sv + so.x), num_tokens, &layers[l], &layouts[l & 1], cap, pos_table, z,
                                           next ? 1 : 0, sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1,
                                           sv + so.xh2, sv + so.hp, (float*)(sv + so.rstd), sv + so.xb, sv + so.xp, stream);

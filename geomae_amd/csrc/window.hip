@@ -824,6 +824,62 @@ extern "C" int32_t geomae_window_bundle_cap(int32_t num_tokens, int32_t max_wind
     return cap;
 }
 
+static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, int* slots_per_sample);
+
+// How many KEPT pillars the fullest window of each of the two layouts (unshifted / shifted) holds: one workgroup, the window
+// tables of both shifts in LDS.  The step engine runs this with the random mask, a step ahead of the encoder that will pack
+// these pillars into bundles, and reads the two numbers back with the pillar counts: the one-launch layer's second kernel
+// (sst_fused.hip sst_layer_fwd_big_kernel: bundles of more than 64 positions = a window that kept more than 64 pillars) is
+// only launched for a layout that has such a window.
+constexpr int kMaxKeepSlots = 12288;             // window slots of BOTH shifts that fit the LDS tables (48 KB)
+__global__ __launch_bounds__(1024) void win_max_keep_kernel(const int32_t* __restrict__ ids_keep, const int32_t* __restrict__ counts,
+                                                            const int4* __restrict__ voxel_coors, WinGeom g0, WinGeom g1, int slots,
+                                                            int32_t* __restrict__ out /* pinned host memory: [2] */) {
+    __shared__ int table[kMaxKeepSlots];
+    __shared__ int best[2];
+    for (int i = threadIdx.x; i < 2 * slots; i += 1024) table[i] = 0;
+    if (threadIdx.x < 2) best[threadIdx.x] = 0;
+    __syncthreads();
+    const int nk = counts[0];
+    for (int i = threadIdx.x; i < nk; i += 1024) {
+        const int4 c = voxel_coors[ids_keep[i]];
+        int w, p;
+        win_of(c, g0, &w, &p);
+        atomicAdd(&table[w], 1);
+        win_of(c, g1, &w, &p);
+        atomicAdd(&table[slots + w], 1);
+    }
+    __syncthreads();
+    int m0 = 0, m1 = 0;
+    for (int i = threadIdx.x; i < slots; i += 1024) { m0 = max(m0, table[i]); m1 = max(m1, table[slots + i]); }
+    atomicMax(&best[0], m0);
+    atomicMax(&best[1], m1);
+    __syncthreads();
+    if (threadIdx.x < 2) out[threadIdx.x] = best[threadIdx.x];
+}
+
+// -> out[0], out[1] (device-visible host memory): the largest number of kept pillars in one window, unshifted / shifted
+// layout; -1, -1 when the window tables do not fit (the caller then assumes large windows exist)
+namespace geomae {
+int window_max_keep(const int32_t* ids_keep, const int32_t* counts, const int32_t* voxel_coors, int batch_size,
+                    const GeomaeWindowConfig* cfg, int32_t* out, hipStream_t stream);
+}
+int geomae::window_max_keep(const int32_t* ids_keep, const int32_t* counts, const int32_t* voxel_coors, int batch_size,
+                            const GeomaeWindowConfig* cfg, int32_t* out, hipStream_t stream) {
+    WinGeom g0, g1;
+    int sps = 0;
+    int rc = win_geom(cfg, 0, &g0, &sps);
+    if (rc) return rc;
+    if ((rc = win_geom(cfg, 1, &g1, &sps))) return rc;
+    const int slots = batch_size * sps;
+    if (2 * slots > kMaxKeepSlots) {
+        out[0] = out[1] = -1;                    // (host write: the caller reads it behind its own event anyway)
+        return GEOMAE_OK;
+    }
+    hipLaunchKernelGGL(win_max_keep_kernel, dim3(1), dim3(1024), 0, stream, ids_keep, counts, (const int4*)voxel_coors, g0, g1, slots, out);
+    return check_launch("win_max_keep_kernel");
+}
+
 static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, int* slots_per_sample) {
     GEOMAE_REQUIRE(cfg, "window: null config");
     GEOMAE_REQUIRE(shift_index == 0 || shift_index == 1, "window: shift_index must be 0 or 1");
