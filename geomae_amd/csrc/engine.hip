@@ -139,6 +139,7 @@ struct Engine {
     int32_t last_V = 0, last_keep = 0, last_mask = 0;
     int64_t off_losses = 0, off_ids_keep = 0, off_ids_mask = 0, off_voxel_coors = 0;
     int32_t cells = 0, gz = 1, gy = 1, gx = 1, s_low = 1, s_med = 1;
+    int last_maxkeep[2] = {-1, -1}, last_big_layouts = 3;   // the last step's fullest windows / which layouts took the second launch
     double host_step_s = 0.0, host_blocked_s = 0.0;      // cumulative wall time inside step calls / in the readback wait
     // a step that fails AFTER its first launch leaves streams, events and the workspace in an undefined state
     bool enqueue_started = false, poisoned = false;
@@ -682,6 +683,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
             big = (b.host_maxkeep[0] < 0 || b.host_maxkeep[0] > 64 ? 1 : 0) | (b.host_maxkeep[1] < 0 || b.host_maxkeep[1] > 64 ? 2 : 0);
         }
         set_fused_big_layouts(big);
+        e->last_big_layouts = big;
+        e->last_maxkeep[0] = b.host_maxkeep && !b.mask_injected ? b.host_maxkeep[0] : -1;
+        e->last_maxkeep[1] = b.host_maxkeep && !b.mask_injected ? b.host_maxkeep[1] : -1;
     }
     ENG_CALL(geomae_sst_stack_forward(vf, nk, L_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, sb_enc, z_enc, nk,
                                       nullptr, b.ids_keep, e->profiler, main));
@@ -1094,5 +1098,6 @@ extern "C" int geomae_pretrain_last_sizes(void* engine, int64_t* out) {
     GEOMAE_REQUIRE(e && out, "pretrain: null argument");
     out[0] = e->last_N; out[1] = e->last_V; out[2] = e->last_keep; out[3] = e->last_mask; out[4] = e->opt_steps;
     out[5] = (int64_t)e->mask_draws;
+    out[6] = e->last_maxkeep[0]; out[7] = e->last_maxkeep[1]; out[8] = e->last_big_layouts;
     return GEOMAE_OK;
 }

@@ -356,9 +356,10 @@ class PretrainEngine:
         return float(out[0]), float(out[1]), int(out[2])
 
     def last_sizes(self):
-        out = (ctypes.c_int64 * 6)()
+        out = (ctypes.c_int64 * 9)()
         check(self.lib.geomae_pretrain_last_sizes(ctypes.c_void_p(self.handle), out), "geomae_pretrain_last_sizes")
-        return dict(N=out[0], V=out[1], n_keep=out[2], n_mask=out[3], optimizer_steps=out[4], mask_draws=out[5])
+        return dict(N=out[0], V=out[1], n_keep=out[2], n_mask=out[3], optimizer_steps=out[4], mask_draws=out[5],
+                    max_window_keep=(out[6], out[7]), big_bundle_layouts=out[8])
 
     def last_ids(self):
         s = self.last_sizes()

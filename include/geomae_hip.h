@@ -816,8 +816,11 @@ int64_t geomae_pretrain_result_offset(void* engine, int32_t what);
 int geomae_pretrain_host_times(void* engine, double* out /*host [3]*/);
 /* AdamW's step counter (bias correction): set it when optimizer state is loaded from a checkpoint */
 int geomae_pretrain_set_optimizer_steps(void* engine, int64_t steps_taken);
-/* host-side sizes of the last step: out[0..5] = N, V, n_keep, n_mask, optimizer steps taken, masks drawn */
-int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [6]*/);
+/* host-side sizes of the last step: out[0..5] = N, V, n_keep, n_mask, optimizer steps taken, masks drawn; out[6..7] = kept
+ * pillars in the fullest window of the unshifted / shifted layout as counted a step ahead with the random mask (-1: unknown --
+ * injected mask, window tables too large), out[8] = which of the two layouts ran the one-launch layer's second kernel for
+ * bundles of more than four tiles (bit s = layout s) */
+int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [9]*/);
 
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */

@@ -65,6 +65,63 @@ def test_engine_gradients_match_python_explicit_schedule():
         assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6), k
 
 
+def test_engine_knows_its_fullest_window_and_runs_large_bundles():
+    """Round 5: the one-launch encoder layer runs bundles of more than four tiles (a window that kept more than 64 pillars) in
+    a second kernel, and the engine launches it only for a layout whose fullest window -- counted a step ahead with the random
+    mask, read back with the pillar counts -- is that large.  (a) the two counts equal a recount from the step's own ids and
+    coordinates; (b) with a keep fraction of 0.8 full windows keep ~115 pillars: the engine must take the second launch, and
+    its gradients must agree with the Python schedule, which always launches both kernels."""
+    import geomae_amd
+    from geomae_amd.configs import mae_sst_model
+    from geomae_amd.train import Trainer
+    from geomae_amd.engine import PretrainEngine
+    from geomae_amd import synth
+
+    def recount(eng, wcfg):
+        ik, _ = eng.last_ids()
+        vc = eng.last_voxel_coors()[ik.long()].long()                       # (b, z, y, x)
+        wx, wy = wcfg["window_shape"][0], wcfg["window_shape"][1]
+        nwx = (wcfg["bev_shape"][0] + wx - 1) // wx + 1
+        nwy = (wcfg["bev_shape"][1] + wy - 1) // wy + 1
+        out = []
+        for sx, sy in ((0, 0), (wcfg["shift"][0], wcfg["shift"][1])):
+            x = vc[:, 3] + (wx - sx if sx > 0 else 0)
+            y = vc[:, 2] + (wy - sy if sy > 0 else 0)
+            w = vc[:, 0] * (nwx * nwy) + (x // wx) * nwy + y // wy
+            out.append(int(torch.bincount(w).max()))
+        return tuple(out)
+
+    for keep, expect_big in ((None, False), (0.8, True)):
+        torch.manual_seed(3)
+        cfg = mae_sst_model(encoder_num_blocks=2, decoder_num_blocks=1)
+        cfg["backbone"]["compute_dtype"] = "bf16"
+        if keep is not None:
+            cfg["random_mask_ratio"] = 1.0 - keep
+        m_py = geomae_amd.build_model(cfg).cuda().train()
+        m_c = copy.deepcopy(m_py)
+        tr_py, tr_c = Trainer(m_py), Trainer(m_c)
+        pts = [torch.as_tensor(synth.lidar_frame(900 + b), device="cuda") for b in range(2)]      # full 32-beam frames: dense windows
+        tr_py.flat.zero_grad()
+        losses_py = m_py.train_step_explicit(pts)
+        torch.cuda.synchronize()
+        eng = PretrainEngine(m_c, tr_c.flat, tr_c.opt, 10.0)
+        tr_c.flat.zero_grad()
+        losses_c, _ = eng.step(pts, None, 1e-5, run_optimizer=False)
+        torch.cuda.synchronize()
+        s = eng.last_sizes()
+        w_ = m_c.backbone._wcfg
+        wcfg = dict(window_shape=list(w_.window_shape), shift=list(w_.shift), bev_shape=list(w_.bev_shape))
+        assert tuple(s["max_window_keep"]) == recount(eng, wcfg), (s["max_window_keep"], recount(eng, wcfg))
+        big = tuple(k > 64 for k in s["max_window_keep"])
+        assert s["big_bundle_layouts"] == (1 if big[0] else 0) | (2 if big[1] else 0), s
+        assert (s["big_bundle_layouts"] != 0) == expect_big, s
+        lp = torch.stack([losses_py[k] for k in m_py.LOSS_KEYS])
+        assert torch.allclose(losses_c, lp, rtol=1.5e-3, atol=1e-6), (losses_c, lp)
+        worst = max((_rel(tr_c.flat.grad[off:off + p.numel()], tr_py.flat.grad[off:off + p.numel()]), name)
+                    for name, off, p in zip(tr_py.flat.names, tr_py.flat.offsets, tr_py.flat.params))
+        assert worst[0] < 2e-2, worst
+
+
 def test_engine_training_steps_match_python_trainer():
     from geomae_amd.train import Trainer
     m_py = _build()
