@@ -771,6 +771,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         DwMidFlush mf;
         if (defer_enc_dw && enc_every > 0) { mf.side = geo; mf.ev = e->ev[kEncMid]; mf.every = enc_every; }
         MidFlushScope mid(mf);
+        set_fused_big_layouts(e->last_big_layouts);      // (as for the forward: no bundle of more than four tiles -> one launch per layer)
         ENG_CALL(geomae_sst_stack_backward(dxa, dxb, nk, L_enc, G_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, w_enc,
                                            wb_enc, d_vf, b.ids_keep, V, nullptr, 0, 1, e->profiler, main));
     }

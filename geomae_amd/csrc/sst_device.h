@@ -636,6 +636,12 @@ int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int nu
                                  int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
                                  long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
                                  unsigned* sync, hipStream_t stream);
+// sst_fused.hip: the backward of one layer as ONE launch (bundles of at most four tiles); called per layer by sst_stack.hip
+int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
+                             const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
+                             const GeomaeSstLayerGrads* g, const GeomaeSstStackLayout* layout, int bundle_cap, const void* qkv,
+                             const void* attn, const float* lse, const void* xh1, const void* xh2, const void* hp, const float* rstd,
+                             void* dqkv, void* du, void* dv, void* dhp, void* h, hipStream_t stream);
 inline LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
     L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;

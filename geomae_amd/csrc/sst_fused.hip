@@ -625,6 +625,376 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_stack_fwd_kernel(FusedSt
     }
 }
 
+// ==================================================================================================================
+// One launch per SST layer, BACKWARD (round 5): LayerNorm-2 backward -> FFN backward (GELU') -> LayerNorm-1 backward ->
+// out-projection backward -> window attention backward -> in-projection backward + residual, for one bundle of windows per
+// workgroup.  Reference: the autograd of EncoderLayer / WindowAttention (mmdet3d/models/sst/sst_basic_block.py:26-61, 85-147).
+// The unfused build runs a layer's backward as two launches (sst_ffn_bwd_kernel with the in-projection backward of the layer
+// above as its head, win_attn_bwd_kernel), with dattn, dqkv and dx_res making a round trip through HBM between them.
+//
+// Same shape as the forward kernel above: 8 waves, wave w = channel tile w = head w; GEMMs N-split and weight-stationary on
+// the TRANSPOSED fragment-major matrices (W2^T, W1^T, Wo^T, Wqk^T, Wv^T: the packed block holds them), activations as B
+// operands from LDS rows; the two LayerNorm backwards merge their per-token sums across waves through LDS.  The attention
+// backward of head w runs inside wave w: q, k, v, dO as T-layout registers (S^T = K Q^T, dP^T = V dO^T), the transposed
+// operands of the three token contractions (K^T, Q^T, dO^T) by ds_read_b64_tr_b16 from a wave-private LDS copy of the head's
+// slices -- no workgroup barrier inside the attention.  dq, dk, dv leave as bf16 rows (the operands of the weight-gradient
+// contraction) and feed the in-projection backward from LDS; the layer's input gradient is written IN PLACE over its output
+// gradient (a bundle reads and writes the same token rows).
+// Bundles of 1-4 tiles only: a stack whose layouts may hold a larger one keeps the unfused backward (the engine knows a step
+// ahead, window.hip window_max_keep).
+constexpr int kBRows = 64;                                           // token rows of a bundle (<= 4 tiles)
+constexpr int kBRowQ = 2 * (384 + 8);                                // bytes of a bf16 row of 384 channels (+16 B)
+constexpr int kBLdsRA = 0, kBLdsRH = kBRows * kFRow;                 // 128-wide rows | 256-wide rows; the 384-wide rows alias both
+constexpr int kBLdsRed = kBLdsRH + kBRows * kFRowH;
+static_assert(kBRows * kBRowQ <= kBLdsRed, "the dqkv rows must fit over the two row buffers");
+constexpr int kBLdsWl = kBLdsRed + kBRows * 64;
+constexpr int kBLdsHead = kBLdsWl + kBRows * 4;                      // per wave: K, Q, dO slices [64][16] bf16, L, D [64] f32
+constexpr int kBHeadBytes = 3 * kBRows * 32 + 2 * kBRows * 4;
+constexpr int kBLdsPg = kBLdsHead + 8 * kBHeadBytes;                 // LayerNorm parameter gradients of the workgroup: [4][128] f32
+constexpr int kBLdsBytes = kBLdsPg + 4 * 128 * 4;
+
+struct FusedBwd {
+    const float* dz;              // gradient of the layer's output: token order tile-blocked, or (dz_rowmajor) row-major [n][128]
+    const float* dz_add;          // optional second summand (row-major only)
+    int dz_rowmajor;
+    float* dx;                    // gradient of the layer's input: tile-blocked (may alias dz); or (dx_rowmajor) row-major [n][128],
+    const int32_t* out_rows; int n_out;   // ... optionally scattered: row out_rows[token] of [n_out][128]
+    int dx_rowmajor;
+    const int32_t* bun_tok; const int4* plan; const int32_t* num_bundles;
+    LayerW W;
+    int n;
+    const bf16_t *qkv, *attn, *xh1, *xh2, *hp;                       // saved by the forward (token order, tile-blocked)
+    const float *lse, *rstd;
+    bf16_t *dqkv, *du, *dv, *dhp, *h;                                // operands of the weight-gradient contraction (written)
+    float *dg1, *dbe1, *dg2, *dbe2;                                  // LayerNorm parameter gradients (accumulated)
+};
+
+__device__ __forceinline__ uint2 lds_tr(const char* slice, int row0, int lane16) {
+    return tr_read(reinterpret_cast<const bf16_t*>(slice + (row0 + (lane16 >> 2)) * 32 + 8 * (lane16 & 3)));
+}
+
+template <int NT>
+__device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, const int T, char* lds) {
+#define FOR_TILES(it) _Pragma("unroll") for (int it = 0; it < NT; ++it)
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int t = lane & 15, g = lane >> 4;
+    char* RA = lds + kBLdsRA;
+    char* RH = lds + kBLdsRH;
+    char* RQ = lds + kBLdsRA;
+    float* red = reinterpret_cast<float*>(lds + kBLdsRed);
+    int* wl = reinterpret_cast<int*>(lds + kBLdsWl);
+    char* hs = lds + kBLdsHead + w * kBHeadBytes;                    // this wave's head slices
+    char* Ks = hs; char* Qs = hs + kBRows * 32; char* Os = hs + 2 * kBRows * 32;
+    float* Ls = reinterpret_cast<float*>(hs + 3 * kBRows * 32);
+    float* Ds = Ls + kBRows;
+    float* pgrad = reinterpret_cast<float*>(lds + kBLdsPg);
+    const LayerW& W = A.W;
+    const int perm_b = 2 * (32 * (w >> 1) + 8 * g + 4 * (w & 1));
+
+    // ---- plan records, then everything that hangs on the token ids
+    int tok[NT];
+    FOR_TILES(it) {
+        const int idx = 16 * it + t;
+        int4 rec = make_int4(-1, 0, -1 - idx, 0);
+        if (idx < T) rec = A.plan[s0 + idx];
+        tok[it] = rec.x;
+        if (w == 0 && g == 0) wl[idx] = rec.z;
+    }
+    f32x4 d[NT];                                                     // the running gradient: this wave's 16 channels of every row
+    uint2 xh2[NT];
+    float r1[NT], r2[NT];
+    {
+        const __amdgpu_buffer_rsrc_t zres = whole_rsrc(A.dz), ares = whole_rsrc(A.dz_add ? A.dz_add : A.dz);
+        const __amdgpu_buffer_rsrc_t x2r = whole_rsrc(A.xh2), rsr = whole_rsrc(A.rstd);
+        FOR_TILES(it) {
+            const int tk = tok[it];
+            const int off = tk < 0 ? kFOor : (A.dz_rowmajor ? tk * 512 + 64 * w + 16 * g : blk_off<4>(tk, 128, w, g));
+            d[it] = buf_load_f32x4(zres, off);
+            if (A.dz_add) d[it] += buf_load_f32x4(ares, off);
+            xh2[it] = buf_load_b64(x2r, tk < 0 ? kFOor : blk_off<2>(tk, 128, w, g));
+            const uint2 rr = buf_load_b64(rsr, tk < 0 ? kFOor : tk * 8);
+            r1[it] = __uint_as_float(rr.x); r2[it] = __uint_as_float(rr.y);
+        }
+    }
+    uint4 w2a[4], w2b[4];
+    load_wfrag<128>(W.frag + kOffW2T, 2 * w, lane, w2a);
+    load_wfrag<128>(W.frag + kOffW2T, 2 * w + 1, lane, w2b);
+    const f32x4 g2 = load_f4(W.g2 + 16 * w + 4 * g), g1 = load_f4(W.g1 + 16 * w + 4 * g);
+
+    // ---- LayerNorm-2 backward: d <- rstd2 (d g2 - mean(d g2) - xhat2 mean(d g2 xhat2)); parameter gradients of this tile
+    f32x4 pg = {0.f, 0.f, 0.f, 0.f}, pb = {0.f, 0.f, 0.f, 0.f};       // sum_t d * xhat, sum_t d (this lane's token column)
+    FOR_TILES(it) {
+        const f32x4 x = unpack4(xh2[it]);
+        pg += d[it] * x;
+        pb += d[it];
+        d[it] *= g2;
+        const float a = rows4_sum((d[it][0] + d[it][1]) + (d[it][2] + d[it][3]));
+        const float b = rows4_sum((d[it][0] * x[0] + d[it][1] * x[1]) + (d[it][2] * x[2] + d[it][3] * x[3]));
+        if (g == 0) *reinterpret_cast<float2*>(red + (16 * it + t) * 16 + 2 * w) = make_float2(a, b);
+    }
+    __syncthreads();                                                                           // (1) LN2 sums
+    FOR_TILES(it) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(red + (16 * it + t) * 16 + 4 * i);
+        const f32x4 sm = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        const float m1 = (sm[0] + sm[2]) * (1.0f / 128.0f), m2 = (sm[1] + sm[3]) * (1.0f / 128.0f);
+        d[it] = (d[it] - m1 - unpack4(xh2[it]) * m2) * r2[it];        // d(y + f)
+        *reinterpret_cast<uint2*>(RA + (16 * it + t) * kFRow + perm_b) = pack4(d[it]);
+    }
+    {   // dv operand of dW2 + LayerNorm-2 parameter gradients
+        const __amdgpu_buffer_rsrc_t dvr = whole_rsrc(A.dv);
+        FOR_TILES(it) buf_store_b64(dvr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(d[it]));
+        // (parked in LDS -- this wave owns these channels -- and flushed once per workgroup at the end of the kernel: issued
+        //  here, ~170 workgroups x 64 atomics on the same few cache lines sit in front of every later load of the wave)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
+            if (t == 0) { pgrad[0 * 128 + 16 * w + 4 * g + r] += sg; pgrad[1 * 128 + 16 * w + 4 * g + r] += sb; }
+        }
+    }
+    // the forward's saved pre-activations of this wave's two hidden tiles, and xhat1: in flight under the barrier + GEMM
+    uint2 hpa[NT], hpb[NT], xh1[NT];
+    {
+        const __amdgpu_buffer_rsrc_t hpr = whole_rsrc(A.hp), x1r = whole_rsrc(A.xh1);
+        FOR_TILES(it) {
+            const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 256, 2 * w, g) : kFOor;
+            hpa[it] = buf_load_b64(hpr, o2);
+            hpb[it] = buf_load_b64(hpr, o2 + 512);
+            xh1[it] = buf_load_b64(x1r, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor);
+        }
+    }
+    uint4 w1[8];
+    load_wfrag<256>(W.frag + kOffW1T, w, lane, w1);
+    __syncthreads();                                                                           // (2) d(y + f) rows in LDS
+
+    // ---- FFN backward: dh = d W2 (hidden tiles 2w, 2w + 1), dhp = dh gelu'(hp), h = gelu(hp)
+    {
+        const __amdgpu_buffer_rsrc_t dhr = whole_rsrc(A.dhp), hr = whole_rsrc(A.h);
+        FOR_TILES(it) {
+            const char* row = RA + (16 * it + t) * kFRow + 16 * g;
+            f32x4 ha = {0.f, 0.f, 0.f, 0.f}, hb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const uint4 b = lds_b128(row + 64 * kk);
+                ha = mfma32(w2a[kk], b, ha);
+                hb = mfma32(w2b[kk], b, hb);
+            }
+            f32x4 va, ga, vb, gb;
+            gelu_fwd_bwd4(unpack4(hpa[it]), &va, &ga);
+            gelu_fwd_bwd4(unpack4(hpb[it]), &vb, &gb);
+            const uint2 pa = pack4(ha * ga), pbk = pack4(hb * gb);
+            *reinterpret_cast<uint4*>(RH + (16 * it + t) * kFRowH + 2 * (32 * w + 8 * g)) = make_uint4(pa.x, pa.y, pbk.x, pbk.y);
+            const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 256, 2 * w, g) : kFOor;
+            buf_store_b64(dhr, o2, pa);
+            buf_store_b64(dhr, o2 + 512, pbk);
+            buf_store_b64(hr, o2, pack4(va));
+            buf_store_b64(hr, o2 + 512, pack4(vb));
+        }
+    }
+    uint4 wo[4];
+    load_wfrag<128>(W.frag + kOffWoT, w, lane, wo);
+    __syncthreads();                                                                           // (3) dhp rows in LDS
+
+    // ---- dy = d(y + f) + dhp W1 (channel tile w); LayerNorm-1 backward
+    pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg;
+    FOR_TILES(it) {
+        const char* row = RH + (16 * it + t) * kFRowH + 16 * g;
+        f32x4 a = d[it];
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) a = mfma32(w1[kk], lds_b128(row + 64 * kk), a);
+        const f32x4 x = unpack4(xh1[it]);
+        pg += a * x;
+        pb += a;
+        a *= g1;
+        d[it] = a;
+        const float sa = rows4_sum((a[0] + a[1]) + (a[2] + a[3]));
+        const float sb = rows4_sum((a[0] * x[0] + a[1] * x[1]) + (a[2] * x[2] + a[3] * x[3]));
+        if (g == 0) *reinterpret_cast<float2*>(red + (16 * it + t) * 16 + 2 * w) = make_float2(sa, sb);
+    }
+    // this head's q, k, v, attention output and log-sum-exp: in flight under the barrier and the out-projection backward
+    uint2 qf[NT], kf[NT], vf[NT], of[NT];
+    float lse[NT];
+    {
+        const __amdgpu_buffer_rsrc_t qr = whole_rsrc(A.qkv), orr = whole_rsrc(A.attn), lr = whole_rsrc(A.lse);
+        FOR_TILES(it) {
+            const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 384, w, g) : kFOor;
+            qf[it] = buf_load_b64(qr, o2);
+            kf[it] = buf_load_b64(qr, o2 + 8 * 512);
+            vf[it] = buf_load_b64(qr, o2 + 16 * 512);
+            of[it] = buf_load_b64(orr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor);
+            lse[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lr, tok[it] >= 0 ? (tok[it] * 8 + w) * 4 : kFOor, 0, 0));
+        }
+    }
+    __syncthreads();                                                                           // (4) LN1 sums
+    FOR_TILES(it) {
+        f32x4 a4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a4[i] = *reinterpret_cast<const f32x4*>(red + (16 * it + t) * 16 + 4 * i);
+        const f32x4 sm = (a4[0] + a4[1]) + (a4[2] + a4[3]);
+        const float m1 = (sm[0] + sm[2]) * (1.0f / 128.0f), m2 = (sm[1] + sm[3]) * (1.0f / 128.0f);
+        d[it] = (d[it] - m1 - unpack4(xh1[it]) * m2) * r1[it];        // du = d(x + attention branch): also the residual part of dx
+        *reinterpret_cast<uint2*>(RA + (16 * it + t) * kFRow + perm_b) = pack4(d[it]);
+    }
+    {
+        const __amdgpu_buffer_rsrc_t dur = whole_rsrc(A.du);
+        FOR_TILES(it) buf_store_b64(dur, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(d[it]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
+            if (t == 0) { pgrad[2 * 128 + 16 * w + 4 * g + r] += sg; pgrad[3 * 128 + 16 * w + 4 * g + r] += sb; }
+        }
+    }
+    __syncthreads();                                                                           // (5) du rows in LDS
+
+    // ---- dO of head w = du Wo (channel tile w), then the attention backward of head w inside this wave
+    uint2 dof[NT];
+    FOR_TILES(it) {
+        const char* row = RA + (16 * it + t) * kFRow + 16 * g;
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) a = mfma32(wo[kk], lds_b128(row + 64 * kk), a);
+        dof[it] = pack4(a);
+        // delta_i = sum_d dO[i][d] O[i][d] over the head's 16 channels (dO as the bf16 the contractions see)
+        const f32x4 dob = unpack4(dof[it]), ob = unpack4(of[it]);
+        const float dl = rows4_sum((dob[0] * ob[0] + dob[1] * ob[1]) + (dob[2] * ob[2] + dob[3] * ob[3]));
+        const int idx = 16 * it + t;
+        *reinterpret_cast<uint2*>(Ks + idx * 32 + 8 * g) = kf[it];
+        *reinterpret_cast<uint2*>(Qs + idx * 32 + 8 * g) = qf[it];
+        *reinterpret_cast<uint2*>(Os + idx * 32 + 8 * g) = dof[it];
+        if (g == 0) { Ls[idx] = idx < T ? lse[it] : INFINITY; Ds[idx] = dl; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const float scale = 0.25f;
+    uint2 dqb[NT], dkb[NT], dvb[NT];
+    // pass 1, dQ: lane = query i (column), rows = keys 4g + r of tile jt
+    FOR_TILES(it) {
+        const int wq = wl[16 * it + t];
+        const float Li = Ls[16 * it + t], Di = Ds[16 * it + t];
+        f32x4 dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sT = mfma16(kf[jt], qf[it], z4);
+            const f32x4 dpT = mfma16(vf[jt], dof[it], z4);
+            const int4 W4 = *reinterpret_cast<const int4*>(wl + 16 * jt + 4 * g);
+            const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
+            f32x4 ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (Wr[r] == wq) ? __expf(sT[r] * scale - Li) : 0.0f;
+                ds[r] = p * (dpT[r] - Di) * scale;
+            }
+            dq = mfma16(lds_tr(Ks, 16 * jt + 4 * g, t), pack4(ds), dq);          // dQ^T[d][i] += K^T[d][j] dS^T[j][i]
+        }
+        dqb[it] = pack4(dq);
+        __builtin_amdgcn_sched_barrier(0);                               // (keeps the next tile's LDS reads from piling up: NT = 4 spilled)
+    }
+    // pass 2, dK and dV: lane = key j (column), rows = queries 4g + r of tile it
+    FOR_TILES(jt) {
+        const int wk = wl[16 * jt + t];
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int it = 0; it < NT; ++it) {
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 sS = mfma16(qf[it], kf[jt], z4);
+            const f32x4 dp = mfma16(dof[it], vf[jt], z4);
+            const int i0 = 16 * it + 4 * g;
+            const f32x4 L4 = *reinterpret_cast<const f32x4*>(Ls + i0), D4 = *reinterpret_cast<const f32x4*>(Ds + i0);
+            const int4 W4 = *reinterpret_cast<const int4*>(wl + i0);
+            const int Wr[4] = {W4.x, W4.y, W4.z, W4.w};
+            f32x4 pp, ds;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float p = (Wr[r] == wk) ? __expf(sS[r] * scale - L4[r]) : 0.0f;
+                pp[r] = p;
+                ds[r] = p * (dp[r] - D4[r]) * scale;
+            }
+            dv = mfma16(lds_tr(Os, i0, t), pack4(pp), dv);                       // dV^T[d][j] += dO^T[d][i] P[i][j]
+            dk = mfma16(lds_tr(Qs, i0, t), pack4(ds), dk);                       // dK^T[d][j] += Q^T[d][i] dS[i][j]
+        }
+        dkb[jt] = pack4(dk);
+        dvb[jt] = pack4(dv);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    uint4 wqk[8], wv[4];                                             // (behind the attention: its operands are dead)
+    load_wfrag<256>(W.frag + kOffWqkT, w, lane, wqk);
+    load_wfrag<128>(W.frag + kOffWvT, w, lane, wv);
+    __syncthreads();                                                                           // (6) du rows consumed by every wave
+    {
+        const __amdgpu_buffer_rsrc_t dqr = whole_rsrc(A.dqkv);
+        FOR_TILES(it) {
+            char* row = RQ + (16 * it + t) * kBRowQ + perm_b;
+            *reinterpret_cast<uint2*>(row) = dqb[it];
+            *reinterpret_cast<uint2*>(row + 256) = dkb[it];
+            *reinterpret_cast<uint2*>(row + 512) = dvb[it];
+            const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 384, w, g) : kFOor;
+            buf_store_b64(dqr, o2, dqb[it]);
+            buf_store_b64(dqr, o2 + 8 * 512, dkb[it]);
+            buf_store_b64(dqr, o2 + 16 * 512, dvb[it]);
+        }
+    }
+    __syncthreads();                                                                           // (7) dqkv rows in LDS
+
+    // ---- dx = du + dqk Wqk + dv Wv (channel tile w)
+    {
+        const __amdgpu_buffer_rsrc_t xr = whole_rsrc(A.dx);
+        FOR_TILES(it) {
+            const char* row = RQ + (16 * it + t) * kBRowQ + 16 * g;
+            f32x4 a = d[it];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) a = mfma32(wqk[kk], lds_b128(row + 64 * kk), a);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) a = mfma32(wv[kk], lds_b128(row + 512 + 64 * kk), a);
+            const int tk = tok[it];
+            int off = kFOor;
+            if (tk >= 0) {
+                if (A.out_rows) {
+                    const int orow = A.out_rows[tk];
+                    off = orow < A.n_out ? orow * 512 + 64 * w + 16 * g : kFOor;
+                } else if (A.dx_rowmajor) {
+                    off = tk * 512 + 64 * w + 16 * g;
+                } else {
+                    off = blk_off<4>(tk, 128, w, g);
+                }
+            }
+            buf_store_f32x4(xr, off, a);
+        }
+    }
+#undef FOR_TILES
+}
+
+__global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_bwd_kernel(FusedBwd A) {
+    __shared__ __attribute__((aligned(16))) char lds[kBLdsBytes];
+    const int NB = A.num_bundles[0];
+    reinterpret_cast<float*>(lds + kBLdsPg)[threadIdx.x] = 0.f;          // 512 threads = [4][128]
+    bool any = false;
+    for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+        any = true;
+        const int s0 = A.bun_tok[b];
+        const int T = A.bun_tok[b + 1] - s0;
+        const int nt = (T + 15) >> 4;
+        switch (nt) {
+            case 1: fused_bwd_body<1>(A, s0, T, lds); break;
+            case 2: fused_bwd_body<2>(A, s0, T, lds); break;
+            case 3: fused_bwd_body<3>(A, s0, T, lds); break;
+            case 4: fused_bwd_body<4>(A, s0, T, lds); break;
+            default: break;                                  // (the host keeps the unfused backward for such layouts)
+        }
+        if (b + (int)gridDim.x < NB) __syncthreads();
+    }
+    if (!any) return;                                        // (workgroup-uniform)
+    __syncthreads();
+    {
+        const int k = threadIdx.x >> 7, c = threadIdx.x & 127;
+        float* dst = k == 0 ? A.dg2 : (k == 1 ? A.dbe2 : (k == 2 ? A.dg1 : A.dbe1));
+        atomicAdd(dst + c, reinterpret_cast<const float*>(lds + kBLdsPg)[threadIdx.x]);
+    }
+}
+
 // one workgroup per bundle; the bundle count lives on the device, its bound from the greedy packing is 2 n / cap + 1
 static int fused_grid(int num_tokens, int max_bundles, int cap) {
     int64_t nb = 2 * (int64_t)num_tokens / (cap > 0 ? cap : 1) + 2;
@@ -695,6 +1065,31 @@ extern "C" int geomae_debug_read_persist_stamps(unsigned long long* host) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(persist_stamps), sizeof(unsigned long long) * 256 * 40);
 }
 #endif
+
+// The backward of one layer as ONE launch (sst_layer_bwd_kernel).  Internal: geomae_sst_stack_backward calls it per layer when
+// the stack qualifies (sst_stack.hip).  dz: tile-blocked token order, or row-major (+ optional dz_add); dx likewise (+ scatter).
+int geomae::sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
+                                     const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
+                                     const GeomaeSstLayerGrads* g, const GeomaeSstStackLayout* layout, int bundle_cap,
+                                     const void* qkv, const void* attn, const float* lse, const void* xh1, const void* xh2,
+                                     const void* hp, const float* rstd, void* dqkv, void* du, void* dv, void* dhp, void* h,
+                                     hipStream_t stream) {
+    GEOMAE_REQUIRE(w && w->frag_p && g && layout && layout->fbun_tok && layout->pos_info && layout->num_fbundles,
+                   "sst_layer_backward_fused: plan / fragment-major weights missing");
+    FusedBwd A;
+    memset(&A, 0, sizeof(A));
+    A.dz = dz; A.dz_add = dz_add; A.dz_rowmajor = dz_rowmajor ? 1 : 0;
+    A.dx = dx; A.dx_rowmajor = dx_rowmajor ? 1 : 0; A.out_rows = out_rows; A.n_out = n_out;
+    A.bun_tok = layout->fbun_tok; A.plan = (const int4*)layout->pos_info; A.num_bundles = layout->num_fbundles;
+    A.W = to_layer(w); A.n = num_tokens;
+    A.qkv = (const bf16_t*)qkv; A.attn = (const bf16_t*)attn; A.xh1 = (const bf16_t*)xh1; A.xh2 = (const bf16_t*)xh2;
+    A.hp = (const bf16_t*)hp; A.lse = lse; A.rstd = rstd;
+    A.dqkv = (bf16_t*)dqkv; A.du = (bf16_t*)du; A.dv = (bf16_t*)dv; A.dhp = (bf16_t*)dhp; A.h = (bf16_t*)h;
+    A.dg1 = g->ln1_w; A.dbe1 = g->ln1_b; A.dg2 = g->ln2_w; A.dbe2 = g->ln2_b;
+    const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
+    hipLaunchKernelGGL(sst_layer_bwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
+    return check_launch("sst_layer_bwd_kernel");
+}
 
 extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, const GeomaeSstLayerWeights* w,
                                         const GeomaeSstStackLayout* layout, int32_t bundle_cap, const float* pos_table,

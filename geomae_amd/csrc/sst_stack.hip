@@ -29,6 +29,12 @@ int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int nu
                                  int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
                                  long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
                                  unsigned* sync, hipStream_t stream);
+// sst_fused.hip: the backward of one layer as ONE launch (bundles of at most four tiles)
+int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
+                             const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
+                             const GeomaeSstLayerGrads* g, const GeomaeSstStackLayout* layout, int bundle_cap, const void* qkv,
+                             const void* attn, const float* lse, const void* xh1, const void* xh2, const void* hp, const float* rstd,
+                             void* dqkv, void* du, void* dv, void* dhp, void* h, hipStream_t stream);
 }
 
 namespace geomae {
@@ -317,6 +323,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
                                          int32_t defer_last_weight_grad, void* profiler, hipStream_t stream) {
     const int live_row = first_live_row();          // as in the forward: the TOP layer's dead rows
     set_first_live_row(0);
+    const int big_layouts = take_fused_big_layouts();    // (which layouts may hold a bundle of more than four tiles; default: both)
     if (num_tokens <= 0) return GEOMAE_OK;
     int rc = check_stack(layers, num_layers, layouts, "sst_stack_backward");
     if (rc) return rc;
@@ -343,6 +350,45 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     struct OperandFormScope {                       // y / x "formed on load" switches: cleared on every exit path
         ~OperandFormScope() { set_y_from_xhat(false); set_x_from_xhat(false); (void)take_dw_dead_rows(); }
     } operand_scope;
+    // ---- one launch per layer (sst_fused.hip sst_layer_bwd_kernel) where the forward took its one-launch form, every
+    // contraction is queued (defer all: per-layer operand slabs) and no layout holds a bundle of more than four tiles (the
+    // caller says so: common.h set_fused_big_layouts; the step engine knows a step ahead).  GEOMAE_FUSED_BWD=0: never.
+    static const bool fused_bwd_switch = [] { const char* e = getenv("GEOMAE_FUSED_BWD"); return !(e && e[0] == '0'); }();
+    static const bool y_switch0 = [] { const char* e = getenv("GEOMAE_Y_FROM_XHAT"); return !(e && e[0] == '0'); }();
+    const bool fused_bwd = fused_bwd_switch && defer_all && big_layouts == 0 && live_row == 0 && !tail_sum && fused_layers_enabled(num_tokens) &&
+                           layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
+                           saved_flag() == kSavedBf16 && y_switch0 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p;
+    for (int l = num_layers - 1; fused_bwd && l >= 0 && rc == GEOMAE_OK; --l) {
+        const char* sv = base + so.stride * l;
+        char* ws = w + sc.set0 + l * sc.set_bytes;
+        const bool top = l + 1 == num_layers;
+        const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
+        float* dxbuf = (float*)(w + sc.dx_res);                    // the running input gradient: tile-blocked, rewritten in place
+        {
+            Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
+            rc = sst_layer_backward_fused(top ? dz : dxbuf, top ? dz_add : nullptr, top, l == 0 ? dx_out : dxbuf, l == 0,
+                                          l == 0 ? output_rows : nullptr, l == 0 ? num_output_rows : 0, num_tokens, &layers[l], &grads[l],
+                                          &layouts[l & 1], cap, sv + so.qkv, sv + so.attn, (const float*)(sv + so.lse), sv + so.xh1,
+                                          sv + so.xh2, sv + so.hp, (const float*)(sv + so.rstd), ws + sc.dqkv, ws + sc.du, ws + sc.dv,
+                                          ws + sc.dhp, ws + sc.h, stream);
+        }
+        if (rc) break;
+        LayerLayoutScope lay(kBlk | saved_flag());
+        set_y_from_xhat(true, layers[l].ln1_w, layers[l].ln1_b);
+        const bool x_from_xhat = l > 0 && x_from_xhat_enabled();
+        set_x_from_xhat(x_from_xhat, x_from_xhat ? layers[l - 1].ln2_w : nullptr, x_from_xhat ? layers[l - 1].ln2_b : nullptr);
+        const char* x_operand = x_from_xhat ? base + so.stride * (l - 1) + so.xh2 : sv + so.xb;
+        defer_next_weight_grad();                                  // (defer all: queued for geomae_flush_weight_grad)
+        rc = geomae_sst_weight_grad(num_tokens, ws + sc.dqkv, sv + so.xp, x_operand, ws + sc.du, sv + so.attn, ws + sc.dhp, sv + so.xh1,
+                                    ws + sc.dv, ws + sc.h, &grads[l], stream);
+        const DwMidFlush mf = dw_mid_flush();
+        if (rc == GEOMAE_OK && l > 0 && mf.side && mf.ev && mf.every > 0 && (num_layers - l) % mf.every == 0) {
+            GEOMAE_HIP(hipEventRecord(mf.ev, stream));
+            GEOMAE_HIP(hipStreamWaitEvent(mf.side, mf.ev, 0));
+            rc = flush_pending_weight_grad(mf.side);
+        }
+    }
+    if (fused_bwd) return rc;
     for (int l = num_layers - 1; l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         const GeomaeSstStackLayout& L = layouts[l & 1];
