@@ -743,17 +743,6 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
         d[it] = (d[it] - m1 - unpack4(xh2[it]) * m2) * r2[it];        // d(y + f)
         *reinterpret_cast<uint2*>(RA + (16 * it + t) * kFRow + perm_b) = pack4(d[it]);
     }
-    {   // dv operand of dW2 + LayerNorm-2 parameter gradients
-        const __amdgpu_buffer_rsrc_t dvr = whole_rsrc(A.dv);
-        FOR_TILES(it) buf_store_b64(dvr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(d[it]));
-        // (parked in LDS -- this wave owns these channels -- and flushed once per workgroup at the end of the kernel: issued
-        //  here, ~170 workgroups x 64 atomics on the same few cache lines sit in front of every later load of the wave)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
-            if (t == 0) { pgrad[0 * 128 + 16 * w + 4 * g + r] += sg; pgrad[1 * 128 + 16 * w + 4 * g + r] += sb; }
-        }
-    }
     // the forward's saved pre-activations of this wave's two hidden tiles, and xhat1: in flight under the barrier + GEMM
     uint2 hpa[NT], hpb[NT], xh1[NT];
     {
@@ -765,10 +754,24 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             xh1[it] = buf_load_b64(x1r, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor);
         }
     }
+    // (loads first: vmcnt retires in order, a load issued behind these stores would wait for them where it is used)
+    {   // dv operand of dW2 + LayerNorm-2 parameter gradients
+        const __amdgpu_buffer_rsrc_t dvr = whole_rsrc(A.dv);
+        FOR_TILES(it) buf_store_b64(dvr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(d[it]));
+        // (parked in LDS -- this wave owns these channels -- and flushed once per workgroup at the end of the kernel: issued
+        //  here, ~170 workgroups x 64 atomics on the same few cache lines sit in front of every later load of the wave)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
+            if (t == 0) { pgrad[0 * 128 + 16 * w + 4 * g + r] += sg; pgrad[1 * 128 + 16 * w + 4 * g + r] += sb; }
+        }
+    }
     uint4 w1[8];
     load_wfrag<256>(W.frag + kOffW1T, w, lane, w1);
     __syncthreads();                                                                           // (2) d(y + f) rows in LDS
 
+    uint4 wo[4];
+    load_wfrag<128>(W.frag + kOffWoT, w, lane, wo);                  // (first use behind the next barrier; ahead of this phase's stores)
     // ---- FFN backward: dh = d W2 (hidden tiles 2w, 2w + 1), dhp = dh gelu'(hp), h = gelu(hp)
     {
         const __amdgpu_buffer_rsrc_t dhr = whole_rsrc(A.dhp), hr = whole_rsrc(A.h);
@@ -793,8 +796,6 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             buf_store_b64(hr, o2 + 512, pack4(vb));
         }
     }
-    uint4 wo[4];
-    load_wfrag<128>(W.frag + kOffWoT, w, lane, wo);
     __syncthreads();                                                                           // (3) dhp rows in LDS
 
     // ---- dy = d(y + f) + dhp W1 (channel tile w); LayerNorm-1 backward

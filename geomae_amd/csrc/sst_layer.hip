@@ -1367,7 +1367,10 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     // of 16 jobs; config 3: 7.29 / 6.37 / 6.07 / 5.91 / 6.00 / 6.15 ms at 2 / 3 / 4 / 6 / 8 / 12 -- fewer do not finish before
     // the step's join, more slow the main stream's kernels)
     static const int g_env = [] { const char* e = getenv("GEOMAE_DW_CHUNKS"); return e ? atoi(e) : 0; }();                // (A/B)
-    int G = 96 / A.njobs;
+    // (round 5, with the one-launch encoder backward: its ~165 workgroups hold a CU each too, and 165 + 96 > 256 sent some of
+    //  them to a second round -- 80 workgroups at the sizes where that kernel runs beside these launches: config 2
+    //  1.735 / 1.700 / 1.71 / 1.81 ms at 96 / 80 / 64 / 48)
+    int G = (A.n <= 32768 ? 80 : 96) / A.njobs;
     if (G > 24) G = 24;
     if (g_env > 0) G = g_env;
     const int by_tokens = cdiv(A.n, 2 * kDlSlabTok);                   // at least two slabs per workgroup
