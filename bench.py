@@ -211,7 +211,7 @@ def main():
     # sets); dw_kernel's launches are deferred to the geometry stream and timed THERE (thread profiler, csrc/sst_layer.hip).
     TIMED = ("sst_ffn_bwd_kernel", "sst_ffn_bwd_dw_kernel", "win_attn_bwd_kernel", "sst_ffn_fwd_kernel",
              "sst_ffn_fwd_pair_kernel", "sst_qkv_bwd_kernel", "win_attn_fwd_kernel", "sst_qkv_fwd_kernel",
-             "sst_layer_fwd_kernel", "dw_kernel")
+             "sst_layer_fwd_kernel", "sst_layer_bwd_kernel", "dw_kernel")
     # The kernel instrumented INSIDE the timed region is the TIMED kernel with the largest share of the committed
     # rocprofv3 --kernel-trace --stats table of this workload (profiles/rNN_<workload>_kernel_stats.csv, newest round); the
     # others are timed in extra steps behind it, and `roofline` reports whichever turned out largest by measured time per
@@ -369,25 +369,34 @@ def main():
         # round 5: the encoder's contractions leave its backward launches too (csrc/engine.hip GEOMAE_ENC_DW_DEFER): no
         # sst_ffn_bwd_dw_kernel launch at all, 20 plain ffn-backward launches (17 of them with a B1 head), and every layer's
         # contraction in the layer-form launches on the geometry stream (csrc/dw_device.h: <= 4 layers per launch)
-        all_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 0 and round(lps("sst_ffn_bwd_kernel")) == 20
+        all_deferred = round(lps("sst_ffn_bwd_dw_kernel")) == 0 and round(lps("sst_ffn_bwd_kernel")) in (20, 8)
+        # ... and the encoder's backward as ONE launch per layer (csrc/sst_fused.hip sst_layer_bwd_kernel, 12 per step): the
+        # ffn-backward / attention-backward / stand-alone in-projection-backward launches left are the decoders' (8 / 8 / 2)
+        fused_bwd = round(lps("sst_layer_bwd_kernel")) == 12
         M_rows = float(n_d - n_e)
-        flops_step = {"sst_ffn_bwd_kernel": (F3 * (12 * n_e + 8 * n_d) + F1 * (11 * n_e + 6 * n_d)) if all_deferred else
+        ATT_B = 2 * 5 * 16 * 8                                          # attention backward FLOPs per (query, key) pair of a window
+        flops_step = {"sst_layer_bwd_kernel": (F3 + F1) * 12 * n_e + ATT_B * sq_e,
+                      "sst_ffn_bwd_kernel": (F3 * 8 * n_d + F1 * 6 * n_d) if fused_bwd else
+                                            (F3 * (12 * n_e + 8 * n_d) + F1 * (11 * n_e + 6 * n_d)) if all_deferred else
                                             (F3 * (n_e + 8 * n_d) + F1 * 6 * n_d if dec_deferred else F3 * (n_e + 2 * n_d)),
                       "sst_ffn_bwd_dw_kernel": (F3 + F1 + DW) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
                       "sst_ffn_fwd_kernel": F3 * 8 * n_d + F1 * 6 * n_d,
                       "sst_ffn_fwd_pair_kernel": F3 * 12 * n_e + F1 * 11 * n_e,
-                      "sst_qkv_fwd_kernel": F1 * ((0 if fused_enc else n_e) + 2 * n_d), "sst_qkv_bwd_kernel": F1 * (n_e + 2 * n_d),
+                      "sst_qkv_fwd_kernel": F1 * ((0 if fused_enc else n_e) + 2 * n_d),
+                      "sst_qkv_bwd_kernel": F1 * ((0 if fused_bwd else n_e) + 2 * n_d),
                       "win_attn_fwd_kernel": 2 * 2 * 16 * 8 * (sq_sum - (sq_e if fused_enc else 0.0)),
-                      "win_attn_bwd_kernel": 2 * 5 * 16 * 8 * sq_sum,
+                      "win_attn_bwd_kernel": ATT_B * (sq_sum - (sq_e if fused_bwd else 0.0)),
                       "sst_layer_fwd_kernel": (F3 + F1) * 12 * n_e + 2 * 2 * 16 * 8 * sq_e,
                       # every stand-alone contraction of the step: the decoders' 8 layers + the encoder's first layer (its
                       # other 11 ride in sst_ffn_bwd_dw_kernel), the six heads (800 x 128 per masked row), VFE layer 1
                       "dw_kernel": DW * ((8 * n_d if (dec_deferred or all_deferred) else 2 * n_d) + (12 * n_e if all_deferred else n_e))
                                    + 2 * 800 * 128 * M_rows + 2 * 128 * 128 * n_pts}
-        expect = {"sst_ffn_bwd_kernel": 20.0 if all_deferred else (9.0 if dec_deferred else 3.0),
+        expect = {"sst_layer_bwd_kernel": 12.0,
+                  "sst_ffn_bwd_kernel": 8.0 if fused_bwd else 20.0 if all_deferred else (9.0 if dec_deferred else 3.0),
                   "sst_ffn_bwd_dw_kernel": 11.0 if dec_deferred else 17.0,
                   "sst_ffn_fwd_kernel": 8.0, "sst_ffn_fwd_pair_kernel": 12.0, "sst_qkv_fwd_kernel": 2.0 if fused_enc else 3.0,
-                  "sst_qkv_bwd_kernel": 3.0, "win_attn_fwd_kernel": 8.0 if fused_enc else 20.0, "win_attn_bwd_kernel": 20.0,
+                  "sst_qkv_bwd_kernel": 2.0 if fused_bwd else 3.0, "win_attn_fwd_kernel": 8.0 if fused_enc else 20.0,
+                  "win_attn_bwd_kernel": 8.0 if fused_bwd else 20.0,
                   "sst_layer_fwd_kernel": 12.0, "dw_kernel": None}
         launches_step = {k: lps(k) for k in flops_step}
         report_name = {}
@@ -409,15 +418,18 @@ def main():
         # 1.3 KB; a contraction reads 8 tasks x 2 operands x 256 B; attention forward reads qkv 768 and writes attn 256 + lse 32,
         # its backward reads qkv + attn + dattn + lse and writes dqkv 768.
         F3B, F1B, B3B, B1B, DWB, AFB, ABB = 2304.0, 1024.0, 4450.0, 1300.0, 4096.0, 1056.0, 2080.0
-        bytes_step = {"sst_ffn_bwd_kernel": (B3B * (12 * n_e + 8 * n_d) + B1B * (11 * n_e + 6 * n_d)) if all_deferred else
+        # the one-launch backward: reads dz 512 + xhat1/xhat2/hp/attn/qkv 1792 + lse/rstd 40, writes dx 512 + dv/dhp/h/du/dqkv 2304
+        bytes_step = {"sst_layer_bwd_kernel": (512 + 1792 + 40 + 512 + 2304) * 12 * n_e,
+                      "sst_ffn_bwd_kernel": (B3B * 8 * n_d + B1B * 6 * n_d) if fused_bwd else
+                                            (B3B * (12 * n_e + 8 * n_d) + B1B * (11 * n_e + 6 * n_d)) if all_deferred else
                                             (B3B * (n_e + 8 * n_d) + B1B * 6 * n_d if dec_deferred else B3B * (n_e + 2 * n_d)),
                       "sst_ffn_bwd_dw_kernel": (B3B + B1B + DWB) * (11 * n_e + (0 if dec_deferred else 6 * n_d)),
                       "sst_ffn_fwd_kernel": F3B * 8 * n_d + F1B * 6 * n_d,
                       "sst_ffn_fwd_pair_kernel": F3B * 12 * n_e + F1B * 11 * n_e,
                       "sst_qkv_fwd_kernel": (512 + F1B) * ((0 if fused_enc else n_e) + 2 * n_d),
-                      "sst_qkv_bwd_kernel": (B1B + 512) * (n_e + 2 * n_d),
+                      "sst_qkv_bwd_kernel": (B1B + 512) * ((0 if fused_bwd else n_e) + 2 * n_d),
                       "win_attn_fwd_kernel": AFB * (8 * n_d + (0 if fused_enc else 12 * n_e)),
-                      "win_attn_bwd_kernel": ABB * (12 * n_e + 8 * n_d),
+                      "win_attn_bwd_kernel": ABB * ((0 if fused_bwd else 12 * n_e) + 8 * n_d),
                       "sst_layer_fwd_kernel": (512 + F3B + F1B + 256 + 32) * 12 * n_e,
                       # (algorithmic: 8 tasks x 2 operands x 256 B per token and layer -- SURVEY's figure; the layer-form kernel
                       #  reads 3.25 KB of it once, dw_device.h)
@@ -557,7 +569,7 @@ def main():
                 u = json.load(open(upath))
                 out["mfma_busy_stored"] = {"source": f"{os.path.relpath(upath, ROOT)} (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles))",
                                            **{k: u[k]["mfma_busy_frac"] for k in ("win_attn_fwd_kernel", "win_attn_bwd_kernel",
-                                                                                  "sst_layer_fwd_kernel", "sst_ffn_fwd_kernel",
+                                                                                  "sst_layer_fwd_kernel", "sst_layer_bwd_kernel", "dw_layer_kernel", "sst_ffn_fwd_kernel",
                                                                                   "sst_ffn_fwd_pair_kernel", "sst_ffn_bwd_kernel",
                                                                                   "sst_ffn_bwd_dw_kernel", "dw_kernel",
                                                                                   "vfe_layer1_kernel") if k in u}}

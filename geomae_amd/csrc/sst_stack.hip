@@ -365,7 +365,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
         float* dxbuf = (float*)(w + sc.dx_res);                    // the running input gradient: tile-blocked, rewritten in place
         {
-            Timed t(profiler, GEOMAE_KERNEL_FFN_BWD, stream);
+            Timed t(profiler, GEOMAE_KERNEL_LAYER_BWD, stream);
             rc = sst_layer_backward_fused(top ? dz : dxbuf, top ? dz_add : nullptr, top, l == 0 ? dx_out : dxbuf, l == 0,
                                           l == 0 ? output_rows : nullptr, l == 0 ? num_output_rows : 0, num_tokens, &layers[l], &grads[l],
                                           &layouts[l & 1], cap, sv + so.qkv, sv + so.attn, (const float*)(sv + so.lse), sv + so.xh1,

@@ -1345,7 +1345,7 @@ def vfe_backward(plan, m0, vf, dvf, params, world=1, group=None, zeros=None, sid
 PROFILER = None        # bench.py: handle from geomae_profiler_create, passed to every stack call
 KERNEL_IDS = dict(sst_qkv_fwd_kernel=1, win_attn_fwd_kernel=2, sst_ffn_fwd_kernel=3, sst_ffn_bwd_kernel=4,
                   win_attn_bwd_kernel=5, sst_qkv_bwd_kernel=6, dw_kernel=7, sst_ffn_bwd_dw_kernel=8,
-                  sst_ffn_fwd_pair_kernel=9, sst_layer_fwd_kernel=10)
+                  sst_ffn_fwd_pair_kernel=9, sst_layer_fwd_kernel=10, sst_layer_bwd_kernel=11)
 
 
 def _stack_layouts(layouts):

@@ -829,7 +829,8 @@ enum { GEOMAE_KERNEL_QKV_FWD = 1, GEOMAE_KERNEL_ATTN_FWD = 2, GEOMAE_KERNEL_FFN_
        GEOMAE_KERNEL_FFN_BWD_DW = 8 /* the ffn-backward launches that carry a weight-gradient contraction
                                        (sst_ffn_bwd_dw_kernel); 4 = those that do not (sst_ffn_bwd_kernel) */,
        GEOMAE_KERNEL_FFN_FWD_PAIR = 9 /* sst_ffn_fwd_pair_kernel launches; 3 = sst_ffn_fwd_kernel launches */,
-       GEOMAE_KERNEL_LAYER_FWD = 10 /* sst_layer_fwd_kernel: the one-launch layer forward */ };
+       GEOMAE_KERNEL_LAYER_FWD = 10 /* sst_layer_fwd_kernel: the one-launch layer forward */,
+       GEOMAE_KERNEL_LAYER_BWD = 11 /* sst_layer_bwd_kernel: the one-launch layer backward */ };
 void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches);
 int32_t geomae_profiler_read(void* profiler, float* ms_out, int32_t capacity);
 void geomae_profiler_destroy(void* profiler);

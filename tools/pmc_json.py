@@ -29,7 +29,7 @@ if steps:
     res["_steps_in_run"] = steps
 for k in sorted(set(f) & set(w)):
     if not (k.startswith("sst_") or k.startswith("win_") or k.startswith("vfe_") or k.startswith("voxelize") or
-            k.startswith("scan_") or k in ("dw_kernel", "dw_layer_kernel", "dw_layer_reduce_kernel", "sst_layer_fwd_kernel", "sst_stack_fwd_kernel", "dw_reduce_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
+            k.startswith("scan_") or k in ("dw_kernel", "dw_layer_kernel", "dw_layer_reduce_kernel", "sst_layer_fwd_kernel", "sst_layer_bwd_kernel", "sst_layer_fwd_big_kernel", "sst_stack_fwd_kernel", "dw_reduce_kernel", "heads_loss_kernel", "adamw_kernel", "hist_kernel", "place_kernel",
                                             "centroid_targets_kernel", "normal_curv_kernel", "normal_eig_kernel",
                                             "occ_count_kernel", "random_mask_kernel", "random_mask_win_kernel", "zero_arena_kernel", "grad_sumsq_kernel",
                                             "pack_weights_kernel", "rows_to_blocked_f32_kernel", "gather_token_coors_kernel")):

@@ -82,5 +82,12 @@ enc_att_b = [r for r in att_b if wgs(r) != big_att]
 qkv_f = [r for r in step if "sst_qkv_fwd_kernel" in r["Kernel_Name"]]
 window("decoders forward ", qkv_f[0] if qkv_f else None, ffn_f[-1] if ffn_f else None)
 window("decoders backward", ffn_b[0] if ffn_b else None, dec_att_b[-1] if dec_att_b else None)
-window("encoder backward ", enc_att_b[0] if enc_att_b else None, enc_att_b[-1] if enc_att_b else None)
+lay_b = [r for r in step if "sst_layer_bwd_kernel" in r["Kernel_Name"]]           # the one-launch encoder backward (round 5)
+if lay_b:
+    window("encoder backward ", lay_b[0], lay_b[-1])
+else:
+    window("encoder backward ", enc_att_b[0] if enc_att_b else None, enc_att_b[-1] if enc_att_b else None)
+lay_f = [r for r in step if "sst_layer_fwd_kernel" in r["Kernel_Name"]]
+if lay_f:
+    window("encoder forward  ", lay_f[0], lay_f[-1])
 window("whole step       ", step[0], step[-1])
