@@ -1035,7 +1035,10 @@ extern "C" int geomae_pretrain_set_mask(void* engine, const int32_t* ids_keep, i
     ENG_CALL(check_launch("token_rows_from_ids_kernel"));
     b.n_keep = num_keep;
     b.n_mask = num_mask;
-    b.mask_injected = true;              // (host_maxkeep describes the drawn mask, not this one)
+    // the fullest windows of THIS mask (the drawn mask's numbers no longer apply): counted again, read back before the step
+    ENG_CALL(window_max_keep(b.ids_keep, b.counts, b.voxel_coors, e->cfg.batch_size, &e->cfg.window, b.host_maxkeep, stream));
+    GEOMAE_HIP(hipEventRecord(b.readback2, stream));
+    b.mask_injected = false;
     // the step's side streams read the mask: order them behind this stream
     GEOMAE_HIP(hipEventRecord(e->ev[kFirstMain], stream));
     GEOMAE_HIP(hipStreamWaitEvent(e->geo, e->ev[kFirstMain], 0));

@@ -136,7 +136,14 @@ def test_engine_step_matches_reference_at_full_size(golden_dir, case):
     assert [f.shape[0] for f in frames] == list(K("n_points"))
     model = _model(GEOM_WAYMO if case == "c4" else None)
     losses, tr, eng = _engine_step(model, frames, K("ids_keep"), K("ids_mask"))
-    assert eng.last_sizes()["V"] == int(K("V"))
+    sz = eng.last_sizes()
+    assert sz["V"] == int(K("V"))
+    # which form the encoder took (round 5): the reference's mask is recounted by geomae_pretrain_set_mask; without a window that
+    # kept more than 64 pillars the encoder's layers are ONE launch each, forward and backward -- at config 2 (the benchmarked
+    # case, <= 12288 kept pillars) that is the form this comparison pins to the reference
+    print(f"\n{case}: fullest windows {sz['max_window_keep']}, layouts with large bundles {sz['big_bundle_layouts']}", flush=True)
+    if case == "c2":
+        assert sz["big_bundle_layouts"] == 0 and max(sz["max_window_keep"]) <= 64, sz
     ref = dict(zip([str(n) for n in K("loss_names")], [float(v) for v in K("loss_vals")]))
     gn = dict(zip([str(n) for n in K("grad_names")], [float(v) for v in K("grad_norms")]))
     _compare(case, model, losses, ref, gn, [(k, n, K(k)) for k, n in BIG_FULL], TOL_BIG)
