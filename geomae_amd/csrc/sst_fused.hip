@@ -692,6 +692,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
     const LayerW& W = A.W;
     const int perm_b = 2 * (32 * (w >> 1) + 8 * g + 4 * (w & 1));
 
+    FUSED_STAMP(0);
     // ---- plan records, then everything that hangs on the token ids
     int tok[NT];
     FOR_TILES(it) {
@@ -733,7 +734,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
         const float b = rows4_sum((d[it][0] * x[0] + d[it][1] * x[1]) + (d[it][2] * x[2] + d[it][3] * x[3]));
         if (g == 0) *reinterpret_cast<float2*>(red + (16 * it + t) * 16 + 2 * w) = make_float2(a, b);
     }
+    FUSED_STAMP(1);
     __syncthreads();                                                                           // (1) LN2 sums
+    FUSED_STAMP(2);
     FOR_TILES(it) {
         f32x4 a4[4];
 #pragma unroll
@@ -758,17 +761,20 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
     {   // dv operand of dW2 + LayerNorm-2 parameter gradients
         const __amdgpu_buffer_rsrc_t dvr = whole_rsrc(A.dv);
         FOR_TILES(it) buf_store_b64(dvr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor, pack4(d[it]));
-        // (parked in LDS -- this wave owns these channels -- and flushed once per workgroup at the end of the kernel: issued
-        //  here, ~170 workgroups x 64 atomics on the same few cache lines sit in front of every later load of the wave)
+        // (parked in LDS -- ds_add_f32 without a return: no round trip -- and flushed once per workgroup at the end of the
+        //  kernel: issued to memory here, ~170 workgroups x 64 atomics on the same few cache lines sit in front of every later
+        //  load of the wave; as a read-modify-write of LDS they were 8 dependent round trips, ~2 k cycles per LayerNorm)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
-            if (t == 0) { pgrad[0 * 128 + 16 * w + 4 * g + r] += sg; pgrad[1 * 128 + 16 * w + 4 * g + r] += sb; }
+            if (t == 0) { atomicAdd(&pgrad[0 * 128 + 16 * w + 4 * g + r], sg); atomicAdd(&pgrad[1 * 128 + 16 * w + 4 * g + r], sb); }
         }
     }
     uint4 w1[8];
     load_wfrag<256>(W.frag + kOffW1T, w, lane, w1);
+    FUSED_STAMP(3);
     __syncthreads();                                                                           // (2) d(y + f) rows in LDS
+    FUSED_STAMP(4);
 
     uint4 wo[4];
     load_wfrag<128>(W.frag + kOffWoT, w, lane, wo);                  // (first use behind the next barrier; ahead of this phase's stores)
@@ -796,7 +802,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             buf_store_b64(hr, o2 + 512, pack4(vb));
         }
     }
+    FUSED_STAMP(5);
     __syncthreads();                                                                           // (3) dhp rows in LDS
+    FUSED_STAMP(6);
 
     // ---- dy = d(y + f) + dhp W1 (channel tile w); LayerNorm-1 backward
     pg = f32x4{0.f, 0.f, 0.f, 0.f}; pb = pg;
@@ -828,7 +836,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             lse[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lr, tok[it] >= 0 ? (tok[it] * 8 + w) * 4 : kFOor, 0, 0));
         }
     }
+    FUSED_STAMP(7);
     __syncthreads();                                                                           // (4) LN1 sums
+    FUSED_STAMP(8);
     FOR_TILES(it) {
         f32x4 a4[4];
 #pragma unroll
@@ -844,10 +854,12 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float sg = row16_sum(pg[r]), sb = row16_sum(pb[r]);
-            if (t == 0) { pgrad[2 * 128 + 16 * w + 4 * g + r] += sg; pgrad[3 * 128 + 16 * w + 4 * g + r] += sb; }
+            if (t == 0) { atomicAdd(&pgrad[2 * 128 + 16 * w + 4 * g + r], sg); atomicAdd(&pgrad[3 * 128 + 16 * w + 4 * g + r], sb); }
         }
     }
+    FUSED_STAMP(9);
     __syncthreads();                                                                           // (5) du rows in LDS
+    FUSED_STAMP(10);
 
     // ---- dO of head w = du Wo (channel tile w), then the attention backward of head w inside this wave
     uint2 dof[NT];
@@ -869,6 +881,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    FUSED_STAMP(11);
     const float scale = 0.25f;
     uint2 dqb[NT], dkb[NT], dvb[NT];
     // pass 1, dQ: lane = query i (column), rows = keys 4g + r of tile jt
@@ -894,6 +907,9 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
         dqb[it] = pack4(dq);
         __builtin_amdgcn_sched_barrier(0);                               // (keeps the next tile's LDS reads from piling up: NT = 4 spilled)
     }
+    FUSED_STAMP(12);
+    uint4 wqk[8], wv[4];                                             // the in-projection's weights: in flight under pass 2
+    load_wfrag<256>(W.frag + kOffWqkT, w, lane, wqk);
     // pass 2, dK and dV: lane = key j (column), rows = queries 4g + r of tile it
     FOR_TILES(jt) {
         const int wk = wl[16 * jt + t];
@@ -921,8 +937,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
         dvb[jt] = pack4(dv);
         __builtin_amdgcn_sched_barrier(0);
     }
-    uint4 wqk[8], wv[4];                                             // (behind the attention: its operands are dead)
-    load_wfrag<256>(W.frag + kOffWqkT, w, lane, wqk);
+    FUSED_STAMP(13);
     load_wfrag<128>(W.frag + kOffWvT, w, lane, wv);
     __syncthreads();                                                                           // (6) du rows consumed by every wave
     {
@@ -939,6 +954,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
         }
     }
     __syncthreads();                                                                           // (7) dqkv rows in LDS
+    FUSED_STAMP(14);
 
     // ---- dx = du + dqk Wqk + dv Wv (channel tile w)
     {
@@ -965,6 +981,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             buf_store_f32x4(xr, off, a);
         }
     }
+    FUSED_STAMP(15);
 #undef FOR_TILES
 }
 
