@@ -678,7 +678,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         // the one-launch layer's second kernel): known since the batch's stage 1, a step ago
         int big = 3;
         static const bool skip_big = [] { const char* v = getenv("GEOMAE_FUSED_SKIP_BIG"); return !v || v[0] != '0'; }();
-        if (skip_big && !b.mask_injected && b.host_maxkeep) {
+        // (a bundle packs whole windows up to its cap: only with a cap of at most 64 positions does "no window above 64" mean "no
+        //  bundle above four tiles" -- the packing of token sets above 12288 and GEOMAE_BUNDLE_CAP use larger caps)
+        if (skip_big && !b.mask_injected && b.host_maxkeep && geomae_window_bundle_cap(nk, max_tokens) <= 64) {
             GEOMAE_HIP(hipEventSynchronize(b.readback2));            // (stage 1 of this batch ended during the previous step)
             big = (b.host_maxkeep[0] < 0 || b.host_maxkeep[0] > 64 ? 1 : 0) | (b.host_maxkeep[1] < 0 || b.host_maxkeep[1] > 64 ? 2 : 0);
         }

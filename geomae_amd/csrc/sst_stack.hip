@@ -54,7 +54,7 @@ static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 // three-launch form, with two workgroups per CU, moves more tokens per us (52 vs 72 us per layer), and so it does at the
 // decoders' sizes (tools/fused_layer_time.py).  Automatic = token sets of at most kFusedMaxTokens.
 static int g_fused_mode = [] { const char* e = getenv("GEOMAE_FUSED_LAYERS"); return e ? atoi(e) : 1; }();
-constexpr int kFusedMaxTokens = 12288;
+static const int kFusedMaxTokens = [] { const char* e = getenv("GEOMAE_FUSED_MAX_TOKENS"); return e ? atoi(e) : 12288; }();
 static bool fused_layers_enabled(int num_tokens) { return g_fused_mode == 2 || ((g_fused_mode == 1 || g_fused_mode == 3) && num_tokens <= kFusedMaxTokens); }
 // mode 3: as 1, but one launch per LAYER (never the persistent whole-stack launch): A/B runs
 
