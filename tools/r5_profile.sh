@@ -25,7 +25,7 @@ done
 if echo "$WLS" | grep -q nuscenes1; then
   python bench.py > /tmp/b.json 2> /tmp/b.err; cp /tmp/b.json gpurun_out/r05_bench.json
   python bench.py --gpus 1 --steps 20 --warmup 5 > /tmp/b.json 2>> /tmp/b.err; cp /tmp/b.json gpurun_out/r05_bench_driver_cmd.json
-  GEOMAE_FORCE_EXCHANGE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > /tmp/b.json 2>> /tmp/b.err; cp /tmp/b.json gpurun_out/r05_bench_nccl_w1.json
+  GEOMAE_FORCE_EXCHANGE=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline 2>> /tmp/b.err | grep "^{" | tail -1 > gpurun_out/r05_bench_nccl_w1.json
   bash tools/trace.sh r05 --steps 12 --warmup 6 --no-cpu-baseline > /dev/null
   python tools/timeline_digest.py gpurun_out/trace_r05/kernel_trace.csv +8 > gpurun_out/r05_step_timeline.txt 2>&1
   # HBM bytes per dispatch by kernel AND grid size (encoder- vs decoder-size launches), then the decoder-backward window of a
