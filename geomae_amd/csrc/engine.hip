@@ -727,9 +727,11 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(geomae_heads_weight_grad(nm, h_dl, h_cm, h_dm, &m.head_grads, geo));
     mark(e, pHeads, main);
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
-    // (GEOMAE_DEC_DW_EVERY=k: the decoders' contractions flushed to the geometry stream every k layers instead of behind the
-    //  whole stack -- A/B; default 0 = behind the stack)
-    static const int dec_every = [] { const char* v = getenv("GEOMAE_DEC_DW_EVERY"); return v ? atoi(v) : 0; }();
+    // The decoders' contractions go to the geometry stream every two layers while the frame is small enough for the 80-workgroup
+    // contraction budget (n <= 32768: 1.680 vs 1.689 ms at config 2, five alternated runs), and behind the whole stack above that
+    // (Waymo geometry 4.275 vs 4.247 ms with the flush, config 3 flat).  GEOMAE_DEC_DW_EVERY=k overrides (0 = behind the stack).
+    static const int dec_every_env = [] { const char* v = getenv("GEOMAE_DEC_DW_EVERY"); return v ? atoi(v) : -1; }();
+    const int dec_every = dec_every_env >= 0 ? dec_every_env : (n <= 32768 ? 2 : 0);
     struct MidFlushScopeD {
         explicit MidFlushScopeD(const DwMidFlush& f) { set_dw_mid_flush(f); }
         ~MidFlushScopeD() { set_dw_mid_flush(DwMidFlush()); }
