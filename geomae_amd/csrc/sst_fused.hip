@@ -190,6 +190,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
         const int idx = 16 * it + t;
         rec[it] = make_int4(-1, 0, -1 - idx, 0);
         if (idx < T) rec[it] = A.plan[s0 + idx];
+#ifdef FUSED_ABL_NO_PLAN             // (timing ablation: what the plan hop costs the chain -- records from arithmetic)
+        if (idx < T) rec[it] = make_int4(s0 + idx, idx, s0, s0 + T);
+#endif
     }
     const f32x4 prm_r = params_issue(W);
     uint4 wq[4], wk[4], wv[4], wo[4], w1a[4], w1b[4], w2[8];
@@ -215,6 +218,9 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             }
             xr[it] = (COH && A.coh_in) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 16)) : buf_load_f32x4(xres, off);
             pv[it] = buf_load_f32x4(pres, tk >= 0 ? rec[it].y * 512 + 64 * w + 16 * g : kFOor);
+#ifdef FUSED_ABL_NO_ROWS             // (timing ablation: the row hop)
+            xr[it] = f32x4{0.01f * off, 0.5f, -0.5f, 0.25f}; pv[it] = f32x4{0.f, 0.1f, 0.2f, 0.3f};
+#endif
         }
         // the in-projection's weights BEHIND the row loads: the rows (the longer dependent chain: plan -> row) are not
         // queued behind 96 KB of fragments, and the fragments land under the LDS writes and the barrier
@@ -464,8 +470,12 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFw
     // (bun_tok holds max_bundles + 1 >= gridDim.x + 1 words: read before the bundle count is known, one round trip less)
     const int NB = A.num_bundles[0];
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
+#ifdef FUSED_ABL_NO_BUNTOK           // (timing ablation: the bundle-table hop)
+        const int s0 = 40 * b, T = 40;
+#else
         const int s0 = A.bun_tok[b];
         const int T = A.bun_tok[b + 1] - s0;
+#endif
         const int nt = (T + 15) >> 4;
         switch (nt) {
             case 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;

@@ -47,21 +47,30 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         for (int64_t e = blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) aux[dst + e] = flat[src + e];
         return;
     }
-    // 32-bit index arithmetic (a matrix has at most 384 x 256 elements): the 64-bit division per element was most of
-    // this kernel's 20 us, which it spends beside the next step's first (latency-bound) kernels
+    // One thread = 8 consecutive positions of one output row = ONE 16-byte store (K is a multiple of 32; in the fragment-major
+    // form the 8 positions of a lane are contiguous too).  Round 4's form -- one 2-byte store per thread, scattered for the
+    // transposed and the fragment-major copies -- showed as 110 MB of write traffic per step for 30 MB of copies.  32-bit
+    // index arithmetic (a matrix has at most 384 x 256 elements).
     const bool tp = tr & 1, frag = tr & 4;
-    const int K = (int)(tp ? rows : cols), C = (int)cols, T = (int)total;
+    const int K = (int)(tp ? rows : cols), C = (int)cols, T8 = (int)(total >> 3);
     const float* __restrict__ w = flat + src;
     bf16_t* __restrict__ out = packed + dst;
-    for (int e = blockIdx.x * 256 + threadIdx.x; e < T; e += gridDim.x * 256) {
+    for (int e8 = blockIdx.x * 256 + threadIdx.x; e8 < T8; e8 += gridDim.x * 256) {
+        const int e = e8 * 8;
         const int r = e / K;
         const int p = e - r * K;
-        const int k = kperm(p);
-        const float v = tp ? w[k * C + r] : w[r * C + k];
+        unsigned int q[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k0 = kperm(p + 2 * i), k1 = kperm(p + 2 * i + 1);
+            const float v0 = tp ? w[k0 * C + r] : w[r * C + k0];
+            const float v1 = tp ? w[k1 * C + r] : w[r * C + k1];
+            q[i] = (unsigned int)f2bf_bits(v0) | ((unsigned int)f2bf_bits(v1) << 16);
+        }
         // fragment-major (tr & 4; the one-launch layer kernels, sst_fused.hip): the 16 rows x 32 positions that one MFMA A
         // fragment of 64 lanes covers are one contiguous 1-KB piece [out tile][k step][lane = 16 g + row][8 positions]
-        const int d = frag ? ((r >> 4) * (K >> 5) + (p >> 5)) * 512 + ((((p >> 3) & 3) << 4) + (r & 15)) * 8 + (p & 7) : e;
-        out[d] = (bf16_t)f2bf_bits(v);
+        const int d = frag ? ((r >> 4) * (K >> 5) + (p >> 5)) * 512 + ((((p >> 3) & 3) << 4) + (r & 15)) * 8 : e;
+        *reinterpret_cast<uint4*>(out + d) = make_uint4(q[0], q[1], q[2], q[3]);
     }
 }
 
@@ -1058,8 +1067,9 @@ extern "C" int geomae_pack_weights(const float* flat_params, const int64_t* desc
                                    int64_t max_elems, void* packed_bf16, float* aux_f32, hipStream_t stream) {
     if (num_desc <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(desc && packed_bf16 && max_elems > 0 && max_elems < (1ll << 30), "pack_weights: bad argument");
-    int gx = (int)((max_elems + 255) / 256);
+    int gx = (int)((max_elems / 8 + 255) / 256);          // a thread packs 8 elements
     if (gx > 128) gx = 128;
+    if (gx < 1) gx = 1;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(gx, num_desc), dim3(256), 0, stream, flat_params, desc,
                        (bf16_t*)packed_bf16, aux_f32);
     return check_launch("pack_weights_kernel");

@@ -1353,3 +1353,34 @@ def test_fused_heads_loss_matches_prediction_path(dev, golden_dir):
         if r > 3e-2:
             bad[k] = r
     assert not bad, bad
+
+
+def test_pack_weights_layouts_bit_exact(dev):
+    """geomae_pack_weights against the layouts include/geomae_hip.h documents, restated in numpy: row-major K-permuted, its
+    transposed form, and the fragment-major form of both (every copy is written with 16-byte stores, 8 positions a thread)."""
+    from geomae_amd import ops
+    rng = np.random.default_rng(5)
+    mats = [(384, 128), (128, 256), (256, 128), (128, 128)]
+    srcs = [torch.as_tensor(rng.standard_normal(s).astype(np.float32), device=dev) for s in mats]
+    perm = lambda p: (p & ~31) + 16 * ((p >> 2) & 1) + 4 * ((p >> 3) & 3) + (p & 3)
+    desc, off, want = [], 0, []
+    for w, (r, c) in zip(srcs, mats):
+        for mode in (0, 1, 4, 5):
+            desc.append([w.data_ptr() // 4, r, c, mode, off])
+            W = w.cpu().numpy()
+            M = W.T if mode & 1 else W                        # [R][K]: dst[j][p] = M[j][perm(p)]
+            R, K = M.shape
+            rows = M[:, perm(np.arange(K))]
+            if mode & 4:
+                out = np.empty(R * K, np.float32)
+                rr, pp = np.meshgrid(np.arange(R), np.arange(K), indexing="ij")
+                d = ((rr >> 4) * (K >> 5) + (pp >> 5)) * 512 + ((((pp >> 3) & 3) << 4) + (rr & 15)) * 8 + (pp & 7)
+                out[d.ravel()] = rows.ravel()
+            else:
+                out = rows.ravel()
+            want.append(torch.as_tensor(out).to(torch.bfloat16))
+            off += r * c
+    packed = torch.full((off,), float("nan"), dtype=torch.bfloat16, device=dev)
+    ops.pack_weights(torch.tensor(desc, dtype=torch.int64, device=dev), len(desc), 384 * 256, packed)
+    got = packed.cpu().view(torch.int16)
+    assert torch.equal(got, torch.cat(want).view(torch.int16))
