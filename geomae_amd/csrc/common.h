@@ -65,6 +65,11 @@ int first_live_row();
 // the first kernel's outputs.  One-shot: taken (and cleared) by the callee.
 void set_mid_launch_event(hipEvent_t ev);
 hipEvent_t take_mid_launch_event();
+// ... and a stream that the launches BEHIND that event move to (it waits for the event first): the callee's remaining kernels
+// leave the caller's stream, which goes on with what needs only the first kernel's outputs.  One-shot as the event; ignored
+// without one.
+void set_mid_launch_side(hipStream_t side);
+hipStream_t take_mid_launch_side();
 // which variant of a layer kernel the last launch on this thread used (0 = plain; 1 = sst_ffn_fwd_pair_kernel /
 // sst_ffn_bwd_dw_kernel): the stack's per-kernel timer (bench.py's roofline) keeps a launch's events only if it was the
 // kernel asked for, so that its averages are those of ONE kernel of the rocprofv3 table

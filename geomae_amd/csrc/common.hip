@@ -34,6 +34,9 @@ int first_live_row() { return g_first_live_row; }
 static thread_local hipEvent_t g_mid_launch_event = nullptr;
 void set_mid_launch_event(hipEvent_t ev) { g_mid_launch_event = ev; }
 hipEvent_t take_mid_launch_event() { hipEvent_t ev = g_mid_launch_event; g_mid_launch_event = nullptr; return ev; }
+static thread_local hipStream_t g_mid_launch_side = nullptr;
+void set_mid_launch_side(hipStream_t side) { g_mid_launch_side = side; }
+hipStream_t take_mid_launch_side() { hipStream_t s = g_mid_launch_side; g_mid_launch_side = nullptr; return s; }
 static thread_local int g_last_kernel_variant = 0;
 void set_last_kernel_variant(int v) { g_last_kernel_variant = v; }
 int last_kernel_variant() { return g_last_kernel_variant; }

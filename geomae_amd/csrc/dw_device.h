@@ -317,4 +317,51 @@ __global__ __launch_bounds__(256) void dw_layer_reduce_kernel(DlReduce R) {
     dl_reduce(R, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
+// A SPLIT job's reduction (one [128 x 128] product, up to 96 chunks x 2 halves per slot): with one slot per thread the sum
+// was 6 dependent rounds of 32 loads in 4096 threads = 13 us on the step's tail (the VFE's layer-1 weight gradient is the
+// last contraction of a step).  Two levels instead: a workgroup = 16 slots x 16 groups, thread (slot, k) sums chunks k, k + 16,
+// ... (both halves) -- at most 12 loads, all in flight --, the groups meet in LDS and are added in group order: the result
+// still does not depend on arrival order.  256 workgroups.
+__global__ __launch_bounds__(256) void dw_split_reduce_kernel(DlReduce R) {
+    __shared__ f32x4 red[16][16];
+    const int sl = threadIdx.x & 15, k = threadIdx.x >> 4;
+    const int sa = blockIdx.x * 16 + sl;                      // active slot 0..4095: (tile, thread of the first half)
+    const int tile = sa >> 8, th = sa & 255;
+    const int q = tile * kDlThreads + th;
+    const float* p = R.partial + 4 * q;
+    f32x4 v[2 * (kDlMaxChunks / 16)];
+#pragma unroll
+    for (int i = 0; i < kDlMaxChunks / 16; ++i) {
+        const int u = k + 16 * i;
+        v[2 * i] = v[2 * i + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (u < R.G) {
+            v[2 * i] = *reinterpret_cast<const f32x4*>(p + (size_t)u * kDlPartialFloats);
+            v[2 * i + 1] = *reinterpret_cast<const f32x4*>(p + (size_t)u * kDlPartialFloats + 4 * 256);
+        }
+    }
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 2 * (kDlMaxChunks / 16); ++i) s += v[i];
+    red[k][sl] = s;
+    __syncthreads();
+    if (k == 0) {
+        const int a = tile >> 2, b = tile & 3, w = th >> 6, lane = th & 63, g = lane >> 4, o = lane & 15;
+        int half, wr, wc;
+        dl_wave_role(kDlSplit, w, &half, &wr, &wc);
+        const DlOut& O = R.job[0].out[0];
+        float* c0 = O.C + (int64_t)(64 * wr + 16 * a + 4 * g) * O.ldc + 64 * wc + 16 * b + o;
+        f32x4 t = red[0][sl];
+#pragma unroll
+        for (int j = 1; j < 16; ++j) t += red[j][sl];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c0[(int64_t)r * O.ldc] += t[r];
+    }
+    if (R.job[0].out[0].dbias && blockIdx.x == 0 && threadIdx.x < 128) {      // column sums of the A operand
+        const float* pb = R.partial + kDlTileSlots * 4 + threadIdx.x;
+        float sb = 0.f;
+        for (int u = 0; u < R.G; ++u) sb += pb[(size_t)u * kDlPartialFloats];
+        R.job[0].out[0].dbias[threadIdx.x] += sb;
+    }
+}
+
 }  // namespace geomae

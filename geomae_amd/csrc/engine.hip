@@ -105,7 +105,7 @@ struct WinLayout {
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
-          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kEncMid, kDecMidA, kDecMidB, kNumEv };
+          kPacked, kFirstMain, kNextReady, kMoments0, kMoments1, kZeroLate, kEncMid, kDecMidA, kDecMidB, kVfeSide, kNumEv };
 enum Phase { pStart, pVfeFwd, pLayouts, pEncFwd, pDecFwd, pHeads, pDecBwd, pEncBwd, pVfeStats, pVfeL1, pVfeL0, pVfeBwd, pOpt, kNumPhase };
 
 struct Engine {
@@ -804,21 +804,32 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD1, main);
         n_eff = (float)((double)c.world_size * (double)N);
     }
-    // (the event sits between the layer-1 sweep and the routing sweep: the layer-1 weight-gradient contraction needs
-    //  only dy1 / g and runs on the geometry stream BESIDE the routing sweep -- recorded behind both, its 30 us were what
-    //  the main stream waited for at the end of the backward)
+    // The step's tail.  Behind the layer-1 sweep two branches remain: the layer-1 weight-gradient contraction (needs dy1 / g:
+    // a SPLIT job + its reduction, ~17 + 5 us) and the routing sweep + layer-0 finalize (~22 + 5 us).  Three placements
+    // measured (same box, alternating, ms per step): contraction on the geometry stream beside the routing sweep 1.690 (kept);
+    // everything in line on the main stream 1.696 (GEOMAE_VFE_TAIL=main); contraction on the main stream and the routing sweep
+    // + finalize on the decoder-B stream, idle at that point, 1.695 (GEOMAE_VFE_TAIL=side; single-rank BatchNorm only).  An
+    // event hop between two streams costs 8-15 us on this stack (the kernel trace shows the waiting queue starting that late):
+    // a branch moved to another stream pays two of them, about what running it in line costs.
+    static const int tail_mode = [] {
+        const char* v = getenv("GEOMAE_VFE_TAIL");
+        if (v && !strcmp(v, "main")) return 1;
+        if (v && !strcmp(v, "side")) return 2;
+        if (const char* o = getenv("GEOMAE_VFE_DW1_MAIN")) return o[0] == '1' ? 1 : 0;      // (older spelling)
+        return 0;
+    }();
+    const int tail = (tail_mode == 2 && !fold) ? 0 : tail_mode;
     set_mid_launch_event(e->ev[kVfeL1]);
+    if (tail == 2) set_mid_launch_side(aux);
     const int rc_l1 = geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, nullptr, dh0, dm0, use_bs0,
                                                  fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main);
-    (void)take_mid_launch_event();                       // (an early error return leaves it set)
+    (void)take_mid_launch_event();                       // (an early error return leaves them set)
+    (void)take_mid_launch_side();
     ENG_CALL(rc_l1);
     mark(e, pVfeL1, main);
-    // one [128,128] output contracted over all N points: through the split-K workspace + a reduction launch (round 5: a SPLIT
-    // job of the layer-form contraction, 29 us with its reduction at 106 k points).  GEOMAE_VFE_DW1_MAIN=1: on the main stream,
-    // in line behind the layer-1 sweep (A/B).
-    static const bool dw1_on_main = [] { const char* v = getenv("GEOMAE_VFE_DW1_MAIN"); return v && v[0] == '1'; }();
-    hipStream_t dw1_stream = dw1_on_main ? main : geo;
-    if (!dw1_on_main) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
+    // one [128,128] output contracted over all N points: through the split-K workspace + a reduction launch
+    hipStream_t dw1_stream = tail == 0 ? geo : main;
+    if (tail == 0) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
     set_dw_partial(dw1_partial);
     int rc_dw1 = geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, dw1_stream);
     set_dw_partial(nullptr);
@@ -828,8 +839,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         ENG_CALL(geomae_bn_param_grad_add(use_bs0, 64, m.bn_dbeta[0], m.bn_dgamma[0], main));
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD0, main);
     }
+    hipStream_t l0_stream = tail == 2 ? aux : main;
     ENG_CALL(geomae_vfe_backward_layer0(&va, &bn, dh0, use_bs0, n_eff, N, dy1_b, g_b, m.vfe_dw0, nullptr,
-                                        fold ? m.bn_dbeta[0] : nullptr, fold ? m.bn_dgamma[0] : nullptr, main));
+                                        fold ? m.bn_dbeta[0] : nullptr, fold ? m.bn_dgamma[0] : nullptr, l0_stream));
+    if (tail == 2) ENG_CALL(order_after(e, kVfeSide, aux, main));
     mark(e, pVfeL0, main);
     ENG_CALL(order_after(e, kGeoDone, geo, main));
     mark(e, pVfeBwd, main);

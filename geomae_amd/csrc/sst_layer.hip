@@ -1432,8 +1432,13 @@ int geomae::launch_dw_split(const bf16_t* A, const bf16_t* B, int n, float* C, f
     DlReduce R;
     R.partial = partial; R.njobs = 1; R.G = G;
     R.job[0].kind = kDlSplit; R.job[0].pad_ = 0; R.job[0].out[0] = S.job[0].out[0]; R.job[0].out[1] = S.job[0].out[1];
-    hipLaunchKernelGGL(dw_layer_reduce_kernel, dim3(cdiv(kDlTileSlots, 256)), dim3(256), 0, stream, R);
-    return check_launch("dw_layer_reduce_kernel");
+    static const bool two_level = [] { const char* v = getenv("GEOMAE_DW_SPLIT_REDUCE"); return !v || v[0] != '0'; }();   // (0: A/B)
+    if (!two_level) {
+        hipLaunchKernelGGL(dw_layer_reduce_kernel, dim3(cdiv(kDlTileSlots, 256)), dim3(256), 0, stream, R);
+        return check_launch("dw_layer_reduce_kernel");
+    }
+    hipLaunchKernelGGL(dw_split_reduce_kernel, dim3(kDlTileSlots / 2 / 16), dim3(256), 0, stream, R);
+    return check_launch("dw_split_reduce_kernel");
 }
 
 int geomae::launch_dw(const DwTasks& T, int num_tasks, int num_tokens, hipStream_t stream) {

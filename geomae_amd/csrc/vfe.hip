@@ -1759,8 +1759,13 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
     hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
                        bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0, d_beta1, d_gamma1);
     hipEvent_t mid = take_mid_launch_event();          // dy1 / g are complete here: the caller's dW1 contraction may start
+    hipStream_t side = take_mid_launch_side();         // ... and the routing sweep may leave the caller's stream
     if ((rc = check_launch("vfe_bwd_layer1_kernel"))) return rc;
     if (mid) GEOMAE_HIP(hipEventRecord(mid, stream));
+    if (mid && side) {
+        GEOMAE_HIP(hipStreamWaitEvent(side, mid, 0));
+        stream = side;
+    }
     if (a->moments && a->dw0_acc) {
         GEOMAE_ZERO(a->dw0_acc, 64 * 16 * sizeof(float), stream);
         hipLaunchKernelGGL(vfe_bwd_route0_kernel<true>, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, bn0, (const float*)dm0,
