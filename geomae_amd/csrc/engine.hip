@@ -7,12 +7,14 @@
 // anything slower (round-1 driver run: 3.6 ms/step with identical kernel durations).
 //
 // Streams (the caller's `stream` = main, plus the two side streams given at creation):
-//   main     zero arena -> VFE forward -> [wait layouts] -> encoder -> decoder A -> [join B] -> heads+loss ->
-//            decoder A backward -> [join B] -> encoder backward -> VFE backward -> [join geometry] -> clip + AdamW
-//   geometry token coordinates -> four window layouts; later the weight-gradient contractions that only the optimizer
-//            reads (heads, layer 0 of the three stacks, VFE layer 1) and, at world > 1, the gradient-exchange hooks
-//   dec_b    zero arena of everything later -> NEXT batch's stage 1 -> geometric targets -> decoder B forward /
-//            backward -> (after the optimizer) bf16 re-pack of the updated weights
+//   main     zero arena -> VFE forward -> [wait layouts] -> encoder -> decoder A -> its heads + losses -> decoder A backward ->
+//            [join B] -> encoder backward -> VFE backward -> [join geometry] -> clip + AdamW
+//   geometry zero arena of everything behind the VFE forward -> token coordinates -> four window layouts; later every
+//            weight-gradient contraction (heads, the three stacks, VFE layer 1) and, at world > 1, the gradient-exchange hooks
+//   dec_b    geometric targets -> NEXT batch's stage 1 -> [fork behind the encoder] decoder B forward -> its head + loss ->
+//            decoder B backward -> (after the optimizer) bf16 re-pack of the updated weights
+// Every wait of the main stream on another stream's event puts a barrier packet into its queue: 6-8 us even when the event
+// completed long ago (the neighbouring kernels no longer overlap) -- three are left per step.
 #include "common.h"
 #include "../../include/geomae_hip.h"
 #include <chrono>
@@ -582,6 +584,17 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     e->packed_fresh = false;
     const int64_t win_tables = geomae_window_build_batch_table_bytes(ns, 4, c.batch_size, &c.window);
     GEOMAE_REQUIRE(win_tables >= 0 && win_tables <= win_wsb, "pretrain_step: bad window table size");
+    // The zero arena of everything behind the VFE forward (gradient rows of the decoders' outputs, BatchNorm backward sums, the
+    // losses) is filled HERE, on the geometry stream, in front of the layouts: the main stream's wait for the layouts covers
+    // it, and the decoder-B stream forks from the main stream behind that wait.  (Until round 5 the decoder-B stream filled it
+    // behind the VFE forward: one more event for the main stream to wait on in front of the heads -- a satisfied wait still
+    // costs the queue a barrier packet, ~6-8 us with the lost overlap of the neighbouring kernels -- and one for dec_b.)
+    // GEOMAE_ZERO_LATE=aux: the earlier placement (A/B).
+    static const bool zero_on_aux = [] { const char* v = getenv("GEOMAE_ZERO_LATE"); return v && !strcmp(v, "aux"); }();
+    if (!zero_on_aux) {
+        ENG_CALL(zero_arena(zl0, zl_bytes, geo));
+        ENG_CALL(zero_arena(losses, 32, geo));
+    }
     ENG_CALL(geomae_gather_token_coors_zero(b.ids_keep, nk, b.ids_mask, nm, b.voxel_coors, coors_all, nullptr, win_ws,
                                             win_tables, geo));
     {
@@ -662,12 +675,12 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         ENG_CALL(geomae_vfe_layer1(&va, m0, vf, main));
     }
     mark(e, pVfeFwd, main);
-    ENG_CALL(order_after(e, kVfeDone, main, aux));
-
-    // ---------------- dec_b: late zero arena (its other work of the step started before the VFE forward, above)
-    ENG_CALL(zero_arena(zl0, zl_bytes, aux));
-    ENG_CALL(zero_arena(losses, 32, aux));
-    GEOMAE_HIP(hipEventRecord(e->ev[kZeroLate], aux));
+    if (zero_on_aux) {
+        ENG_CALL(order_after(e, kVfeDone, main, aux));
+        ENG_CALL(zero_arena(zl0, zl_bytes, aux));
+        ENG_CALL(zero_arena(losses, 32, aux));
+        GEOMAE_HIP(hipEventRecord(e->ev[kZeroLate], aux));
+    }
     const int nxt = 1 - e->pending;
 
     // ---------------- main: encoder, decoders
@@ -714,8 +727,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         ENG_CALL(order_after(e, kHeads, main, geo));
         GEOMAE_HIP(hipStreamWaitEvent(aux, e->ev[kHeads], 0));
     } else {
-        // (d_cen / d_cen2 / losses were zeroed on the decoder-B stream, long ago: one already-complete event to wait for)
-        GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kZeroLate], 0));
+        // (d_cen / d_cen2 / d_den / losses were zeroed on the geometry stream in front of the layouts: both streams are behind them)
+        if (zero_on_aux) GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[kZeroLate], 0));
         ENG_CALL(geomae_heads_loss_centroid_accumulate(cen, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed, t_mmed,
                                                        t_ctop, t_occ, c.loss_weights, losses, d_cen, d_cen2, h_dl, h_cm, main));
         ENG_CALL(geomae_heads_loss_density_accumulate(den, nk, nm, m.head_w_packed, m.head_bias, t_normal, c.loss_weights,
