@@ -211,6 +211,8 @@ SIGNATURES = {
                                                  P, c_int32, P, c_int32, c_int32, P, P]),
     "geomae_flush_weight_grad": (ctypes.c_int, [P]),
     "geomae_vfe_weight_grad1": (ctypes.c_int, [P, P, c_int64, P, P]),
+    "geomae_vfe_weight_grad1_workspace_bytes": (c_int64, []),
+    "geomae_vfe_weight_grad1_ws": (ctypes.c_int, [P, P, c_int64, P, P, c_int64, P]),
     "geomae_window_rank": (ctypes.c_int, [P, P, P, c_int64, P, P, P]),
     "geomae_rows_scatter": (ctypes.c_int, [P, P, c_int64, c_int32, P, P]),
     "geomae_rows_gather": (ctypes.c_int, [P, P, c_int64, c_int32, P, P]),

@@ -1816,3 +1816,18 @@ extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16,
         return launch_dw_split((const bf16_t*)dy1_bf16, (const bf16_t*)g_bf16, (int)num_points, dw1, T.partial, stream);
     return launch_dw(T, 1, (int)num_points, stream);
 }
+
+extern "C" int64_t geomae_vfe_weight_grad1_workspace_bytes(void) { return 2 * kDwPartialBytes; }
+
+extern "C" int geomae_vfe_weight_grad1_ws(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1,
+                                          void* workspace, int64_t workspace_bytes, hipStream_t stream) {
+    if (num_points <= 0) return GEOMAE_OK;
+    GEOMAE_REQUIRE(dy1_bf16 && g_bf16 && dw1 && workspace, "vfe_weight_grad1_ws: null argument");
+    GEOMAE_REQUIRE(num_points < (1ll << 31) - 64, "vfe_weight_grad1_ws: too many points");
+    if (workspace_bytes < 2 * kDwPartialBytes) {
+        set_error("vfe_weight_grad1_ws: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)(2 * kDwPartialBytes));
+        return GEOMAE_ERR_WORKSPACE;
+    }
+    return launch_dw_split((const bf16_t*)dy1_bf16, (const bf16_t*)g_bf16, (int)num_points, dw1, (float*)workspace, stream);
+}
+

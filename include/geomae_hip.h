@@ -504,6 +504,14 @@ int geomae_vfe_backward_layer0(const GeomaeVfeArgs* args, const GeomaeBnState* b
  * the layer-0 backward (it is read only by the optimizer). */
 int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1 /*[128,128] +=*/,
                             geomaeStream_t stream);
+/* The same product through a caller's split-K workspace (what the step engine runs): up to 96 workgroups each contract a
+ * chunk of the points (operand slabs global -> LDS by buffer_load ... lds, csrc/dw_device.h SPLIT job) and leave fp32
+ * partials in `workspace`; a second launch sums them in a fixed order and adds the sum to dw1 -- no atomics, the result does
+ * not depend on arrival order.  workspace_bytes >= geomae_vfe_weight_grad1_workspace_bytes(); rows of dy1 / g past
+ * num_points (the last 16-point block's padding) may hold anything. */
+int64_t geomae_vfe_weight_grad1_workspace_bytes(void);
+int geomae_vfe_weight_grad1_ws(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1 /*[128,128] +=*/,
+                               void* workspace, int64_t workspace_bytes, geomaeStream_t stream);
 /* d_beta / d_gamma (both or neither): single-process callers let the kernels add bsums (= d beta, d gamma) to the
  * BatchNorm parameter gradients; with naiveSyncBN1d the caller adds the LOCAL sums itself before all-reducing them. */
 

@@ -1384,3 +1384,45 @@ def test_pack_weights_layouts_bit_exact(dev):
     ops.pack_weights(torch.tensor(desc, dtype=torch.int64, device=dev), len(desc), 384 * 256, packed)
     got = packed.cpu().view(torch.int16)
     assert torch.equal(got, torch.cat(want).view(torch.int16))
+
+
+@pytest.mark.parametrize("N", [1, 63, 64, 1000, 103457])
+def test_vfe_weight_grad1_workspace_form(dev, N):
+    """dW1 += dy1^T g through the caller's split-K workspace (the step engine's form: a SPLIT job of the layer-form contraction
+    + the two-level reduction) against a float64 product of the same bf16 operands: ragged point counts, NaN in the padding
+    rows of the last 16-point block, accumulation into dw1, and bit-identical results from run to run (no atomics)."""
+    from geomae_amd import _lib
+    lib = _lib.load()
+    g_ = torch.Generator(device="cpu").manual_seed(N)
+    Np = (N + 15) // 16 * 16
+
+    def blocked(x):                                # row-major [N,128] bf16 -> [Np/16][8][16][16], padding rows NaN
+        full = torch.full((Np, 128), float("nan"), dtype=torch.bfloat16)
+        full[:N] = x
+        return full.view(Np // 16, 16, 8, 16).permute(0, 2, 1, 3).contiguous().to(dev)
+
+    dy = torch.randn(N, 128, generator=g_).to(torch.bfloat16)
+    gi = torch.randn(N, 128, generator=g_).to(torch.bfloat16)
+    dy_b, g_b = blocked(dy), blocked(gi)
+    want = dy.double().T @ gi.double()
+    wsb = lib.geomae_vfe_weight_grad1_workspace_bytes()
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = []
+    for rep in range(2):
+        dw = torch.ones(128, 128, device=dev)      # += : starts from ones
+        for _ in range(2):
+            rc = lib.geomae_vfe_weight_grad1_ws(ctypes.c_void_p(dy_b.data_ptr()), ctypes.c_void_p(g_b.data_ptr()), N,
+                                                ctypes.c_void_p(dw.data_ptr()), ctypes.c_void_p(ws.data_ptr()), wsb, stream)
+            assert rc == 0, lib.geomae_last_error()
+        torch.cuda.synchronize()
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+    got = (outs[0].double() - 1.0) / 2.0
+    assert torch.isfinite(got).all()
+    scale = max(1.0, want.abs().max().item())
+    assert (got - want).abs().max().item() <= 2e-5 * scale, (got - want).abs().max().item() / scale
+    # a workspace that is too small is refused
+    rc = lib.geomae_vfe_weight_grad1_ws(ctypes.c_void_p(dy_b.data_ptr()), ctypes.c_void_p(g_b.data_ptr()), N,
+                                        ctypes.c_void_p(outs[0].data_ptr()), ctypes.c_void_p(ws.data_ptr()), 1024, stream)
+    assert rc != 0
