@@ -1380,7 +1380,11 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     // (round 5, with the one-launch encoder backward: its ~165 workgroups hold a CU each too, and 165 + 96 > 256 sent some of
     //  them to a second round -- 80 workgroups at the sizes where that kernel runs beside these launches: config 2
     //  1.735 / 1.700 / 1.71 / 1.81 ms at 96 / 80 / 64 / 48)
-    int G = (A.n <= 32768 ? 80 : 96) / A.njobs;
+    // (GEOMAE_DW_BUDGET_MID=w: the budget of launches of 12289-32768 tokens -- config 2's decoders, which run beside the OTHER
+    //  decoder's backward, not beside the one-launch encoder kernels -- A/B)
+    static const int mid_env = [] { const char* e = getenv("GEOMAE_DW_BUDGET_MID"); return e ? atoi(e) : 0; }();
+    const int budget = A.n <= 12288 ? 80 : A.n <= 32768 ? (mid_env > 0 ? mid_env : 80) : 96;
+    int G = budget / A.njobs;
     if (G > 24) G = 24;
     if (g_env > 0) G = g_env;
     const int by_tokens = cdiv(A.n, 2 * kDlSlabTok);                   // at least two slabs per workgroup
