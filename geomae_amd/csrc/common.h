@@ -124,7 +124,10 @@ void set_defer_all_weight_grads(bool on);
 // wait for it and launches the contractions queued so far there (geomae_flush_weight_grad(side)) -- the caller flushes the
 // rest behind the stack.  How the ENCODER's contractions leave its backward launches (round 5): merged launches of four layers
 // on the geometry stream beside the layers still to come, instead of riding in every ffn-backward launch.
-struct DwMidFlush { hipStream_t side = nullptr; hipEvent_t ev = nullptr; int every = 0; };
+struct DwMidFlush { hipStream_t side = nullptr; hipEvent_t ev = nullptr; int every = 0; int budget = 0; };   // budget: workgroups of a flush on the way (0 = default)
+// the workgroup budget of the NEXT contraction launch of this thread (one-shot; 0 = by size, sst_layer.hip launch_dw_layers)
+void set_dw_budget_hint(int workgroups);
+int take_dw_budget_hint();
 void set_dw_mid_flush(const DwMidFlush& f);
 DwMidFlush dw_mid_flush();
 bool defer_all_weight_grads();

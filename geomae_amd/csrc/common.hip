@@ -52,6 +52,9 @@ bool take_fused_big_next() { const bool b = g_fused_big_next; g_fused_big_next =
 static thread_local DwMidFlush g_dw_mid_flush;
 void set_dw_mid_flush(const DwMidFlush& f) { g_dw_mid_flush = f; }
 DwMidFlush dw_mid_flush() { return g_dw_mid_flush; }
+static thread_local int g_dw_budget_hint = 0;
+void set_dw_budget_hint(int w) { g_dw_budget_hint = w; }
+int take_dw_budget_hint() { const int w = g_dw_budget_hint; g_dw_budget_hint = 0; return w; }
 static thread_local int g_dw_dead_rows = 0;
 void set_dw_dead_rows(int rows) { g_dw_dead_rows = rows > 0 ? rows : 0; }
 int take_dw_dead_rows() { const int r = g_dw_dead_rows; g_dw_dead_rows = 0; return r; }

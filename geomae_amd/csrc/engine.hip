@@ -745,6 +745,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // (Waymo geometry 4.275 vs 4.247 ms with the flush, config 3 flat).  GEOMAE_DEC_DW_EVERY=k overrides (0 = behind the stack).
     static const int dec_every_env = [] { const char* v = getenv("GEOMAE_DEC_DW_EVERY"); return v ? atoi(v) : -1; }();
     const int dec_every = dec_every_env >= 0 ? dec_every_env : (n <= 32768 ? 2 : 0);
+    static const int dec_mid_budget = [] { const char* v = getenv("GEOMAE_DEC_MID_BUDGET"); return v ? atoi(v) : 0; }();   // (A/B)
     struct MidFlushScopeD {
         explicit MidFlushScopeD(const DwMidFlush& f) { set_dw_mid_flush(f); }
         ~MidFlushScopeD() { set_dw_mid_flush(DwMidFlush()); }
@@ -752,7 +753,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     {
         DeferAllScope defer(defer_dec_dw);
         DwMidFlush mfd;
-        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidB]; mfd.every = dec_every; }
+        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidB]; mfd.every = dec_every; mfd.budget = dec_mid_budget; }
         MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
                                            w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
@@ -764,7 +765,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     {
         DeferAllScope defer(defer_dec_dw);
         DwMidFlush mfd;
-        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidA]; mfd.every = dec_every; }
+        if (defer_dec_dw && dec_every > 0) { mfd.side = geo; mfd.ev = e->ev[kDecMidA]; mfd.every = dec_every; mfd.budget = dec_mid_budget; }
         MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
                                            w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));

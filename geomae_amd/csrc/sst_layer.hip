@@ -1383,7 +1383,8 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     // (GEOMAE_DW_BUDGET_MID=w: the budget of launches of 12289-32768 tokens -- config 2's decoders, which run beside the OTHER
     //  decoder's backward, not beside the one-launch encoder kernels -- A/B)
     static const int mid_env = [] { const char* e = getenv("GEOMAE_DW_BUDGET_MID"); return e ? atoi(e) : 0; }();
-    const int budget = A.n <= 12288 ? 80 : A.n <= 32768 ? (mid_env > 0 ? mid_env : 80) : 96;
+    const int hint = take_dw_budget_hint();
+    const int budget = hint > 0 ? hint : A.n <= 12288 ? 80 : A.n <= 32768 ? (mid_env > 0 ? mid_env : 80) : 96;
     int G = budget / A.njobs;
     if (G > 24) G = 24;
     if (g_env > 0) G = g_env;

@@ -447,7 +447,9 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
             if (rc == GEOMAE_OK && defer_all && mf.side && mf.ev && mf.every > 0 && (num_layers - l) % mf.every == 0) {
                 GEOMAE_HIP(hipEventRecord(mf.ev, stream));
                 GEOMAE_HIP(hipStreamWaitEvent(mf.side, mf.ev, 0));
+                set_dw_budget_hint(mf.budget);
                 rc = flush_pending_weight_grad(mf.side);
+                (void)take_dw_budget_hint();
             }
         } else {
             // the first layer's contraction feeds nothing but the optimizer: a caller with another stream to spare
