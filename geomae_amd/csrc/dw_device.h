@@ -37,7 +37,10 @@ namespace geomae {
 
 constexpr int kDlThreads = 512;
 constexpr int kDlSlabTok = 32;                    // one MFMA K-step
-constexpr int kDlRing = 4;
+#ifndef GEOMAE_DL_RING
+#define GEOMAE_DL_RING 4
+#endif
+constexpr int kDlRing = GEOMAE_DL_RING;          // slabs of the LDS ring (tools/dw_bench.hip built with 2: 119 instead of 83 us)
 constexpr int kDlSlabBytes = 32768;               // VO: 4 streams x 2 token blocks x 4 KB; QK / W1 / W2 use 24 KB of it
 constexpr int kDlLdsBias = kDlRing * kDlSlabBytes;
 constexpr int kDlLdsBytes = kDlLdsBias + 256 * 4;
