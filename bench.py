@@ -467,6 +467,34 @@ def main():
                     kern[k]["hbm_view"] = {"achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(gbs / 8000.0, 4),
                                            "traffic_over_algorithmic": round(tr_b / (bytes_step[k] / launches_step[k]), 3)}
+        # The contraction launches are throttled ON PURPOSE (csrc/sst_layer.hip launch_dw_layers: 80 workgroups of one per CU for
+        # token sets up to 32768, 96 above -- they share the chip with the backward of the next stack): what that many CUs can
+        # stream at all is measured by tools/lds_dma_bench.hip (profiles/r05_microbench_lds_dma.txt: 512-thread workgroups moving
+        # 24-KB slabs global -> LDS and nothing else), so the launch is also priced against THAT ceiling.
+        if "dw_kernel" in kern:
+            ceil_path = os.path.join(ROOT, "profiles", "r05_microbench_lds_dma.txt")
+            budget = 80 if n_d <= 32768 else 96
+            ceiling = None
+            if os.path.exists(ceil_path):
+                import re as _re
+                pts = {}
+                for line in open(ceil_path):
+                    m_ = _re.match(r"LDS-direct, ring 4\s+(\d+) workgroups:\s+([0-9.]+) GB/s", line)
+                    if m_:
+                        pts[int(m_.group(1))] = float(m_.group(2))
+                xs = sorted(pts)
+                if xs and xs[0] <= budget <= xs[-1]:
+                    ceiling = float(np.interp(budget, xs, [pts[x] for x in xs]))
+            moved = kern["dw_kernel"].get("hbm_view", {}).get("achieved")
+            kern["dw_kernel"]["throttle"] = {
+                "workgroups_per_launch": budget, "one_workgroup_per_cu": True,
+                "stream_ceiling_at_that_many_workgroups_gbs": round(ceiling, 1) if ceiling else None,
+                "ceiling_source": "profiles/r05_microbench_lds_dma.txt (tools/lds_dma_bench.hip, alone on the chip)" if ceiling else None,
+                "frac_of_that_ceiling_pmc_bytes": round(moved / ceiling, 4) if (ceiling and moved) else None,
+                "frac_of_that_ceiling_algorithmic_bytes": round(kern["dw_kernel"]["achieved"] / ceiling, 4)
+                if (ceiling and kern["dw_kernel"].get("bound") == "hbm") else None,
+                "note": "in the step the launches share HBM with the main stream's kernels; alone on the chip the same kernel moves "
+                        "5.2-5.5 TB/s on 192-256 workgroups (tools/dw_bench.hip)"}
         # the dominant kernel: largest measured time per step LESS the empty event pairs (a kernel with many short launches
         # is not promoted by the instrumentation's own queue time) -- what the rocprofv3 table ranks by
         largest = max(kern, key=lambda k: kern[k]["ms_per_step"]) if kern else None
