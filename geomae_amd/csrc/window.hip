@@ -448,6 +448,9 @@ __device__ __forceinline__ void stage_tokens(const AttnPlan& P, const BundleCtx&
     for (int k = 0; k < kStageIters; ++k) {
         const int row = (k * kAttnBlk + threadIdx.x) >> 1;
         tk[k] = row < B.T ? (P.pos_info ? P.pos_info[B.s0 + row].x : toks[row]) : -1;
+#ifdef ATTN_ABL_IDENTITY            // (timing ablation: rows addressed by bundle position -- what slot-order q / k / v would cost)
+        tk[k] = row < B.T ? B.s0 + row : -1;
+#endif
     }
 }
 
