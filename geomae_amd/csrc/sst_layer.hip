@@ -55,6 +55,16 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     const int K = (int)(tp ? rows : cols), C = (int)cols, T8 = (int)(total >> 3);
     const float* __restrict__ w = flat + src;
     bf16_t* __restrict__ out = packed + dst;
+    if ((K & 7) || (dst & 7) || (frag && ((rows | cols) & 31))) {
+        // a shape the 16-byte form does not cover (none in this library: 128 / 256 / 384 / 800 rows x 128 / 256 columns): element-wise
+        const int T = (int)total;
+        for (int e = blockIdx.x * 256 + threadIdx.x; e < T; e += gridDim.x * 256) {
+            const int r = e / K, p = e - r * K, k = kperm(p);
+            const int d = frag ? ((r >> 4) * (K >> 5) + (p >> 5)) * 512 + ((((p >> 3) & 3) << 4) + (r & 15)) * 8 + (p & 7) : e;
+            out[d] = (bf16_t)f2bf_bits(tp ? w[k * C + r] : w[r * C + k]);
+        }
+        return;
+    }
     for (int e8 = blockIdx.x * 256 + threadIdx.x; e8 < T8; e8 += gridDim.x * 256) {
         const int e = e8 * 8;
         const int r = e / K;

@@ -293,8 +293,9 @@ typedef struct GeomaeSstLayerGrads { /* fp32 gradient buffers, ACCUMULATED into 
 /* desc: device int64 [num_desc, 5] rows {src_offset, rows, cols, transpose, dst_offset} (elements);
  * writes bf16 dst[r][p] = W[r][perm(p)] or, transposed (transpose & 1), dst[c][p] = W[perm(p)][c]; transpose & 4: the
  * same matrix stored fragment-major ([row / 16][p / 32][lane = 16 ((p / 8) % 4) + row % 16][p % 8]: the 1-KB piece one
- * MFMA A fragment covers is contiguous).  Packed matrices: rows and cols multiples of 32, dst_offset a multiple of 8
- * elements (a thread writes 8 consecutive bf16 with one 16-byte store).  src_offset is relative
+ * MFMA A fragment covers is contiguous).  Packed matrices: with the contraction length a multiple of 8 and dst_offset a
+ * multiple of 8 elements a thread writes 8 consecutive bf16 with one 16-byte store (every matrix of this library); other
+ * shapes take an element-wise path.  src_offset is relative
  * to flat_params; flat_params may be NULL with src_offset = (device address / 4) for scattered tensors. */
 int geomae_pack_weights(const float* flat_params, const int64_t* desc, int32_t num_desc, int64_t max_elems,
                         void* packed_bf16, float* aux_f32 /* target of transpose==2 rows: plain fp32 gather */,
