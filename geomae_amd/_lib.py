@@ -250,7 +250,8 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    # GEOMAE_LIB=<path>: another build of the same library (tools/build_timing.py variants in A/B runs); still no fallback
+    path = path or os.environ.get("GEOMAE_LIB") or LIB_PATH
     if not os.path.exists(path):
         raise GeomaeLibraryError(
             f"{path} not found: build it with `python -m geomae_amd.csrc.build` "

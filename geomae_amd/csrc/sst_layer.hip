@@ -240,6 +240,10 @@ __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_fwd_kernel(const float* 
     xh1_out = nullptr; xh2_out = nullptr; hp_out = nullptr; rstd_out = nullptr; N.x_b = nullptr;
 #endif
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
+#ifdef FFN_ABL_ONE_PER_CU
+    __shared__ float abl_pad[5120];
+    if (n < 0) { abl_pad[threadIdx.x] = 1.f; __syncthreads(); z[0] = abl_pad[threadIdx.x ^ 1]; }
+#endif
     __shared__ __attribute__((aligned(16))) float prm[kPrmFloats];
     PrmRegs prm_r;
     ffn_params_issue(W, N.wqkv ? N.bqkv : nullptr, prm_r);
@@ -686,7 +690,14 @@ __device__ __forceinline__ void ffn_bwd_body(const FfnBwdArgs& A, int block, bf1
 __global__ __launch_bounds__(kLayerBlk, 2) void sst_ffn_bwd_kernel(FfnBwdArgs A) {
     __shared__ __attribute__((aligned(16))) bf16_t smem[kWeightLds];
     __shared__ float red[4][4][128];
+#ifdef FFN_ABL_ONE_PER_CU                  // (timing ablation: 16 KB more LDS = ONE workgroup per CU instead of two -- what occupancy is worth)
+    __shared__ float abl_pad[4096];
+    if (A.n < 0) abl_pad[threadIdx.x] = 1.f;
+#endif
     ffn_bwd_body(A, blockIdx.x, smem, red);
+#ifdef FFN_ABL_ONE_PER_CU
+    if (A.n < 0) A.dx_res[0] = abl_pad[threadIdx.x ^ 1];
+#endif
 }
 
 // (Round 5: a PAIR form of this kernel -- 32 tokens per workgroup, two waves per 16-token tile each computing half of every
