@@ -513,6 +513,16 @@ def main():
             gbs = traffic["_bytes_per_step"] / (step_ms * 1e-3) / 1e9
             step_roofline["hbm"] = {"bytes_per_step": int(traffic["_bytes_per_step"]), "source": traffic_src, "achieved": round(gbs, 1),
                                     "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4)}
+            # what a kernel that only copies gets on this part (tools/rw_mix_bench.hip: read + write mixes 3 : 1 ... 1 : 3)
+            mix_path = os.path.join(ROOT, "profiles", "r05_microbench_rw_mix.txt")
+            if os.path.exists(mix_path):
+                import re as _re
+                mix = [float(m_.group(1)) for m_ in (_re.search(r"workgroups:\s+([0-9.]+) GB/s", l_) for l_ in open(mix_path)
+                                                     if l_.startswith("read ") and "write" in l_.split("workgroups")[0] and "only" not in l_) if m_]
+                if mix:
+                    step_roofline["hbm"]["copy_kernel_read_write_mix_gbs"] = [round(min(mix), 1), round(max(mix), 1)]
+                    step_roofline["hbm"]["frac_of_copy_kernel_mean"] = round(gbs / (sum(mix) / len(mix)), 4)
+                    step_roofline["hbm"]["copy_source"] = "profiles/r05_microbench_rw_mix.txt"
         # ---- north_star's "per bucket" MFMA utilisation.  This build has no length buckets: windows are packed into bundles
         # and the attention kernels issue 16 x 16 score tiles over the key-tile range of each query tile.  Density = useful
         # score entries (sum_w n_w^2) / (256 x tiles issued): what fraction of an issued attention MFMA's rows x columns
