@@ -47,7 +47,8 @@ class GeomaeSstStackLayout(ctypes.Structure):
 class GeomaeVfeArgs(ctypes.Structure):
     _fields_ = [("feat_sorted", c_void_p), ("pid_sorted", c_void_p), ("seg_start", c_void_p), ("num_points", c_int64),
                 ("max_pillars", c_int32), ("w0", c_void_p), ("w1", c_void_p), ("scale0", c_void_p), ("shift0", c_void_p),
-                ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p), ("pillar_ties", c_void_p)]
+                ("scale1", c_void_p), ("shift1", c_void_p), ("moments", c_void_p), ("dw0_acc", c_void_p), ("pillar_ties", c_void_p),
+                ("layer1_bf16", c_int32)]
 
 
 class GeomaeBnFold(ctypes.Structure):
@@ -88,7 +89,7 @@ class GeomaePretrainConfig(ctypes.Structure):
                 ("loss_weights", c_float * 6), ("vfe_voxel_size", c_float * 3), ("vfe_center_offset", c_float * 3),
                 ("bn_eps", c_float), ("bn_momentum", c_float), ("beta1", c_float), ("beta2", c_float),
                 ("adam_eps", c_float), ("weight_decay", c_float), ("max_grad_norm", c_float), ("world_size", c_int32), ("sync_bn", c_int32),
-                ("exchange_always", c_int32)]
+                ("exchange_always", c_int32), ("vfe_bf16", c_int32)]
 
 
 class GeomaePretrainModel(ctypes.Structure):

@@ -640,6 +640,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     va.w0 = m.vfe_w0; va.w1 = m.vfe_w1;
     va.scale0 = bn_scale0; va.shift0 = bn_shift0; va.scale1 = bn_scale1; va.shift1 = bn_shift1;
     va.moments = b.moments; va.dw0_acc = dw0_acc; va.pillar_ties = vfe_ties;
+    va.layer1_bf16 = c.vfe_bf16;
     if (b.moments_exchanged) {
         // (mean, mean of squares) of all ranks straight from the averaged moments: no collective in the VFE forward
         GEOMAE_HIP(hipStreamWaitEvent(main, e->ev[e->pending == 0 ? kMoments0 : kMoments1], 0));

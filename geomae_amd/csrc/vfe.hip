@@ -247,7 +247,10 @@ __device__ __forceinline__ BSplit split_operand(const f32x4 (&v)[8]) {
 // NG output tiles starting at ot0 advance together over k (independent accumulators back to back).  The order of
 // the terms inside every accumulator is fixed (k step, then hi*hi, lo*hi, hi*lo), so any grouping gives
 // bit-identical results.
-template <int NG>
+// PLAIN (GeomaeVfeArgs.layer1_bf16, the bf16 compute mode of the step): the hi * hi product alone -- one MFMA per k step instead of
+// three, half the LDS weight reads; the operands are then plain bf16 roundings of g / dy1 and W1 (2^-9 relative per term, the
+// grade of the SST layers' GEMMs), still the same function in every sweep: the recomputed activations stay bit-identical.
+template <int NG, bool PLAIN = false>
 __device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, const BSplit& x, int ot0, f32x4 (&y)[NG],
                                              int lane) {
     const int o = lane & 15, g = lane >> 4;
@@ -261,14 +264,16 @@ __device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, cons
 #pragma unroll
         for (int u = 0; u < NG; ++u) {
             ah[u] = *reinterpret_cast<const uint4*>(wh + 16 * u * kW1bLd + 32 * kk);
-            al[u] = *reinterpret_cast<const uint4*>(wl + 16 * u * kW1bLd + 32 * kk);
+            if (!PLAIN) al[u] = *reinterpret_cast<const uint4*>(wl + 16 * u * kW1bLd + 32 * kk);
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.h[kk], y[u]);
+        if (!PLAIN) {
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
+            for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
+            for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
+        }
     }
 }
 // The transposed product from the SAME LDS copy: dg[t][16*ot + 4g + r] = sum_o W1[o][.] dy1[t][o].  The contraction now
@@ -278,7 +283,7 @@ __device__ __forceinline__ void layer1_group(const float* __restrict__ W1s, cons
 // (m & 3) of the tile (chunk q of a 32-column block sits at position 8 (q & 3) + 4 (q >> 2) of the K-permuted row).
 // Same products in the same order as a GEMM against a transposed copy, without the copy (a second 69.6 KB that does not
 // fit beside the first): the backward sweep no longer parks dy1 in HBM between a W1 pass and a W1^T pass.
-template <int NG>
+template <int NG, bool PLAIN = false>
 __device__ __forceinline__ void layer1_group_t(const float* __restrict__ W1s, const BSplit& x, int ot0, f32x4 (&y)[NG],
                                                int lane) {
     const int m = lane & 15, g = lane >> 4;
@@ -296,21 +301,26 @@ __device__ __forceinline__ void layer1_group_t(const float* __restrict__ W1s, co
             const bf16_t* ph = wh + 32 * kk * kW1bLd + col;
             const bf16_t* pl = wl + 32 * kk * kW1bLd + col;
             const uint2 h0 = tr_read(ph), h1 = tr_read(ph + 16 * kW1bLd);
-            const uint2 l0 = tr_read(pl), l1 = tr_read(pl + 16 * kW1bLd);
             ah[u] = make_uint4(h0.x, h0.y, h1.x, h1.y);
-            al[u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            if (!PLAIN) {
+                const uint2 l0 = tr_read(pl), l1 = tr_read(pl + 16 * kW1bLd);
+                al[u] = make_uint4(l0.x, l0.y, l1.x, l1.y);
+            }
         }
 #pragma unroll
         for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.h[kk], y[u]);
+        if (!PLAIN) {
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
+            for (int u = 0; u < NG; ++u) y[u] = mfma32(al[u], x.h[kk], y[u]);
 #pragma unroll
-        for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
+            for (int u = 0; u < NG; ++u) y[u] = mfma32(ah[u], x.l[kk], y[u]);
+        }
     }
 }
+template <bool PLAIN>
 __device__ __forceinline__ void layer1_linear(const float* __restrict__ W1s, const BSplit& x, f32x4 (&y)[8], int lane) {
-    layer1_group<4>(W1s, x, 0, reinterpret_cast<f32x4(&)[4]>(y[0]), lane);
-    layer1_group<4>(W1s, x, 4, reinterpret_cast<f32x4(&)[4]>(y[4]), lane);
+    layer1_group<4, PLAIN>(W1s, x, 0, reinterpret_cast<f32x4(&)[4]>(y[0]), lane);
+    layer1_group<4, PLAIN>(W1s, x, 4, reinterpret_cast<f32x4(&)[4]>(y[4]), lane);
 }
 
 template <int NT>
@@ -353,7 +363,7 @@ __device__ __forceinline__ void stage_w0(const float* __restrict__ w0, float* W0
 // T-layout (sst_device.h kperm): dst[o][p] = W1[o][kperm(p)], or with `transpose` (dg = dy1 W1: outputs are the
 // input channels) dst[k][p] = W1[kperm(p)][k].  kperm^-1(32 b + 16 h + 4 q + e) = 32 b + 8 q + 4 h + e: four
 // consecutive source columns stay consecutive.
-__device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1s, bool transpose) {
+__device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1s, bool transpose, bool with_lo = true) {
     bf16_t* wh = reinterpret_cast<bf16_t*>(W1s);
     bf16_t* wl = wh + 128 * kW1bLd;
     for (int e = threadIdx.x; e < 128 * 32; e += kVfeBlk) {
@@ -365,7 +375,7 @@ __device__ __forceinline__ void stage_w1(const float* __restrict__ w1, float* W1
         if (!transpose) {
             const int p = (c4 & ~31) + 8 * ((c4 >> 2) & 3) + 4 * ((c4 >> 4) & 1);
             *reinterpret_cast<uint2*>(wh + r * kW1bLd + p) = make_uint2(h01, h23);
-            *reinterpret_cast<uint2*>(wl + r * kW1bLd + p) = make_uint2(l01, l23);
+            if (with_lo) *reinterpret_cast<uint2*>(wl + r * kW1bLd + p) = make_uint2(l01, l23);
         } else {
             const int p = (r & ~31) + 8 * ((r >> 2) & 3) + 4 * ((r >> 4) & 1) + (r & 3);
             wh[(c4 + 0) * kW1bLd + p] = (bf16_t)(h01 & 0xffffu); wh[(c4 + 1) * kW1bLd + p] = (bf16_t)(h01 >> 16);
@@ -884,13 +894,14 @@ __device__ __forceinline__ void recompute_g_from(const VfeW& W, const float* W0s
 }
 
 // sweep 1 of layer 1: statistics of y1 = W1 [h0 | m0]
+template <bool PLAIN>
 __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                              double* __restrict__ sums1) {
     __shared__ float W0s[64 * 16];
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
-    stage_w1(W.w1, W1s, false);
+    stage_w1(W.w1, W1s, false, !PLAIN);
     VFE_STAGE_BN0_FWD(W, Ws)
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -914,7 +925,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 y2[2];
-            layer1_group<2>(W1l, gs, ot0, y2, lane);
+            layer1_group<2, PLAIN>(W1l, gs, ot0, y2, lane);
             if (valid) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) { s1[ot0 + u] += y2[u]; s2[ot0 + u] += y2[u] * y2[u]; }
@@ -927,6 +938,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_stats1_kernel(VfeGeo G, VfeW W, c
 }
 
 // sweep 2 of layer 1: h1 = ReLU(BN(y1)), voxel_feats = segmented max (zero-filled by the caller)
+template <bool PLAIN>
 __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                              float* __restrict__ vf, unsigned char* __restrict__ ties,
                                                              BnFoldDev F, const double* __restrict__ sums1) {
@@ -936,7 +948,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
     __shared__ __attribute__((aligned(16))) float bn1f_s[2][128];
     VFE_T_ENTRY();
     stage_w0(W.w0, W0s);
-    stage_w1(W.w1, W1s, false);
+    stage_w1(W.w1, W1s, false, !PLAIN);
     VFE_STAGE_BN0_FWD(W, Ws)
     if (F.on) {
         if (threadIdx.x < 128) bn_fold_channel(F, 128, threadIdx.x, sums1[threadIdx.x], sums1[128 + threadIdx.x], bn1f_s[0], bn1f_s[1]);
@@ -967,7 +979,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_layer1_kernel(VfeGeo G, VfeW W, c
         VFE_T(0);
         recompute_g_from(Wl, W0s + oz, cur, lane, y0, gin);
         VFE_T(1);
-        layer1_linear(W1s + oz, split_operand(gin), y1, lane);
+        layer1_linear<PLAIN>(W1s + oz, split_operand(gin), y1, lane);
         if (more) tile_m0_issue(m0, lane, nxt);
         VFE_T(2);
         bn_affine<8>(y1, Wl.scale1, Wl.shift1, h1, lane);             // (the clamp follows the max: seg_scan TRACK)
@@ -1077,6 +1089,7 @@ __global__ __launch_bounds__(1024) void vfe_bwd_stats1_pillars_kernel(const floa
     }
 }
 
+template <bool PLAIN>
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW W, const float* __restrict__ m0,
                                                                  const float* __restrict__ vf, const float* __restrict__ dvf,
                                                                  Bn1 bn, double* __restrict__ bsums1,
@@ -1101,7 +1114,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
     __shared__ __attribute__((aligned(16))) float W1s[128 * kW1Ld];
     __shared__ float red[kVfeWaves * 2 * 128];
     stage_w0(W.w0, W0s);
-    stage_w1(W.w1, W1s, false);
+    stage_w1(W.w1, W1s, false, !PLAIN);
     VFE_STAGE_BN0_FWD(W, Ws)
     VFE_STAGE_BN1(bn, bns)
     __syncthreads();
@@ -1131,7 +1144,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
             for (int q = 0; q < 4; q += 2) {
                 const int ot0 = 4 * half + q;
                 f32x4 y4[2];
-                layer1_group<2>(W1s + oz, gs, ot0, y4, lane);
+                layer1_group<2, PLAIN>(W1s + oz, gs, ot0, y4, lane);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     f32x4 dh, yh;
@@ -1153,6 +1166,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_stats1_kernel(VfeGeo G, VfeW 
 //   dy1 = invstd1 * (dyh - S1/n - yhat * S2/n)  -> bf16 copy + g bf16 copy (operands of dW1 = dy1^T g)
 //   dg = dy1 W1 ; dh0_direct = dg[:, :64] (stored fp32) ; dm0 = segmented sum of dg[:, 64:] (zero-filled by
 //   the caller; pillars that straddle waves are combined with float atomics)
+template <bool PLAIN>
 __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     VfeGeo G, VfeW W, const float* __restrict__ m0, const float* __restrict__ vf, const float* __restrict__ dvf, Bn1 bn,
     const double* __restrict__ bsums1, float n_eff, bf16_t* __restrict__ dy1_b, bf16_t* __restrict__ g_b,
@@ -1185,7 +1199,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
     // copy with transposing LDS reads (layer1_group_t), so dy1 stays in registers between the two: one sweep.  (Until
     // round 2 the sweep was split: A1 computed dy1 with W1 and parked it in HBM as fp32, the workgroup re-staged W1^T,
     // A2 re-read dy1 -- 108 MB of the kernel's 234 MB.)
-    stage_w1(W.w1, W1s, false);
+    stage_w1(W.w1, W1s, false, !PLAIN);
     __syncthreads();
     SegCarry<1> carry;
     carry.init(G, R);
@@ -1217,11 +1231,11 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
             const BSplit gs = split_operand(gin);
             // the MFMAs of channel-tile pair k + 1 are issued before the routing arithmetic of pair k
             f32x4 ya[2], yb[2];
-            layer1_group<2>(W1s + oz, gs, 0, ya, lane);
+            layer1_group<2, PLAIN>(W1s + oz, gs, 0, ya, lane);
             if (more) tile_m0_issue(m0, lane, nxt);
 #pragma unroll
             for (int ot0 = 0; ot0 < 8; ot0 += 2) {
-                if (ot0 + 2 < 8) layer1_group<2>(W1s + oz, gs, ot0 + 2, yb, lane);
+                if (ot0 + 2 < 8) layer1_group<2, PLAIN>(W1s + oz, gs, ot0 + 2, yb, lane);
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int ot = ot0 + u;
@@ -1254,7 +1268,7 @@ __global__ __launch_bounds__(kVfeBlk) void vfe_bwd_layer1_kernel(
 #pragma unroll
         for (int ot0 = 0; ot0 < 8; ot0 += 2) {
             f32x4 d2[2];
-            layer1_group_t<2>(W1l, ds, ot0, d2, lane);
+            layer1_group_t<2, PLAIN>(W1l, ds, ot0, d2, lane);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int ct = ot0 + u;
@@ -1543,6 +1557,8 @@ static int vfe_common(const GeomaeVfeArgs* a, VfeGeo* G, VfeW* W, const char* wh
     W->w0 = a->w0; W->w1 = a->w1; W->scale0 = a->scale0; W->shift0 = a->shift0; W->scale1 = a->scale1; W->shift1 = a->shift1;
     return GEOMAE_OK;
 }
+// the layer-1 sweeps' two forms: bf16 x 3 split products (fp32 grade) | plain bf16 products (GeomaeVfeArgs.layer1_bf16)
+#define VFE_L1_FORM(a, kernel) ((a)->layer1_bf16 ? kernel<true> : kernel<false>)
 static dim3 vfe_grid(const GeomaeVfeArgs* a) { return dim3(cdiv(cdiv(a->num_points, kVfePts), kVfeWaves)); }
 
 #ifdef GEOMAE_PHASE_TIMING
@@ -1651,7 +1667,7 @@ extern "C" int geomae_vfe_layer0(const GeomaeVfeArgs* a, float* m0, double* sums
     GEOMAE_ZERO(m0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
     hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, BnFoldDev{}, (const double*)nullptr);
     if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
-    hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_stats1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
     return check_launch("vfe_stats1_kernel");
 }
 
@@ -1678,7 +1694,7 @@ extern "C" int geomae_vfe_layer0_bn(const GeomaeVfeArgs* a, const GeomaeBnFold* 
     GEOMAE_ZERO(m0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
     hipLaunchKernelGGL(vfe_layer0_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, F, a->moments);
     if ((rc = check_launch("vfe_layer0_kernel"))) return rc;
-    hipLaunchKernelGGL(vfe_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_stats1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, (const float*)m0, sums1);
     return check_launch("vfe_stats1_kernel");
 }
 
@@ -1689,7 +1705,7 @@ extern "C" int geomae_vfe_layer1(const GeomaeVfeArgs* a, const float* m0, float*
     GEOMAE_REQUIRE(m0 && voxel_feats && a->scale0 && a->shift0 && a->scale1 && a->shift1, "vfe_layer1: null argument");
     GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
     if (a->pillar_ties) GEOMAE_ZERO(a->pillar_ties, (size_t)a->max_pillars, stream);
-    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties,
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_layer1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties,
                        BnFoldDev{}, (const double*)nullptr);
     return check_launch("vfe_layer1_kernel");
 }
@@ -1705,7 +1721,7 @@ extern "C" int geomae_vfe_layer1_bn(const GeomaeVfeArgs* a, const GeomaeBnFold* 
                    "vfe_layer1_bn: null argument, or args->scale1 / shift1 are not the fold's outputs");
     GEOMAE_ZERO(voxel_feats, (size_t)a->max_pillars * 128 * sizeof(float), stream);
     if (a->pillar_ties) GEOMAE_ZERO(a->pillar_ties, (size_t)a->max_pillars, stream);
-    hipLaunchKernelGGL(vfe_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties, F, sums1);
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_layer1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, a->pillar_ties, F, sums1);
     return check_launch("vfe_layer1_kernel");
 }
 
@@ -1736,7 +1752,7 @@ extern "C" int geomae_vfe_backward_stats(const GeomaeVfeArgs* a, const GeomaeBnS
         const int rc2 = check_launch("vfe_bwd_stats1_pillars_kernel");
         if (rc2) return rc2;
     }
-    hipLaunchKernelGGL(vfe_bwd_stats1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats,
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_bwd_stats1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats,
                        d_voxel_feats, bn, bsums1, (const unsigned char*)a->pillar_ties);
     return check_launch("vfe_bwd_stats1_kernel");
 }
@@ -1756,7 +1772,7 @@ extern "C" int geomae_vfe_backward_layer1(const GeomaeVfeArgs* a, const GeomaeBn
                    bsums0 && n_eff > 0, "vfe_backward_layer1: null argument");
     GEOMAE_ZERO(bsums0, 128 * sizeof(double), stream);
     GEOMAE_ZERO(dm0, (size_t)a->max_pillars * 64 * sizeof(float), stream);
-    hipLaunchKernelGGL(vfe_bwd_layer1_kernel, vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
+    hipLaunchKernelGGL(VFE_L1_FORM(a, vfe_bwd_layer1_kernel), vfe_grid(a), dim3(kVfeBlk), 0, stream, G, W, m0, voxel_feats, d_voxel_feats,
                        bn, bsums1_global, n_eff, (bf16_t*)dy1_bf16, (bf16_t*)g_bf16, dy1_f32, dh0, dm0, d_beta1, d_gamma1);
     hipEvent_t mid = take_mid_launch_event();          // dy1 / g are complete here: the caller's dW1 contraction may start
     hipStream_t side = take_mid_launch_side();         // ... and the routing sweep may leave the caller's stream

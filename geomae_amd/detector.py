@@ -60,6 +60,10 @@ class MultiSubVoxelDynamicVoxelNetSSL(nn.Module):
         self.voxel_layer = ops.Voxelization(**voxel_layer)
         self.voxel_encoder = build_voxel_encoder(voxel_encoder)
         self.backbone = build_backbone(backbone)
+        # one compute mode for the whole step: the voxel encoder's layer-1 GEMMs follow the backbone's compute_dtype
+        # (voxel_encoder.py DynamicScatterVFE.compute_dtype; a stand-alone encoder keeps the fp32-grade products)
+        if hasattr(self.voxel_encoder, "compute_dtype") and getattr(self.backbone, "compute_dtype", None) in ("bf16", "fp32"):
+            self.voxel_encoder.compute_dtype = self.backbone.compute_dtype
         self.reg_loss = build_loss(loss)
         self.mse_loss, self.use_focal_mask, self.normalize_sub_voxel = mse_loss, use_focal_mask, normalize_sub_voxel
         self.cls_loss = build_loss(dict(type="CrossEntropyLoss", use_sigmoid=True, loss_weight=1.0))

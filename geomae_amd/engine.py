@@ -82,6 +82,7 @@ class PretrainEngine:
         c.exchange_always = int(self.exchange)
         from .norm import NaiveSyncBatchNorm1d
         c.sync_bn = int(isinstance(n0, NaiveSyncBatchNorm1d))          # a config with plain 'BN1d' keeps local statistics
+        c.vfe_bf16 = int(ve.layer1_bf16)                                # (the detector copied the backbone's compute_dtype)
         return c
 
     def _model_struct(self):

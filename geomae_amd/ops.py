@@ -1190,7 +1190,7 @@ def vfe_prepare_points(points, seg, voxel_size, center_offset, zeros=None):
 class VfePlan:
     """Per-batch state of the fused VFE sweeps: pillar mean, sorted point features, the argument struct."""
 
-    def __init__(self, points, seg, w0, w1, voxel_size, center_offset, zeros=None, prepared=None):
+    def __init__(self, points, seg, w0, w1, voxel_size, center_offset, zeros=None, prepared=None, layer1_bf16=False):
         from ._lib import GeomaeVfeArgs
         dev = points.device
         self.points, self.seg, self.N, self.V = points, seg, points.shape[0], seg.V
@@ -1210,6 +1210,7 @@ class VfePlan:
         a.scale1, a.shift1 = self.bn[1, 0].data_ptr(), self.bn[1, 1].data_ptr()
         if self.moments is not None:
             a.moments = self.moments.data_ptr()
+        a.layer1_bf16 = int(bool(layer1_bf16))     # plain bf16 layer-1 products (the bf16 compute mode) | bf16 x 3, fp32 grade
         self.args = a
         self._keep = (w0, w1)
 

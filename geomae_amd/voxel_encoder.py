@@ -39,7 +39,8 @@ class _FusedVFE(torch.autograd.Function):
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         sync = world > 1 and isinstance(enc.vfe_layers[0].norm, __import__("geomae_amd").norm.NaiveSyncBatchNorm1d)
         world = world if sync else 1
-        plan = ops.VfePlan(points, seg, w0, w1, (enc.vx, enc.vy, enc.vz), (enc.x_offset, enc.y_offset, enc.z_offset))
+        plan = ops.VfePlan(points, seg, w0, w1, (enc.vx, enc.vy, enc.vz), (enc.x_offset, enc.y_offset, enc.z_offset),
+                           layer1_bf16=enc.layer1_bf16)
         vf, m0 = ops.vfe_forward(plan, enc.vfe_layers[0].norm, enc.vfe_layers[1].norm, world)
         ctx.plan, ctx.world = plan, world
         ctx.params = dict(w0=w0, g0=g0, b0=b0, w1=w1, g1=g1, b1=b1)
@@ -103,6 +104,15 @@ class DynamicScatterVFE(nn.Module):
         self.unique_once = unique_once
 
     use_fused = True      # set False to run the composed (ATen + segment kernels) form, kept for A/B tests
+    # Arithmetic of the fused sweeps' two 128 x 128 layer-1 GEMMs (utils.py:130-144's Linear): 'fp32' = bf16 x 3 split products
+    # (fp32 grade: what a stand-alone encoder and the tight parity tests run), 'bf16' = one bf16 MFMA product with fp32
+    # accumulation, as SURVEY 8(d) lists this GEMM for BASELINE config 2.  Not a constructor argument (the reference's config
+    # has none): the detector copies its backbone's compute_dtype here, so the whole step runs in one mode.
+    compute_dtype = "fp32"
+
+    @property
+    def layer1_bf16(self):
+        return self.compute_dtype == "bf16"
 
     def fused_ok(self, features, seg, return_inv):
         return (self.use_fused and seg is not None and self.training and features.is_cuda and not return_inv
@@ -127,7 +137,8 @@ class DynamicScatterVFE(nn.Module):
         import contextlib
         with (ops.prezeroed() if zeros is not None else contextlib.nullcontext()):
             plan = ops.VfePlan(features, seg, l0.linear.weight, l1.linear.weight, (self.vx, self.vy, self.vz),
-                               (self.x_offset, self.y_offset, self.z_offset), zeros=zeros, prepared=prepared)
+                               (self.x_offset, self.y_offset, self.z_offset), zeros=zeros, prepared=prepared,
+                               layer1_bf16=self.layer1_bf16)
             vf, m0 = ops.vfe_forward(plan, l0.norm, l1.norm, world, zeros=zeros)
         return vf, (plan, m0, vf, world)
 

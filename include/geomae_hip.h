@@ -430,6 +430,15 @@ typedef struct GeomaeVfeArgs {
                                                         of the BatchNorm-backward sums of geomae_vfe_backward_stats follows
                                                         from its [128] rows alone (sum d_vf, sum d_vf * yhat(vf) where vf > 0):
                                                         only the marked pillars' points are swept.  NULL: all points are */
+    int32_t layer1_bf16;                             /* 0: the two 128 x 128 layer-1 GEMMs (utils.py:130-144's Linear; forward,
+                                                        recomputation, dg = dy1 W1) as bf16 x 3 split products, fp32 grade --
+                                                        what compute_dtype 'fp32' and the tight parity tests use.  != 0: ONE
+                                                        bf16 product (operands rounded to bf16, fp32 accumulation; BatchNorm
+                                                        sums, max-pool routing and everything of layer 0 stay fp32 / fp64):
+                                                        the bf16 compute mode of the pre-training step, a third of the MFMA
+                                                        issue of those sweeps.  Every sweep of one forward / backward pair must
+                                                        see the same value (the backward routes by equality with the recomputed
+                                                        forward value) */
 } GeomaeVfeArgs;
 /* decorated point features [x y z i dt | xyz - pillar mean | xyz - pillar centre | 0...] in pillar order
  * (voxel_encoder.py:372-397); voxel_size (vx,vy,vz) and center_offset = v/2 + range_min are host arrays */
@@ -727,6 +736,8 @@ typedef struct GeomaePretrainConfig {
                                         0 = plain BatchNorm1d statistics of the local batch whatever the world size */
     int32_t exchange_always;         /* != 0: run the world_size > 1 schedule (hooks, SyncBN exchanges, optimizer as a
                                         separate call) even at world_size 1 -- exercises the RCCL path on one GPU */
+    int32_t vfe_bf16;                /* GeomaeVfeArgs.layer1_bf16 of every VFE sweep of the step: != 0 = the voxel encoder's
+                                        layer-1 GEMMs as plain bf16 products (the bf16 compute mode, BASELINE config 2) */
 } GeomaePretrainConfig;
 
 /* Device pointers of the model (parameters and gradients are views of the flat buffers; all of them must stay where

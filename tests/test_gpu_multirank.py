@@ -43,6 +43,12 @@ def _worker(rank, world, port, tmp):
         fused = geomae_amd.build_model(cfg).cuda().train()
         import geomae_oracle as O
         fused.load_state_dict(O.make_params(7, 1, 1), strict=False)       # the weights of tests/golden/g_syncbn_w2.npz
+        # sections 1, 3, 4, 5 hold the voxel encoder's cross-rank BatchNorm to the REFERENCE's fixture at fp32 tolerances
+        # (running statistics to 1e-5): they run its fp32-grade layer-1 products.  The plain-bf16 products the bf16 step
+        # uses (DynamicScatterVFE.compute_dtype, tests/test_gpu_parity.py::test_vfe_plain_bf16_layer1_products) go through
+        # the same exchanges; section 2's training steps run them at world size 2.
+        assert fused.voxel_encoder.compute_dtype == "bf16"     # (copied from the backbone by the detector)
+        fused.voxel_encoder.compute_dtype = "fp32"
         fused_init = copy.deepcopy(fused)                      # the initial state, for the reference run of section 4
         composed = copy.deepcopy(fused)
         composed.voxel_encoder.use_fused = False               # torch ops + the NaiveSyncBatchNorm1d module
@@ -99,6 +105,7 @@ def _worker(rank, world, port, tmp):
         # (first: the gradient buffer the optimizer reads.  The explicit schedule starts the all-reduce of the early
         #  segment from the geometry stream while the encoder backward runs; the autograd path reduces everything after
         #  its backward on one stream.  Same sums up to the atomics / bf16 noise floor of tests/test_gpu_parity.py.)
+        fused.voxel_encoder.compute_dtype = "bf16"            # (the step's own mode: plain bf16 layer-1 products)
         auto = copy.deepcopy(fused)
         tr, tr_auto = Trainer(fused), Trainer(auto)
         tr_auto.explicit_schedule = False

@@ -9,7 +9,7 @@ which = sys.argv[1] if len(sys.argv) > 1 else "enc"
 if len(sys.argv) > 2:
     os.environ["GEOMAE_BUNDLE_CAP"] = sys.argv[2]
 from geomae_amd import _lib
-timing = os.path.join(ROOT, "tools", "libgeomae_timing.so")
+timing = os.environ.get("GEOMAE_TIMING_LIB") or os.path.join(ROOT, "tools", "libgeomae_timing.so")
 lib = _lib.load(path=timing if os.path.exists(timing) and not os.environ.get("NO_STAMPS") else None)
 import geomae_amd
 from geomae_amd import synth, ops
