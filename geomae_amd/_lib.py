@@ -107,6 +107,60 @@ class GeomaePretrainModel(ctypes.Structure):
                  ("bn_sync_feat_moments", c_void_p)])
 
 
+class GeomaeTuning(ctypes.Structure):
+    """include/geomae_hip.h GeomaeTuning: the one surface of kernel-form / schedule switches."""
+    _fields_ = [(n, c_int32) for n in (
+        "size", "fused_layers", "fused_max_tokens", "fused_bwd", "ws_layers", "ws_bwd", "ws_bundle_cap", "ws_max_workgroups",
+        "bundle_cap", "saved_f32", "x_from_xhat", "y_from_xhat", "pair_kernels", "attn_heads", "dw_layer_form", "dw_chunks",
+        "dw_budget_mid", "dw_split_reduce", "dw_defer_all", "dec_dw_every", "dec_mid_budget", "enc_dw_defer", "zero_late_aux",
+        "fused_skip_big", "heads_joint")] + [("reserved", c_int32 * 8)]
+
+
+# environment variable -> GeomaeTuning field, read ONCE when the library is loaded (the library itself reads no environment)
+TUNING_ENV = {
+    "GEOMAE_FUSED_LAYERS": "fused_layers", "GEOMAE_FUSED_MAX_TOKENS": "fused_max_tokens", "GEOMAE_FUSED_BWD": "fused_bwd",
+    "GEOMAE_WS_LAYERS": "ws_layers", "GEOMAE_WS_BWD": "ws_bwd", "GEOMAE_WS_BUNDLE_CAP": "ws_bundle_cap",
+    "GEOMAE_WS_MAX_WORKGROUPS": "ws_max_workgroups", "GEOMAE_BUNDLE_CAP": "bundle_cap", "GEOMAE_SAVED_F32": "saved_f32",
+    "GEOMAE_X_FROM_XHAT": "x_from_xhat", "GEOMAE_Y_FROM_XHAT": "y_from_xhat", "GEOMAE_PAIR_KERNELS": "pair_kernels",
+    "GEOMAE_ATTN_HEADS": "attn_heads", "GEOMAE_DW_LAYER_FORM": "dw_layer_form", "GEOMAE_DW_CHUNKS": "dw_chunks",
+    "GEOMAE_DW_BUDGET_MID": "dw_budget_mid", "GEOMAE_DW_SPLIT_REDUCE": "dw_split_reduce", "GEOMAE_DW_DEFER_ALL": "dw_defer_all",
+    "GEOMAE_DEC_DW_EVERY": "dec_dw_every", "GEOMAE_DEC_MID_BUDGET": "dec_mid_budget", "GEOMAE_ENC_DW_DEFER": "enc_dw_defer",
+    "GEOMAE_ZERO_LATE_AUX": "zero_late_aux", "GEOMAE_FUSED_SKIP_BIG": "fused_skip_big", "GEOMAE_HEADS_JOINT": "heads_joint",
+}
+
+
+def get_tuning():
+    t = GeomaeTuning()
+    check(load().geomae_get_tuning(ctypes.byref(t)), "geomae_get_tuning")
+    return t
+
+
+def set_tuning(**fields):
+    """Change fields of the process-wide GeomaeTuning (between steps); returns the PREVIOUS values of the fields set."""
+    t = get_tuning()
+    old = {k: getattr(t, k) for k in fields}
+    for k, v in fields.items():
+        if k not in dict(GeomaeTuning._fields_) or k in ("size", "reserved"):
+            raise KeyError(f"GeomaeTuning has no field {k!r}")
+        setattr(t, k, int(v))
+    check(load().geomae_set_tuning(ctypes.byref(t)), "geomae_set_tuning")
+    return old
+
+
+def _apply_tuning_env(lib):
+    t = GeomaeTuning()
+    if lib.geomae_get_tuning(ctypes.byref(t)) != 0:
+        raise GeomaeLibraryError("geomae_get_tuning failed")
+    touched = False
+    for env, field in TUNING_ENV.items():
+        v = os.environ.get(env)
+        if v is not None and v != "":
+            setattr(t, field, int(v))
+            touched = True
+    if touched and lib.geomae_set_tuning(ctypes.byref(t)) != 0:
+        raise GeomaeLibraryError("geomae_set_tuning failed: " + lib.geomae_last_error().decode("utf-8", "replace"))
+
+
 PRETRAIN_HOOK = ctypes.CFUNCTYPE(None, c_void_p, c_int32, c_void_p)
 
 F3 = POINTER(c_float)
@@ -185,6 +239,8 @@ SIGNATURES = {
     "geomae_gather_token_coors_zero": (ctypes.c_int, [P, c_int32, P, c_int32, P, P, P, P, c_int64, P]),
     "geomae_window_build_batch_table_bytes": (c_int64, [POINTER(c_int32), c_int32, c_int32, POINTER(GeomaeWindowConfig)]),
     "geomae_set_accumulators_prezeroed": (ctypes.c_int, [c_int32]),
+    "geomae_get_tuning": (ctypes.c_int, [POINTER(GeomaeTuning)]),
+    "geomae_set_tuning": (ctypes.c_int, [POINTER(GeomaeTuning)]),
     "geomae_heads_loss_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P]),
     "geomae_sst_set_pair_kernels": (None, [c_int32]),
     "geomae_heads_loss_split_accumulate": (ctypes.c_int, [P, P, c_int32, c_int32, P, P, P, P, P, P, P, P, P, F3, P, P, P, P, P, P, P, P]),
@@ -264,6 +320,8 @@ def load(path=None):
         fn.argtypes = args
     if lib.geomae_abi_version() != 1:
         raise GeomaeLibraryError(f"ABI version {lib.geomae_abi_version()} != 1")
+    lib.geomae_last_error.restype = ctypes.c_char_p
+    _apply_tuning_env(lib)
     _lib = lib
     return lib
 

@@ -14,6 +14,12 @@
 namespace geomae {
 
 void set_error(const char* fmt, ...);
+}  // namespace geomae
+struct GeomaeTuning;
+namespace geomae {
+// the process-wide tuning surface (include/geomae_hip.h GeomaeTuning; common.hip)
+const GeomaeTuning& tuning();
+GeomaeTuning& tuning_mut();          // (the older per-switch setters of the C ABI write through this)
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

@@ -70,5 +70,44 @@ extern "C" int geomae_set_accumulators_prezeroed(int32_t enabled) {
     return GEOMAE_OK;
 }
 
+namespace geomae {
+static GeomaeTuning default_tuning() {
+    GeomaeTuning t;
+    memset(&t, 0, sizeof(t));
+    t.size = (int32_t)sizeof(GeomaeTuning);
+    t.fused_layers = 1; t.fused_max_tokens = 12288; t.fused_bwd = 1;
+    t.ws_layers = 0; t.ws_bwd = 0; t.ws_bundle_cap = 144; t.ws_max_workgroups = 0; t.bundle_cap = 0;
+    t.saved_f32 = 0; t.x_from_xhat = 1; t.y_from_xhat = 1; t.pair_kernels = -1; t.attn_heads = 0;
+    t.dw_layer_form = 1; t.dw_chunks = 0; t.dw_budget_mid = 0; t.dw_split_reduce = 1;
+    t.dw_defer_all = 1; t.dec_dw_every = -1; t.dec_mid_budget = 0; t.enc_dw_defer = 1; t.zero_late_aux = 0;
+    t.fused_skip_big = 1; t.heads_joint = 0;
+    return t;
+}
+static GeomaeTuning g_tuning = default_tuning();
+const GeomaeTuning& tuning() { return g_tuning; }
+GeomaeTuning& tuning_mut() { return g_tuning; }
+}  // namespace geomae
+
+extern "C" int geomae_get_tuning(GeomaeTuning* out) {
+    GEOMAE_REQUIRE(out, "get_tuning: null argument");
+    *out = geomae::g_tuning;
+    return GEOMAE_OK;
+}
+extern "C" int geomae_set_tuning(const GeomaeTuning* in) {
+    GEOMAE_REQUIRE(in && in->size == (int32_t)sizeof(GeomaeTuning), "set_tuning: null argument or a struct of another size (%d, expected %d)",
+                   in ? in->size : -1, (int)sizeof(GeomaeTuning));
+    GeomaeTuning t = *in;
+    auto clamp = [](int32_t v, int32_t lo, int32_t hi) { return v < lo ? lo : (v > hi ? hi : v); };
+    t.fused_layers = clamp(t.fused_layers, 0, 3); t.fused_max_tokens = clamp(t.fused_max_tokens, 0, 1 << 30);
+    t.ws_layers = clamp(t.ws_layers, 0, 2); t.ws_bundle_cap = clamp(t.ws_bundle_cap, 16, 144);
+    t.ws_max_workgroups = clamp(t.ws_max_workgroups, 0, 4096); t.bundle_cap = clamp(t.bundle_cap, 0, 144);
+    t.pair_kernels = clamp(t.pair_kernels, -1, 1);
+    t.attn_heads = (t.attn_heads == 1 || t.attn_heads == 2 || t.attn_heads == 4) ? t.attn_heads : 0;
+    t.dw_chunks = clamp(t.dw_chunks, 0, 64); t.dw_budget_mid = clamp(t.dw_budget_mid, 0, 4096);
+    t.dec_dw_every = clamp(t.dec_dw_every, -1, 64); t.dec_mid_budget = clamp(t.dec_mid_budget, 0, 4096);
+    geomae::g_tuning = t;
+    return GEOMAE_OK;
+}
+
 extern "C" const char* geomae_last_error(void) { return geomae::g_err; }
 extern "C" int32_t geomae_abi_version(void) { return GEOMAE_ABI_VERSION; }

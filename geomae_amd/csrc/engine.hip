@@ -527,7 +527,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // contractions' 4 KB per token and layer its phase is 0.49 -> 0.41 ms, while the encoder backward -- one workgroup
     // chain per CU, half the chip idle -- takes them in for +0.02 ms.  The ENCODER's own contractions keep riding: queued
     // behind its backward they are twelve launches of one round each, 0.11 ms that nothing is left to hide.
-    static const bool defer_dec_dw = [] { const char* v = getenv("GEOMAE_DW_DEFER_ALL"); return !v || v[0] != '0'; }();
+    const bool defer_dec_dw = tuning().dw_defer_all != 0;
     struct DeferAllScope {
         explicit DeferAllScope(bool on) { set_defer_all_weight_grads(on); }
         ~DeferAllScope() { set_defer_all_weight_grads(false); }
@@ -589,8 +589,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // it, and the decoder-B stream forks from the main stream behind that wait.  (Until round 5 the decoder-B stream filled it
     // behind the VFE forward: one more event for the main stream to wait on in front of the heads -- a satisfied wait still
     // costs the queue a barrier packet, ~6-8 us with the lost overlap of the neighbouring kernels -- and one for dec_b.)
-    // GEOMAE_ZERO_LATE=aux: the earlier placement (A/B).
-    static const bool zero_on_aux = [] { const char* v = getenv("GEOMAE_ZERO_LATE"); return v && !strcmp(v, "aux"); }();
+    // GeomaeTuning.zero_late_aux: the earlier placement (A/B).
+    const bool zero_on_aux = tuning().zero_late_aux != 0;
     if (!zero_on_aux) {
         ENG_CALL(zero_arena(zl0, zl_bytes, geo));
         ENG_CALL(zero_arena(losses, 32, geo));
@@ -691,9 +691,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         // which of the encoder's two layouts hold a window with more than 64 kept pillars (= a bundle of more than four tiles:
         // the one-launch layer's second kernel): known since the batch's stage 1, a step ago
         int big = 3;
-        static const bool skip_big = [] { const char* v = getenv("GEOMAE_FUSED_SKIP_BIG"); return !v || v[0] != '0'; }();
+        const bool skip_big = tuning().fused_skip_big != 0;
         // (a bundle packs whole windows up to its cap: only with a cap of at most 64 positions does "no window above 64" mean "no
-        //  bundle above four tiles" -- the packing of token sets above 12288 and GEOMAE_BUNDLE_CAP use larger caps)
+        //  bundle above four tiles" -- the packing of token sets above 12288 and GeomaeTuning.bundle_cap may use larger caps)
         if (skip_big && !b.mask_injected && b.host_maxkeep && geomae_window_bundle_cap(nk, max_tokens) <= 64) {
             GEOMAE_HIP(hipEventSynchronize(b.readback2));            // (stage 1 of this batch ended during the previous step)
             big = (b.host_maxkeep[0] < 0 || b.host_maxkeep[0] > 64 ? 1 : 0) | (b.host_maxkeep[1] < 0 || b.host_maxkeep[1] > 64 ? 2 : 0);
@@ -718,8 +718,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     // on into that stack's backward -- neither waits for the other stack's forward (one launch for all heads needed the
     // decoder-B stream to join the main stream in front of it and to fork again behind it: two cross-queue hand-overs of
     // ~13 us on the critical path).  The density decoder feeds ONE head (nor_top -> loss_curv_around), the centroid
-    // decoder the other five.  GEOMAE_HEADS_JOINT=1: the joint launch.
-    static const bool heads_joint = [] { const char* v = getenv("GEOMAE_HEADS_JOINT"); return v && v[0] == '1'; }();
+    // decoder the other five.  GeomaeTuning.heads_joint: the joint launch.
+    const bool heads_joint = tuning().heads_joint != 0;
     if (heads_joint) {
         ENG_CALL(order_after(e, kJoinDecFwd, aux, main));
         ENG_CALL(geomae_heads_loss_split_accumulate(cen, den, nk, nm, m.head_w_packed, m.head_bias, t_clow, t_mlow, t_cmed,
@@ -743,10 +743,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     // The decoders' contractions go to the geometry stream every two layers while the frame is small enough for the 80-workgroup
     // contraction budget (n <= 32768: 1.680 vs 1.689 ms at config 2, five alternated runs), and behind the whole stack above that
-    // (Waymo geometry 4.275 vs 4.247 ms with the flush, config 3 flat).  GEOMAE_DEC_DW_EVERY=k overrides (0 = behind the stack).
-    static const int dec_every_env = [] { const char* v = getenv("GEOMAE_DEC_DW_EVERY"); return v ? atoi(v) : -1; }();
+    // (Waymo geometry 4.275 vs 4.247 ms with the flush, config 3 flat).  GeomaeTuning.dec_dw_every = k overrides (0 = behind the stack).
+    const int dec_every_env = tuning().dec_dw_every;
     const int dec_every = dec_every_env >= 0 ? dec_every_env : (n <= 32768 ? 2 : 0);
-    static const int dec_mid_budget = [] { const char* v = getenv("GEOMAE_DEC_MID_BUDGET"); return v ? atoi(v) : 0; }();   // (A/B)
+    const int dec_mid_budget = tuning().dec_mid_budget;   // (A/B)
     struct MidFlushScopeD {
         explicit MidFlushScopeD(const DwMidFlush& f) { set_dw_mid_flush(f); }
         ~MidFlushScopeD() { set_dw_mid_flush(DwMidFlush()); }
@@ -779,9 +779,10 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     {
         // (round 5) the ENCODER's contractions leave its backward launches too: queued per layer and flushed to the geometry
         // stream every `every` layers as one merged launch of the layer-form contraction (csrc/dw_device.h) -- the ffn-backward
-        // launches carry no riders (GEOMAE_ENC_DW_DEFER=0: riding as in rounds 2-4; GEOMAE_ENC_DW_EVERY: layers per flush)
-        static const bool defer_enc_dw = [] { const char* v = getenv("GEOMAE_ENC_DW_DEFER"); return !v || v[0] != '0'; }();
-        static const int enc_every = [] { const char* v = getenv("GEOMAE_ENC_DW_EVERY"); return v ? atoi(v) : 4; }();
+        // launches carry no riders (GeomaeTuning.enc_dw_defer = 0: riding as in rounds 2-4; four layers per flush: 2 / 3 / 4 / 6
+        // measured in round 5, docs/LAB_NOTES.md)
+        const bool defer_enc_dw = tuning().enc_dw_defer != 0;
+        const int enc_every = 4;
         DeferAllScope defer(defer_enc_dw);
         struct MidFlushScope {
             explicit MidFlushScope(const DwMidFlush& f) { set_dw_mid_flush(f); }
@@ -821,21 +822,12 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     }
     // The step's tail.  Behind the layer-1 sweep two branches remain: the layer-1 weight-gradient contraction (needs dy1 / g:
     // a SPLIT job + its reduction, ~17 + 5 us) and the routing sweep + layer-0 finalize (~22 + 5 us).  Three placements
-    // measured (same box, alternating, ms per step): contraction on the geometry stream beside the routing sweep 1.690 (kept);
-    // everything in line on the main stream 1.696 (GEOMAE_VFE_TAIL=main); contraction on the main stream and the routing sweep
-    // + finalize on the decoder-B stream, idle at that point, 1.695 (GEOMAE_VFE_TAIL=side; single-rank BatchNorm only).  An
-    // event hop between two streams costs 8-15 us on this stack (the kernel trace shows the waiting queue starting that late):
-    // a branch moved to another stream pays two of them, about what running it in line costs.
-    static const int tail_mode = [] {
-        const char* v = getenv("GEOMAE_VFE_TAIL");
-        if (v && !strcmp(v, "main")) return 1;
-        if (v && !strcmp(v, "side")) return 2;
-        if (const char* o = getenv("GEOMAE_VFE_DW1_MAIN")) return o[0] == '1' ? 1 : 0;      // (older spelling)
-        return 0;
-    }();
-    const int tail = (tail_mode == 2 && !fold) ? 0 : tail_mode;
+    // measured in round 5 (same box, alternating, ms per step): contraction on the geometry stream beside the routing sweep 1.690
+    // (kept); everything in line on the main stream 1.696; contraction on the main stream and the routing sweep + finalize on
+    // the decoder-B stream, idle at that point, 1.695.  An event hop between two streams costs 8-15 us on this stack (the
+    // kernel trace shows the waiting queue starting that late): a branch moved to another stream pays two of them, about what
+    // running it in line costs.  The switch of that experiment is gone; the first placement is what runs.
     set_mid_launch_event(e->ev[kVfeL1]);
-    if (tail == 2) set_mid_launch_side(aux);
     const int rc_l1 = geomae_vfe_backward_layer1(&va, &bn, m0, vf, d_vf, use_bs1, n_eff, dy1_b, g_b, nullptr, dh0, dm0, use_bs0,
                                                  fold ? m.bn_dbeta[1] : nullptr, fold ? m.bn_dgamma[1] : nullptr, main);
     (void)take_mid_launch_event();                       // (an early error return leaves them set)
@@ -843,8 +835,8 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
     ENG_CALL(rc_l1);
     mark(e, pVfeL1, main);
     // one [128,128] output contracted over all N points: through the split-K workspace + a reduction launch
-    hipStream_t dw1_stream = tail == 0 ? geo : main;
-    if (tail == 0) GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
+    hipStream_t dw1_stream = geo;
+    GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kVfeL1], 0));
     set_dw_partial(dw1_partial);
     int rc_dw1 = geomae_vfe_weight_grad1(dy1_b, g_b, N, m.vfe_dw1, dw1_stream);
     set_dw_partial(nullptr);
@@ -854,10 +846,9 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         ENG_CALL(geomae_bn_param_grad_add(use_bs0, 64, m.bn_dbeta[0], m.bn_dgamma[0], main));
         e->hook(e->hook_user, GEOMAE_HOOK_BN_BWD0, main);
     }
-    hipStream_t l0_stream = tail == 2 ? aux : main;
+    hipStream_t l0_stream = main;
     ENG_CALL(geomae_vfe_backward_layer0(&va, &bn, dh0, use_bs0, n_eff, N, dy1_b, g_b, m.vfe_dw0, nullptr,
                                         fold ? m.bn_dbeta[0] : nullptr, fold ? m.bn_dgamma[0] : nullptr, l0_stream));
-    if (tail == 2) ENG_CALL(order_after(e, kVfeSide, aux, main));
     mark(e, pVfeL0, main);
     ENG_CALL(order_after(e, kGeoDone, geo, main));
     mark(e, pVfeBwd, main);

@@ -631,17 +631,17 @@ struct LayerW {
 constexpr int kOffWqkv = 0, kOffWqkT = 49152, kOffWvT = 81920, kOffWo = 98304, kOffWoT = 114688, kOffW1 = 131072,
               kOffW1T = 163840, kOffW2 = 196608, kOffW2T = 229376, kPackedPerLayer = 262144;
 #ifdef GEOMAE_HIP_H
-// sst_fused.hip: every layer of a stack in ONE persistent launch (grid barrier between layers); +1: not applicable
-int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
-                                 int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
-                                 long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
-                                 unsigned* sync, hipStream_t stream);
 // sst_fused.hip: the backward of one layer as ONE launch (bundles of at most four tiles); called per layer by sst_stack.hip
 int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
                              const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
                              const GeomaeSstLayerGrads* g, const GeomaeSstStackLayout* layout, int bundle_cap, const void* qkv,
                              const void* attn, const float* lse, const void* xh1, const void* xh2, const void* hp, const float* rstd,
                              void* dqkv, void* du, void* dv, void* dhp, void* h, hipStream_t stream);
+// sst_ws.hip: the forward of one layer as ONE weight-stationary launch (workgroups loop over bundles; windows of up to 144 positions)
+int sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* w,
+                         const GeomaeSstStackLayout* layout, const float* pos_table, float* z, bool z_blocked, void* qkv,
+                         void* attn, float* lse, void* xh1, void* xh2, void* hp, float* rstd, void* xb, void* xp,
+                         int dead_rows, int max_workgroups, hipStream_t stream);
 inline LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
     L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;

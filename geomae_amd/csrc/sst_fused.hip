@@ -29,141 +29,14 @@
 
 #include "sst_device.h"
 
+#include "fused_device.h"
+
 namespace geomae {
-
-typedef __attribute__((ext_vector_type(4))) short bf16x4_s;
-
-__device__ __forceinline__ bf16x4_s as_bf4(uint2 v) { return __builtin_bit_cast(bf16x4_s, v); }
-__device__ __forceinline__ f32x4 mfma16(uint2 a, uint2 b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(as_bf4(a), as_bf4(b), c, 0, 0, 0);
-}
-__device__ __forceinline__ f32x4 mfma32_2(uint2 a0, uint2 a1, uint2 b0, uint2 b1, f32x4 c) {
-    return mfma32(make_uint4(a0.x, a0.y, a1.x, a1.y), make_uint4(b0.x, b0.y, b1.x, b1.y), c);
-}
-
-// phase stamps (tools/fused_layer_time.py builds a second library with -DGEOMAE_PHASE_TIMING; a no-op in the product build)
-#ifdef GEOMAE_PHASE_TIMING
-#define FUSED_STAMP(i)                                                                                          \
-    do {                                                                                                        \
-        if ((threadIdx.x & 63) == 0 && blockIdx.x < GEOMAE_STAMP_BLOCKS)                                        \
-            geomae_stamps[blockIdx.x * GEOMAE_STAMP_SLOTS + (threadIdx.x >> 8) * 16 + (i)] = clock64();           \
-    } while (0)
-#else
-#define FUSED_STAMP(i) do {} while (0)
-#endif
-
-constexpr int kFusedThreads = 512;
-constexpr int kFMaxT = 144;              // tokens per bundle (a 12 x 12 window)
-constexpr int kFRow = 2 * (128 + 8);     // bytes of one bf16 row of 128 channels in LDS (+16 B: conflict-free b128 reads)
-constexpr int kFRowH = 2 * (256 + 8);    // ... of 256 channels
-constexpr int kFOor = 0x7fff0000;        // a byte offset past every buffer: loads return 0, stores are dropped
-// LDS: [X / Y | XP | O] (H aliases XP + O) | LayerNorm statistics [token][wave][2] | window start / end per position
-constexpr int kFLdsX = 0, kFLdsXP = kFMaxT * kFRow, kFLdsO = 2 * kFMaxT * kFRow, kFLdsRed = 3 * kFMaxT * kFRow;
-constexpr int kFLdsWl = kFLdsRed + kFMaxT * 64, kFLdsWh = kFLdsWl + kFMaxT * 4, kFLdsPrm = kFLdsWh + kFMaxT * 4;
-constexpr int kFLdsBytes = kFLdsPrm + 1408 * 4;
-static_assert(kFMaxT * kFRowH <= 2 * kFMaxT * kFRow, "H must fit in XP + O");
-
-struct FusedFwd {
-    const float* x;              // layer input, token order: tile-blocked [ceil16(n)][128] fp32 -- unless M.src is set
-    SstInputMap M;               // first layer of a stack: row-major source rows (+ row map, + fill row), common.h
-    const int32_t* bun_tok;      // [NB + 1] bundle b covers plan positions [bun_tok[b], bun_tok[b + 1])
-    const int4* plan;            // per position: (token, in-window position, window start, window end)
-    const int32_t* num_bundles;
-    const float* pos_table;      // [wx * wy][128]
-    LayerW W;
-    int n;
-    float eps;
-    float* z;                    // layer output [n][128] fp32: tile-blocked (z_blocked) or row-major
-    int z_blocked;
-    // saved for the backward (token order, tile-blocked; all or none)
-    bf16_t *qkv, *attn, *xh1, *xh2, *hp, *xb, *xp;
-    float *lse, *rstd;
-    // persistent form (sst_stack_fwd_kernel): x was written by OTHER workgroups of this launch (read past the L1: sc1), z is
-    // read by other workgroups of this launch (written through: sc0 sc1)
-    int coh_in = 0, coh_out = 0;
-};
-
-// byte offset of lane (token, g)'s 4 channels of channel tile ct in a tile-blocked [.][ld] tensor of E-byte elements
-template <int E>
-__device__ __forceinline__ int blk_off(int tok, int ld, int ct, int g) {
-    return (tok >> 4) * (16 * ld * E) + ct * (256 * E) + (tok & 15) * (16 * E) + g * (4 * E);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t whole_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p), 0, kFOor, 0x00020000);   // (offsets >= kFOor are out of range)
-}
-// (timing ablations: FUSED_ABL_NO_SAVE drops every store of the saved activations -- descriptors of zero records --,
-// FUSED_ABL_NO_Z the layer's output too: what the bytes a launch leaves dirty in L2 cost at its end)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t saved_rsrc(const void* p) {
-#ifdef FUSED_ABL_NO_SAVE
-    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(p), 0, 0, 0x00020000);
-#else
-    return whole_rsrc(p);
-#endif
-}
-__device__ __forceinline__ void buf_store_f32x4(__amdgpu_buffer_rsrc_t r, int off, f32x4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, off, 0, 0);
-}
-__device__ __forceinline__ void buf_store_f32(__amdgpu_buffer_rsrc_t r, int off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, off, 0, 0);
-}
-__device__ __forceinline__ uint4 lds_b128(const char* p) { return *reinterpret_cast<const uint4*>(p); }
-
-// A fragments of output tile `ot` of a FRAGMENT-MAJOR packed [N][K] matrix (pack_weights_kernel, tr & 4): one contiguous
-// 1-KB piece per (tile, k step).  (Read as 16 rows x 64 B from the row-major copy the same fetch took 8 k cycles longer
-// per workgroup: every 128-byte line was requested twice, by two different instructions.)
-template <int K>
-__device__ __forceinline__ void load_wfrag(const bf16_t* __restrict__ Wf, int ot, int lane, uint4 (&f)[K / 32]) {
-#ifdef FUSED_ABL_NO_WEIGHTS          // (timing ablation: what the weight fetch costs the chain)
-#pragma unroll
-    for (int kk = 0; kk < K / 32; ++kk) f[kk] = make_uint4(lane, ot, kk, 0x3c003c00u);
-    return;
-#endif
-    const bf16_t* p = Wf + (size_t)ot * (16 * K) + 8 * lane;
-#pragma unroll
-    for (int kk = 0; kk < K / 32; ++kk) f[kk] = *reinterpret_cast<const uint4*>(p + 512 * kk);
-}
-__device__ __forceinline__ f32x4 load_f4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-
-// LayerNorm over the 128 channels of a token that 8 waves hold 16 channels each of: every wave leaves (sum, sum of squares)
-// of its 16 channels -- two INDEPENDENT cross-lane reductions (the Welford form, mean first and then the centred squares,
-// was one dependent chain twice as long on the critical path of two phases) -- and every wave merges the eight pairs.
-// The inputs are residual sums of LayerNorm outputs (|mean| of the order of sigma), far from the cancellation regime of
-// E[x^2] - E[x]^2 in fp32.
-__device__ __forceinline__ void ln_merge(const float* red_tok, float eps, float* mean_out, float* rstd_out) {
-    f32x4 a[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4*>(red_tok + 4 * i);
-    const f32x4 s = (a[0] + a[1]) + (a[2] + a[3]);
-    const float mean = (s[0] + s[2]) * (1.0f / 128.0f);
-    const float var = fmaxf((s[1] + s[3]) * (1.0f / 128.0f) - mean * mean, 0.0f);
-    *mean_out = mean;
-    *rstd_out = rsqrtf(var + eps);
-}
-// this wave's (sum, sum of squares) of the 16 channels it holds of token (lane & 15): u = 4 channels per lane group
-__device__ __forceinline__ void ln_partial(const f32x4 u, float* red_tok_wave, int g) {
-    const float s = rows4_sum((u[0] + u[1]) + (u[2] + u[3]));
-    const float q = rows4_sum((u[0] * u[0] + u[1] * u[1]) + (u[2] * u[2] + u[3] * u[3]));
-    if (g == 0) *reinterpret_cast<float2*>(red_tok_wave) = make_float2(s, q);
-}
-
-// fp32 parameter vectors of the layer, fetched once per workgroup into LDS (read back with ds_read: a global load at the
-// point of use waits behind every store the wave issued before it -- vmcnt retires in order on gfx9)
-constexpr int kPBq = 0, kPBo = 384, kPG1 = 512, kPBe1 = 640, kPB1 = 768, kPB2 = 1024, kPG2 = 1152, kPBe2 = 1280, kPFloats = 1408;
-__device__ __forceinline__ f32x4 params_issue(const LayerW& W) {
-    const int s = threadIdx.x;                                        // float4 slot 0..351
-    const float* src = s < 96 ? W.bqkv + 4 * s : s < 128 ? W.bo + 4 * (s - 96) : s < 160 ? W.g1 + 4 * (s - 128)
-                     : s < 192 ? W.be1 + 4 * (s - 160) : s < 256 ? W.b1 + 4 * (s - 192) : s < 288 ? W.b2 + 4 * (s - 256)
-                     : s < 320 ? W.g2 + 4 * (s - 288) : W.be2 + 4 * (s - 320);
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (s < kPFloats / 4) v = *reinterpret_cast<const f32x4*>(src);
-    return v;
-}
 
 // NT: tiles the body is unrolled for.  EXACT: the bundle has exactly NT tiles -- straight-line code (the scheduler overlaps
 // the tiles' chains), all tile pairs of the attention computed (the mask does the block-diagonal).  !EXACT: nt <= NT tiles
 // behind scalar branches, key-tile ranges.  Weight fragments are fetched two phases ahead of their first use.
-// COH: the persistent form's coherent residual-stream accesses (FusedFwd.coh_in / coh_out); compiled out of the per-layer launch
-template <int NT, bool EXACT, bool COH = false>
+template <int NT, bool EXACT>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, const int T, const int nt_in, char* lds) {
     const int nt = EXACT ? NT : nt_in;
 #define FOR_TILES(it) _Pragma("unroll") for (int it = 0; it < NT; ++it) if (EXACT || it < nt)
@@ -216,7 +89,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             } else {
                 off = tk >= 0 ? blk_off<4>(tk, 128, w, g) : kFOor;
             }
-            xr[it] = (COH && A.coh_in) ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 16)) : buf_load_f32x4(xres, off);
+            xr[it] = buf_load_f32x4(xres, off);
             pv[it] = buf_load_f32x4(pres, tk >= 0 ? rec[it].y * 512 + 64 * w + 16 * g : kFOor);
 #ifdef FUSED_ABL_NO_ROWS             // (timing ablation: the row hop)
             xr[it] = f32x4{0.01f * off, 0.5f, -0.5f, 0.25f}; pv[it] = f32x4{0.f, 0.1f, 0.2f, 0.3f};
@@ -449,8 +322,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             const f32x4 zz = xh * g2 + be2;
             const int zo = tk < 0 ? kFOor : (A.z_blocked ? blk_off<4>(tk, 128, w, g) : tk * 512 + 64 * w + 16 * g);
 #ifndef FUSED_ABL_NO_Z
-            if (COH && A.coh_out) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, zz), z_r, zo, 0, 17);
-            else buf_store_f32x4(z_r, zo, zz);
+            buf_store_f32x4(z_r, zo, zz);
 #endif
         }
     }
@@ -461,7 +333,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 // The exact bodies (bundles of 1-4 tiles: every bundle of the packing but a single window that kept more than 64 pillars) and
 // the generic 5-9-tile body are TWO kernels (round 5).  In one kernel the generic body set the register allocation of
 // everything -- 256 VGPRs, 69 spilled, 280 B of scratch per lane -- and the layer took 26.3 us; the exact bodies alone (212 / 234
-// VGPRs, no scratch) take 21.4 us (tools/persist_time.py, config 2's encoder).  The second launch finds the large bundles
+// VGPRs, no scratch) take 21.4 us (round 5's stack-alone timing, config 2's encoder).  The second launch finds the large bundles
 // itself (the bundle count and sizes live on the device): every workgroup scans the bundle table, the k-th large bundle goes
 // to workgroup k mod grid; a layout without one costs that launch a scan (~2 us).  (Measured and dropped: the generic body as
 // a noinline call inside one kernel -- 35.5 us per layer.)
@@ -526,112 +398,6 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_big_kernel(Fus
             __syncthreads();
         }
         base = total;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// PERSISTENT form (round 5): all layers of a stack in ONE launch.  A launch per layer costs the stack a kernel boundary, the
-// dispatch ramp and a cold start per layer (~5-9 us of the 24.5 us a layer took at config 2, with 163 workgroups of 15-19 us
-// each); here the workgroups stay, and layers are separated by a grid barrier built for what crosses it:
-//  * the only data layer l + 1 reads from OTHER workgroups is z (the residual stream): written through (sc0 sc1 stores) and
-//    read past the L1 (sc1 loads) -- no agent-scope release (an L2 write-back of every line the 140 KB of saved activations
-//    per workgroup left dirty: ~6 us, MI355X_MICROARCH.md) and no acquire;
-//  * arrival: each wave drains its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE relaxed agent-scope add on the counter
-//    of the workgroup's slot class (blockIdx & 7: eight counters 128 B apart, ~20 arrivals each instead of 163 on one word);
-//    departure: eight lanes poll the eight counters (sc1 loads, s_sleep between polls) until each holds its expected count;
-//  * every workgroup must be resident: the grid is capped at the CU count (one 134-KB-LDS workgroup per CU) and workgroups
-//    loop over bundles; a bounded spin (kSpinLimit polls, ~0.3 s) raises an error word instead of hanging the device.
-// The saved activations are plain stores: only later launches (the backward) read them.
-constexpr int kPMaxLayers = 12;
-constexpr int kSyncStrideWords = 32;             // counters 128 B apart
-constexpr int kSyncErrWord = 8 * kSyncStrideWords;
-constexpr int kSpinLimit = 1 << 19;
-struct FusedStack {
-    const float* x0; SstInputMap M;              // layer 0 input: tile-blocked x0, or the row-major source map
-    const int32_t* bun_tok[2]; const int4* plan[2]; const int32_t* num_bundles[2];
-    const float* pos_table;
-    const bf16_t* frag[kPMaxLayers];
-    const float* prm[kPMaxLayers][8];            // bqkv, bo, g1, be1, b1, b2, g2, be2
-    char* saved; long long stride;               // layer l's saved tensors at saved + l * stride + off_*
-    long long off_x, off_qkv, off_attn, off_lse, off_xh1, off_xh2, off_hp, off_rstd, off_xb, off_xp;
-    float* z_out;                                // last layer's output, row-major
-    int n, num_layers, skip_x_above0;
-    float eps;
-    unsigned* sync;                              // zeroed by the host before the launch: 8 counters + error word
-};
-static_assert(sizeof(FusedStack) <= 2048, "kernel arguments");
-
-__device__ __forceinline__ void stack_grid_barrier(unsigned* sync, int phase /* 1, 2, ... */) {
-    __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): this wave's stores (z written through) have completed
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        if (lane == 0) __hip_atomic_fetch_add(sync + (blockIdx.x & 7) * kSyncStrideWords, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // slot class c holds the blocks b with b % 8 == c: ceil((grid - c) / 8) of them
-        const unsigned expect = lane < 8 ? (unsigned)(((int)gridDim.x - lane + 7) / 8) * (unsigned)phase : 0u;
-        int spins = 0;
-        for (;;) {
-            const unsigned v = lane < 8 ? __hip_atomic_load(sync + lane * kSyncStrideWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-            if (__builtin_amdgcn_ballot_w64(v < expect) == 0) break;
-            if (++spins > kSpinLimit || __hip_atomic_load(sync + kSyncErrWord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                if (lane == 0) __hip_atomic_store(sync + kSyncErrWord, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;                           // (results of this launch are invalid; the host can read the error word)
-            }
-            __builtin_amdgcn_s_sleep(8);
-        }
-    }
-    __syncthreads();
-}
-
-// -DGEOMAE_PERSIST_STAMPS (tools/persist_time.py with a timing build): s_memrealtime (100 MHz, one clock for the device) at
-// the start of every layer, the end of its bundles and behind its barrier, per workgroup
-#ifdef GEOMAE_PERSIST_STAMPS
-static __device__ unsigned long long persist_stamps[256 * 40];
-#define PSTAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) persist_stamps[blockIdx.x * 40 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define PSTAMP(i) do {} while (0)
-#endif
-
-__global__ __launch_bounds__(kFusedThreads, 2) void sst_stack_fwd_kernel(FusedStack S) {
-    __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
-    for (int l = 0; l < S.num_layers; ++l) {
-        PSTAMP(3 * l);
-        FusedFwd A;
-        char* sv = S.saved + S.stride * l;
-        const bool last = l + 1 == S.num_layers;
-        A.x = l == 0 ? S.x0 : reinterpret_cast<const float*>(sv + S.off_x);
-        A.M = l == 0 ? S.M : SstInputMap{nullptr, 0, nullptr, nullptr};
-        A.bun_tok = S.bun_tok[l & 1]; A.plan = S.plan[l & 1]; A.num_bundles = S.num_bundles[l & 1];
-        A.pos_table = S.pos_table;
-        A.W.frag = S.frag[l];
-        A.W.bqkv = S.prm[l][0]; A.W.bo = S.prm[l][1]; A.W.g1 = S.prm[l][2]; A.W.be1 = S.prm[l][3];
-        A.W.b1 = S.prm[l][4]; A.W.b2 = S.prm[l][5]; A.W.g2 = S.prm[l][6]; A.W.be2 = S.prm[l][7];
-        A.n = S.n; A.eps = S.eps;
-        A.z = last ? S.z_out : reinterpret_cast<float*>(sv + S.stride + S.off_x);
-        A.z_blocked = last ? 0 : 1;
-        A.qkv = (bf16_t*)(sv + S.off_qkv); A.attn = (bf16_t*)(sv + S.off_attn); A.xh1 = (bf16_t*)(sv + S.off_xh1);
-        A.xh2 = (bf16_t*)(sv + S.off_xh2); A.hp = (bf16_t*)(sv + S.off_hp);
-        A.xb = (l > 0 && S.skip_x_above0) ? nullptr : (bf16_t*)(sv + S.off_xb);
-        A.xp = (bf16_t*)(sv + S.off_xp); A.lse = (float*)(sv + S.off_lse); A.rstd = (float*)(sv + S.off_rstd);
-        A.coh_in = l > 0; A.coh_out = !last;
-        const int NB = A.num_bundles[0];
-        for (int b = blockIdx.x; b < NB; b += gridDim.x) {
-            const int s0 = A.bun_tok[b];
-            int T = A.bun_tok[b + 1] - s0;
-            if (T > kFMaxT) T = kFMaxT;
-            const int nt = (T + 15) >> 4;
-            switch (nt) {
-                case 1: fused_fwd_body<1, true, true>(A, s0, T, nt, lds); break;
-                case 2: fused_fwd_body<2, true, true>(A, s0, T, nt, lds); break;
-                case 3: fused_fwd_body<3, true, true>(A, s0, T, nt, lds); break;
-                case 4: fused_fwd_body<4, true, true>(A, s0, T, nt, lds); break;
-                default: fused_fwd_body<9, false, true>(A, s0, T, nt, lds); break;
-            }
-            __syncthreads();                      // the LDS rows are free for the next bundle / layer
-        }
-        PSTAMP(3 * l + 1);
-        if (!last) stack_grid_barrier(S.sync, l + 1);
-        PSTAMP(3 * l + 2);
     }
 }
 
@@ -1044,53 +810,6 @@ extern "C" int geomae_debug_read_fused_stamps(unsigned long long* host, int clea
         hipMemcpyToSymbol(HIP_SYMBOL(geomae_stamps), zeros, sizeof(zeros));
     }
     return 0;
-}
-#endif
-
-// All layers of a stack in one launch (sst_stack_fwd_kernel).  -> GEOMAE_OK / error, or +1 when this stack cannot take that form (the
-// caller then launches layer by layer).  `sync` = kStackSyncBytes of device memory, zeroed here on `stream`.
-int geomae::sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
-                                         int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
-                                         long long stride, const long long* off /* x qkv attn lse xh1 xh2 hp rstd xb xp */,
-                                         float* z_out, bool skip_x_above0, int bundle_cap, unsigned* sync, hipStream_t stream) {
-    if (num_layers > kPMaxLayers || num_layers < 2 || bundle_cap > kFMaxT) return 1;
-    static const int cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-    }();
-    if (cus < 8) return 1;
-    FusedStack S;
-    memset(&S, 0, sizeof(S));
-    S.x0 = x_in; S.M = M;
-    for (int k = 0; k < 2; ++k) {
-        S.bun_tok[k] = layouts[k].fbun_tok; S.plan[k] = (const int4*)layouts[k].pos_info; S.num_bundles[k] = layouts[k].num_fbundles;
-    }
-    S.pos_table = pos_table;
-    for (int l = 0; l < num_layers; ++l) {
-        const GeomaeSstLayerWeights& w = layers[l];
-        if (!w.frag_p || !w.bqkv || !w.bo || !w.ln1_w || !w.ln1_b || !w.b1 || !w.b2 || !w.ln2_w || !w.ln2_b || w.ln_eps != layers[0].ln_eps)
-            return 1;
-        S.frag[l] = (const bf16_t*)w.frag_p;
-        const float* prm[8] = {w.bqkv, w.bo, w.ln1_w, w.ln1_b, w.b1, w.b2, w.ln2_w, w.ln2_b};
-        for (int k = 0; k < 8; ++k) S.prm[l][k] = prm[k];
-    }
-    S.saved = saved; S.stride = stride;
-    S.off_x = off[0]; S.off_qkv = off[1]; S.off_attn = off[2]; S.off_lse = off[3]; S.off_xh1 = off[4]; S.off_xh2 = off[5];
-    S.off_hp = off[6]; S.off_rstd = off[7]; S.off_xb = off[8]; S.off_xp = off[9];
-    S.z_out = z_out; S.n = num_tokens; S.num_layers = num_layers; S.skip_x_above0 = skip_x_above0 ? 1 : 0;
-    S.eps = layers[0].ln_eps; S.sync = sync;
-    int grid = fused_grid(num_tokens, layouts[0].max_bundles < layouts[1].max_bundles ? layouts[0].max_bundles : layouts[1].max_bundles, bundle_cap);
-    if (grid > cus) grid = cus;                  // every workgroup must be resident: one per CU (134 KB of LDS)
-    GEOMAE_HIP(hipMemsetAsync(sync, 0, kStackSyncBytes, stream));
-    hipLaunchKernelGGL(sst_stack_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, S);
-    return check_launch("sst_stack_fwd_kernel");
-}
-
-#ifdef GEOMAE_PERSIST_STAMPS
-extern "C" int geomae_debug_read_persist_stamps(unsigned long long* host) {
-    hipDeviceSynchronize();
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(persist_stamps), sizeof(unsigned long long) * 256 * 40);
 }
 #endif
 

@@ -1102,19 +1102,16 @@ constexpr int kMaxLayerTokens = 2700000;
 #define GEOMAE_CHECK_TOKENS(n, who) GEOMAE_REQUIRE((n) <= kMaxLayerTokens, who ": more than 2.7 M tokens per call")
 
 // The pair kernels pay when one workgroup per CU covers the whole launch (one wave per SIMD either way, twice the CUs
-// busy); past that the single-wave form's lower total work wins.  GEOMAE_PAIR_KERNELS=0 / 1 (environment) or
-// geomae_sst_set_pair_kernels force the choice (A/B runs, the bit-identity test).
-static int g_pair_mode = [] {
-    const char* e = getenv("GEOMAE_PAIR_KERNELS");
-    return e ? atoi(e) : -1;
-}();
+// busy); past that the single-wave form's lower total work wins.  GeomaeTuning.pair_kernels = 0 / 1 (or
+// geomae_sst_set_pair_kernels) force the choice (A/B runs, the bit-identity test).
 // rows the stack marked dead for the NEXT ffn forward / backward call of this host thread (sst_stack.hip)
 #define t_skip_rows (geomae::first_live_row())
 static bool use_pair_kernels(int tiles) {
-    if (g_pair_mode >= 0) return g_pair_mode != 0;
+    const int mode = tuning().pair_kernels;
+    if (mode >= 0) return mode != 0;
     return cdiv(tiles, 2) <= 256;
 }
-extern "C" void geomae_sst_set_pair_kernels(int32_t mode) { g_pair_mode = mode < 0 ? -1 : (mode != 0); }
+extern "C" void geomae_sst_set_pair_kernels(int32_t mode) { tuning_mut().pair_kernels = mode < 0 ? -1 : (mode != 0); }
 
 extern "C" int geomae_sst_qkv_forward(const float* x, const int32_t* tok_pos, const float* pos_table,
                                       const GeomaeSstLayerWeights* w, int32_t num_tokens, void* qkv_bf16,
@@ -1294,7 +1291,7 @@ extern "C" int geomae_sst_weight_grad(int32_t num_tokens, const void* dqkv_bf16,
     T.t[7] = {dv,   128, 0,   h,  256, 128, g->w2, 256, 0,   128, nullptr, 128};  // dW2 cols 128..255
     PendingDw P{T, 8, num_tokens, true};
     const int dead = take_dw_dead_rows();
-    static const bool layer_form = [] { const char* e = getenv("GEOMAE_DW_LAYER_FORM"); return !(e && e[0] == '0'); }();   // (A/B)
+    const bool layer_form = tuning().dw_layer_form != 0;   // (A/B)
     if (layer_form && T.blocked && dw_partial()) {      // the stacks' contractions: four jobs of the layer-form kernel
         P.has_layer = true;
         P.partial_base = dw_partial();
@@ -1397,13 +1394,13 @@ int geomae::launch_dw_layers(const PendingDw* P, int count, hipStream_t stream) 
     // in the step 96 workgroups are the optimum at every size (config 2: 1.860 / 1.860 / 1.86 / 1.91 ms at 4 / 6 / 8 / 12 chunks
     // of 16 jobs; config 3: 7.29 / 6.37 / 6.07 / 5.91 / 6.00 / 6.15 ms at 2 / 3 / 4 / 6 / 8 / 12 -- fewer do not finish before
     // the step's join, more slow the main stream's kernels)
-    static const int g_env = [] { const char* e = getenv("GEOMAE_DW_CHUNKS"); return e ? atoi(e) : 0; }();                // (A/B)
+    const int g_env = tuning().dw_chunks;                // (A/B)
     // (round 5, with the one-launch encoder backward: its ~165 workgroups hold a CU each too, and 165 + 96 > 256 sent some of
     //  them to a second round -- 80 workgroups at the sizes where that kernel runs beside these launches: config 2
     //  1.735 / 1.700 / 1.71 / 1.81 ms at 96 / 80 / 64 / 48)
-    // (GEOMAE_DW_BUDGET_MID=w: the budget of launches of 12289-32768 tokens -- config 2's decoders, which run beside the OTHER
+    // (GeomaeTuning.dw_budget_mid = w: the budget of launches of 12289-32768 tokens -- config 2's decoders, which run beside the OTHER
     //  decoder's backward, not beside the one-launch encoder kernels -- A/B)
-    static const int mid_env = [] { const char* e = getenv("GEOMAE_DW_BUDGET_MID"); return e ? atoi(e) : 0; }();
+    const int mid_env = tuning().dw_budget_mid;
     const int hint = take_dw_budget_hint();
     const int budget = hint > 0 ? hint : A.n <= 12288 ? 80 : A.n <= 32768 ? (mid_env > 0 ? mid_env : 80) : 96;
     int G = budget / A.njobs;
@@ -1458,7 +1455,7 @@ int geomae::launch_dw_split(const bf16_t* A, const bf16_t* B, int n, float* C, f
     DlReduce R;
     R.partial = partial; R.njobs = 1; R.G = G;
     R.job[0].kind = kDlSplit; R.job[0].pad_ = 0; R.job[0].out[0] = S.job[0].out[0]; R.job[0].out[1] = S.job[0].out[1];
-    static const bool two_level = [] { const char* v = getenv("GEOMAE_DW_SPLIT_REDUCE"); return !v || v[0] != '0'; }();   // (0: A/B)
+    const bool two_level = tuning().dw_split_reduce != 0;   // (0: A/B)
     if (!two_level) {
         hipLaunchKernelGGL(dw_layer_reduce_kernel, dim3(cdiv(kDlTileSlots, 256)), dim3(256), 0, stream, R);
         return check_launch("dw_layer_reduce_kernel");

@@ -24,11 +24,11 @@
 #include <vector>
 
 namespace geomae {
-// sst_fused.hip: every layer of a stack in ONE persistent launch (grid barrier between layers); +1: not applicable
-int sst_stack_forward_persistent(const float* x_in, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* layers,
-                                 int num_layers, const GeomaeSstStackLayout* layouts, const float* pos_table, char* saved,
-                                 long long stride, const long long* off, float* z_out, bool skip_x_above0, int bundle_cap,
-                                 unsigned* sync, hipStream_t stream);
+// sst_ws.hip: the forward of one layer as ONE weight-stationary launch (workgroups loop over bundles; windows of up to 144 positions)
+int sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* w,
+                         const GeomaeSstStackLayout* layout, const float* pos_table, float* z, bool z_blocked, void* qkv,
+                         void* attn, float* lse, void* xh1, void* xh2, void* hp, float* rstd, void* xb, void* xp,
+                         int dead_rows, int max_workgroups, hipStream_t stream);
 // sst_fused.hip: the backward of one layer as ONE launch (bundles of at most four tiles)
 int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
                              const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
@@ -47,34 +47,44 @@ namespace geomae {
 
 static inline int64_t al256(int64_t b) { return (b + 255) / 256 * 256; }
 
-// geomae_sst_set_fused_layers / GEOMAE_FUSED_LAYERS = 0 (never) | 1 (automatic) | 2 (always)
+// GeomaeTuning.fused_layers (geomae_sst_set_fused_layers) = 0 (never) | 1 (automatic) | 2 (always)
 // The one-launch layer kernel is a LATENCY design: one workgroup of 8 waves per bundle and CU (134 KB of LDS), every
 // wave walking the whole layer for its channel slice.  It wins where a layer's launches do not fill the chip anyway (the
 // encoder's kept pillars at BASELINE configs 1 / 2: 26.1 vs 27.7 us per layer); at 28 k tokens (config 3's encoder) the
 // three-launch form, with two workgroups per CU, moves more tokens per us (52 vs 72 us per layer), and so it does at the
 // decoders' sizes (tools/fused_layer_time.py).  Automatic = token sets of at most kFusedMaxTokens.
-static int g_fused_mode = [] { const char* e = getenv("GEOMAE_FUSED_LAYERS"); return e ? atoi(e) : 1; }();
-static const int kFusedMaxTokens = [] { const char* e = getenv("GEOMAE_FUSED_MAX_TOKENS"); return e ? atoi(e) : 12288; }();
-static bool fused_layers_enabled(int num_tokens) { return g_fused_mode == 2 || ((g_fused_mode == 1 || g_fused_mode == 3) && num_tokens <= kFusedMaxTokens); }
-// mode 3: as 1, but one launch per LAYER (never the persistent whole-stack launch): A/B runs
+static bool fused_layers_enabled(int num_tokens) {
+    const GeomaeTuning& t = tuning();
+    return t.fused_layers == 2 || ((t.fused_layers == 1 || t.fused_layers == 3) && num_tokens <= t.fused_max_tokens);
+}
+// The weight-stationary one-launch layer (sst_ws.hip) takes the token sets ABOVE that range (GeomaeTuning.ws_layers = 1), or
+// every token set (2); fused_layers == 2 ("always the one-bundle-per-workgroup form": tests, A/B) wins over it.
+static bool ws_layers_enabled(int num_tokens) {
+    const GeomaeTuning& t = tuning();
+    if (t.fused_layers == 2) return false;
+    return t.ws_layers == 2 || (t.ws_layers == 1 && num_tokens > t.fused_max_tokens);
+}
+static int ws_workgroups() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    const int m = tuning().ws_max_workgroups;
+    return m > 0 ? m : cus;
+}
 
 struct SavedOffsets {
     int64_t x, qkv, attn, lse, xh1, xh2, hp, rstd, xb, xp, stride;
 };
 // layout flags of sst_layer.hip (kLayBlocked / kLayXBlocked / kLayZBlocked)
 constexpr int kBlk = 1, kXBlk = 2, kZBlk = 4, kSavedBf16 = 8;
-// bf16 saved x-hat rows (sst_layer.hip kLaySavedBf16); GEOMAE_SAVED_F32=1 keeps them fp32 (A/B runs, parity checks)
-static int saved_flag() {
-    static const int f = [] { const char* e = getenv("GEOMAE_SAVED_F32"); return (e && e[0] == '1') ? 0 : kSavedBf16; }();
-    return f;
-}
+// bf16 saved x-hat rows (sst_layer.hip kLaySavedBf16); GeomaeTuning.saved_f32 keeps them fp32 (A/B runs, parity checks)
+static int saved_flag() { return tuning().saved_f32 ? 0 : kSavedBf16; }
 
 // dW_v's operand x of the layers above the first: formed by the contraction from the layer below's saved xhat2 (bf16 saves
-// only; GEOMAE_X_FROM_XHAT=0: the stored copy, A/B runs).  The forward then stores no x copy for those layers.
-static bool x_from_xhat_enabled() {
-    static const bool on = [] { const char* e = getenv("GEOMAE_X_FROM_XHAT"); return !(e && e[0] == '0'); }();
-    return on && saved_flag() == kSavedBf16;
-}
+// only; GeomaeTuning.x_from_xhat = 0: the stored copy, A/B runs).  The forward then stores no x copy for those layers.
+static bool x_from_xhat_enabled() { return tuning().x_from_xhat && saved_flag() == kSavedBf16; }
 
 // The stack's own buffers are tile-blocked ([n/16][C/16][16][16], sst_device.h "Row layouts"): sized for ceil16(n) rows
 static SavedOffsets saved_offsets(int64_t n, int heads) {
@@ -163,7 +173,7 @@ void profiler_end(void* prof, hipStream_t s) {
 
 using namespace geomae;
 
-extern "C" void geomae_sst_set_fused_layers(int32_t mode) { g_fused_mode = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
+extern "C" void geomae_sst_set_fused_layers(int32_t mode) { tuning_mut().fused_layers = mode < 0 ? 0 : (mode > 2 ? 2 : mode); }
 
 extern "C" void* geomae_profiler_create(int32_t kernel_id, int32_t max_launches) {
     Profiler* p = new Profiler();
@@ -192,7 +202,7 @@ extern "C" void geomae_profiler_destroy(void* prof) {
 }
 
 extern "C" int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads) {
-    return saved_offsets(num_tokens, num_heads).stride * num_layers + kStackSyncBytes;   // (+ the persistent forward's counters)
+    return saved_offsets(num_tokens, num_heads).stride * num_layers + kStackSyncBytes;   // (+ 2 KB kept from the round-5 layout)
 }
 extern "C" int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens) { return scratch_offsets(num_tokens).total; }
 extern "C" int64_t geomae_sst_stack_scratch_bytes_layers(int32_t num_tokens, int32_t num_layers) {
@@ -235,26 +245,29 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         explicit SkipXCopyScope(bool on) { set_skip_x_copy(on); }
         ~SkipXCopyScope() { set_skip_x_copy(false); }
     };
+    // ---- one weight-stationary launch per layer (sst_ws.hip) for the large token sets: the decoders, config 3's encoder
+    if (ws_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
+        saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
+        const int wgs = ws_workgroups();
+        for (int l = 0; l < num_layers; ++l) {
+            char* sv = base + so.stride * l;
+            const bool next = l + 1 < num_layers;
+            float* z = next ? (float*)(sv + so.stride + so.x) : z_out;
+            Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
+            const SstInputMap M = l == 0 ? SstInputMap{x_in, num_input_rows, fill_row, input_rows} : SstInputMap{nullptr, 0, nullptr, nullptr};
+            const bool skip_x = l > 0 && x_from_xhat_enabled();   // (the contraction forms x from the layer below's saved xhat2)
+            rc = sst_layer_forward_ws((const float*)(sv + so.x), M, num_tokens, &layers[l], &layouts[l & 1], pos_table, z, next,
+                                      sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1, sv + so.xh2, sv + so.hp,
+                                      (float*)(sv + so.rstd), skip_x ? nullptr : sv + so.xb, sv + so.xp, next ? 0 : live_row, wgs, stream);
+            if (rc) return rc;
+        }
+        return GEOMAE_OK;
+    }
     // ---- one launch per layer (sst_fused.hip) when the layouts carry the build's plan.  Same saved tensors, same layouts
     // as the three-launch form below (which stays for layouts without a plan, GEOMAE_SAVED_F32=1 and A/B runs).
     if (fused_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
         saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
         const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
-        // ... or ONE launch for the whole stack (sst_stack_fwd_kernel: the workgroups stay, a grid barrier between layers);
-        // its counters live behind the layers' saved tensors.  GEOMAE_PERSISTENT_FWD=0: a launch per layer.
-        // Measured (tools/persist_time.py, s_memrealtime stamps per layer and workgroup, config 2's encoder): the barrier costs
-        // 1-2 us behind the last arrival, a bundle's chain 20 us (median) to 21-27 us (the layer's longest) -- the stack takes
-        // 308-314 us either way (launch per layer: 310-317), and in the step a launch that holds every CU's LDS for 300 us
-        // keeps the decoder-B stream's kernels out (dec_bwd +0.07 ms).  OFF by default (GEOMAE_PERSISTENT_FWD=1: on).
-        static const bool persistent = [] { const char* e = getenv("GEOMAE_PERSISTENT_FWD"); return e && e[0] == '1'; }();
-        if (persistent && g_fused_mode != 3 && saved_bytes >= so.stride * num_layers + kStackSyncBytes) {
-            const long long off[10] = {so.x, so.qkv, so.attn, so.lse, so.xh1, so.xh2, so.hp, so.rstd, so.xb, so.xp};
-            Timed t(profiler, GEOMAE_KERNEL_LAYER_FWD, stream);
-            rc = sst_stack_forward_persistent(x_in, SstInputMap{x_in, num_input_rows, fill_row, input_rows}, num_tokens, layers,
-                                              num_layers, layouts, pos_table, base, so.stride, off, z_out, x_from_xhat_enabled(), cap,
-                                              (unsigned*)(base + so.stride * num_layers), stream);
-            if (rc <= 0) return rc;             // (+1: this stack cannot take that form)
-        }
         for (int l = 0; l < num_layers; ++l) {
             char* sv = base + so.stride * l;
             const bool next = l + 1 < num_layers;
@@ -353,8 +366,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     // ---- one launch per layer (sst_fused.hip sst_layer_bwd_kernel) where the forward took its one-launch form, every
     // contraction is queued (defer all: per-layer operand slabs) and no layout holds a bundle of more than four tiles (the
     // caller says so: common.h set_fused_big_layouts; the step engine knows a step ahead).  GEOMAE_FUSED_BWD=0: never.
-    static const bool fused_bwd_switch = [] { const char* e = getenv("GEOMAE_FUSED_BWD"); return !(e && e[0] == '0'); }();
-    static const bool y_switch0 = [] { const char* e = getenv("GEOMAE_Y_FROM_XHAT"); return !(e && e[0] == '0'); }();
+    const bool fused_bwd_switch = tuning().fused_bwd != 0, y_switch0 = tuning().y_from_xhat != 0;
     const bool fused_bwd = fused_bwd_switch && defer_all && big_layouts == 0 && live_row == 0 && !tail_sum && fused_layers_enabled(num_tokens) &&
                            layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
                            saved_flag() == kSavedBf16 && y_switch0 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p;
@@ -399,7 +411,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
         const char* ws_up = w + sc.set0 + (defer_all ? (l + 1 < num_layers ? l + 1 : l) : ((l + 1) & 1)) * sc.set_bytes;   // slabs of the layer above
         // saved activations in bf16: the ffn backward stores no y = affine(xhat1) copy for dW1, the contraction forms it from
         // the forward's saved xhat1 while it loads its slabs (DwTask.b_scale)
-        static const bool y_switch = [] { const char* e = getenv("GEOMAE_Y_FROM_XHAT"); return !(e && e[0] == '0'); }();   // (A/B)
+        const bool y_switch = tuning().y_from_xhat != 0;   // (A/B)
         const bool y_from_xhat = y_switch && saved_flag() == kSavedBf16;
         set_y_from_xhat(y_from_xhat, layers[l].ln1_w, layers[l].ln1_b);
         // ... and dW_v's x of the layers above the first from the saved xhat2 of the layer below (x = z of that layer)

@@ -1827,7 +1827,7 @@ extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16,
     T.partial = dw_partial();        // a caller's split-K workspace (csrc/engine.hip), summed by its next geomae_flush_weight_grad
     // with a workspace: the layer-form contraction (LDS-direct operand slabs, its own reduction launch); GEOMAE_DW_LAYER_FORM=0:
     // the old kernel (A/B)
-    static const bool layer_form = [] { const char* e = getenv("GEOMAE_DW_LAYER_FORM"); return !(e && e[0] == '0'); }();
+    const bool layer_form = tuning().dw_layer_form != 0;
     if (layer_form && T.partial && num_points < (1ll << 31) - 64)
         return launch_dw_split((const bf16_t*)dy1_bf16, (const bf16_t*)g_bf16, (int)num_points, dw1, T.partial, stream);
     return launch_dw(T, 1, (int)num_points, stream);

@@ -816,12 +816,15 @@ extern "C" int geomae_debug_read_attn_stamps(unsigned long long* host) {
 
 // Bundle size of the SECOND packing of a layout (fbun_tok: the one-launch layer kernel's work items, sst_fused.hip; the
 // attention kernels keep whole-window bundles).  That kernel runs one workgroup per bundle whose dependent chain grows with
-// the bundle, on a 256-CU chip: small token sets want many small bundles.  GEOMAE_BUNDLE_CAP overrides.
+// the bundle, on a 256-CU chip: small token sets want many small bundles.  GeomaeTuning.bundle_cap overrides.
 extern "C" int32_t geomae_window_bundle_cap(int32_t num_tokens, int32_t max_window_tokens) {
-    static const int forced = [] { const char* e = getenv("GEOMAE_BUNDLE_CAP"); return e ? atoi(e) : 0; }();
-    // <= 12288 tokens (the token sets the one-launch layer kernel takes, sst_stack.hip): three 16-token tiles per bundle
-    // (measured at 6.6 k tokens: 26.8 / 25.3 / 27.8 us per layer at caps 40 / 48 / 56); above: whole windows
-    int cap = forced > 0 ? forced : (num_tokens <= 12288 ? 48 : max_window_tokens);
+    const GeomaeTuning& tn = tuning();
+    // <= fused_max_tokens (12288: the token sets the one-bundle-per-workgroup kernel takes, sst_stack.hip): three 16-token tiles
+    // per bundle (measured at 6.6 k tokens: 26.8 / 25.3 / 27.8 us per layer at caps 40 / 48 / 56); above: the weight-stationary
+    // kernel's work items (sst_ws.hip: the weights stay in registers, so a bundle only has to amortise its six barriers --
+    // GeomaeTuning.ws_bundle_cap), or whole windows where that form is off
+    int cap = tn.bundle_cap > 0 ? tn.bundle_cap
+            : (num_tokens <= tn.fused_max_tokens ? 48 : (tn.ws_layers ? tn.ws_bundle_cap : max_window_tokens));
     if (cap < 16) cap = 16;
     if (cap > max_window_tokens) cap = max_window_tokens;
     return cap;
@@ -1007,9 +1010,9 @@ static int attn_grid(int num_tokens, int num_heads, int max_bundles, int cap) {
     return (int)(items < 256 * 16 ? items : 256 * 16);
 }
 
-// heads per attention workgroup (see win_attn_fwd_kernel); GEOMAE_ATTN_HEADS=1/2/4 forces it (A/B runs)
+// heads per attention workgroup (see win_attn_fwd_kernel); GeomaeTuning.attn_heads = 1/2/4 forces it (A/B runs)
 static int attn_heads_per_wg(int num_tokens, int num_heads) {
-    static const int forced = [] { const char* e = getenv("GEOMAE_ATTN_HEADS"); return e ? atoi(e) : 0; }();
+    const int forced = tuning().attn_heads;
     int h = forced ? forced : (num_tokens > 8192 ? 4 : 1);      // decoder forward phase 0.342 / 0.332 / 0.327 ms at 1 / 2 / 4
     while (h > 1 && num_heads % h) h >>= 1;
     return h == 4 || h == 2 ? h : 1;

@@ -33,6 +33,49 @@ const char* geomae_last_error(void);
  * geomae_vfe_backward_stats (bsums1), geomae_vfe_backward_layer1 (bsums0, dm0), geomae_grad_sumsq (sumsq).
  * A training step zeroes one arena off the critical path instead of a dozen small fills between dependent kernels. */
 int geomae_set_accumulators_prezeroed(int32_t enabled);
+
+/* ------------------------------------------------------------------ tuning surface
+ * Every switch that selects a kernel form, a schedule or a launch shape lives HERE: one process-wide struct with defaults,
+ * read by the library where the choice is made (no getenv under csrc/).  geomae_get_tuning fills the caller's struct with
+ * the current values; geomae_set_tuning replaces them (fields outside their range are clamped; `size` must be
+ * sizeof(GeomaeTuning)).  The Python binding reads the GEOMAE_* environment variables of the same names ONCE at load
+ * (geomae_amd/_lib.py TUNING_ENV) and applies them through this call; tests and A/B tools call it in-process.  DESIGN.md
+ * section 9 is the table of the fields with what each was measured against.  Set it between steps, not while one is enqueued. */
+typedef struct GeomaeTuning {
+    int32_t size;                  /* sizeof(GeomaeTuning) */
+    /* which form a layer stack takes (sst_stack.hip) */
+    int32_t fused_layers;          /* 1  | 0: never the one-launch layer of sst_fused.hip, 1: token sets <= fused_max_tokens, 2: always, 3: as 1 (kept for A/B scripts) */
+    int32_t fused_max_tokens;      /* 12288 */
+    int32_t fused_bwd;             /* 1  | one-launch backward where the forward took the one-launch form */
+    int32_t ws_layers;             /* 0  | the looping one-launch layer of sst_ws.hip (windows of up to 144 positions): 0 never, 1 token sets >
+                                      fused_max_tokens, 2 always.  OFF: measured 5-9 % slower than the three-launch form in the step
+                                      (docs/LAB_NOTES.md "Round 6"); kept as a tested alternative */
+    int32_t ws_bwd;                /* 0  | reserved: a backward of that form (not built: the forward did not win) */
+    int32_t ws_bundle_cap;         /* 144 | soft cap (positions) of the bundles of the token sets the ws form takes */
+    int32_t ws_max_workgroups;     /* 0  | 0 = one per CU */
+    int32_t bundle_cap;            /* 0  | != 0 overrides geomae_window_bundle_cap for every token set */
+    int32_t saved_f32;             /* 0  | 1: x-hat rows saved in fp32 (three-launch form only; parity checks) */
+    int32_t x_from_xhat;           /* 1  | dW_v's operand x of the layers above the first formed from the saved xhat2 of the layer below */
+    int32_t y_from_xhat;           /* 1  | dW1's operand y formed from the saved xhat1 */
+    int32_t pair_kernels;          /* -1 | the 32-token pair form of the ffn forward: -1 by size, 0 never, 1 always */
+    int32_t attn_heads;            /* 0  | heads per workgroup of the window-attention kernels: 0 by size, 1 / 2 / 4 */
+    /* weight-gradient contractions (sst_layer.hip, dw_device.h) */
+    int32_t dw_layer_form;         /* 1  | the layer-form contraction (0: the round-4 task form) */
+    int32_t dw_chunks;             /* 0  | token chunks per job (0 = by size) */
+    int32_t dw_budget_mid;         /* 0  | workgroup budget of a flush on the way (0 = default 80) */
+    int32_t dw_split_reduce;       /* 1  | two-level reduction of the SPLIT job's partials */
+    /* step engine schedule (engine.hip) */
+    int32_t dw_defer_all;          /* 1  | the decoders' contractions leave their backward launches for the geometry stream */
+    int32_t dec_dw_every;          /* -1 | flush period (layers) of the decoders' contractions: -1 by size, 0 behind the stack */
+    int32_t dec_mid_budget;        /* 0  | workgroup budget of those flushes (0 = default) */
+    int32_t enc_dw_defer;          /* 1  | the encoder's contractions on the geometry stream, flushed every four layers */
+    int32_t zero_late_aux;         /* 0  | 1: the zero arena filled on the decoder-B stream (the round-4 placement) */
+    int32_t fused_skip_big;        /* 1  | skip the one-launch layer's second kernel when no window kept more than 64 pillars */
+    int32_t heads_joint;           /* 0  | 1: all six heads in one launch on the main stream */
+    int32_t reserved[8];
+} GeomaeTuning;
+int geomae_get_tuning(GeomaeTuning* out);
+int geomae_set_tuning(const GeomaeTuning* in);
 int32_t geomae_abi_version(void);
 
 /* ------------------------------------------------------------------ A1 dynamic voxelization

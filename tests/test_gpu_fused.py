@@ -99,3 +99,69 @@ def test_one_launch_layer_matches_three_launch_form(dev, case):
     assert _rel(d1, d0) < 1e-2, _rel(d1, d0)
     bad = {k: _rel(g1[k], g0[k]) for k in g0 if _rel(g1[k], g0[k]) > 2e-2}
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", ["decoder_tail", "gather_rows", "encoder_small", "decoder_plain", "cap_144"])
+def test_weight_stationary_layer_matches_three_launch_form(dev, case):
+    """csrc/sst_ws.hip (one launch per layer, workgroups loop over bundles with the layer's weights in registers; windows of up
+    to 144 positions through the run-time tile loops and the online softmax) against the three-launch form inside
+    geomae_sst_stack_forward / _backward: forward output and -- through every saved activation -- input gradient and all
+    parameter gradients.  decoder_tail: all pillars, fill row for the last third (9-tile windows); gather_rows: the input
+    row map; encoder_small: small windows only; decoder_plain: plain input; cap_144: bundles packed up to 144 positions
+    (several windows per 9-tile bundle: the block-diagonal mask across tile pairs)."""
+    from geomae_amd import ops, _lib
+    lib = _lib.load()
+    model = _model(dev, 2, 2)
+    bb = model.backbone
+    frames = [synth.lidar_frame(71), synth.lidar_frame(72, beams=24, n_az=700), synth.lidar_frame(73, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, TOP, RANGE)
+    vc = O.unique_rows(coors)[0]
+    gen = torch.Generator().manual_seed(11)
+    if case == "encoder_small":
+        keep = np.sort(np.random.default_rng(3).permutation(vc.shape[0])[: vc.shape[0] // 3])
+        vc = vc[keep]
+    vc = torch.as_tensor(vc, device=dev)
+    n = vc.shape[0]
+    name = "enc" if case == "encoder_small" else "cen"
+    blocks = bb.encoder_blocks if name == "enc" else bb.decoder_centroid_blocks
+    nl = 2 * len(blocks)
+    bb._packed.refresh()
+    old = _lib.set_tuning(ws_layers=2, fused_layers=1, bundle_cap=144 if case == "cap_144" else 0)
+    try:
+        layouts, _ = bb.get_voxel_info(vc, len(frames))
+        nb = int(layouts[0].num_fbundles.item())
+        sizes = (layouts[0].fbun_tok[1:nb + 1] - layouts[0].fbun_tok[:nb]).cpu().numpy()
+        assert sizes.min() >= 1 and sizes.max() <= 144
+        if case in ("decoder_tail", "decoder_plain", "cap_144"):
+            assert sizes.max() > 64, "the case is meant to reach windows of more than four tiles"
+        w = bb._packed.weight_array(bb._stack_base[name], nl)
+        kw = {}
+        if case == "decoder_tail":
+            n_in = n - n // 3 - 5
+            x = torch.randn(n_in, 128, generator=gen).to(dev)
+            kw["tail"] = (torch.randn(1, 128, generator=gen).to(dev), n - n_in)
+        elif case == "gather_rows":
+            V = n + n // 2 + 3
+            x = torch.randn(V, 128, generator=gen).to(dev)
+            kw["rows"] = torch.randperm(V, generator=gen)[:n].int().to(dev)
+        else:
+            x = torch.randn(n, 128, generator=gen).to(dev)
+        dz = torch.randn(n, 128, generator=gen).to(dev)
+        res = []
+        for ws in (0, 2):
+            _lib.set_tuning(ws_layers=ws, fused_layers=0 if ws == 0 else 1)
+            for p in bb.parameters():
+                p.grad = None
+            g = bb._packed.grad_array(bb._stack_base[name], nl)
+            z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0], **kw)
+            dx = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], saved)
+            torch.cuda.synchronize()
+            res.append((z.clone(), dx.clone(), {k: v.grad.clone() for k, v in blocks.named_parameters()}))
+    finally:
+        _lib.set_tuning(**old)
+    (z0, d0, g0), (z1, d1, g1) = res
+    assert torch.isfinite(z1).all() and torch.isfinite(d1).all()
+    assert _rel(z1, z0) < 4e-3, _rel(z1, z0)
+    assert _rel(d1, d0) < 1e-2, _rel(d1, d0)
+    bad = {k: _rel(g1[k], g0[k]) for k in g0 if _rel(g1[k], g0[k]) > 2e-2}
+    assert not bad, bad
