@@ -259,6 +259,9 @@ SIGNATURES = {
     "geomae_sst_layer_forward": (ctypes.c_int, [P, c_int32, POINTER(GeomaeSstLayerWeights), POINTER(GeomaeSstStackLayout),
                                                 c_int32, P, P, c_int32, P, P, P, P, P, P, P, P, P, P]),
     "geomae_sst_set_fused_layers": (None, [c_int32]),
+    "geomae_sst_last_stack_forms": (ctypes.c_int, [POINTER(c_int32)]),
+    "geomae_sst_set_big_bundle_layouts": (None, [c_int32]),
+    "geomae_sst_fused_dropped_bundles": (ctypes.c_int, [POINTER(c_int64), c_int32]),
     "geomae_sst_stack_saved_bytes": (c_int64, [c_int32, c_int32, c_int32]),
     "geomae_sst_stack_scratch_bytes": (c_int64, [c_int32]),
     "geomae_sst_stack_scratch_bytes_layers": (c_int64, [c_int32, c_int32]),
@@ -294,6 +297,8 @@ SIGNATURES = {
     "geomae_pretrain_host_times": (ctypes.c_int, [c_void_p, POINTER(c_double)]),
     "geomae_pretrain_set_optimizer_steps": (ctypes.c_int, [c_void_p, c_int64]),
     "geomae_pretrain_last_sizes": (ctypes.c_int, [c_void_p, POINTER(c_int64)]),
+    "geomae_pretrain_last_sizes_n": (ctypes.c_int, [c_void_p, POINTER(c_int64), c_int32]),
+    "geomae_pretrain_step_forms": (ctypes.c_int, [c_void_p, POINTER(c_int32), c_int32]),
     "geomae_profiler_create": (c_void_p, [c_int32, c_int32]),
     "geomae_profiler_read": (c_int32, [c_void_p, POINTER(c_float), c_int32]),
     "geomae_profiler_destroy": (None, [c_void_p]),

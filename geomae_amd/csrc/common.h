@@ -106,6 +106,11 @@ float* dw_partial();
 // default: both may.
 void set_fused_big_layouts(int mask);
 int take_fused_big_layouts();
+// which form the LAST geomae_sst_stack_forward / _backward of this host thread took (include/geomae_hip.h GEOMAE_STACK_FORM_*):
+// what geomae_sst_last_stack_forms and the step engine's geomae_pretrain_step_forms report, so that a test can assert that
+// the kernel it means to pin actually ran
+void set_last_stack_form(bool backward, int form);
+int last_stack_form(bool backward);
 void set_fused_big_next(bool possible);          // ... handed on to the next geomae_sst_layer_forward of this thread
 bool take_fused_big_next();
 constexpr int kStackSyncBytes = 2048;      // the persistent stack forward's grid-barrier counters, behind a stack's saved tensors

@@ -46,6 +46,9 @@ float* dw_partial() { return g_dw_partial; }
 static thread_local int g_fused_big_layouts = 3;
 void set_fused_big_layouts(int mask) { g_fused_big_layouts = mask & 3; }
 int take_fused_big_layouts() { const int m = g_fused_big_layouts; g_fused_big_layouts = 3; return m; }
+static thread_local int g_last_stack_form[2] = {-1, -1};
+void set_last_stack_form(bool backward, int form) { g_last_stack_form[backward ? 1 : 0] = form; }
+int last_stack_form(bool backward) { return g_last_stack_form[backward ? 1 : 0]; }
 static thread_local bool g_fused_big_next = true;
 void set_fused_big_next(bool possible) { g_fused_big_next = possible; }
 bool take_fused_big_next() { const bool b = g_fused_big_next; g_fused_big_next = true; return b; }
@@ -106,6 +109,15 @@ extern "C" int geomae_set_tuning(const GeomaeTuning* in) {
     t.dw_chunks = clamp(t.dw_chunks, 0, 64); t.dw_budget_mid = clamp(t.dw_budget_mid, 0, 4096);
     t.dec_dw_every = clamp(t.dec_dw_every, -1, 64); t.dec_mid_budget = clamp(t.dec_mid_budget, 0, 4096);
     geomae::g_tuning = t;
+    return GEOMAE_OK;
+}
+
+extern "C" void geomae_sst_set_big_bundle_layouts(int32_t mask) { geomae::set_fused_big_layouts(mask); }
+
+extern "C" int geomae_sst_last_stack_forms(int32_t* out) {
+    GEOMAE_REQUIRE(out, "sst_last_stack_forms: null argument");
+    out[0] = geomae::last_stack_form(false);
+    out[1] = geomae::last_stack_form(true);
     return GEOMAE_OK;
 }
 

@@ -141,6 +141,7 @@ struct Engine {
     int32_t last_V = 0, last_keep = 0, last_mask = 0;
     int64_t off_losses = 0, off_ids_keep = 0, off_ids_mask = 0, off_voxel_coors = 0;
     int32_t cells = 0, gz = 1, gy = 1, gx = 1, s_low = 1, s_med = 1;
+    int last_forms[6] = {-1, -1, -1, -1, -1, -1};           // GEOMAE_STACK_FORM_* of the last step's stacks: forward enc / den / cen, backward
     int last_maxkeep[2] = {-1, -1}, last_big_layouts = 3;   // the last step's fullest windows / which layouts took the second launch
     double host_step_s = 0.0, host_blocked_s = 0.0;      // cumulative wall time inside step calls / in the readback wait
     // a step that fails AFTER its first launch leaves streams, events and the workspace in an undefined state
@@ -692,27 +693,32 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         // the one-launch layer's second kernel): known since the batch's stage 1, a step ago
         int big = 3;
         const bool skip_big = tuning().fused_skip_big != 0;
+        bool counted = false;                                        // (host_maxkeep is valid only behind readback2)
         // (a bundle packs whole windows up to its cap: only with a cap of at most 64 positions does "no window above 64" mean "no
         //  bundle above four tiles" -- the packing of token sets above 12288 and GeomaeTuning.bundle_cap may use larger caps)
         if (skip_big && !b.mask_injected && b.host_maxkeep && geomae_window_bundle_cap(nk, max_tokens) <= 64) {
             GEOMAE_HIP(hipEventSynchronize(b.readback2));            // (stage 1 of this batch ended during the previous step)
+            counted = true;
             big = (b.host_maxkeep[0] < 0 || b.host_maxkeep[0] > 64 ? 1 : 0) | (b.host_maxkeep[1] < 0 || b.host_maxkeep[1] > 64 ? 2 : 0);
         }
         set_fused_big_layouts(big);
         e->last_big_layouts = big;
-        e->last_maxkeep[0] = b.host_maxkeep && !b.mask_injected ? b.host_maxkeep[0] : -1;
-        e->last_maxkeep[1] = b.host_maxkeep && !b.mask_injected ? b.host_maxkeep[1] : -1;
+        e->last_maxkeep[0] = counted ? b.host_maxkeep[0] : -1;      // (-1: not waited for -- injected mask, the skip switched off, a larger cap)
+        e->last_maxkeep[1] = counted ? b.host_maxkeep[1] : -1;
     }
     ENG_CALL(geomae_sst_stack_forward(vf, nk, L_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, sb_enc, z_enc, nk,
                                       nullptr, b.ids_keep, e->profiler, main));
+    e->last_forms[0] = last_stack_form(false);
     mark(e, pEncFwd, main);
     ENG_CALL(order_after(e, kForkDec, main, aux));
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_forward(z_enc, n, L_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den, sb_dec, den, nk,
                                       m.mask_token, nullptr, e->profiler, aux));
+    e->last_forms[1] = last_stack_form(false);
     set_first_live_row((int)nk);                 // only the masked pillars' rows reach the heads
     ENG_CALL(geomae_sst_stack_forward(z_enc, n, L_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen, sb_dec, cen, nk,
                                       m.mask_token, nullptr, e->profiler, main));
+    e->last_forms[2] = last_stack_form(false);
     mark(e, pDecFwd, main);
     // ---------------- heads + losses BY DECODER: each decoder's stream runs the heads that read its stack and goes straight
     // on into that stack's backward -- neither waits for the other stack's forward (one launch for all heads needed the
@@ -758,6 +764,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_den, nullptr, n, L_den, G_den, nd, lay_dec, m.pos_table, nh, max_tokens, s_den,
                                            w_den, wb_dec, dxb, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, aux));
+        e->last_forms[4] = last_stack_form(true);
     }
     GEOMAE_HIP(hipEventRecord(e->ev[kAuxBwd], aux));
     GEOMAE_HIP(hipStreamWaitEvent(geo, e->ev[kAuxBwd], 0));
@@ -770,6 +777,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         MidFlushScopeD mid(mfd);
         ENG_CALL(geomae_sst_stack_backward(d_cen, d_cen2, n, L_cen, G_cen, nd, lay_dec, m.pos_table, nh, max_tokens, s_cen,
                                            w_cen, wb_dec, dxa, nullptr, 0, m.mask_token_grad, nk, 1, e->profiler, main));
+        e->last_forms[5] = last_stack_form(true);
     }
     ENG_CALL(order_after(e, kMainDecBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));
@@ -794,6 +802,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
         set_fused_big_layouts(e->last_big_layouts);      // (as for the forward: no bundle of more than four tiles -> one launch per layer)
         ENG_CALL(geomae_sst_stack_backward(dxa, dxb, nk, L_enc, G_enc, ne, lay_enc, m.pos_table, nh, max_tokens, s_enc, w_enc,
                                            wb_enc, d_vf, b.ids_keep, V, nullptr, 0, 1, e->profiler, main));
+        e->last_forms[3] = last_stack_form(true);
     }
     ENG_CALL(order_after(e, kEncBwd, main, geo));
     ENG_CALL(geomae_flush_weight_grad(geo));
@@ -1120,6 +1129,22 @@ extern "C" int geomae_pretrain_set_optimizer_steps(void* engine, int64_t steps_t
     return GEOMAE_OK;
 }
 
+extern "C" int geomae_pretrain_last_sizes_n(void* engine, int64_t* out, int32_t capacity) {
+    GEOMAE_REQUIRE(engine && out && capacity >= 0, "pretrain: null argument");
+    int64_t all[9];
+    const int rc = geomae_pretrain_last_sizes(engine, all);
+    if (rc) return rc;
+    const int n = capacity < 9 ? capacity : 9;
+    for (int i = 0; i < n; ++i) out[i] = all[i];
+    return n;
+}
+extern "C" int geomae_pretrain_step_forms(void* engine, int32_t* out, int32_t capacity) {
+    Engine* e = (Engine*)engine;
+    GEOMAE_REQUIRE(e && out && capacity >= 0, "pretrain: null argument");
+    const int n = capacity < 6 ? capacity : 6;
+    for (int i = 0; i < n; ++i) out[i] = e->last_forms[i];
+    return n;
+}
 extern "C" int geomae_pretrain_last_sizes(void* engine, int64_t* out) {
     Engine* e = (Engine*)engine;
     GEOMAE_REQUIRE(e && out, "pretrain: null argument");

@@ -50,6 +50,7 @@ struct FusedFwd {
     float eps;
     float* z;                    // layer output [n][128] fp32: tile-blocked (z_blocked) or row-major
     int z_blocked;
+    int big_follows = 1;         // the launch for bundles of more than four tiles follows (0: the caller promised there is none)
     // saved for the backward (token order, tile-blocked; all or none)
     bf16_t *qkv, *attn, *xh1, *xh2, *hp, *xb, *xp;
     float *lse, *rstd;

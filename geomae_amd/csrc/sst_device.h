@@ -641,7 +641,7 @@ int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowma
 int sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* w,
                          const GeomaeSstStackLayout* layout, const float* pos_table, float* z, bool z_blocked, void* qkv,
                          void* attn, float* lse, void* xh1, void* xh2, void* hp, float* rstd, void* xb, void* xp,
-                         int dead_rows, int max_workgroups, hipStream_t stream);
+                         int dead_rows, int max_workgroups, int min_tiles, hipStream_t stream);
 inline LayerW to_layer(const GeomaeSstLayerWeights* w) {
     LayerW L;
     L.wqkv = (const bf16_t*)w->wqkv_p; L.wqkT = (const bf16_t*)w->wqkT_p; L.wvT = (const bf16_t*)w->wvT_p;

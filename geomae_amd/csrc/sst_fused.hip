@@ -34,8 +34,15 @@
 namespace geomae {
 
 // NT: tiles the body is unrolled for.  EXACT: the bundle has exactly NT tiles -- straight-line code (the scheduler overlaps
-// the tiles' chains), all tile pairs of the attention computed (the mask does the block-diagonal).  !EXACT: nt <= NT tiles
+// the tiles' chains), all tile pairs of the attention computed (the mask does the block-diagonal); the only form instantiated
+// since round 6 (bundles of more than four tiles: sst_ws.hip).  !EXACT: nt <= NT tiles
 // behind scalar branches, key-tile ranges.  Weight fragments are fetched two phases ahead of their first use.
+// A bundle of more than four tiles that NO launch will run -- the forward's second kernel was skipped, or the one-launch
+// backward met one -- is a broken promise of the caller (common.h set_fused_big_layouts: "this layout holds none"): the
+// tokens would silently keep stale values.  The kernels count such bundles here; geomae_sst_fused_dropped_bundles reads the
+// count (tests assert 0; round 5 shipped NaN losses for an hour through exactly this hole).
+static __device__ unsigned int g_fused_dropped = 0;
+
 template <int NT, bool EXACT>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, const int T, const int nt_in, char* lds) {
     const int nt = EXACT ? NT : nt_in;
@@ -330,13 +337,13 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 #undef FOR_TILES
 }
 
-// The exact bodies (bundles of 1-4 tiles: every bundle of the packing but a single window that kept more than 64 pillars) and
-// the generic 5-9-tile body are TWO kernels (round 5).  In one kernel the generic body set the register allocation of
-// everything -- 256 VGPRs, 69 spilled, 280 B of scratch per lane -- and the layer took 26.3 us; the exact bodies alone (212 / 234
-// VGPRs, no scratch) take 21.4 us (round 5's stack-alone timing, config 2's encoder).  The second launch finds the large bundles
-// itself (the bundle count and sizes live on the device): every workgroup scans the bundle table, the k-th large bundle goes
-// to workgroup k mod grid; a layout without one costs that launch a scan (~2 us).  (Measured and dropped: the generic body as
-// a noinline call inside one kernel -- 35.5 us per layer.)
+// The exact bodies run the bundles of 1-4 tiles: every bundle of the packing but a single window that kept more than 64 pillars.
+// Those (5-9 tiles) are a SECOND launch.  Round 5 had a generic 9-tile instance of the body above for them: inside this kernel it
+// set the register allocation of everything (256 VGPRs, 69 spilled, 26.3 us per layer against 21.4 us for the exact bodies alone),
+// as a kernel of its own it still carried 74 spilled registers and 300 B of scratch per lane.  Since round 6 the second launch is
+// the looping kernel of sst_ws.hip with min_tiles = 5 (run-time tile loops, online softmax, no scratch): every workgroup looks at
+// the bundles of its stride and leaves the small ones alone; a layout without a large bundle costs that launch a scan (~2 us),
+// which the step engine avoids by knowing the fullest window a step ahead (window.hip window_max_keep).
 __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFwd A) {
     __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
     // (bun_tok holds max_bundles + 1 >= gridDim.x + 1 words: read before the bundle count is known, one round trip less)
@@ -354,50 +361,11 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFw
             case 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
             case 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
             case 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
-            default: break;                                  // 5-9 tiles: sst_layer_fwd_big_kernel
+            default:                                         // 5-9 tiles: the second launch (sst_ws.hip, min_tiles = 5)
+                if (!A.big_follows && threadIdx.x == 0) atomicAdd(&g_fused_dropped, 1u);
+                break;
         }
         if (b + (int)gridDim.x < NB) __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_big_kernel(FusedFwd A) {
-    __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
-    __shared__ int wave_cnt[kFusedThreads / 64];
-    const int NB = A.num_bundles[0];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int base = 0;                                            // large bundles in front of the current chunk of the table
-    for (int b0 = 0; b0 < NB; b0 += kFusedThreads) {         // (workgroup-uniform trip count)
-        const int b = b0 + threadIdx.x;
-        int s0 = 0, T = 0;
-        if (b < NB) { s0 = A.bun_tok[b]; T = A.bun_tok[b + 1] - s0; }
-        const bool big = T > 64;
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(big);
-        if (lane == 0) wave_cnt[wave] = __builtin_popcountll(m);
-        __syncthreads();
-        int before = base, total = base;
-#pragma unroll
-        for (int w = 0; w < kFusedThreads / 64; ++w) {
-            const int c = wave_cnt[w];
-            if (w < wave) before += c;
-            total += c;
-        }
-        __syncthreads();                                     // (wave_cnt is rewritten by the next chunk)
-        // the chunk's large bundles, in table order: this workgroup runs those with rank % grid == its index.  The body needs
-        // the whole workgroup: the ranks go through LDS one at a time.
-        const int my_rank = before + __builtin_popcountll(m & ((1ull << lane) - 1ull));
-        for (int r = base + ((int)blockIdx.x + (int)gridDim.x - base % (int)gridDim.x) % (int)gridDim.x; r < total; r += gridDim.x) {
-            int* slot = reinterpret_cast<int*>(lds);         // (free between bodies)
-            if (big && my_rank == r) { slot[0] = s0; slot[1] = T; }
-            __syncthreads();
-            const int rs0 = slot[0];
-            int rT = slot[1];
-            __syncthreads();
-            if (rT > kFMaxT) rT = kFMaxT;    // (a layout built for windows of more than 144 tokens: never past the LDS rows;
-                                             //  the stack forward refuses such layouts on the host, max_window_tokens <= 144)
-            fused_fwd_body<9, false>(A, rs0, rT, (rT + 15) >> 4, lds);
-            __syncthreads();
-        }
-        base = total;
     }
 }
 
@@ -480,7 +448,8 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
     }
     f32x4 d[NT];                                                     // the running gradient: this wave's 16 channels of every row
     uint2 xh2[NT];
-    float r1[NT], r2[NT];
+    float r1[NT], r2[NT];                                             // (rstd of LayerNorm 1 is fetched where it is used: four registers
+                                                                      //  fewer across the FFN backward, the NT = 4 body's spills)
     {
         const __amdgpu_buffer_rsrc_t zres = whole_rsrc(A.dz), ares = whole_rsrc(A.dz_add ? A.dz_add : A.dz);
         const __amdgpu_buffer_rsrc_t x2r = whole_rsrc(A.xh2), rsr = whole_rsrc(A.rstd);
@@ -490,8 +459,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             d[it] = buf_load_f32x4(zres, off);
             if (A.dz_add) d[it] += buf_load_f32x4(ares, off);
             xh2[it] = buf_load_b64(x2r, tk < 0 ? kFOor : blk_off<2>(tk, 128, w, g));
-            const uint2 rr = buf_load_b64(rsr, tk < 0 ? kFOor : tk * 8);
-            r1[it] = __uint_as_float(rr.x); r2[it] = __uint_as_float(rr.y);
+            r2[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsr, tk < 0 ? kFOor : tk * 8 + 4, 0, 0));
         }
     }
     uint4 w2a[4], w2b[4];
@@ -602,7 +570,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
     uint2 qf[NT], kf[NT], vf[NT], of[NT];
     float lse[NT];
     {
-        const __amdgpu_buffer_rsrc_t qr = whole_rsrc(A.qkv), orr = whole_rsrc(A.attn), lr = whole_rsrc(A.lse);
+        const __amdgpu_buffer_rsrc_t qr = whole_rsrc(A.qkv), orr = whole_rsrc(A.attn), lr = whole_rsrc(A.lse), rs1 = whole_rsrc(A.rstd);
         FOR_TILES(it) {
             const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 384, w, g) : kFOor;
             qf[it] = buf_load_b64(qr, o2);
@@ -610,6 +578,7 @@ __device__ __forceinline__ void fused_bwd_body(const FusedBwd& A, const int s0, 
             vf[it] = buf_load_b64(qr, o2 + 16 * 512);
             of[it] = buf_load_b64(orr, tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor);
             lse[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(lr, tok[it] >= 0 ? (tok[it] * 8 + w) * 4 : kFOor, 0, 0));
+            r1[it] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs1, tok[it] >= 0 ? tok[it] * 8 : kFOor, 0, 0));
         }
     }
     FUSED_STAMP(7);
@@ -776,7 +745,9 @@ __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_bwd_kernel(FusedBw
             case 2: fused_bwd_body<2>(A, s0, T, lds); break;
             case 3: fused_bwd_body<3>(A, s0, T, lds); break;
             case 4: fused_bwd_body<4>(A, s0, T, lds); break;
-            default: break;                                  // (the host keeps the unfused backward for such layouts)
+            default:                                         // (the host keeps the unfused backward for such layouts)
+                if (threadIdx.x == 0) atomicAdd(&g_fused_dropped, 1u);
+                break;
         }
         if (b + (int)gridDim.x < NB) __syncthreads();
     }
@@ -838,6 +809,19 @@ int geomae::sst_layer_backward_fused(const float* dz, const float* dz_add, bool 
     return check_launch("sst_layer_bwd_kernel");
 }
 
+extern "C" int geomae_sst_fused_dropped_bundles(int64_t* out, int32_t reset) {
+    GEOMAE_REQUIRE(out, "sst_fused_dropped_bundles: null argument");
+    unsigned int v = 0;
+    GEOMAE_HIP(hipDeviceSynchronize());
+    GEOMAE_HIP(hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fused_dropped), sizeof(v)));
+    if (reset) {
+        const unsigned int z = 0;
+        GEOMAE_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_fused_dropped), &z, sizeof(z)));
+    }
+    *out = v;
+    return GEOMAE_OK;
+}
+
 extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, const GeomaeSstLayerWeights* w,
                                         const GeomaeSstStackLayout* layout, int32_t bundle_cap, const float* pos_table,
                                         float* z, int32_t z_blocked, void* qkv_bf16, void* attn_bf16, float* lse,
@@ -865,14 +849,16 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
     A.pos_table = pos_table; A.W = to_layer(w); A.n = num_tokens; A.eps = w->ln_eps; A.z = z; A.z_blocked = z_blocked;
     A.qkv = (bf16_t*)qkv_bf16; A.attn = (bf16_t*)attn_bf16; A.xh1 = (bf16_t*)xhat1_bf16; A.xh2 = (bf16_t*)xhat2_bf16;
     A.hp = (bf16_t*)hp_bf16; A.xb = skip_x_copy() ? nullptr : (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
+    A.big_follows = big_possible ? 1 : 0;
     const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
     hipLaunchKernelGGL(sst_layer_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
     rc = check_launch("sst_layer_fwd_kernel");
     if (rc) return rc;
     // the bundles of 5-9 tiles (a window that kept more than 64 pillars): rare in the token sets this form is chosen for, the
-    // rule at the decoders' sizes (geomae_sst_set_fused_layers(2), tests)
-    const int big_grid = num_tokens <= 12288 ? 16 : (grid < 256 ? grid : 256);
+    // rule at the decoders' sizes (geomae_sst_set_fused_layers(2), tests).  Since round 6 the looping kernel of sst_ws.hip runs
+    // them (run-time tile loops, no scratch; the generic 9-tile body it replaces held 74 spilled registers and 300 B of scratch
+    // per lane): every workgroup looks at the bundles of its stride and leaves those of at most four tiles alone.
     if (!big_possible) return GEOMAE_OK;         // (the caller knows this layout's fullest window: common.h set_fused_big_layouts)
-    hipLaunchKernelGGL(sst_layer_fwd_big_kernel, dim3(big_grid), dim3(kFusedThreads), 0, stream, A);
-    return check_launch("sst_layer_fwd_big_kernel");
+    return sst_layer_forward_ws(x, M, num_tokens, w, layout, pos_table, z, z_blocked != 0, qkv_bf16, attn_bf16, lse, xhat1_bf16,
+                                xhat2_bf16, hp_bf16, rstd, A.xb, xp_bf16, 0, grid < 256 ? grid : 256, 5, stream);
 }

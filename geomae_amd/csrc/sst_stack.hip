@@ -28,7 +28,7 @@ namespace geomae {
 int sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* w,
                          const GeomaeSstStackLayout* layout, const float* pos_table, float* z, bool z_blocked, void* qkv,
                          void* attn, float* lse, void* xh1, void* xh2, void* hp, float* rstd, void* xb, void* xp,
-                         int dead_rows, int max_workgroups, hipStream_t stream);
+                         int dead_rows, int max_workgroups, int min_tiles, hipStream_t stream);
 // sst_fused.hip: the backward of one layer as ONE launch (bundles of at most four tiles)
 int sst_layer_backward_fused(const float* dz, const float* dz_add, bool dz_rowmajor, float* dx, bool dx_rowmajor,
                              const int32_t* out_rows, int n_out, int num_tokens, const GeomaeSstLayerWeights* w,
@@ -249,6 +249,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     if (ws_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
         saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
         const int wgs = ws_workgroups();
+        set_last_stack_form(false, GEOMAE_STACK_FORM_LOOPING);
         for (int l = 0; l < num_layers; ++l) {
             char* sv = base + so.stride * l;
             const bool next = l + 1 < num_layers;
@@ -258,7 +259,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
             const bool skip_x = l > 0 && x_from_xhat_enabled();   // (the contraction forms x from the layer below's saved xhat2)
             rc = sst_layer_forward_ws((const float*)(sv + so.x), M, num_tokens, &layers[l], &layouts[l & 1], pos_table, z, next,
                                       sv + so.qkv, sv + so.attn, (float*)(sv + so.lse), sv + so.xh1, sv + so.xh2, sv + so.hp,
-                                      (float*)(sv + so.rstd), skip_x ? nullptr : sv + so.xb, sv + so.xp, next ? 0 : live_row, wgs, stream);
+                                      (float*)(sv + so.rstd), skip_x ? nullptr : sv + so.xb, sv + so.xp, next ? 0 : live_row, wgs, 1, stream);
             if (rc) return rc;
         }
         return GEOMAE_OK;
@@ -268,6 +269,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
     if (fused_layers_enabled(num_tokens) && layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
         saved_flag() == kSavedBf16 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p) {
         const int cap = geomae_window_bundle_cap(num_tokens, max_window_tokens);
+        set_last_stack_form(false, GEOMAE_STACK_FORM_ONE_LAUNCH);
         for (int l = 0; l < num_layers; ++l) {
             char* sv = base + so.stride * l;
             const bool next = l + 1 < num_layers;
@@ -284,6 +286,7 @@ extern "C" int geomae_sst_stack_forward(const float* x_in, int32_t num_tokens, c
         }
         return GEOMAE_OK;
     }
+    set_last_stack_form(false, GEOMAE_STACK_FORM_THREE_LAUNCH);
     // the input conversion (row-major x_in [gathered by input_rows, followed by fill_row] -> tile-blocked x of layer 0)
     // is done by F1 of layer 0 itself (common.h SstInputMap); it used to be a 5-13 us launch in front of every stack
     // F1 of layer l+1 rides at the end of F3 of layer l (geomae_sst_ffn_qkv_forward): 2 launches per layer
@@ -343,7 +346,14 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     GEOMAE_REQUIRE(dz && grads && pos_table && saved && scratch && dx_out, "sst_stack_backward: null argument");
     const SavedOffsets so = saved_offsets(num_tokens, num_heads);
     // "defer all": the contractions run after the whole stack, so every layer keeps its own operand slabs
-    const bool defer_all = defer_all_weight_grads();
+    // (defer_last_weight_grad == 2: the caller's "defer all" -- every layer's contraction queued for geomae_flush_weight_grad,
+    //  scratch sized by geomae_sst_stack_scratch_bytes_layers -- what the step engine sets through common.h)
+    const bool defer_all = defer_all_weight_grads() || defer_last_weight_grad == 2;
+    struct DeferAllArgScope {
+        bool on;
+        explicit DeferAllArgScope(bool o) : on(o) { if (on) set_defer_all_weight_grads(true); }
+        ~DeferAllArgScope() { if (on) set_defer_all_weight_grads(false); }
+    } defer_arg_scope(defer_last_weight_grad == 2 && !defer_all_weight_grads());
     const int n_sets = defer_all ? (num_layers < 2 ? 2 : num_layers) : 2;
     const ScratchOffsets sc = scratch_offsets(num_tokens, n_sets);
     if (scratch_bytes < sc.total) {
@@ -370,6 +380,7 @@ extern "C" int geomae_sst_stack_backward(const float* dz, const float* dz_add, i
     const bool fused_bwd = fused_bwd_switch && defer_all && big_layouts == 0 && live_row == 0 && !tail_sum && fused_layers_enabled(num_tokens) &&
                            layouts[0].fbun_tok && layouts[0].pos_info && layouts[1].fbun_tok && layouts[1].pos_info &&
                            saved_flag() == kSavedBf16 && y_switch0 && num_heads == 8 && max_window_tokens <= 144 && layers[0].frag_p;
+    set_last_stack_form(true, fused_bwd ? GEOMAE_STACK_FORM_ONE_LAUNCH : GEOMAE_STACK_FORM_THREE_LAUNCH);
     for (int l = num_layers - 1; fused_bwd && l >= 0 && rc == GEOMAE_OK; --l) {
         const char* sv = base + so.stride * l;
         char* ws = w + sc.set0 + l * sc.set_bytes;

@@ -108,7 +108,9 @@ __device__ __forceinline__ void ws_plan_commit(char* tab, const int4 rec) {
 // MAPPED: the stack's first layer (row-major source rows, row map, fill row: common.h SstInputMap) -- compiled apart, so that
 // the other layers' loads carry no conditional side loads (behind one the compiler waits with vmcnt(0): for the weights too)
 template <bool MAPPED>
-__global__ __launch_bounds__(kWsThreads, 2) void sst_layer_fwd_ws_kernel(FusedFwd A, int dead_end) {
+// `min_tiles`: bundles of fewer tiles are left alone (5: the second launch of geomae_sst_layer_forward, whose first kernel ran the
+// bundles of 1-4 tiles with its straight-line bodies)
+__global__ __launch_bounds__(kWsThreads, 2) void sst_layer_fwd_ws_kernel(FusedFwd A, int dead_end, int min_tiles) {
     __shared__ __attribute__((aligned(16))) char lds[kWLdsBytes];
     const int NB = A.num_bundles[0];
     if ((int)blockIdx.x >= NB) return;                                // (workgroup-uniform)
@@ -166,6 +168,12 @@ __global__ __launch_bounds__(kWsThreads, 2) void sst_layer_fwd_ws_kernel(FusedFw
             if (Tn > kFMaxT) Tn = kFMaxT;
         }
         const int4 recn = ws_plan_issue(A, s0n, Tn);
+        if (nt < min_tiles) {                                        // (uniform) not this launch's bundle: only hand the tables on
+            ws_plan_commit(lds + kWLdsTab + (par ^ 1) * kWTabBytes, recn);
+            __syncthreads();
+            s0 = s0n; T = Tn;
+            continue;
+        }
         WS_STAMP(0);
 
         // The weights are fetched per bundle, a phase or two ahead of their first use (fragment-major, L2): a bundle is up to
@@ -521,11 +529,12 @@ extern "C" int geomae_debug_read_ws_stamps(unsigned long long* host, int clear) 
 
 // The forward of one layer as ONE weight-stationary launch (sst_layer_fwd_ws_kernel).  Internal: geomae_sst_stack_forward
 // calls it per layer for the token sets above the one-bundle-per-workgroup form's range (sst_stack.hip).  Same arguments and
-// saved tensors as geomae_sst_layer_forward; `dead_rows`: common.h set_first_live_row of the stack's LAST layer.
+// saved tensors as geomae_sst_layer_forward; `dead_rows`: common.h set_first_live_row of the stack's LAST layer; `min_tiles`:
+// 1, or 5 as the second launch of geomae_sst_layer_forward (the bundles its straight-line bodies leave).
 int geomae::sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_tokens, const GeomaeSstLayerWeights* w,
                                  const GeomaeSstStackLayout* layout, const float* pos_table, float* z, bool z_blocked,
                                  void* qkv, void* attn, float* lse, void* xh1, void* xh2, void* hp, float* rstd, void* xb,
-                                 void* xp, int dead_rows, int max_workgroups, hipStream_t stream) {
+                                 void* xp, int dead_rows, int max_workgroups, int min_tiles, hipStream_t stream) {
     GEOMAE_REQUIRE(w && w->frag_p && layout && layout->fbun_tok && layout->pos_info && layout->num_fbundles && layout->max_bundles >= 1,
                    "sst_layer_forward_ws: plan / fragment-major weights missing");
     GEOMAE_REQUIRE(num_tokens > 0 && num_tokens <= 2700000, "sst_layer_forward_ws: token count out of range");
@@ -536,7 +545,7 @@ int geomae::sst_layer_forward_ws(const float* x, const SstInputMap& M, int num_t
     A.xb = (bf16_t*)xb; A.xp = (bf16_t*)xp; A.lse = lse; A.rstd = rstd;
     int grid = layout->max_bundles < max_workgroups ? layout->max_bundles : max_workgroups;
     if (grid < 1) grid = 1;
-    if (M.src) hipLaunchKernelGGL(sst_layer_fwd_ws_kernel<true>, dim3(grid), dim3(kWsThreads), 0, stream, A, (dead_rows / 64) * 64);
-    else hipLaunchKernelGGL(sst_layer_fwd_ws_kernel<false>, dim3(grid), dim3(kWsThreads), 0, stream, A, (dead_rows / 64) * 64);
+    if (M.src) hipLaunchKernelGGL(sst_layer_fwd_ws_kernel<true>, dim3(grid), dim3(kWsThreads), 0, stream, A, (dead_rows / 64) * 64, min_tiles);
+    else hipLaunchKernelGGL(sst_layer_fwd_ws_kernel<false>, dim3(grid), dim3(kWsThreads), 0, stream, A, (dead_rows / 64) * 64, min_tiles);
     return check_launch("sst_layer_fwd_ws_kernel");
 }

@@ -835,7 +835,7 @@ static int win_geom(const GeomaeWindowConfig* cfg, int shift_index, WinGeom* g, 
 // How many KEPT pillars the fullest window of each of the two layouts (unshifted / shifted) holds: one workgroup, the window
 // tables of both shifts in LDS.  The step engine runs this with the random mask, a step ahead of the encoder that will pack
 // these pillars into bundles, and reads the two numbers back with the pillar counts: the one-launch layer's second kernel
-// (sst_fused.hip sst_layer_fwd_big_kernel: bundles of more than 64 positions = a window that kept more than 64 pillars) is
+// (sst_ws.hip sst_layer_fwd_ws_kernel with min_tiles = 5: bundles of more than 64 positions = a window that kept more than 64 pillars) is
 // only launched for a layout that has such a window.
 constexpr int kMaxKeepSlots = 12288;             // window slots of BOTH shifts that fit the LDS tables (48 KB)
 __global__ __launch_bounds__(1024) void win_max_keep_kernel(const int32_t* __restrict__ ids_keep, const int32_t* __restrict__ counts,

@@ -356,9 +356,23 @@ class PretrainEngine:
         check(self.lib.geomae_pretrain_host_times(ctypes.c_void_p(self.handle), out), "geomae_pretrain_host_times")
         return float(out[0]), float(out[1]), int(out[2])
 
+    STACK_FORMS = {-1: "none", 0: "three_launch", 1: "one_launch", 2: "looping"}
+
+    def last_forms(self):
+        """Which kernel form each layer stack of the last step took (include/geomae_hip.h GEOMAE_STACK_FORM_*):
+        {'enc_fwd': 'one_launch', 'den_fwd': ..., 'cen_fwd': ..., 'enc_bwd': ..., 'den_bwd': ..., 'cen_bwd': ...}."""
+        out = (ctypes.c_int32 * 6)()
+        n = self.lib.geomae_pretrain_step_forms(ctypes.c_void_p(self.handle), out, 6)
+        if n != 6:
+            check(n if n < 0 else -1, "geomae_pretrain_step_forms")
+        names = ("enc_fwd", "den_fwd", "cen_fwd", "enc_bwd", "den_bwd", "cen_bwd")
+        return {k: self.STACK_FORMS.get(int(v), str(int(v))) for k, v in zip(names, out)}
+
     def last_sizes(self):
         out = (ctypes.c_int64 * 9)()
-        check(self.lib.geomae_pretrain_last_sizes(ctypes.c_void_p(self.handle), out), "geomae_pretrain_last_sizes")
+        n = self.lib.geomae_pretrain_last_sizes_n(ctypes.c_void_p(self.handle), out, 9)
+        if n != 9:
+            check(n if n < 0 else -1, "geomae_pretrain_last_sizes_n")
         return dict(N=out[0], V=out[1], n_keep=out[2], n_mask=out[3], optimizer_steps=out[4], mask_draws=out[5],
                     max_window_keep=(out[6], out[7]), big_bundle_layouts=out[8])
 

@@ -1369,7 +1369,7 @@ def _stream_of(stream):
     return _stream() if stream is None else ctypes.c_void_p(stream.cuda_stream)
 
 
-def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None, tail=None, rows=None):
+def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, out=None, tail=None, rows=None, big_layouts=None):
     """weights: ctypes array of GeomaeSstLayerWeights (one per layer).  -> z [n,128] f32, saved blob (uint8).
     Buffers are allocated on the CURRENT stream; the kernels are enqueued on `stream` (default: current).
     out: optional preallocated contiguous [n,128] f32 destination of z.
@@ -1389,6 +1389,8 @@ def sst_stack_forward(x, weights, layouts, pos_table, num_heads, stream=None, ou
         if fill.numel() != x.shape[1]:
             raise RuntimeError("sst_stack_forward: fill_row must have one row of x's width")
         n = n_in + int(extra)
+    if big_layouts is not None:       # the caller's promise for this call: which layouts may hold a bundle of more than four tiles
+        lib.geomae_sst_set_big_bundle_layouts(int(big_layouts))
     sb = lib.geomae_sst_stack_saved_bytes(n, nl, num_heads)
     saved = torch.empty(max(sb, 1), dtype=torch.uint8, device=x.device)
     if out is None:
@@ -1410,19 +1412,39 @@ def flush_weight_grad(stream=None):
     check(_lib.load().geomae_flush_weight_grad(_stream_of(stream)), "geomae_flush_weight_grad")
 
 
+def last_stack_forms():
+    """(forward, backward) form of the last sst_stack_forward / sst_stack_backward of this thread: 0 three-launch, 1 one-launch,
+    2 looping (include/geomae_hip.h GEOMAE_STACK_FORM_*), -1 none yet."""
+    out = (ctypes.c_int32 * 2)()
+    check(_lib.load().geomae_sst_last_stack_forms(out), "geomae_sst_last_stack_forms")
+    return int(out[0]), int(out[1])
+
+
+def fused_dropped_bundles(reset=True):
+    """Bundles of more than four tiles that no one-launch kernel ran since the last reset (a broken big-bundle promise); syncs."""
+    out = ctypes.c_int64(0)
+    check(_lib.load().geomae_sst_fused_dropped_bundles(ctypes.byref(out), int(bool(reset))), "geomae_sst_fused_dropped_bundles")
+    return int(out.value)
+
+
 def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, saved, stream=None, defer_last=False,
-                       scatter=None, dz_add=None, tail_sum=None):
+                       scatter=None, dz_add=None, tail_sum=None, defer_all=False, big_layouts=None):
     """defer_last: leave the first layer's weight-gradient contraction recorded (-> also returns the scratch buffer,
     which must stay alive until flush_weight_grad's kernel ran).
     scatter = (rows int32 [n], dst [m,128] f32): the input gradient of token t is written to dst[rows[t]] (the
     transpose of sst_stack_forward's `rows`; dst's other rows are left as they are) and dst is returned as dx.
     dz_add: optional second summand of the output gradient (>= n rows; the stack reads dz + dz_add).
     tail_sum = (acc [128] or [1,128] f32, from_row): the column sums of dx[from_row:] are ADDED into acc (the gradient of
-    sst_stack_forward's fill row)."""
+    sst_stack_forward's fill row).
+    defer_all: EVERY layer's contraction is left recorded for flush_weight_grad (the step engine's mode; one slab set per layer;
+    -> returns (dx, scratch)).  big_layouts: the caller's promise for this call (geomae_sst_set_big_bundle_layouts): bit s =
+    layout s may hold a bundle of more than four tiles (None: both may)."""
     lib = _lib.load()
     _check_input(dz, "dz", torch.float32)
     nl = len(weights)
-    wb = lib.geomae_sst_stack_scratch_bytes(n)
+    wb = lib.geomae_sst_stack_scratch_bytes_layers(n, nl) if defer_all else lib.geomae_sst_stack_scratch_bytes(n)
+    if big_layouts is not None:
+        lib.geomae_sst_set_big_bundle_layouts(int(big_layouts))
     scratch = torch.empty(max(wb, 1), dtype=torch.uint8, device=dz.device)
     rows, n_out = None, 0
     if scatter is not None:
@@ -1446,8 +1468,8 @@ def sst_stack_backward(dz, n, weights, grads, layouts, pos_table, num_heads, sav
             raise RuntimeError("sst_stack_backward: dz_add must hold at least n rows of dz's width")
     check(lib.geomae_sst_stack_backward(_ptr(dz), _ptr(dz_add), n, weights, grads, nl, _stack_layouts(layouts), _ptr(pos_table),
                                         num_heads, layouts[0].max_tokens, _ptr(saved), _ptr(scratch), wb, _ptr(dx),
-                                        _ptr(rows), n_out, _ptr(tsum), int(tfrom), int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
+                                        _ptr(rows), n_out, _ptr(tsum), int(tfrom), 2 if defer_all else int(bool(defer_last)), ctypes.c_void_p(PROFILER) if PROFILER else None,
                                         _stream_of(stream)),
           "geomae_sst_stack_backward")
     # `scratch` must outlive the kernels: a caller that runs the stack on a stream of its own keeps it until the join
-    return (dx, scratch) if (stream is not None or defer_last) else dx
+    return (dx, scratch) if (stream is not None or defer_last or defer_all) else dx

@@ -606,6 +606,20 @@ int geomae_sst_layer_forward(const float* x, int32_t num_tokens, const GeomaeSst
  * Process-wide; A/B measurements and tests. */
 void geomae_sst_set_fused_layers(int32_t mode);
 
+/* which form the last geomae_sst_stack_forward (out[0]) / geomae_sst_stack_backward (out[1]) of THIS host thread took; -1: none
+ * yet.  Forward: THREE_LAUNCH = qkv / attention / ffn kernels, ONE_LAUNCH = sst_layer_fwd_kernel (+ its second kernel for
+ * bundles of more than four tiles), LOOPING = sst_layer_fwd_ws_kernel.  Backward: THREE_LAUNCH = the ffn / attention backward
+ * launches per layer, ONE_LAUNCH = sst_layer_bwd_kernel. */
+/* Per host thread, consumed by the NEXT geomae_sst_stack_forward / _backward (default: both): bit s = layout s (unshifted /
+ * shifted) MAY hold a bundle of more than four tiles in its second packing.  A caller that knows better (the step engine counts
+ * the kept pillars of the fullest window a step ahead, geomae_window_max_keep) clears the bits: the one-launch forward then skips
+ * its second kernel for that layout and the backward may take its one-launch form.  The promise is checked on the device:
+ * geomae_sst_fused_dropped_bundles (host-synchronising; measurement / tests) counts bundles that no launch ran. */
+void geomae_sst_set_big_bundle_layouts(int32_t mask);
+int geomae_sst_fused_dropped_bundles(int64_t* out /*host*/, int32_t reset);
+enum { GEOMAE_STACK_FORM_THREE_LAUNCH = 0, GEOMAE_STACK_FORM_ONE_LAUNCH = 1, GEOMAE_STACK_FORM_LOOPING = 2 };
+int geomae_sst_last_stack_forms(int32_t* out /*host [2]*/);
+
 int64_t geomae_sst_stack_saved_bytes(int32_t num_tokens, int32_t num_layers, int32_t num_heads);
 int64_t geomae_sst_stack_scratch_bytes(int32_t num_tokens);
 /* scratch for a backward whose weight-gradient contractions are all deferred to geomae_flush_weight_grad (the step
@@ -635,7 +649,11 @@ int geomae_sst_stack_backward(const float* dz, const float* dz_add /*or NULL*/, 
  * the stack's last data kernel: the gradient of the fill row of geomae_sst_stack_forward (the decoders' mask token). */
 /* defer_last_weight_grad != 0: the weight-gradient contraction of the stack's FIRST layer (the last kernel of the
  * backward, read only by the optimizer) is recorded instead of launched; geomae_flush_weight_grad(other_stream)
- * launches it there (order other_stream behind `stream` first), beside whatever the caller enqueues next on `stream`. */
+ * launches it there (order other_stream behind `stream` first), beside whatever the caller enqueues next on `stream`.
+ * defer_last_weight_grad == 2: EVERY layer's contraction is recorded ("defer all": what the step engine runs) -- the scratch
+ * must then hold one set of operand slabs per layer (geomae_sst_stack_scratch_bytes_layers) and stay alive until the flush;
+ * only in this mode, with no bundle of more than four tiles promised (geomae_sst_set_big_bundle_layouts(0)) and a token set
+ * the one-launch forward took, does the backward take its one-launch form (geomae_sst_last_stack_forms tells). */
 int geomae_flush_weight_grad(geomaeStream_t stream);
 
 /* ------------------------------------------------------------------ N3 DynamicScatter native op
@@ -885,6 +903,12 @@ int geomae_pretrain_set_optimizer_steps(void* engine, int64_t steps_taken);
  * injected mask, window tables too large), out[8] = which of the two layouts ran the one-launch layer's second kernel for
  * bundles of more than four tiles (bit s = layout s) */
 int geomae_pretrain_last_sizes(void* engine, int64_t* out /*host [9]*/);
+/* the same with the caller's capacity stated: writes min(capacity, 9) words and returns the number written (negative: error).
+ * New callers use this one; the array above grew from 6 to 9 words in round 5 with no way for an older caller to notice. */
+int geomae_pretrain_last_sizes_n(void* engine, int64_t* out, int32_t capacity);
+/* which kernel form each layer stack of the LAST step took (GEOMAE_STACK_FORM_*): out[0..2] = forward of the encoder, the
+ * density decoder, the centroid decoder; out[3..5] = their backward.  Writes min(capacity, 6) words, returns the number written. */
+int geomae_pretrain_step_forms(void* engine, int32_t* out, int32_t capacity);
 
 /* measurement only: HIP events recorded on the launch stream around every launch of ONE kernel of the stack
  * calls (bench.py's roofline).  read() synchronises on the events and returns the launch durations in ms. */

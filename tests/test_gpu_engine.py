@@ -124,18 +124,18 @@ def test_engine_knows_its_fullest_window_and_runs_large_bundles():
 
 def test_engine_with_a_larger_bundle_cap_keeps_the_second_launch():
     """"No window kept more than 64 pillars" means "no bundle of more than four tiles" only while the second packing's cap is at
-    most 64 positions (48 for the token sets the one-launch layers take).  With GEOMAE_BUNDLE_CAP=96 bundles of several small
-    windows exceed four tiles: the engine must keep the second launch (and the two-launch backward) -- round 5 shipped for an hour
-    without that condition and produced NaN losses.  The variable is read once per process: a subprocess runs the
-    engine-vs-Python-schedule comparison under it."""
-    import os
-    import subprocess
-    import sys
-    here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_gpu_engine as t; "
-            "t.test_engine_gradients_match_python_explicit_schedule(); print('OK')" % (here, os.path.dirname(here)))
-    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GEOMAE_BUNDLE_CAP="96"), capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    most 64 positions (48 for the token sets the one-launch layers take).  With GeomaeTuning.bundle_cap = 96 bundles of several
+    small windows exceed four tiles: the engine must keep the second launch (and the two-launch backward) -- round 5 shipped for
+    an hour without that condition and produced NaN losses.  In-process since round 6: the switch is a field of the tuning
+    surface (geomae_set_tuning), not an environment variable cached in a function-local static."""
+    from geomae_amd import _lib
+    old = _lib.set_tuning(bundle_cap=96)
+    try:
+        assert _lib.get_tuning().bundle_cap == 96
+        test_engine_gradients_match_python_explicit_schedule()
+    finally:
+        _lib.set_tuning(**old)
+    assert _lib.get_tuning().bundle_cap == old["bundle_cap"]
 
 
 def test_engine_training_steps_match_python_trainer():

@@ -97,6 +97,13 @@ def test_engine_step_matches_reference_pipeline_fixture(golden_dir):
     ref = dict(zip([str(n) for n in g["loss_names"]], [float(v) for v in g["loss_vals"]]))
     gn = dict(zip([str(n) for n in g["grad_names"]], [float(v) for v in g["grad_norms"]]))
     _compare("pipeline_full", model, losses, ref, gn, [(k, n, g[k]) for k, n in SMALL_FULL], TOL_SMALL)
+    # which kernels this comparison pinned: every stack is small enough for the one-launch forward; the
+    # encoder's backward is one launch per layer unless a window kept more than 64 pillars (an injected mask: unknown -> the
+    # two-launch form), the decoders' keeps the two-launch form (dead rows, the mask-token sum)
+    forms = eng.last_forms()
+    assert forms["enc_fwd"] == forms["den_fwd"] == forms["cen_fwd"] == "one_launch", forms
+    assert forms["den_bwd"] == forms["cen_bwd"] == "three_launch", forms
+    assert forms["enc_bwd"] == ("one_launch" if eng.last_sizes()["big_bundle_layouts"] == 0 else "three_launch"), forms
     # the prefetched batch is pending and steps with a RANDOM mask next: finite, same sizes
     tr.flat.zero_grad()
     l2, _ = eng.step(eng.pending, None, 1e-5, run_optimizer=False)
@@ -106,7 +113,7 @@ def test_engine_step_matches_reference_pipeline_fixture(golden_dir):
 
 
 def test_one_launch_layer_generic_body_matches_reference_fixture(golden_dir):
-    """the generic 5-9-tile body of the one-launch layer kernel (fused_fwd_body<9, false>) runs in the
+    """the 5-9-tile path of the one-launch layer (round 5: fused_fwd_body<9, false>; since round 6 the looping kernel of sst_ws.hip) runs in the
     product only for a window that kept more than 64 pillars, and was pinned by a self-comparison alone.  Here the one-launch
     form is forced for EVERY stack (geomae_sst_set_fused_layers(2)): the decoders' token sets pack bundles of up to 144
     positions, so their eight layers go through that body -- and the step is held to the reference fixture at the same
@@ -144,6 +151,16 @@ def test_engine_step_matches_reference_at_full_size(golden_dir, case):
     print(f"\n{case}: fullest windows {sz['max_window_keep']}, layouts with large bundles {sz['big_bundle_layouts']}", flush=True)
     if case == "c2":
         assert sz["big_bundle_layouts"] == 0 and max(sz["max_window_keep"]) <= 64, sz
+    # ... and that it DID take it (the choice hangs on six run-time conditions; a silent fall-back to the
+    # two-launch backward would keep this comparison green): the engine reports the form of every stack of the step
+    forms = eng.last_forms()
+    print(f"{case}: stack forms {forms}", flush=True)
+    assert forms["den_fwd"] == forms["cen_fwd"] == "three_launch" and forms["den_bwd"] == forms["cen_bwd"] == "three_launch", forms
+    want = "one_launch" if sz["n_keep"] <= 12288 else "three_launch"        # (GeomaeTuning.fused_max_tokens)
+    assert forms["enc_fwd"] == want, (forms, sz)
+    assert forms["enc_bwd"] == (want if sz["big_bundle_layouts"] == 0 else "three_launch"), (forms, sz)
+    if case == "c2":
+        assert forms["enc_fwd"] == "one_launch" and forms["enc_bwd"] == "one_launch", forms
     ref = dict(zip([str(n) for n in K("loss_names")], [float(v) for v in K("loss_vals")]))
     gn = dict(zip([str(n) for n in K("grad_names")], [float(v) for v in K("grad_norms")]))
     _compare(case, model, losses, ref, gn, [(k, n, K(k)) for k, n in BIG_FULL], TOL_BIG)

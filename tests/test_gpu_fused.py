@@ -165,3 +165,96 @@ def test_weight_stationary_layer_matches_three_launch_form(dev, case):
     assert _rel(d1, d0) < 1e-2, _rel(d1, d0)
     bad = {k: _rel(g1[k], g0[k]) for k in g0 if _rel(g1[k], g0[k]) > 2e-2}
     assert not bad, bad
+
+
+def _encoder_small_case(dev, seed=9):
+    from geomae_amd import ops
+    model = _model(dev, 2, 2)
+    bb = model.backbone
+    frames = [synth.lidar_frame(71), synth.lidar_frame(72, beams=24, n_az=700), synth.lidar_frame(73, beams=16, n_az=300)]
+    _, coors = O.voxelize_batch(frames, TOP, RANGE)
+    vc = O.unique_rows(coors)[0]
+    keep = np.sort(np.random.default_rng(3).permutation(vc.shape[0])[: vc.shape[0] // 3])
+    vc = torch.as_tensor(vc[keep], device=dev)
+    bb._packed.refresh()
+    layouts, _ = bb.get_voxel_info(vc, len(frames))
+    gen = torch.Generator().manual_seed(seed)
+    n = vc.shape[0]
+    return model, bb, layouts, n, torch.randn(n, 128, generator=gen).to(dev), torch.randn(n, 128, generator=gen).to(dev)
+
+
+def test_one_launch_backward_matches_two_launch_backward_at_stack_level(dev):
+    """sst_layer_bwd_kernel pinned DIRECTLY -- geomae_sst_stack_backward with every contraction queued
+    (defer_last_weight_grad = 2) and the promise "no bundle of more than four tiles", once with GeomaeTuning.fused_bwd on and
+    once off, on the same saved activations of a one-launch forward.  geomae_sst_last_stack_forms says which backward ran (a
+    silent fall-back to the two-launch form would make this a self-comparison), geomae_sst_fused_dropped_bundles that no bundle
+    was skipped."""
+    from geomae_amd import ops, _lib
+    model, bb, layouts, n, x, dz = _encoder_small_case(dev)
+    blocks = bb.encoder_blocks
+    nl = 2 * len(blocks)
+    for L in layouts:
+        nb = int(L.num_fbundles.item())
+        sizes = (L.fbun_tok[1:nb + 1] - L.fbun_tok[:nb]).cpu().numpy()
+        assert sizes.max() <= 64, "the case must hold no bundle of more than four tiles"
+    w = bb._packed.weight_array(bb._stack_base["enc"], nl)
+    ops.fused_dropped_bundles(reset=True)
+    res, forms = [], []
+    old = _lib.get_tuning().fused_bwd
+    try:
+        for fused_bwd in (0, 1):
+            _lib.set_tuning(fused_bwd=fused_bwd)
+            for p in bb.parameters():
+                p.grad = None
+            g = bb._packed.grad_array(bb._stack_base["enc"], nl)
+            z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0], big_layouts=0)
+            dx, scratch = ops.sst_stack_backward(dz, n, w, g, layouts, bb.pos_table, bb.nhead[0], saved, defer_all=True, big_layouts=0)
+            forms.append(ops.last_stack_forms())
+            ops.flush_weight_grad()
+            torch.cuda.synchronize()
+            res.append((z.clone(), dx.clone(), {k: v.grad.clone() for k, v in blocks.named_parameters()}))
+            del scratch
+    finally:
+        _lib.set_tuning(fused_bwd=old)
+    assert forms == [(1, 0), (1, 1)], forms                     # one-launch forward both times; two-launch, then one-launch backward
+    assert ops.fused_dropped_bundles() == 0
+    (z0, d0, g0), (z1, d1, g1) = res
+    assert torch.equal(z0, z1)
+    assert torch.isfinite(d1).all()
+    assert _rel(d1, d0) < 1e-2, _rel(d1, d0)
+    bad = {k: _rel(g1[k], g0[k]) for k in g0 if _rel(g1[k], g0[k]) > 2e-2}
+    assert not bad, bad
+
+
+def test_a_broken_big_bundle_promise_is_counted(dev):
+    """the one-launch kernels skip bundles of more than four tiles on a host-side promise.  A wrong promise (here: the
+    decoders' token set, windows of up to 144 pillars, declared free of large bundles) must not pass silently: the kernels count
+    every bundle no launch ran, geomae_sst_fused_dropped_bundles reads the count."""
+    from geomae_amd import ops, _lib
+    lib = _lib.load()
+    model = _model(dev, 2, 2)
+    bb = model.backbone
+    frames = [synth.lidar_frame(71), synth.lidar_frame(72, beams=24, n_az=700)]
+    _, coors = O.voxelize_batch(frames, TOP, RANGE)
+    vc = torch.as_tensor(O.unique_rows(coors)[0], device=dev)
+    n = vc.shape[0]
+    bb._packed.refresh()
+    old = _lib.set_tuning(bundle_cap=48)
+    try:
+        layouts, _ = bb.get_voxel_info(vc, len(frames))
+        nb = int(layouts[0].num_fbundles.item())
+        sizes = (layouts[0].fbun_tok[1:nb + 1] - layouts[0].fbun_tok[:nb]).cpu().numpy()
+        n_big = int((sizes > 64).sum())
+        assert n_big > 0
+        nl = 2 * len(bb.decoder_centroid_blocks)
+        w = bb._packed.weight_array(bb._stack_base["cen"], nl)
+        x = torch.randn(n, 128, device=dev)
+        ops.fused_dropped_bundles(reset=True)
+        lib.geomae_sst_set_fused_layers(2)
+        ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0])                  # no promise: the second launch runs
+        assert ops.fused_dropped_bundles() == 0
+        ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0], big_layouts=0)   # a wrong promise
+        assert ops.fused_dropped_bundles() >= n_big
+    finally:
+        lib.geomae_sst_set_fused_layers(1)
+        _lib.set_tuning(**old)
