@@ -417,7 +417,10 @@ def main():
         # 4.45 KB (reads dz 512, xhat1/xhat2/hp/attn 1280, writes dv/dhp/h/du/dx_res/dattn 2304, + LayerNorm rows), a B1 head
         # 1.3 KB; a contraction reads 8 tasks x 2 operands x 256 B; attention forward reads qkv 768 and writes attn 256 + lse 32,
         # its backward reads qkv + attn + dattn + lse and writes dqkv 768.
-        F3B, F1B, B3B, B1B, DWB, AFB, ABB = 2304.0, 1024.0, 4450.0, 1300.0, 4096.0, 1056.0, 2080.0
+        # The contraction: 3.25 KB per token and layer = 13 x 256-byte operand rows (the four jobs of
+        # csrc/dw_device.h read [dq | dk] 512 + xp 256, dhp 512 + xhat1 256, dv 256 + h 512, dv_ 256 + x 256 + du 256 + attn 256;
+        # task pairs that share an operand read it once -- the round-4 task form read 4 KB).
+        F3B, F1B, B3B, B1B, DWB, AFB, ABB = 2304.0, 1024.0, 4450.0, 1300.0, 3328.0, 1056.0, 2080.0
         # the one-launch backward: reads dz 512 + xhat1/xhat2/hp/attn/qkv 1792 + lse/rstd 40, writes dx 512 + dv/dhp/h/du/dqkv 2304
         bytes_step = {"sst_layer_bwd_kernel": (512 + 1792 + 40 + 512 + 2304) * 12 * n_e,
                       "sst_ffn_bwd_kernel": (B3B * 8 * n_d + B1B * 6 * n_d) if fused_bwd else
@@ -431,8 +434,7 @@ def main():
                       "win_attn_fwd_kernel": AFB * (8 * n_d + (0 if fused_enc else 12 * n_e)),
                       "win_attn_bwd_kernel": ABB * ((0 if fused_bwd else 12 * n_e) + 8 * n_d),
                       "sst_layer_fwd_kernel": (512 + F3B + F1B + 256 + 32) * 12 * n_e,
-                      # (algorithmic: 8 tasks x 2 operands x 256 B per token and layer -- SURVEY's figure; the layer-form kernel
-                      #  reads 3.25 KB of it once, dw_device.h)
+                      # (3328 B per token-layer; + the heads' rows and the VFE layer-1 operands)
                       "dw_kernel": DWB * ((8 * n_d if (dec_deferred or all_deferred) else 2 * n_d) + (12 * n_e if all_deferred else n_e))
                                    + 2 * (800 + 128) * M_rows + 2 * 2 * 128 * n_pts}
         kern = {}
@@ -472,6 +474,28 @@ def main():
         # stream at all is measured by tools/lds_dma_bench.hip (profiles/r05_microbench_lds_dma.txt: 512-thread workgroups moving
         # 24-KB slabs global -> LDS and nothing else), so the launch is also priced against THAT ceiling.
         if "dw_kernel" in kern:
+            tl = (8 * n_d if (dec_deferred or all_deferred) else 2 * n_d) + (12 * n_e if all_deferred else n_e)
+            kern["dw_kernel"]["bytes_formula"] = (
+                f"(token-layers {int(tl)} x 3328 B [13 operand rows of 256 B, DESIGN.md section 3] + masked rows {int(M_rows)} x 1856 B "
+                f"[heads: 800 + 128 bf16] + points {int(n_pts)} x 512 B [VFE layer 1: dy1, g]) / {launches_step['dw_kernel']:.2f} launches per step"
+                " / avg_launch_ms_less_event_pair")
+            # the same kernel ALONE on the chip (tools/dw_bench.hip, committed output): what the throttled in-step figure is not
+            alone_path = os.path.join(ROOT, "profiles", "r06_microbench_dw_alone.txt")
+            if os.path.exists(alone_path):
+                import re as _re
+                best = None
+                for line in open(alone_path):
+                    m_ = _re.search(r"n =\s*(\d+), (\d+) layer\(s\) per launch, G =\s*(\d+) \(\s*(\d+) workgroups\): ([0-9.]+) us with its reduction "
+                                    r"\(([0-9.]+) without\) = ([0-9.]+) us per layer", line)
+                    # (the decoder-size run of the file: the largest n, then the fastest launch shape)
+                    if m_ and (best is None or (int(m_.group(1)), -float(m_.group(7))) > (best[1], -best[0])):
+                        best = (float(m_.group(7)), int(m_.group(1)), int(m_.group(2)), int(m_.group(4)))
+                if best:
+                    us_layer, n_al, layers_al, wg_al = best
+                    gbs_al = n_al * 3328.0 / (us_layer * 1e-6) / 1e9
+                    kern["dw_kernel"]["alone"] = {"achieved": round(gbs_al, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs_al / 8000.0, 4),
+                                                  "us_per_layer": us_layer, "tokens": n_al, "layers_per_launch": layers_al, "workgroups": wg_al,
+                                                  "bytes_formula": "tokens x 3328 B / us_per_layer", "source": "profiles/r06_microbench_dw_alone.txt (tools/dw_bench.hip)"}
             ceil_path = os.path.join(ROOT, "profiles", "r05_microbench_lds_dma.txt")
             budget = 80 if n_d <= 32768 else 96
             ceiling = None

@@ -14,7 +14,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-fast-math"
 # Floating-point contraction: OFF where results are compared bit-for-bit with the oracle / torch (voxel indices,
 # geometric targets, the input pipeline, the AdamW update); ON (fused multiply-add) in the MFMA kernels, whose
 # parity is a tolerance anyway: 9-12 % fewer VALU instructions in the layer kernels.
-CONTRACT_FAST = {"sst_layer.hip", "window.hip", "heads_loss.hip", "vfe.hip", "sst_ws.hip"}
+CONTRACT_FAST = {"sst_layer.hip", "window.hip", "heads_loss.hip", "vfe.hip", "sst_ws.hip", "sst_fused.hip"}
 
 
 def flags_for(src):
