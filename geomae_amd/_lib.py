@@ -29,7 +29,7 @@ class GeomaeWindowConfig(ctypes.Structure):
 class GeomaeWindowBuildJob(ctypes.Structure):
     _fields_ = ([("coors", c_void_p), ("num_tokens", c_int32), ("shift_index", c_int32)]
                 + [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "bun_start",
-                                           "num_bundles", "bun_tok", "pos_info", "fbun_tok", "num_fbundles")])
+                                           "num_bundles", "bun_tok", "pos_info", "fbun_tok", "num_fbundles", "fitems", "num_fitems")])
 
 
 class GeomaeSstLayerWeights(ctypes.Structure):
@@ -41,7 +41,7 @@ class GeomaeSstLayerWeights(ctypes.Structure):
 class GeomaeSstStackLayout(ctypes.Structure):
     _fields_ = [(n, c_void_p) for n in ("win_start", "win_tokens", "tok_win", "tok_pos", "bun_start", "num_bundles")] + \
                [("max_bundles", c_int32), ("bun_tok", c_void_p), ("pos_info", c_void_p), ("fbun_tok", c_void_p),
-                ("num_fbundles", c_void_p)]
+                ("num_fbundles", c_void_p), ("fitems", c_void_p), ("num_fitems", c_void_p)]
 
 
 class GeomaeVfeArgs(ctypes.Structure):
@@ -113,7 +113,7 @@ class GeomaeTuning(ctypes.Structure):
         "size", "fused_layers", "fused_max_tokens", "fused_bwd", "ws_layers", "ws_bwd", "ws_bundle_cap", "ws_max_workgroups",
         "bundle_cap", "saved_f32", "x_from_xhat", "y_from_xhat", "pair_kernels", "attn_heads", "dw_layer_form", "dw_chunks",
         "dw_budget_mid", "dw_split_reduce", "dw_defer_all", "dec_dw_every", "dec_mid_budget", "enc_dw_defer", "zero_late_aux",
-        "fused_skip_big", "heads_joint")] + [("reserved", c_int32 * 8)]
+        "fused_skip_big", "heads_joint", "fwd_item_cap")] + [("reserved", c_int32 * 7)]
 
 
 # environment variable -> GeomaeTuning field, read ONCE when the library is loaded (the library itself reads no environment)
@@ -125,7 +125,7 @@ TUNING_ENV = {
     "GEOMAE_ATTN_HEADS": "attn_heads", "GEOMAE_DW_LAYER_FORM": "dw_layer_form", "GEOMAE_DW_CHUNKS": "dw_chunks",
     "GEOMAE_DW_BUDGET_MID": "dw_budget_mid", "GEOMAE_DW_SPLIT_REDUCE": "dw_split_reduce", "GEOMAE_DW_DEFER_ALL": "dw_defer_all",
     "GEOMAE_DEC_DW_EVERY": "dec_dw_every", "GEOMAE_DEC_MID_BUDGET": "dec_mid_budget", "GEOMAE_ENC_DW_DEFER": "enc_dw_defer",
-    "GEOMAE_ZERO_LATE_AUX": "zero_late_aux", "GEOMAE_FUSED_SKIP_BIG": "fused_skip_big", "GEOMAE_HEADS_JOINT": "heads_joint",
+    "GEOMAE_ZERO_LATE_AUX": "zero_late_aux", "GEOMAE_FUSED_SKIP_BIG": "fused_skip_big", "GEOMAE_HEADS_JOINT": "heads_joint", "GEOMAE_FWD_ITEM_CAP": "fwd_item_cap",
 }
 
 

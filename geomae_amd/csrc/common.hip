@@ -83,7 +83,7 @@ static GeomaeTuning default_tuning() {
     t.saved_f32 = 0; t.x_from_xhat = 1; t.y_from_xhat = 1; t.pair_kernels = -1; t.attn_heads = 0;
     t.dw_layer_form = 1; t.dw_chunks = 0; t.dw_budget_mid = 0; t.dw_split_reduce = 1;
     t.dw_defer_all = 1; t.dec_dw_every = -1; t.dec_mid_budget = 0; t.enc_dw_defer = 1; t.zero_late_aux = 0;
-    t.fused_skip_big = 1; t.heads_joint = 0;
+    t.fused_skip_big = 1; t.heads_joint = 0; t.fwd_item_cap = 0;
     return t;
 }
 static GeomaeTuning g_tuning = default_tuning();
@@ -108,6 +108,7 @@ extern "C" int geomae_set_tuning(const GeomaeTuning* in) {
     t.attn_heads = (t.attn_heads == 1 || t.attn_heads == 2 || t.attn_heads == 4) ? t.attn_heads : 0;
     t.dw_chunks = clamp(t.dw_chunks, 0, 64); t.dw_budget_mid = clamp(t.dw_budget_mid, 0, 4096);
     t.dec_dw_every = clamp(t.dec_dw_every, -1, 64); t.dec_mid_budget = clamp(t.dec_mid_budget, 0, 4096);
+    t.fwd_item_cap = t.fwd_item_cap <= 0 ? 0 : clamp(t.fwd_item_cap, 16, 64);
     geomae::g_tuning = t;
     return GEOMAE_OK;
 }

@@ -104,6 +104,7 @@ struct WinLayout {
     int32_t n = 0, max_windows = 1;
     int32_t *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles, *bun_tok, *pos_info;
     int32_t *fbun_tok, *num_fbundles;
+    int32_t *fitems, *num_fitems;
 };
 
 enum Ev { kStepEnd, kLayouts, kVfeDone, kForkDec, kJoinDecFwd, kHeads, kAuxBwd, kMainDecBwd, kEncBwd, kVfeL1, kGeoDone,
@@ -382,6 +383,8 @@ void carve_layout(Arena& a, const GeomaePretrainConfig& c, int32_t n, WinLayout*
     L->pos_info = a.take<int32_t>(n1 * 4);
     L->fbun_tok = a.take<int32_t>(mw + 1);
     L->num_fbundles = a.take<int32_t>(1);
+    L->fitems = a.take<int32_t>(8 * (mw + 1));       // [2 (mw + 1)][4]: the one-launch forward's work items
+    L->num_fitems = a.take<int32_t>(1);
 }
 
 void stack_layouts(const WinLayout* L, GeomaeSstStackLayout* out) {
@@ -390,6 +393,7 @@ void stack_layouts(const WinLayout* L, GeomaeSstStackLayout* out) {
         out[i].tok_pos = L[i].tok_pos; out[i].bun_start = L[i].bun_start; out[i].num_bundles = L[i].num_bundles;
         out[i].max_bundles = L[i].max_windows; out[i].bun_tok = L[i].bun_tok; out[i].pos_info = L[i].pos_info;
         out[i].fbun_tok = L[i].fbun_tok; out[i].num_fbundles = L[i].num_fbundles;
+        out[i].fitems = L[i].fitems; out[i].num_fitems = L[i].num_fitems;
     }
 }
 
@@ -606,6 +610,7 @@ int run_step(Engine* e, const float* const* next_frames, const int64_t* next_siz
             jobs[k].tok_pos = lay[k].tok_pos; jobs[k].num_windows = lay[k].num_windows; jobs[k].bun_start = lay[k].bun_start;
             jobs[k].num_bundles = lay[k].num_bundles; jobs[k].bun_tok = lay[k].bun_tok; jobs[k].pos_info = lay[k].pos_info;
             jobs[k].fbun_tok = lay[k].fbun_tok; jobs[k].num_fbundles = lay[k].num_fbundles;
+            jobs[k].fitems = lay[k].fitems; jobs[k].num_fitems = lay[k].num_fitems;
         }
         set_window_tables_prezeroed(true);         // (cleared by the gather above)
         const int rc_win = geomae_window_build_batch(jobs, 4, c.batch_size, &c.window, win_ws, win_wsb, geo);

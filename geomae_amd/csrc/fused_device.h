@@ -50,6 +50,8 @@ struct FusedFwd {
     float eps;
     float* z;                    // layer output [n][128] fp32: tile-blocked (z_blocked) or row-major
     int z_blocked;
+    const int4* items = nullptr;         // forward work items (window.hip item_pack: first position, positions, first query tile,
+    const int32_t* num_items = nullptr;  // query tiles), or null / 0 items: the kernel walks bun_tok
     int big_follows = 1;         // the launch for bundles of more than four tiles follows (0: the caller promised there is none)
     // saved for the backward (token order, tile-blocked; all or none)
     bf16_t *qkv, *attn, *xh1, *xh2, *hp, *xb, *xp;

@@ -43,10 +43,16 @@ namespace geomae {
 // count (tests assert 0; round 5 shipped NaN losses for an hour through exactly this hole).
 static __device__ unsigned int g_fused_dropped = 0;
 
-template <int NT, bool EXACT>
+// Q0, NQ (round 6): the QUERY tiles [Q0, Q0 + NQ) this work item owns.  Rows, k and v^T are made for all NT tiles of the bundle
+// (the attention needs every key of a window), q / attention / the row-wise rest and every store only for the owned tiles: a
+// bundle of three or four tiles is two work items in two workgroups (window.hip item_pack), each a chain of about two tiles.
+template <int NT, bool EXACT, int Q0 = 0, int NQ = NT>
 __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, const int T, const int nt_in, char* lds) {
+    static_assert(Q0 >= 0 && NQ >= 1 && Q0 + NQ <= NT, "query tiles inside the bundle");
     const int nt = EXACT ? NT : nt_in;
 #define FOR_TILES(it) _Pragma("unroll") for (int it = 0; it < NT; ++it) if (EXACT || it < nt)
+#define FOR_OWN(it) _Pragma("unroll") for (int it = Q0; it < Q0 + NQ; ++it) if (EXACT || it < nt)
+#define OWN(it) ((it) >= Q0 && (it) < Q0 + NQ)
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // head = channel tile of this wave
     const int t = lane & 15, g = lane >> 4;
@@ -118,7 +124,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             const uint2 xb = pack4(xr[it]), xpb = pack4(xr[it] + pv[it]);
             *reinterpret_cast<uint2*>(X + idx * kFRow + perm_b) = xb;
             *reinterpret_cast<uint2*>(XP + idx * kFRow + perm_b) = xpb;
-            if (save) {
+            if (save && OWN(it)) {
                 const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 128, w, g) : kFOor;
                 if (A.xb) buf_store_b64(xb_r, o2, xb);             // (null: geomae::set_skip_x_copy -- layers above the first)
                 buf_store_b64(xp_r, o2, xpb);
@@ -147,15 +153,15 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             f32x4 aq = bq, ak = bk, av = bv, avt = {bvn, bvn, bvn, bvn};
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                aq = mfma32(wq[kk], bxp[kk], aq);
+                if (OWN(it)) aq = mfma32(wq[kk], bxp[kk], aq);       // (q and the T-layout v only for the owned query tiles)
                 ak = mfma32(wk[kk], bxp[kk], ak);
                 avt = mfma32(bx[kk], wv[kk], avt);
-                av = mfma32(wv[kk], bx[kk], av);
+                if (OWN(it)) av = mfma32(wv[kk], bx[kk], av);
             }
             qf[it] = pack4(aq);
             kf[it] = pack4(ak);
             vtf[it] = pack4(avt);
-            if (save) {
+            if (save && OWN(it)) {
                 const int o2 = tok[it] >= 0 ? blk_off<2>(tok[it], 384, w, g) : kFOor;
                 buf_store_b64(qkv_r, o2, qf[it]);
                 buf_store_b64(qkv_r, o2 + 8 * 512, kf[it]);
@@ -171,7 +177,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t attn_r = saved_rsrc(A.attn), lse_r = saved_rsrc(A.lse);
         const float scale = 0.25f;                                   // 1 / sqrt(16)
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             const int first = 16 * it;
             int jlo = 0, jhi = NT - 1;
             if (!EXACT) {
@@ -241,7 +247,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     // ---- phase D: u = x + attn Wo^T + bo (channel tile w), LayerNorm 1
     {
         const f32x4 bo = load_f4(prm + kPBo + 16 * w + 4 * g);
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             const char* orow = O + (16 * it + t) * kFRow + 16 * g;
             f32x4 au = bo;
 #pragma unroll
@@ -256,7 +262,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t xh1_r = saved_rsrc(A.xh1), rstd_r = saved_rsrc(A.rstd);
         const f32x4 g1 = load_f4(prm + kPG1 + 16 * w + 4 * g), be1 = load_f4(prm + kPBe1 + 16 * w + 4 * g);
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             float mean, rstd;
             ln_merge(red + (16 * it + t) * 16, A.eps, &mean, &rstd);
             f32x4 xh = (xr[it] - mean) * rstd;
@@ -276,7 +282,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t hp_r = saved_rsrc(A.hp);
         const f32x4 b1a = load_f4(prm + kPB1 + 32 * w + 4 * g), b1b = load_f4(prm + kPB1 + 32 * w + 16 + 4 * g);
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             const char* yrow = X + (16 * it + t) * kFRow + 16 * g;
             f32x4 ha = b1a, hb = b1b;
 #pragma unroll
@@ -302,7 +308,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     // ---- phase F: v = y + h W2^T + b2, LayerNorm 2
     {
         const f32x4 b2 = load_f4(prm + kPB2 + 16 * w + 4 * g);
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             const char* hrow = H + (16 * it + t) * kFRowH + 16 * g;
             f32x4 a = b2;
 #pragma unroll
@@ -317,7 +323,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t xh2_r = saved_rsrc(A.xh2), rstd_r = saved_rsrc(A.rstd), z_r = whole_rsrc(A.z);
         const f32x4 g2 = load_f4(prm + kPG2 + 16 * w + 4 * g), be2 = load_f4(prm + kPBe2 + 16 * w + 4 * g);
-        FOR_TILES(it) {
+        FOR_OWN(it) {
             float mean, rstd;
             ln_merge(red + (16 * it + t) * 16, A.eps, &mean, &rstd);
             const f32x4 xh = (xr[it] - mean) * rstd;
@@ -335,6 +341,8 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     }
     FUSED_STAMP(14);
 #undef FOR_TILES
+#undef FOR_OWN
+#undef OWN
 }
 
 // The exact bodies run the bundles of 1-4 tiles: every bundle of the packing but a single window that kept more than 64 pillars.
@@ -346,6 +354,30 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 // which the step engine avoids by knowing the fullest window a step ahead (window.hip window_max_keep).
 __global__ __launch_bounds__(kFusedThreads, 2) void sst_layer_fwd_kernel(FusedFwd A) {
     __shared__ __attribute__((aligned(16))) char lds[kFLdsBytes];
+    // ---- work items (window.hip item_pack: bundles of a 32-position packing, those of three / four tiles split by query tile)
+    const int NI = A.items ? A.num_items[0] : 0;
+    if (NI > 0) {
+        for (int i = blockIdx.x; i < NI; i += gridDim.x) {
+            const int4 item = A.items[i];
+            const int s0 = item.x, T = item.y, nt = (T + 15) >> 4;
+            switch (nt * 16 + item.z * 4 + item.w) {
+                case 1 * 16 + 0 * 4 + 1: fused_fwd_body<1, true>(A, s0, T, nt, lds); break;
+                case 2 * 16 + 0 * 4 + 2: fused_fwd_body<2, true>(A, s0, T, nt, lds); break;
+                case 3 * 16 + 0 * 4 + 3: fused_fwd_body<3, true>(A, s0, T, nt, lds); break;
+                case 3 * 16 + 0 * 4 + 2: fused_fwd_body<3, true, 0, 2>(A, s0, T, nt, lds); break;
+                case 3 * 16 + 2 * 4 + 1: fused_fwd_body<3, true, 2, 1>(A, s0, T, nt, lds); break;
+                case 4 * 16 + 0 * 4 + 4: fused_fwd_body<4, true>(A, s0, T, nt, lds); break;
+                case 4 * 16 + 0 * 4 + 2: fused_fwd_body<4, true, 0, 2>(A, s0, T, nt, lds); break;
+                case 4 * 16 + 2 * 4 + 2: fused_fwd_body<4, true, 2, 2>(A, s0, T, nt, lds); break;
+                default:                                     // 5-9 tiles: the second launch (sst_ws.hip, min_tiles = 5)
+                    if (nt <= 4 || !A.big_follows) { if (threadIdx.x == 0) atomicAdd(&g_fused_dropped, 1u); }
+                    break;
+            }
+            if (i + (int)gridDim.x < NI) __syncthreads();
+        }
+        return;
+    }
+    // ---- no item list (more bundles than CUs, a caller without one): the bundles of the second packing
     // (bun_tok holds max_bundles + 1 >= gridDim.x + 1 words: read before the bundle count is known, one round trip less)
     const int NB = A.num_bundles[0];
     for (int b = blockIdx.x; b < NB; b += gridDim.x) {
@@ -850,7 +882,11 @@ extern "C" int geomae_sst_layer_forward(const float* x, int32_t num_tokens, cons
     A.qkv = (bf16_t*)qkv_bf16; A.attn = (bf16_t*)attn_bf16; A.xh1 = (bf16_t*)xhat1_bf16; A.xh2 = (bf16_t*)xhat2_bf16;
     A.hp = (bf16_t*)hp_bf16; A.xb = skip_x_copy() ? nullptr : (bf16_t*)x_bf16; A.xp = (bf16_t*)xp_bf16; A.lse = lse; A.rstd = rstd;
     A.big_follows = big_possible ? 1 : 0;
-    const int grid = fused_grid(num_tokens, layout->max_bundles, bundle_cap);
+    if (layout->fitems && layout->num_fitems && tuning().fwd_item_cap > 0) {
+        A.items = (const int4*)layout->fitems; A.num_items = layout->num_fitems;
+    }
+    // (an item list exists only when it fits one round of workgroups; without one the kernel's loop covers any bundle count)
+    const int grid = fused_grid(num_tokens, layout->max_bundles, A.items ? (tuning().fwd_item_cap < bundle_cap ? tuning().fwd_item_cap : bundle_cap) : bundle_cap);
     hipLaunchKernelGGL(sst_layer_fwd_kernel, dim3(grid), dim3(kFusedThreads), 0, stream, A);
     rc = check_launch("sst_layer_fwd_kernel");
     if (rc) return rc;

@@ -61,6 +61,9 @@ struct WinJob {
     int32_t *table, *rank, *win_start, *win_tokens, *tok_win, *tok_pos, *num_windows, *bun_start, *num_bundles;
     int fcap;                // second packing (the one-launch layer kernel's bundles): cap, starts, count; or fbun_tok null
     int32_t *fbun_tok, *num_fbundles;
+    int icap, ibudget;       // the one-launch forward's work items: cap of their packing, workgroups of one round (the CU count)
+    int4* fitems;            // ... (first position, positions, first query tile, query tiles) per item, or null
+    int32_t* num_fitems;
     int32_t* bun_tok;        // optional attention plan (see bundle_setup): token position where each bundle starts
     int4* pos_info;          // ... and per position of win_tokens: (token, in-window position = pos-embed row, window start, window end)
 };
@@ -227,6 +230,85 @@ __device__ __forceinline__ void bundle_pack(const WinJob& j, int cap, int32_t* _
     __syncthreads();
 }
 
+// Work items of the one-launch layer FORWARD (sst_fused.hip; round 6).  Its launch lasts as long as its longest work item --
+// a 3-tile bundle's chain is 29 k cycles, a 4-tile bundle's 38 k, a 2-tile bundle's 21 k (tools/fused_layer_time.py) -- while a
+// small token set has fewer bundles than the device has CUs (163 at config 2's encoder).  So: a THIRD packing with a cap of
+// `icap` (32) positions -- mostly two-tile bundles -- whose three- and four-tile bundles (a window that kept 33-64 pillars) are
+// split by QUERY tile into two items: each computes k / v for the whole bundle, attention and the row-wise rest for its own
+// tiles.  Everything must still fit ONE round of workgroups (`ibudget` = CUs, one 133-KB-LDS workgroup each): the four-tile
+// bundles are split first, the three-tile ones if the count allows; with more bundles than CUs no item list is made
+// (num_fitems = 0) and the kernel walks the second packing as before.  The backward keeps the second packing: it cannot split
+// (dK / dV sum over all queries of a window) and shares the chip with the contraction launches.
+__device__ __forceinline__ void item_pack(const WinJob& j, BundleLds& L, int W, bool in_lds) {
+    if (!in_lds || j.icap <= 0) {
+        if (threadIdx.x == 0) j.num_fitems[0] = 0;
+        return;
+    }
+    // the packing's bundle starts go to the tail of the item buffer (it holds 8 (mw + 1) ints; items grow from its head)
+    const int mw = j.n < j.slots ? j.n : j.slots;
+    int32_t* tmp = reinterpret_cast<int32_t*>(j.fitems) + 7 * ((mw < 1 ? 1 : mw) + 1);
+    bundle_pack(j, j.icap, nullptr, tmp, j.num_fitems, L, W, in_lds);
+    __threadfence_block();
+    __syncthreads();
+    const int nb = j.num_fitems[0];
+    __shared__ int cnt3, cnt4, total;
+    if (threadIdx.x == 0) { cnt3 = 0; cnt4 = 0; total = 0; }
+    // bundle starts into LDS (ja: free after the packing): the items written below may reach the tail of the buffer
+    for (int b = threadIdx.x; b <= nb && b <= 8192; b += 1024) L.ja[b] = tmp[b];
+    __syncthreads();
+    if (nb > j.ibudget || nb > 8191) {                   // (uniform) more bundles than one round of workgroups
+        if (threadIdx.x == 0) j.num_fitems[0] = 0;
+        return;
+    }
+    int c3 = 0, c4 = 0;
+    for (int b = threadIdx.x; b < nb; b += 1024) {
+        const int nt = (L.ja[b + 1] - L.ja[b] + 15) >> 4;
+        c3 += nt == 3; c4 += nt == 4;
+    }
+    if (c3) atomicAdd(&cnt3, c3);
+    if (c4) atomicAdd(&cnt4, c4);
+    __syncthreads();
+    const bool split4 = nb + cnt4 <= j.ibudget, split3 = nb + cnt4 + cnt3 <= j.ibudget;
+    // item offsets: an exclusive scan of the parts per bundle (nb <= 8191: eight bundles per thread, then one scan of 1024 sums)
+    int first = threadIdx.x * 8, mine = 0, parts[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = first + k;
+        int p = 0;
+        if (b < nb) {
+            const int nt = (L.ja[b + 1] - L.ja[b] + 15) >> 4;
+            p = 1 + ((split3 && nt == 3) || (split4 && nt == 4) ? 1 : 0);
+        }
+        parts[k] = p; mine += p;
+    }
+    L.jb[threadIdx.x] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = threadIdx.x >= d ? L.jb[threadIdx.x - d] : 0;
+        __syncthreads();
+        L.jb[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int off = L.jb[threadIdx.x] - mine;
+    if (threadIdx.x == 1023) total = L.jb[1023];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int b = first + k;
+        if (b < nb) {
+            const int s0 = L.ja[b], T = L.ja[b + 1] - s0, nt = (T + 15) >> 4;
+            if (parts[k] == 2) {
+                j.fitems[off] = make_int4(s0, T, 0, 2);
+                j.fitems[off + 1] = make_int4(s0, T, 2, nt - 2);
+            } else {
+                j.fitems[off] = make_int4(s0, T, 0, nt);
+            }
+            off += parts[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) j.num_fitems[0] = total;
+}
+
 __global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
     const WinJob& j = J.j[blockIdx.y];
     __shared__ BundleLds L;
@@ -237,6 +319,7 @@ __global__ __launch_bounds__(1024) void win_bundle_jobs_kernel(WinJobs J) {
     __syncthreads();
     bundle_pack(j, j.cap, j.bun_start, j.bun_tok, j.num_bundles, L, W, in_lds);
     if (j.fbun_tok) bundle_pack(j, j.fcap, nullptr, j.fbun_tok, j.num_fbundles, L, W, in_lds);
+    if (j.fitems) item_pack(j, L, W, in_lds);
 }
 
 // =====================================================================================
@@ -922,6 +1005,15 @@ extern "C" int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_
     return total;
 }
 
+static int device_cus() {
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        return n > 0 ? n : 256;
+    }();
+    return cus;
+}
+
 extern "C" int64_t geomae_window_build_batch_table_bytes(const int32_t* num_tokens, int32_t num_jobs, int32_t batch_size,
                                                          const GeomaeWindowConfig* cfg) {
     if (!num_tokens || num_jobs < 1 || num_jobs > kMaxWinJobs) return -1;
@@ -955,6 +1047,12 @@ extern "C" int geomae_window_build_batch(const GeomaeWindowBuildJob* jobs, int32
         GEOMAE_REQUIRE((in.fbun_tok == nullptr) == (in.num_fbundles == nullptr), "window_build: pass both arrays of the second packing or none");
         GEOMAE_REQUIRE(!in.fbun_tok || in.pos_info, "window_build: the second packing needs the attention plan");
         j.fbun_tok = in.fbun_tok; j.num_fbundles = in.num_fbundles;
+        GEOMAE_REQUIRE((in.fitems == nullptr) == (in.num_fitems == nullptr), "window_build: pass both arrays of the forward work items or none");
+        GEOMAE_REQUIRE(!in.fitems || in.fbun_tok, "window_build: the forward work items need the second packing");
+        j.fitems = (int4*)in.fitems; j.num_fitems = in.num_fitems;
+        // (only the token sets the one-launch forward takes get items: the others' layers never read them)
+        j.icap = (in.fitems && in.num_tokens <= tuning().fused_max_tokens) ? tuning().fwd_item_cap : 0;
+        j.ibudget = device_cus();
         j.win_start = in.win_start; j.win_tokens = in.win_tokens; j.tok_win = in.tok_win; j.tok_pos = in.tok_pos;
         j.num_windows = in.num_windows; j.bun_start = in.bun_start; j.num_bundles = in.num_bundles;
         GEOMAE_REQUIRE((in.bun_tok == nullptr) == (in.pos_info == nullptr), "window_build: pass both attention-plan arrays or none");
@@ -995,7 +1093,7 @@ extern "C" int geomae_window_build(const int32_t* coors, int32_t num_tokens, int
                                    int32_t* num_windows, int32_t* bun_start, int32_t* num_bundles,
                                    void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     GeomaeWindowBuildJob job = {coors, num_tokens, shift_index, win_start, win_tokens, tok_win, tok_pos,
-                                num_windows, bun_start, num_bundles, nullptr, nullptr, nullptr, nullptr};
+                                num_windows, bun_start, num_bundles, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     return geomae_window_build_batch(&job, 1, batch_size, cfg, workspace, workspace_bytes, stream);
 }
 

@@ -811,7 +811,7 @@ def make_window_config(window_shape, shift, bev_shape):
 class WindowLayout:
     """CSR grouping of tokens by window for one shift (replaces the flat2win index dictionaries)."""
     __slots__ = ("win_start", "win_tokens", "tok_win", "tok_pos", "num_windows", "max_windows", "n", "max_tokens",
-                 "bun_start", "num_bundles", "bun_tok", "pos_info", "fbun_tok", "num_fbundles")
+                 "bun_start", "num_bundles", "bun_tok", "pos_info", "fbun_tok", "num_fbundles", "fitems", "num_fitems")
 
 
 def _new_window_layout(n, batch_size, wcfg, dev):
@@ -831,6 +831,7 @@ def _new_window_layout(n, batch_size, wcfg, dev):
     L.num_bundles = torch.empty(1, dtype=torch.int32, device=dev)
     L.bun_tok = L.pos_info = None          # the attention plan: window_build_batch fills it
     L.fbun_tok = L.num_fbundles = None     # ... and the second packing (bundles of the one-launch layer kernel)
+    L.fitems = L.num_fitems = None         # ... and the one-launch forward's work items (query-split bundles)
     return L
 
 
@@ -859,6 +860,9 @@ def window_build_batch(jobs, batch_size, wcfg):
         L.fbun_tok = torch.empty(L.max_windows + 1, dtype=torch.int32, device=coors.device)
         L.num_fbundles = torch.empty(1, dtype=torch.int32, device=coors.device)
         j.fbun_tok, j.num_fbundles = L.fbun_tok.data_ptr(), L.num_fbundles.data_ptr()
+        L.fitems = torch.empty((2 * (L.max_windows + 1), 4), dtype=torch.int32, device=coors.device)
+        L.num_fitems = torch.empty(1, dtype=torch.int32, device=coors.device)
+        j.fitems, j.num_fitems = L.fitems.data_ptr(), L.num_fitems.data_ptr()
         ns[k] = L.n
     wsb = lib.geomae_window_build_batch_workspace_bytes(ns, len(jobs), batch_size, ctypes.byref(wcfg))
     if wsb < 0:
@@ -1362,6 +1366,8 @@ def _stack_layouts(layouts):
             a.bun_tok, a.pos_info = L.bun_tok.data_ptr(), L.pos_info.data_ptr()
         if getattr(L, "fbun_tok", None) is not None and L.num_fbundles is not None:
             a.fbun_tok, a.num_fbundles = L.fbun_tok.data_ptr(), L.num_fbundles.data_ptr()
+        if getattr(L, "fitems", None) is not None and L.num_fitems is not None:
+            a.fitems, a.num_fitems = L.fitems.data_ptr(), L.num_fitems.data_ptr()
     return arr
 
 

@@ -72,7 +72,10 @@ typedef struct GeomaeTuning {
     int32_t zero_late_aux;         /* 0  | 1: the zero arena filled on the decoder-B stream (the round-4 placement) */
     int32_t fused_skip_big;        /* 1  | skip the one-launch layer's second kernel when no window kept more than 64 pillars */
     int32_t heads_joint;           /* 0  | 1: all six heads in one launch on the main stream */
-    int32_t reserved[8];
+    int32_t fwd_item_cap;          /* 0  | != 0 (32): the one-launch forward walks WORK ITEMS -- a packing of that cap whose bundles of three / four
+                                      tiles are split by query tile (GeomaeWindowBuildJob.fitems).  OFF: sst_layer_fwd_kernel 18.3 -> 17.0 us
+                                      per launch, the step within noise (docs/LAB_NOTES.md round 6); 0: the second packing, as the backward */
+    int32_t reserved[7];
 } GeomaeTuning;
 int geomae_get_tuning(GeomaeTuning* out);
 int geomae_set_tuning(const GeomaeTuning* in);
@@ -262,6 +265,12 @@ typedef struct GeomaeWindowBuildJob {
      * geomae_sst_layer_forward -- at most geomae_window_bundle_cap(num_tokens, wx * wy) tokens each unless a single window is
      * larger: fbun_tok [min(n, slots) + 1] positions where they start, num_fbundles [1] */
     int32_t *fbun_tok, *num_fbundles;
+    /* optional WORK ITEMS of the one-launch layer FORWARD (both or neither; needs the second packing; round 6): a third packing
+     * with a cap of GeomaeTuning.fwd_item_cap (0 = none made; 32 when switched on) positions whose bundles of three / four tiles are SPLIT by query tile into
+     * two items -- a launch lasts as long as its longest work item, and the device has more CUs than a small token set has
+     * bundles.  fitems [2 * (min(n, slots) + 1)][4] = (first position, positions, first query tile, query tiles) per item,
+     * num_fitems [1]; 0 items = "not applicable" (more bundles than CUs, huge window tables): the kernel then walks fbun_tok */
+    int32_t *fitems, *num_fitems;
 } GeomaeWindowBuildJob;
 int64_t geomae_window_build_batch_workspace_bytes(const int32_t* num_tokens /*host [num_jobs]*/, int32_t num_jobs,
                                                   int32_t batch_size, const GeomaeWindowConfig* cfg);
@@ -585,6 +594,7 @@ typedef struct GeomaeSstStackLayout {       /* the CSR arrays of geomae_window_b
     int32_t max_bundles;
     const int32_t *bun_tok, *pos_info;      /* the build's attention plan, or both NULL */
     const int32_t *fbun_tok, *num_fbundles; /* the build's second packing (one-launch layer kernel), or both NULL */
+    const int32_t *fitems, *num_fitems;     /* the build's forward work items (GeomaeWindowBuildJob.fitems), or both NULL */
 } GeomaeSstStackLayout;
 /* ------------------------------------------------------------------ A19-A22 one launch per layer (forward)
  * EncoderLayer.forward + WindowAttention.forward (sst_basic_block.py:26-61, 85-102) as ONE kernel, one workgroup per bundle

@@ -258,3 +258,51 @@ def test_a_broken_big_bundle_promise_is_counted(dev):
     finally:
         lib.geomae_sst_set_fused_layers(1)
         _lib.set_tuning(**old)
+
+
+def test_forward_work_items_cover_every_tile_once_and_match_the_unsplit_forward(dev):
+    """Round 6: the one-launch forward walks WORK ITEMS (window.hip item_pack: a 32-position packing whose bundles of three / four
+    tiles are split by query tile into two items, all in one round of workgroups).  The item list must own every tile of every
+    bundle exactly once; the forward through it must equal the forward over the second packing (GeomaeTuning.fwd_item_cap = 0)
+    up to the summation order of the softmax (another tile partition of the same windows)."""
+    from geomae_amd import ops, _lib
+    old_cap = _lib.set_tuning(fwd_item_cap=32)["fwd_item_cap"]          # (off by default: the layouts below are built with it on)
+    try:
+        model, bb, layouts, n, x, dz = _encoder_small_case(dev)
+    finally:
+        _lib.set_tuning(fwd_item_cap=old_cap)
+    nl = 2 * len(bb.encoder_blocks)
+    w = bb._packed.weight_array(bb._stack_base["enc"], nl)
+    n_split = 0
+    for L in layouts:
+        ni = int(L.num_fitems.item())
+        assert 0 < ni <= 2 * (L.max_windows + 1)
+        it = L.fitems[:ni].cpu().numpy()
+        owned = {}
+        for s0, T, q0, nq in it:
+            nt = (T + 15) // 16
+            assert 1 <= T <= 144 and 0 <= q0 and nq >= 1 and q0 + nq <= nt, (s0, T, q0, nq)
+            n_split += int(nq < nt)
+            for q in range(q0, q0 + nq):
+                assert (s0, q) not in owned
+                owned[(s0, q)] = 1
+        # whole bundles: every tile of every bundle start that appears is owned, and the bundles tile the position range
+        starts = sorted({(int(a), int(b)) for a, b, _, _ in it})
+        assert starts[0][0] == 0 and all(starts[i][0] + starts[i][1] == starts[i + 1][0] for i in range(len(starts) - 1))
+        assert starts[-1][0] + starts[-1][1] == n
+        assert len(owned) == sum((T + 15) // 16 for _, T in starts)
+    assert n_split > 0, "the case is meant to hold bundles of three tiles"
+    res = []
+    old = _lib.get_tuning().fwd_item_cap
+    try:
+        for cap in (0, 32):
+            _lib.set_tuning(fwd_item_cap=cap)
+            ops.fused_dropped_bundles(reset=True)
+            z, saved = ops.sst_stack_forward(x, w, layouts, bb.pos_table, bb.nhead[0])
+            torch.cuda.synchronize()
+            assert ops.last_stack_forms()[0] == 1 and ops.fused_dropped_bundles() == 0
+            res.append((z.clone(), saved.clone()))
+    finally:
+        _lib.set_tuning(fwd_item_cap=old)
+    assert torch.isfinite(res[1][0]).all()
+    assert _rel(res[1][0], res[0][0]) < 2e-3, _rel(res[1][0], res[0][0])
