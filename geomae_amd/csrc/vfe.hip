@@ -1817,6 +1817,11 @@ extern "C" int geomae_vfe_backward_layer0(const GeomaeVfeArgs* a, const GeomaeBn
     return geomae_vfe_weight_grad1(dy1_bf16, g_bf16, num_points, dw1, stream);
 }
 
+// The layer-form contraction addresses its operand slabs with 32-bit byte offsets inside a buffer descriptor of
+// n16 * ldblk * 512 bytes (dw_device.h dl_job_body; ldblk = 8 for 128-channel operands): 256 bytes per row must stay below
+// 2^31 -- 8.38 M rows per call.  Above it the SPLIT job is not taken.
+static constexpr int64_t kDwSplitMaxRows = ((1ll << 31) - (1 << 20)) / 256;
+
 extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16, int64_t num_points, float* dw1,
                                        hipStream_t stream) {
     if (num_points <= 0) return GEOMAE_OK;
@@ -1828,8 +1833,9 @@ extern "C" int geomae_vfe_weight_grad1(const void* dy1_bf16, const void* g_bf16,
     // with a workspace: the layer-form contraction (LDS-direct operand slabs, its own reduction launch); GEOMAE_DW_LAYER_FORM=0:
     // the old kernel (A/B)
     const bool layer_form = tuning().dw_layer_form != 0;
-    if (layer_form && T.partial && num_points < (1ll << 31) - 64)
+    if (layer_form && T.partial && num_points <= kDwSplitMaxRows)
         return launch_dw_split((const bf16_t*)dy1_bf16, (const bf16_t*)g_bf16, (int)num_points, dw1, T.partial, stream);
+    GEOMAE_REQUIRE(num_points < (1ll << 31) - 64, "vfe_weight_grad1: too many points");
     return launch_dw(T, 1, (int)num_points, stream);
 }
 
@@ -1839,7 +1845,8 @@ extern "C" int geomae_vfe_weight_grad1_ws(const void* dy1_bf16, const void* g_bf
                                           void* workspace, int64_t workspace_bytes, hipStream_t stream) {
     if (num_points <= 0) return GEOMAE_OK;
     GEOMAE_REQUIRE(dy1_bf16 && g_bf16 && dw1 && workspace, "vfe_weight_grad1_ws: null argument");
-    GEOMAE_REQUIRE(num_points < (1ll << 31) - 64, "vfe_weight_grad1_ws: too many points");
+    GEOMAE_REQUIRE(num_points <= kDwSplitMaxRows, "vfe_weight_grad1_ws: more than 8.38 M points per call (32-bit slab offsets)");
+
     if (workspace_bytes < 2 * kDwPartialBytes) {
         set_error("vfe_weight_grad1_ws: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)(2 * kDwPartialBytes));
         return GEOMAE_ERR_WORKSPACE;
