@@ -177,10 +177,15 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
     {
         const __amdgpu_buffer_rsrc_t attn_r = saved_rsrc(A.attn), lse_r = saved_rsrc(A.lse);
         const float scale = 0.25f;                                   // 1 / sqrt(16)
+#ifdef FUSED_SKIP_PAIRS               // (A/B: tile pairs that no window spans are skipped behind scalar branches in the exact bodies too)
+        constexpr bool RANGES = true;
+#else
+        constexpr bool RANGES = !EXACT;
+#endif
         FOR_OWN(it) {
             const int first = 16 * it;
             int jlo = 0, jhi = NT - 1;
-            if (!EXACT) {
+            if (RANGES) {
                 const int last = first + 15 < T ? first + 15 : T - 1;
                 jlo = __builtin_amdgcn_readfirstlane((wl[first] - s0) >> 4);
                 jhi = __builtin_amdgcn_readfirstlane((wh[last] - 1 - s0) >> 4);
@@ -190,7 +195,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             float m = -INFINITY;
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
-                if (EXACT || (jt >= jlo && jt <= jhi)) {
+                if (!RANGES || (jt >= jlo && jt <= jhi)) {
                     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
                     st[jt] = mfma16(kf[jt], qf[it], z4);          // S^T: rows = keys 4g + r, column = query t
                     const int4 W4 = *reinterpret_cast<const int4*>(wl + 16 * jt + 4 * g);
@@ -206,7 +211,7 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
             uint2 pb[NT];
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt)
-                if (EXACT || (jt >= jlo && jt <= jhi)) {
+                if (!RANGES || (jt >= jlo && jt <= jhi)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float p = __expf(st[jt][r] - m);
@@ -221,8 +226,8 @@ __device__ __forceinline__ void fused_fwd_body(const FusedFwd& A, const int s0, 
 #pragma unroll
             for (int jp = 0; jp < (NT + 1) / 2; ++jp) {
                 const int j0 = 2 * jp, j1 = 2 * jp + 1;
-                const bool a0 = EXACT || (j0 >= jlo && j0 <= jhi);
-                const bool a1 = j1 < NT && (EXACT || (j1 >= jlo && j1 <= jhi));
+                const bool a0 = !RANGES || (j0 >= jlo && j0 <= jhi);
+                const bool a1 = j1 < NT && (!RANGES || (j1 >= jlo && j1 <= jhi));
                 if (a0 || a1) {
                     const uint2 zz = make_uint2(0u, 0u);
                     const int j1c = j1 < NT ? j1 : j0;
