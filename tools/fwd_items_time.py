@@ -1,3 +1,5 @@
+"""The encoder stack forward alone over the one-launch forward's WORK ITEMS (GeomaeTuning.fwd_item_cap = 0 / 32 / 48 / 64; window.hip
+item_pack) for four batches of four frames: item counts, how many are split parts, us per layer.  Usage: python tools/fwd_items_time.py"""
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from geomae_amd import _lib
